@@ -1,0 +1,279 @@
+/* ktx_oracle.c — TEST INFRASTRUCTURE ONLY.
+ *
+ * Plain-C (scalar) restatement of the reference's CPU MoE expert forward — the arithmetic contract the
+ * HIP path has to reproduce.  Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may
+ * load this library; the product path (ktransformers_amd/) never does and fails loudly without its HIP
+ * extension.
+ *
+ * Pinning: tests/test_oracle_vs_reference.py drives this file and the reference's own unmodified kernels
+ * (oracle/_ref/libkt_ref.so, built by oracle/Makefile from /root/reference) on the same seeded inputs and
+ * requires BIT-EXACT bf16 outputs; tests/golden/ holds vectors generated from the reference build so the
+ * same check travels to machines without /root/reference.
+ *
+ * Every function cites the reference lines (relative to /root/reference/kt-kernel/) it restates.
+ * All fp32 arithmetic here is deliberately un-contracted (compile with -ffp-contract=off); where the
+ * reference issues an FMA this file calls fmaf() explicitly.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define KTXO_FMT_AMXINT4 0
+#define KTXO_FMT_AMXINT8 1
+#define KTXO_FMT_RAWINT4 2
+#define KTXO_FMT_FP8 3
+#define KTXO_FMT_BF16 4
+
+/* ------------------------------------------------------------------------------------------------ */
+/* bf16 <-> fp32                                                                                     */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* operators/amx/la/utils.hpp:47-52 (avx512_32xbf16_to_32xfp32): bf16 bits << 16. */
+float ktxo_bf16_to_f32(uint16_t h) {
+  uint32_t u = (uint32_t)h << 16;
+  float f;
+  memcpy(&f, &u, 4);
+  return f;
+}
+
+/* operators/amx/la/utils.hpp:14-17: on AVX512-BF16 hosts (this container and the MI355X box's EPYC 9575F) the
+ * reference converts with VCVTNE2PS2BF16 = round-to-nearest-even, input denormals treated as zero and results
+ * flushed to zero (the instruction ignores MXCSR.DAZ/FTZ and always behaves that way), NaN quieted. */
+uint16_t ktxo_f32_to_bf16(float f) {
+  uint32_t u;
+  memcpy(&u, &f, 4);
+  if ((u & 0x7f800000u) == 0) return (uint16_t)((u >> 16) & 0x8000u);              /* zero / denormal -> +-0 */
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x0040u);     /* NaN -> quiet NaN */
+  return (uint16_t)((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+}
+
+/* _mm512_cvtps_epi32 under default MXCSR = round-to-nearest-even; out of range -> 0x80000000. */
+static inline int32_t cvt_rne_i32(float x) {
+  if (!(x > -2147483904.0f && x < 2147483648.0f)) return INT32_MIN;
+  return (int32_t)lrintf(x); /* FE_TONEAREST is the process default */
+}
+
+/* _mm512_cvtsepi32_epi8: signed saturation. */
+static inline int8_t sat8(int32_t v) { return (int8_t)(v < -128 ? -128 : (v > 127 ? 127 : v)); }
+
+/* ------------------------------------------------------------------------------------------------ */
+/* a6 — activation quantisation, per row int8                                                       */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* BufferAImpl::from_mat, operators/amx/la/amx_buffers.hpp:47-98:
+ *   d = amax / 127 (fp32), id = d ? 1.0f/d : 0, q = sat8(rne(x * id)). */
+void ktxo_quant_act_row(const uint16_t* x, int K, int8_t* q, float* d_out) {
+  float amax = 0.0f;
+  for (int j = 0; j < K; j++) {
+    float a = fabsf(ktxo_bf16_to_f32(x[j]));
+    if (a > amax) amax = a;
+  }
+  float d = amax / 127.0f;
+  float id = d ? 1.0f / d : 0.0f;
+  for (int j = 0; j < K; j++) q[j] = sat8(cvt_rne_i32(ktxo_bf16_to_f32(x[j]) * id));
+  *d_out = d;
+}
+
+/* BufferAKGroupImpl::from_mat, operators/amx/la/amx_buffers.hpp:364-419: the same per (row, group of g). */
+void ktxo_quant_act_row_kgroup(const uint16_t* x, int K, int g, int8_t* q, float* d_out) {
+  for (int kg = 0; kg < K / g; kg++) ktxo_quant_act_row(x + kg * g, g, q + kg * g, d_out + kg);
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* a7 — load-time weight quantisation                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* round_4bit_s8, operators/amx/la/amx_buffers.hpp:527-539: sign-magnitude rounding of an int8 to a multiple
+ * of 16: sign(i) * ((|i| + 8) & 0xF0), all in 8-bit arithmetic. */
+static inline int8_t round_4bit_s8(int8_t x) {
+  uint8_t s = (x & 0x80) ? 0xFF : 0x00;
+  uint8_t a = (uint8_t)(x < 0 ? -x : x);
+  a = (uint8_t)((a + 8) & 0xF0);
+  a = (uint8_t)((a ^ s) - s);
+  return (int8_t)a;
+}
+
+/* BufferBInt4Impl::_pack_block, operators/amx/la/amx_buffers.hpp:541-627 (AMXINT4):
+ *   d[n] = amax_n / 112.0   (double division — the literal is a double — then narrowed to fp32)
+ *   i = sat8(rne(w * (1.0f/d))),  q16 = round_4bit_s8(i)  in {-112,...,112 step 16}.
+ * Output q16 holds the value the kernel multiplies with (nibble << 4), row-major [N, K]; the reference's
+ * tile/VNNI byte layout (same lines) is a pure permutation of these values and is restated separately in
+ * ktxo_pack_amxint4_reference_layout(). */
+void ktxo_quant_weight_amxint4(const uint16_t* w, int N, int K, int8_t* q16, float* d_out) {
+  for (int n = 0; n < N; n++) {
+    const uint16_t* row = w + (size_t)n * K;
+    float amax = 0.0f;
+    for (int j = 0; j < K; j++) {
+      float a = fabsf(ktxo_bf16_to_f32(row[j]));
+      if (a > amax) amax = a;
+    }
+    float d = (float)((double)amax / 112.0);
+    float id = d ? 1.0f / d : 0.0f;
+    for (int j = 0; j < K; j++) q16[(size_t)n * K + j] = round_4bit_s8(sat8(cvt_rne_i32(ktxo_bf16_to_f32(row[j]) * id)));
+    d_out[n] = d;
+  }
+}
+
+/* GemmKernel224Int8::BufferB::_pack_block, operators/amx/la/amx_kernels.hpp:1103-1150 (AMXINT8):
+ *   d[n] = amax_n / 127 (fp32), q = sat8(rne(w * (1.0f/d))). */
+void ktxo_quant_weight_amxint8(const uint16_t* w, int N, int K, int8_t* q, float* d_out) {
+  for (int n = 0; n < N; n++) {
+    const uint16_t* row = w + (size_t)n * K;
+    float amax = 0.0f;
+    for (int j = 0; j < K; j++) {
+      float a = fabsf(ktxo_bf16_to_f32(row[j]));
+      if (a > amax) amax = a;
+    }
+    float d = amax / 127.0f;
+    float id = d ? 1.0f / d : 0.0f;
+    for (int j = 0; j < K; j++) q[(size_t)n * K + j] = sat8(cvt_rne_i32(ktxo_bf16_to_f32(row[j]) * id));
+    d_out[n] = d;
+  }
+}
+
+/* BufferBInt4Impl::to_mat, operators/amx/la/amx_buffers.hpp:683-739: w ~= bf16(float(nibble) * (d * 16.0f)). */
+void ktxo_dequant_weight_amxint4(const int8_t* q16, const float* d, int N, int K, uint16_t* w) {
+  for (int n = 0; n < N; n++) {
+    float vs = d[n] * 16.0f;
+    for (int j = 0; j < K; j++) w[(size_t)n * K + j] = ktxo_f32_to_bf16((float)(q16[(size_t)n * K + j] / 16) * vs);
+  }
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* a10 — SiLU(gate) * up with the reference's polynomial exp                                        */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* amx::exp_avx512, operators/amx/la/amx.hpp:22-45. */
+static inline float exp_poly(float x) {
+  const float log2e = 1.44269504089f;
+  float y = x * log2e;
+  int32_t ip = cvt_rne_i32(y);
+  float frac = y - (float)ip;
+  float p = fmaf(0.0013333558f, frac, 0.0096181291f);
+  p = fmaf(p, frac, 0.0555041087f);
+  p = fmaf(p, frac, 0.2402265069f);
+  p = fmaf(p, frac, 0.6931471805f);
+  p = fmaf(p, frac, 0.9999999995f);
+  float two_pow_i = ldexpf(1.0f, ip); /* _mm512_scalef_ps(1.0, float(ip)) */
+  return two_pow_i * p;
+}
+
+/* amx::act_fn (swiglu_limit == 0, swiglu_alpha == 0), operators/amx/la/amx.hpp:47-76:
+ *   neg = min(0 - g, 88);  act = g / (1 + exp(neg));  return act * u. */
+float ktxo_act_fn(float g, float u) {
+  float neg = 0.0f - g;
+  if (!(neg <= 88.0f)) neg = 88.0f; /* _mm512_min_ps(neg, 88): returns the second operand on NaN */
+  float e = exp_poly(neg);
+  float denom = 1.0f + e;
+  float act = g / denom;
+  return act * u;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* The expert forward                                                                               */
+/* ------------------------------------------------------------------------------------------------ */
+
+typedef struct {
+  int fmt;             /* KTXO_FMT_* */
+  int E, H, I;
+  int group;           /* RAWINT4: k-group size (32); 0 otherwise */
+  /* AMXINT4 / AMXINT8: int8 [E][N][K] holding the integer multiplicand (q16 for int4) and fp32 d [E][N]. */
+  const int8_t* gate_q; const float* gate_d;
+  const int8_t* up_q;   const float* up_d;
+  const int8_t* down_q; const float* down_d;
+  const uint8_t* gpu_experts_mask; /* optional [E]; common.hpp:256-258 should_skip_expert */
+} ktxo_moe;
+
+static inline int skip_expert(const ktxo_moe* m, int64_t id) {
+  return id < 0 || id >= m->E || (m->gpu_experts_mask && m->gpu_experts_mask[id]);
+}
+
+/* a8 + a9 for one (row, matrix): integer_mat_mul + GemmKernel224Int{4,8}::avx_kernel + apply_scale
+ * (operators/amx/la/amx_kernels.hpp:2482-2506,1735-1763,1808-1846) then BufferCImpl::to_mat (amx_buffers.hpp:1716-1732):
+ *   acc  = sum_k a_q[k] * w_q[n][k]          exact int32 over the whole K
+ *   out  = bf16( (a_d * w_d[n]) * float(acc) ). */
+static void gemv_int(const int8_t* aq, float ad, const int8_t* wq, const float* wd, int N, int K, uint16_t* out) {
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; n++) {
+    const int8_t* row = wq + (size_t)n * K;
+    int32_t acc = 0;
+    for (int j = 0; j < K; j++) acc += (int32_t)aq[j] * (int32_t)row[j];
+    float s = ad * wd[n];
+    out[n] = ktxo_f32_to_bf16(s * (float)acc);
+  }
+}
+
+/* AMX_MOE_BASE::forward_prefill / forward_decode, operators/amx/moe_base.hpp:197-654, followed by
+ * TP_MOE<AMX_MOE_BASE>::merge_results with a single TP part, :749-791.
+ *
+ * For each token t and slot j (in order j = 0..k-1, skipping should_skip_expert ids):
+ *   x_q,x_d = QA(x_t)                                   (a6; identical for every expert => computed once)
+ *   g = bf16(GEMM(x_q, Wg_e)), u = bf16(GEMM(x_q, Wu_e)) (a8, a9)
+ *   a = bf16(act_fn(f32(g), f32(u)))                    (a10, moe_base.hpp:693-726)
+ *   a_q,a_d = QA(a)                                     (a11, moe_base.hpp:378-384)
+ *   dn = bf16(GEMM(a_q, Wd_e))
+ *   acc_t = fma(f32(dn), w[t][j], acc_t)                (a12, moe_base.hpp:413-436)
+ * then y_t = bf16( acc_t (+ f32(y_t_old) if incremental) ).
+ *
+ * Optional traces (may be NULL): tr_gate/tr_up/tr_act [T*k][I] and tr_down [T*k][H] bf16 per (t, j).
+ * Returns 0, or -1 for an unsupported format. */
+int ktxo_moe_forward(const ktxo_moe* m, int T, int k, const int64_t* ids, const float* w, const uint16_t* x,
+                     uint16_t* y, int incremental, uint16_t* tr_gate, uint16_t* tr_up, uint16_t* tr_act,
+                     uint16_t* tr_down) {
+  if (m->fmt != KTXO_FMT_AMXINT4 && m->fmt != KTXO_FMT_AMXINT8) return -1;
+  const int H = m->H, I = m->I;
+  int8_t* xq = (int8_t*)malloc((size_t)H);
+  int8_t* aq = (int8_t*)malloc((size_t)I);
+  uint16_t* g = (uint16_t*)malloc(sizeof(uint16_t) * I);
+  uint16_t* u = (uint16_t*)malloc(sizeof(uint16_t) * I);
+  uint16_t* dn = (uint16_t*)malloc(sizeof(uint16_t) * H);
+  float* acc = (float*)malloc(sizeof(float) * H);
+  for (int t = 0; t < T; t++) {
+    float xd;
+    ktxo_quant_act_row(x + (size_t)t * H, H, xq, &xd);
+    for (int e = 0; e < H; e++) acc[e] = 0.0f;
+    for (int j = 0; j < k; j++) {
+      int64_t id = ids[(size_t)t * k + j];
+      if (skip_expert(m, id)) continue;
+      const size_t wo = (size_t)id * I * H;
+      gemv_int(xq, xd, m->gate_q + wo, m->gate_d + (size_t)id * I, I, H, g);
+      gemv_int(xq, xd, m->up_q + wo, m->up_d + (size_t)id * I, I, H, u);
+      if (tr_gate) memcpy(tr_gate + ((size_t)t * k + j) * I, g, sizeof(uint16_t) * I);
+      if (tr_up) memcpy(tr_up + ((size_t)t * k + j) * I, u, sizeof(uint16_t) * I);
+      for (int i = 0; i < I; i++) g[i] = ktxo_f32_to_bf16(ktxo_act_fn(ktxo_bf16_to_f32(g[i]), ktxo_bf16_to_f32(u[i])));
+      if (tr_act) memcpy(tr_act + ((size_t)t * k + j) * I, g, sizeof(uint16_t) * I);
+      float ad;
+      ktxo_quant_act_row(g, I, aq, &ad);
+      gemv_int(aq, ad, m->down_q + wo, m->down_d + (size_t)id * H, H, I, dn);
+      if (tr_down) memcpy(tr_down + ((size_t)t * k + j) * H, dn, sizeof(uint16_t) * H);
+      const float wt = w[(size_t)t * k + j];
+      for (int e = 0; e < H; e++) acc[e] = fmaf(ktxo_bf16_to_f32(dn[e]), wt, acc[e]);
+    }
+    uint16_t* yt = y + (size_t)t * H;
+    for (int e = 0; e < H; e++) {
+      float v = acc[e];
+      if (incremental) v = v + ktxo_bf16_to_f32(yt[e]);
+      yt[e] = ktxo_f32_to_bf16(v);
+    }
+  }
+  free(xq); free(aq); free(g); free(u); free(dn); free(acc);
+  return 0;
+}
+
+/* a5 — token->expert bucketing, operators/amx/moe_base.hpp:208-227: per-expert histogram m_local_num_[e],
+ * arrival rank m_local_pos_[t][j] (token-major, slot-minor), compacted list of active experts in ascending id.
+ * pos[t*k+j] = -1 for skipped slots.  Returns the number of active experts. */
+int ktxo_bucket(int E, const uint8_t* mask, int T, int k, const int64_t* ids, int32_t* num, int32_t* pos,
+                int32_t* expert_id_map) {
+  for (int e = 0; e < E; e++) num[e] = 0;
+  for (int i = 0; i < T; i++)
+    for (int j = 0; j < k; j++) {
+      int64_t id = ids[(size_t)i * k + j];
+      if (id < 0 || id >= E || (mask && mask[id])) { pos[(size_t)i * k + j] = -1; continue; }
+      pos[(size_t)i * k + j] = num[id]++;
+    }
+  int active = 0;
+  for (int e = 0; e < E; e++) if (num[e] > 0) expert_id_map[active++] = e;
+  return active;
+}
