@@ -1,0 +1,94 @@
+/* ktx_moe.h — C ABI of the MI355X-native routed-expert MoE forward (libktx_hip.so).
+ *
+ * Drop-in boundary for the reference's native MoE task protocol (inner seam):
+ *
+ *   reference (CPU)                                            this library (HBM-resident, gfx950)
+ *   ---------------------------------------------------------  -----------------------------------------
+ *   MOEConfig field bag   kt-kernel/ext_bindings.cpp:746-831   ktx_moe_config
+ *   AMXInt4_MOE(config)   kt-kernel/ext_bindings.cpp:447-517   ktx_moe_create
+ *   load_weights_task()   kt-kernel/ext_bindings.cpp:222-239   ktx_moe_load_bf16 / ktx_moe_load_quantized
+ *     (online bf16->int4: operators/amx/moe.hpp:352-387;
+ *      pre-quantised:     operators/amx/moe.hpp:266-300)
+ *   forward_task(bsz_ptr,k,ids,w,in,out,incremental)           ktx_moe_forward
+ *                         kt-kernel/ext_bindings.cpp:240-251
+ *     -> TP_MOE::forward_binding  operators/moe-tp.hpp:195-199
+ *   CPUInfer.submit_with_cuda_stream / sync_with_cuda_stream   (gone: the forward is enqueued on the caller's
+ *                         cpu_backend/cpuinfer.h:87-120         hipStream_t; stream order IS the sync)
+ *
+ * Conventions: every data pointer passed to ktx_moe_forward is a DEVICE pointer on the handle's GPU; the call only
+ * enqueues kernels on `stream` (no host sync, no allocation) and is HIP-graph capturable.  `d_bsz`, like the
+ * reference's bsz_ptr (operators/moe-tp.hpp:209), is read on the device at execution time so one captured graph
+ * serves any batch <= max_len.  All functions return 0 on success, non-zero on error; ktx_last_error() returns the
+ * message of the calling thread's last failure (the reference throws std::runtime_error -> Python RuntimeError).
+ */
+#ifndef KTX_MOE_H
+#define KTX_MOE_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ktx_moe_s* ktx_moe_t;
+typedef void* ktx_stream_t; /* hipStream_t */
+
+/* weight/arithmetic formats = the reference's `method` names (kt-kernel/python/experts.py:316-360) */
+enum ktx_moe_format {
+  KTX_FMT_AMXINT4 = 0, /* per-row signed int4, d = amax/112; int8 per-row activations   (amx/la/amx_buffers.hpp:498-753) */
+  KTX_FMT_AMXINT8 = 1, /* per-row int8,  d = amax/127                                    (amx/la/amx_kernels.hpp:1079-1150) */
+  KTX_FMT_RAWINT4 = 2, /* Kimi-K2 compressed-tensors int4, group 32, bf16 scales          (amx/k2-moe.hpp) */
+  KTX_FMT_FP8 = 3,     /* DeepSeek e4m3 + 128x128 block scale_inv, bf16 activations       (amx/fp8-moe.hpp) */
+  KTX_FMT_BF16 = 4,    /* bf16 weights                                                    (amx/bf16-moe.hpp) */
+};
+
+enum ktx_moe_matrix { KTX_MAT_GATE = 0, KTX_MAT_UP = 1, KTX_MAT_DOWN = 2 };
+
+typedef struct ktx_moe_config {
+  int32_t expert_num;          /* GeneralMOEConfig::expert_num           (operators/common.hpp:232) */
+  int32_t num_experts_per_tok; /* ::num_experts_per_tok                  (:233) */
+  int32_t hidden_size;         /* ::hidden_size                          (:234) */
+  int32_t intermediate_size;   /* ::intermediate_size                    (:235) */
+  int32_t max_len;             /* ::max_len — largest qlen of one forward (:277) */
+  int32_t format;              /* enum ktx_moe_format */
+  int32_t group_size;          /* QuantConfig::group_size (RAWINT4: 32; FP8: 128) (:222-228) */
+  int32_t device;              /* HIP device ordinal */
+  int32_t expert_begin;        /* expert parallelism: this handle owns global experts [expert_begin, expert_begin+expert_num) */
+  int32_t global_expert_num;   /* routing ids are global; ids outside the owned range are skipped like gpu_experts_mask */
+} ktx_moe_config;
+
+const char* ktx_last_error(void);
+
+int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out);
+int ktx_moe_destroy(ktx_moe_t h);
+
+/* Online quantisation on the GPU from bf16 weights, bit-identical to the reference's load_weights() "online quant
+ * from bf16" branch (operators/amx/moe.hpp:352-387 -> BufferB::from_mat).  gate/up: [expert_num][I][H], down:
+ * [expert_num][H][I], bf16, DEVICE pointers (borrowed for the call; the handle keeps its own packed copy, like the
+ * AMX classes do — operators/amx/moe_base.hpp:134-143).  Synchronous. */
+int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down);
+
+/* One expert's pre-quantised matrix, HOST pointers: q = int8 [N][K] row-major integer multiplicands (for AMXINT4
+ * the value nibble*16, i.e. what BufferBInt4Impl::to_mat inverts, amx/la/amx_buffers.hpp:683-739), scale = fp32 [N].
+ * Mirrors the pre-quantised branch of load_weights (operators/amx/moe.hpp:266-300). Synchronous. */
+int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, const float* scale);
+
+/* should_skip_expert mask (operators/common.hpp:241-258): mask[e] != 0 => expert e contributes nothing. HOST ptr, may be NULL. */
+int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask);
+
+/* y[t] = (incremental ? y[t] : 0) + sum_j w[t][j] * Expert_{ids[t][j]}(x[t])   — see DESIGN.md for the exact
+ * rounding contract (= SURVEY.md Appendix A).  d_bsz may be NULL (then qlen is used); otherwise min(*d_bsz, qlen)
+ * tokens are processed and qlen is only the launch bound.  x, y: bf16 [qlen][H]; ids int64 [qlen][k]; w fp32. */
+int ktx_moe_forward(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                    const float* d_weights, const void* d_input, void* d_output, int incremental,
+                    ktx_stream_t stream);
+
+/* Introspection for tests / bench: bytes of packed expert weights resident in HBM; debug taps (device pointers to
+ * the last forward's intermediates in sorted-row order, plus the row of each (t,j) pair). */
+size_t ktx_moe_weight_bytes(ktx_moe_t h);
+int ktx_moe_debug_ptrs(ktx_moe_t h, const void** act_bf16, const void** down_bf16, const int32_t** row_of_pair);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

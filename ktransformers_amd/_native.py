@@ -1,0 +1,151 @@
+"""ctypes binding of the C ABI declared in include/ktx_moe.h.
+
+PyTorch is used only for device memory and streams: every pointer crossing this boundary is a raw device pointer
+(tensor.data_ptr()) and every launch goes on the caller's current HIP stream, so calls are HIP-graph capturable.
+There is NO CPU fallback: if libktx_hip.so is absent the import raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "libktx_hip.so")
+
+FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4}
+MAT_GATE, MAT_UP, MAT_DOWN = 0, 1, 2
+
+
+class KtxError(RuntimeError):
+    """Raised where the reference raises RuntimeError from a C++ std::runtime_error."""
+
+
+class _MoeConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in (
+        "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
+        "device", "expert_begin", "global_expert_num")]
+
+
+def _load() -> C.CDLL:
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} not found: build it with `python -m ktransformers_amd.build` (hipcc, gfx950). "
+            "ktransformers_amd has no CPU fallback.")
+    lib = C.CDLL(LIB_PATH)
+    lib.ktx_last_error.restype = C.c_char_p
+    lib.ktx_moe_create.argtypes = [C.POINTER(_MoeConfig), C.POINTER(C.c_void_p)]
+    lib.ktx_moe_destroy.argtypes = [C.c_void_p]
+    lib.ktx_moe_load_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ktx_moe_load_quantized.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_int, C.c_void_p]
+    lib.ktx_moe_weight_bytes.argtypes = [C.c_void_p]
+    lib.ktx_moe_weight_bytes.restype = C.c_size_t
+    lib.ktx_moe_debug_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    return lib
+
+
+lib = _load()
+
+
+def check(rc: int) -> None:
+    if rc != 0:
+        raise KtxError(lib.ktx_last_error().decode("utf-8", "replace"))
+
+
+def _stream_ptr(device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+class MoEHandle:
+    """Owner of one ktx_moe_t: HBM-resident packed experts + workspace for one MoE layer on one GPU."""
+
+    def __init__(self, expert_num: int, num_experts_per_tok: int, hidden_size: int, intermediate_size: int,
+                 max_len: int, method: str = "AMXINT4", device: int | torch.device = 0, group_size: int = 0,
+                 expert_begin: int = 0, global_expert_num: int = 0):
+        dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if dev.type != "cuda":
+            raise KtxError("MoEHandle needs a HIP device; there is no CPU path")
+        if method not in FMT:
+            raise KtxError(f"unknown method {method!r}")
+        self.device = dev
+        self.E, self.k, self.H, self.I, self.max_len = expert_num, num_experts_per_tok, hidden_size, intermediate_size, max_len
+        self.method = method
+        cfg = _MoeConfig(expert_num, num_experts_per_tok, hidden_size, intermediate_size, max_len, FMT[method],
+                         group_size, dev.index or 0, expert_begin, global_expert_num or expert_num)
+        h = C.c_void_p()
+        check(lib.ktx_moe_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.ktx_moe_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # -- weights ---------------------------------------------------------------------------------
+    def load_bf16(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor) -> None:
+        """Online quantisation from bf16 [E,I,H]/[E,I,H]/[E,H,I] device tensors (reference: moe.hpp:352-387)."""
+        for t, shape in ((gate, (self.E, self.I, self.H)), (up, (self.E, self.I, self.H)), (down, (self.E, self.H, self.I))):
+            if t.dtype != torch.bfloat16 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
+                raise KtxError(f"load_bf16: expected contiguous bf16 {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_moe_load_bf16(self._h, gate.data_ptr(), up.data_ptr(), down.data_ptr()))
+
+    def load_quantized(self, expert: int, which: int, q, scale) -> None:
+        """One expert matrix from host int8 [N,K] multiplicands + fp32 [N] scales (numpy arrays)."""
+        import numpy as np
+        q = np.ascontiguousarray(q, dtype=np.int8)
+        scale = np.ascontiguousarray(scale, dtype=np.float32)
+        check(lib.ktx_moe_load_quantized(self._h, expert, which, q.ctypes.data, scale.ctypes.data))
+
+    def set_expert_mask(self, mask) -> None:
+        if mask is None:
+            check(lib.ktx_moe_set_expert_mask(self._h, None))
+            return
+        import numpy as np
+        m = np.ascontiguousarray(mask, dtype=np.uint8)
+        if m.shape != (self.E,):
+            raise KtxError("mask must have shape [expert_num]")
+        check(lib.ktx_moe_set_expert_mask(self._h, m.ctypes.data))
+
+    @property
+    def weight_bytes(self) -> int:
+        return int(lib.ktx_moe_weight_bytes(self._h))
+
+    # -- forward ---------------------------------------------------------------------------------
+    def forward(self, x: torch.Tensor, expert_ids: torch.Tensor, weights: torch.Tensor, out: torch.Tensor | None = None,
+                incremental: bool = False, bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
+        """x bf16 [T,H]; expert_ids int64 [T,k]; weights fp32 [T,k] -> bf16 [T,H].  Enqueues on the current stream."""
+        T, k = expert_ids.shape
+        if x.dtype != torch.bfloat16 or x.shape != (T, self.H) or not x.is_contiguous():
+            raise KtxError(f"forward: x must be contiguous bf16 [{T},{self.H}]")
+        if expert_ids.dtype != torch.int64 or not expert_ids.is_contiguous():
+            raise KtxError("forward: expert_ids must be contiguous int64 [T,k]")
+        if weights.dtype != torch.float32 or weights.shape != (T, k) or not weights.is_contiguous():
+            raise KtxError("forward: weights must be contiguous fp32 [T,k]")
+        if out is None:
+            if incremental:
+                raise KtxError("forward: incremental=True needs `out` holding the previous output")
+            out = torch.empty_like(x)
+        elif out.dtype != torch.bfloat16 or out.shape != x.shape or not out.is_contiguous():
+            raise KtxError("forward: out must be contiguous bf16 [T,H]")
+        for t in (x, expert_ids, weights, out):
+            if t.device != self.device:
+                raise KtxError(f"forward: tensor on {t.device}, handle on {self.device}")
+        bsz_ptr = None
+        if bsz_tensor is not None:
+            if bsz_tensor.dtype != torch.int32 or bsz_tensor.device != self.device:
+                raise KtxError("forward: bsz_tensor must be int32 on the handle's device")
+            bsz_ptr = bsz_tensor.data_ptr()
+        check(lib.ktx_moe_forward(self._h, bsz_ptr, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
+                                  out.data_ptr(), 1 if incremental else 0, _stream_ptr(self.device)))
+        return out

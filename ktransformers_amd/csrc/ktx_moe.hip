@@ -1,0 +1,779 @@
+// ktx_moe.hip — routed-expert MoE forward for gfx950 (MI355X), hand-written HIP + MFMA.  C ABI in include/ktx_moe.h.
+//
+// Restates on the GPU the arithmetic of the reference's CPU expert path (file:line relative to
+// /root/reference/kt-kernel/):
+//   token->expert bucketing        operators/amx/moe_base.hpp:208-319        -> moe_prep_kernel (block 0)
+//   activation quant (per row i8)  operators/amx/la/amx_buffers.hpp:47-98    -> moe_prep_kernel / moe_actquant_kernel
+//   int4/int8 GEMM, exact int32    operators/amx/la/amx_kernels.hpp:1735-1846,2482-2506 -> moe_gemm_kernel (MFMA i8)
+//   fp32 -> bf16 after each GEMM   operators/amx/la/amx_buffers.hpp:1716-1732 -> epilogue of moe_gemm_kernel
+//   silu(gate)*up, poly exp        operators/amx/moe_base.hpp:693-726, la/amx.hpp:22-76 -> epilogue (GATE_UP)
+//   weighted combine, slot order   operators/amx/moe_base.hpp:413-436,620-638 -> moe_combine_kernel
+//   merge (+incremental) -> bf16   operators/amx/moe_base.hpp:749-791        -> moe_combine_kernel
+//   load-time int4/int8 quantiser  operators/amx/la/amx_buffers.hpp:527-627, la/amx_kernels.hpp:1103-1150
+//                                                                             -> quant_rows_kernel + pack_w*_kernel
+//
+// HBM layout of one weight matrix [N][K] ("W tile layout"; N%16==0, K%128==0):
+//   strip s = n/16, k-step ks = k/128.  Tile (s,ks) is contiguous; lane l = kc*16 + i of a wavefront (i = row within
+//   the strip, kc = 0..3) owns the MFMA A-fragments of both 64-deep halves h of the k-step, where fragment element
+//   e (0..15) multiplies k = ks*128 + kc*32 + h*16 + e.
+//     W4: tile = 1024 B, lane l -> 16 B = dwords P[0..3]; half h uses P[2h], P[2h+1]:
+//           P[2h  ].byte[b] = (q[e=4+b] & 0xF0)  | ((q[e=b]   >> 4) & 0x0F)
+//           P[2h+1].byte[b] = (q[e=12+b] & 0xF0) | ((q[e=8+b] >> 4) & 0x0F)        q = nibble*16 (int8)
+//         so the four int8 fragment registers are ((P<<4)&0xF0F0F0F0, P&0xF0F0F0F0) per dword — 3 VALU ops / 8 weights.
+//     W8: tile = 2048 B, half h at +h*1024, lane l -> 16 int8 = the fragment itself.
+//   One wavefront streams a whole strip (all k-steps) with 1 KiB fully-coalesced dwordx4 loads.
+// Activations are int8 [rows][K]; a chunk of KC = SPC*128 k is staged in LDS as [mt][col=KC/16][tok=16][16 B] so a
+// B-fragment ds_read_b128 (lane = kc*16+tok) is bank-conflict free, and staging stores are 1 KiB contiguous per wave.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cstdio>
+#include <cstring>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/ktx_moe.h"
+#include "ktx_common.h"
+
+// =====================================================================================================
+// error slot
+// =====================================================================================================
+std::string& ktx_err_slot() {
+  static thread_local std::string s;
+  return s;
+}
+int ktx_fail(const std::string& msg) {
+  ktx_err_slot() = msg;
+  return -1;
+}
+extern "C" const char* ktx_last_error(void) { return ktx_err_slot().c_str(); }
+
+// =====================================================================================================
+// device helpers
+// =====================================================================================================
+
+// amx::exp_avx512 (operators/amx/la/amx.hpp:22-45), op for op in fp32 (file is compiled with -ffp-contract=off).
+__device__ __forceinline__ float exp_poly(float x) {
+  const float log2e = 1.44269504089f;
+  float y = x * log2e;
+  float ipf = rintf(y);
+  float frac = y - ipf;
+  float p = fmaf(0.0013333558f, frac, 0.0096181291f);
+  p = fmaf(p, frac, 0.0555041087f);
+  p = fmaf(p, frac, 0.2402265069f);
+  p = fmaf(p, frac, 0.6931471805f);
+  p = fmaf(p, frac, 0.9999999995f);
+  float two_pow_i = ldexpf(1.0f, (int)ipf);
+  return two_pow_i * p;
+}
+
+// amx::act_fn with swiglu_limit == swiglu_alpha == 0 (operators/amx/la/amx.hpp:47-76).
+__device__ __forceinline__ float act_fn(float g, float u) {
+  float neg = 0.0f - g;
+  neg = (neg <= 88.0f) ? neg : 88.0f;
+  float e = exp_poly(neg);
+  float denom = 1.0f + e;
+  float act = g / denom;
+  return act * u;
+}
+
+struct Tile {
+  int expert;  // local expert index
+  int row0;    // first sorted row
+  int nrows;   // <= 16*MT
+  int pad;
+};
+
+// =====================================================================================================
+// K0: prep — block 0 buckets (t,j) pairs by expert; blocks 1.. quantise one token's activations (a5, a6)
+// =====================================================================================================
+#define KTX_EMAX 1024
+
+struct PrepParams {
+  const int32_t* d_bsz;
+  int qlen, k, E, expert_begin, H;
+  int rows_per_tile;  // 16*MT
+  const int64_t* ids;
+  const uint8_t* mask;
+  const bf16_t* x;
+  int8_t* x_q;
+  float* x_d;
+  int32_t* row_of_pair;  // [qlen*k]  -> sorted row or -1
+  int32_t* src_of_row;   // [qlen*k]  sorted row -> token index
+  Tile* tiles;
+  int32_t* counters;  // [0] = num_tiles, [1] = num_rows
+};
+
+__device__ __forceinline__ void quant_row_block(const bf16_t* __restrict__ src, int K, int8_t* __restrict__ dst,
+                                                float* __restrict__ d_out, float* red /* LDS [nwaves] */) {
+  // per row: d = amax/127, id = d ? 1/d : 0, q = sat8(rne(x*id))   (amx_buffers.hpp:47-98)
+  const int tid = threadIdx.x, nthr = blockDim.x;
+  float amax = 0.0f;
+  for (int j = tid * 8; j < K; j += nthr * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(src + j);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      amax = fmaxf(amax, fabsf(bf16_to_f32((bf16_t)(w[q] & 0xffffu))));
+      amax = fmaxf(amax, fabsf(bf16_to_f32((bf16_t)(w[q] >> 16))));
+    }
+  }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) red[tid >> 6] = amax;
+  __syncthreads();
+  float m = 0.0f;
+  for (int w = 0; w < (nthr >> 6); w++) m = fmaxf(m, red[w]);
+  const float d = m / 127.0f;
+  const float id = d ? 1.0f / d : 0.0f;
+  for (int j = tid * 8; j < K; j += nthr * 8) {
+    uint4 v = *reinterpret_cast<const uint4*>(src + j);
+    const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+    uint32_t o[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      int a = quant_rne_sat8(bf16_to_f32((bf16_t)(w[q] & 0xffffu)) * id);
+      int b = quant_rne_sat8(bf16_to_f32((bf16_t)(w[q] >> 16)) * id);
+      o[q >> 1] |= ((uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8)) << ((q & 1) * 16);
+    }
+    *reinterpret_cast<uint2*>(dst + j) = make_uint2(o[0], o[1]);
+  }
+  if (tid == 0) *d_out = d;
+}
+
+__global__ __launch_bounds__(1024) void moe_prep_kernel(PrepParams p) {
+  __shared__ int s_cnt[KTX_EMAX];
+  __shared__ int s_off[KTX_EMAX];
+  __shared__ int s_toff[KTX_EMAX];
+  __shared__ int s_cur[KTX_EMAX];
+  __shared__ float s_red[16];
+  const int tid = threadIdx.x;
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+
+  if (blockIdx.x > 0) {
+    const int t = blockIdx.x - 1;
+    if (t >= T) return;
+    quant_row_block(p.x + (size_t)t * p.H, p.H, p.x_q + (size_t)t * p.H, p.x_d + t, s_red);
+    return;
+  }
+
+  // ---- block 0: histogram -> offsets -> scatter -> tile list ---------------------------------------------
+  const int E = p.E, npairs = T * p.k;
+  for (int e = tid; e < E; e += blockDim.x) { s_cnt[e] = 0; s_cur[e] = 0; }
+  __syncthreads();
+  for (int i = tid; i < npairs; i += blockDim.x) {
+    long long id = p.ids[i] - p.expert_begin;
+    if (id >= 0 && id < E && !(p.mask && p.mask[id])) atomicAdd(&s_cnt[(int)id], 1);
+  }
+  __syncthreads();
+  if (tid < 64) {  // wave 0: exclusive scans of counts and of tile counts
+    const int per = (E + 63) / 64;
+    const int e0 = tid * per;
+    int sum = 0, tsum = 0;
+    for (int e = e0; e < min(e0 + per, E); e++) {
+      sum += s_cnt[e];
+      tsum += (s_cnt[e] + p.rows_per_tile - 1) / p.rows_per_tile;
+    }
+    int inc = sum, tinc = tsum;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      int a = __shfl_up(inc, o, 64), b = __shfl_up(tinc, o, 64);
+      if (tid >= o) { inc += a; tinc += b; }
+    }
+    int run = inc - sum, trun = tinc - tsum;
+    for (int e = e0; e < min(e0 + per, E); e++) {
+      s_off[e] = run;
+      s_toff[e] = trun;
+      run += s_cnt[e];
+      trun += (s_cnt[e] + p.rows_per_tile - 1) / p.rows_per_tile;
+    }
+    if (tid == 63) { p.counters[0] = tinc; p.counters[1] = inc; }
+  }
+  __syncthreads();
+  for (int i = tid; i < npairs; i += blockDim.x) {
+    long long id = p.ids[i] - p.expert_begin;
+    int r = -1;
+    if (id >= 0 && id < E && !(p.mask && p.mask[id])) {
+      r = s_off[(int)id] + atomicAdd(&s_cur[(int)id], 1);
+      p.src_of_row[r] = i / p.k;
+    }
+    p.row_of_pair[i] = r;
+  }
+  for (int e = tid; e < E; e += blockDim.x) {
+    const int c = s_cnt[e];
+    for (int i = 0, r = 0; r < c; i++, r += p.rows_per_tile) {
+      Tile t;
+      t.expert = e; t.row0 = s_off[e] + r; t.nrows = min(p.rows_per_tile, c - r); t.pad = 0;
+      p.tiles[s_toff[e] + i] = t;
+    }
+  }
+}
+
+// =====================================================================================================
+// Kq: per-row int8 quantisation of the activated intermediate (a11: down_ba_->from_mat, moe_base.hpp:378-384)
+// =====================================================================================================
+__global__ __launch_bounds__(256) void moe_actquant_kernel(const bf16_t* __restrict__ a, int K, int8_t* __restrict__ a_q,
+                                                           float* __restrict__ a_d, const int32_t* counters) {
+  __shared__ float s_red[4];
+  const int row = blockIdx.x;
+  if (row >= counters[1]) return;
+  quant_row_block(a + (size_t)row * K, K, a_q + (size_t)row * K, a_d + row, s_red);
+}
+
+// =====================================================================================================
+// K1 / K2: grouped W4A8 / W8A8 GEMM on MFMA i8 (a8, a9, a10)
+// =====================================================================================================
+struct GemmParams {
+  const uint8_t* w0;   // gate (GATE_UP) or down
+  const uint8_t* w1;   // up   (GATE_UP) or nullptr
+  const float* s0;     // scales [E][N]
+  const float* s1;
+  size_t expert_stride;  // bytes of one expert's matrix
+  int N, K;
+  const int8_t* act_q;      // [src rows][K]
+  const float* act_d;       // [src rows]
+  const int32_t* row_src;   // sorted row -> source row (nullptr: identity)
+  const Tile* tiles;
+  const int32_t* counters;
+  bf16_t* out;  // [sorted rows][N]
+};
+
+template <int WBITS>
+struct WFrag {
+  uint4 v[WBITS == 4 ? 1 : 2];
+};
+
+template <int WBITS>
+__device__ __forceinline__ WFrag<WBITS> load_wfrag(const uint8_t* __restrict__ tile_base, int lane) {
+  WFrag<WBITS> f;
+  if constexpr (WBITS == 4) {
+    f.v[0] = *reinterpret_cast<const uint4*>(tile_base + lane * 16);
+  } else {
+    f.v[0] = *reinterpret_cast<const uint4*>(tile_base + lane * 16);
+    f.v[1] = *reinterpret_cast<const uint4*>(tile_base + 1024 + lane * 16);
+  }
+  return f;
+}
+
+template <int WBITS>
+__device__ __forceinline__ void unpack_wfrag(const WFrag<WBITS>& f, v4i& a0, v4i& a1) {
+  if constexpr (WBITS == 4) {
+    const uint32_t m = 0xF0F0F0F0u;
+    a0 = v4i{(int)((f.v[0].x << 4) & m), (int)(f.v[0].x & m), (int)((f.v[0].y << 4) & m), (int)(f.v[0].y & m)};
+    a1 = v4i{(int)((f.v[0].z << 4) & m), (int)(f.v[0].z & m), (int)((f.v[0].w << 4) & m), (int)(f.v[0].w & m)};
+  } else {
+    a0 = v4i{(int)f.v[0].x, (int)f.v[0].y, (int)f.v[0].z, (int)f.v[0].w};
+    a1 = v4i{(int)f.v[1].x, (int)f.v[1].y, (int)f.v[1].z, (int)f.v[1].w};
+  }
+}
+
+template <int WBITS, int MT, int SPC, bool GATE_UP>
+__global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
+  constexpr int NMAT = GATE_UP ? 2 : 1;
+  constexpr int KC = SPC * 128;
+  constexpr int COLS = KC / 16;                       // 16-byte columns per chunk
+  constexpr int BUF_BYTES = MT * COLS * 256;          // one LDS activation buffer
+  constexpr int GROUPS = MT * SPC * 2;                // staging groups of (16 tok x 4 cols)
+  constexpr int UPT = (GROUPS + 3) / 4;               // staging units per thread
+  constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
+
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* Bs = smem;                                               // [2][BUF_BYTES]
+  float* s_ad = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);     // [MT*16]
+  int* s_src = reinterpret_cast<int*>(s_ad + MT * 16);              // [MT*16]
+
+  const int tile_idx = blockIdx.y;
+  if (tile_idx >= p.counters[0]) return;
+  const Tile tile = p.tiles[tile_idx];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int strip = blockIdx.x * 4 + wave;
+  const int NKS = p.K / 128;
+  const int NC = (NKS + SPC - 1) / SPC;
+  const bool strip_ok = strip * 16 < p.N;  // wave-uniform
+
+  // rows of this tile: source row + activation scale
+  if (tid < MT * 16) {
+    int src = -1;
+    float ad = 0.0f;
+    if (tid < tile.nrows) {
+      src = p.row_src ? p.row_src[tile.row0 + tid] : (tile.row0 + tid);
+      ad = p.act_d[src];
+    }
+    s_src[tid] = src;
+    s_ad[tid] = ad;
+  }
+  __syncthreads();
+
+  const uint8_t* wbase[NMAT];
+  wbase[0] = p.w0 + (size_t)tile.expert * p.expert_stride + (size_t)strip * NKS * TILE_BYTES;
+  if constexpr (GATE_UP) wbase[1] = p.w1 + (size_t)tile.expert * p.expert_stride + (size_t)strip * NKS * TILE_BYTES;
+
+  v4i acc[NMAT][MT];
+#pragma unroll
+  for (int m = 0; m < NMAT; m++)
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[m][t] = v4i{0, 0, 0, 0};
+
+  WFrag<WBITS> wA[SPC][NMAT], wB[SPC][NMAT];
+  uint4 breg[UPT];
+
+  auto load_w = [&](WFrag<WBITS>(&dst)[SPC][NMAT], int c) {
+#pragma unroll
+    for (int s = 0; s < SPC; s++) {
+      const int ks = c * SPC + s;
+      if (strip_ok && ks < NKS) {
+#pragma unroll
+        for (int m = 0; m < NMAT; m++) dst[s][m] = load_wfrag<WBITS>(wbase[m] + (size_t)ks * TILE_BYTES, lane);
+      }
+    }
+  };
+  auto load_b = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < UPT; it++) {
+      const int g = it * 4 + wave;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g < GROUPS) {
+        const int mt = g / (SPC * 2), col = (g % (SPC * 2)) * 4 + (lane >> 4);
+        const int src = s_src[mt * 16 + (lane & 15)];
+        const int kb = c * KC + col * 16;
+        if (src >= 0 && kb < p.K) v = *reinterpret_cast<const uint4*>(p.act_q + (size_t)src * p.K + kb);
+      }
+      breg[it] = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < UPT; it++) {
+      const int g = it * 4 + wave;
+      if (g < GROUPS) {
+        const int mt = g / (SPC * 2), col = (g % (SPC * 2)) * 4 + (lane >> 4);
+        *reinterpret_cast<uint4*>(Bs + buf * BUF_BYTES + ((mt * COLS + col) * 16 + (lane & 15)) * 16) = breg[it];
+      }
+    }
+  };
+  auto compute = [&](WFrag<WBITS>(&w)[SPC][NMAT], int c, int buf) {
+    if (!strip_ok) return;
+    const uint8_t* bb = Bs + buf * BUF_BYTES + ((lane >> 4) * 2 * 16 + (lane & 15)) * 16;
+#pragma unroll
+    for (int s = 0; s < SPC; s++) {
+      if (c * SPC + s < NKS) {
+        v4i a[NMAT][2];
+#pragma unroll
+        for (int m = 0; m < NMAT; m++) unpack_wfrag<WBITS>(w[s][m], a[m][0], a[m][1]);
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+          const v4i b0 = *reinterpret_cast<const v4i*>(bb + ((t * COLS + s * 8) * 16) * 16);
+          const v4i b1 = *reinterpret_cast<const v4i*>(bb + ((t * COLS + s * 8 + 1) * 16) * 16);
+#pragma unroll
+          for (int m = 0; m < NMAT; m++) {
+            acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m][0], b0, acc[m][t], 0, 0, 0);
+            acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m][1], b1, acc[m][t], 0, 0, 0);
+          }
+        }
+      }
+    }
+  };
+
+  // ---- software pipeline: weights for chunk c+1 and activations for chunk c+1 are in flight while chunk c computes
+  load_w(wA, 0);
+  load_b(0);
+  store_b(0);
+  __syncthreads();
+  for (int c = 0; c < NC; c += 2) {
+    if (c + 1 < NC) { load_b(c + 1); load_w(wB, c + 1); }
+    compute(wA, c, 0);
+    if (c + 1 < NC) store_b(1);
+    __syncthreads();
+    if (c + 1 < NC) {
+      if (c + 2 < NC) { load_b(c + 2); load_w(wA, c + 2); }
+      compute(wB, c + 1, 1);
+      if (c + 2 < NC) store_b(0);
+      __syncthreads();
+    }
+  }
+
+  // ---- epilogue: scale, round to bf16 (a9), activation (a10), store 4 consecutive n per lane --------------------
+  if (!strip_ok) return;
+  const int tok = lane & 15;
+  const int n0 = strip * 16 + (lane >> 4) * 4;
+  const float4 sc0 = *reinterpret_cast<const float4*>(p.s0 + (size_t)tile.expert * p.N + n0);
+  float4 sc1 = sc0;
+  if constexpr (GATE_UP) sc1 = *reinterpret_cast<const float4*>(p.s1 + (size_t)tile.expert * p.N + n0);
+  const float s0v[4] = {sc0.x, sc0.y, sc0.z, sc0.w};
+  const float s1v[4] = {sc1.x, sc1.y, sc1.z, sc1.w};
+#pragma unroll
+  for (int t = 0; t < MT; t++) {
+    const int row = t * 16 + tok;
+    if (row < tile.nrows) {
+      const float ad = s_ad[row];
+      bf16_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        // GemmKernel224Int4::apply_scale: (a_d * b_d) * float(acc)   (la/amx_kernels.hpp:1808-1846)
+        const bf16_t g = f32_to_bf16((ad * s0v[r]) * (float)acc[0][t][r]);
+        if constexpr (GATE_UP) {
+          const bf16_t u = f32_to_bf16((ad * s1v[r]) * (float)acc[1][t][r]);
+          o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
+        } else {
+          o[r] = g;
+        }
+      }
+      uint2 pk = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+      *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * p.N + n0) = pk;
+    }
+  }
+}
+
+// =====================================================================================================
+// K3: weighted combine in slot order (a12) + merge/incremental + bf16 (a4)
+// =====================================================================================================
+struct CombineParams {
+  const int32_t* d_bsz;
+  int qlen, k, H;
+  const bf16_t* dn;            // [sorted rows][H]
+  const int32_t* row_of_pair;  // [qlen*k]
+  const float* weights;        // [qlen][k]
+  bf16_t* y;                   // [qlen][H]
+  int incremental;
+};
+
+__global__ __launch_bounds__(256) void moe_combine_kernel(CombineParams p) {
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int h = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (h >= p.H) return;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int j = 0; j < p.k; j++) {
+    const int r = p.row_of_pair[t * p.k + j];
+    if (r < 0) continue;
+    const float w = p.weights[t * p.k + j];
+    const uint2 v = *reinterpret_cast<const uint2*>(p.dn + (size_t)r * p.H + h);
+    acc[0] = fmaf(bf16_to_f32((bf16_t)(v.x & 0xffffu)), w, acc[0]);
+    acc[1] = fmaf(bf16_to_f32((bf16_t)(v.x >> 16)), w, acc[1]);
+    acc[2] = fmaf(bf16_to_f32((bf16_t)(v.y & 0xffffu)), w, acc[2]);
+    acc[3] = fmaf(bf16_to_f32((bf16_t)(v.y >> 16)), w, acc[3]);
+  }
+  bf16_t* yp = p.y + (size_t)t * p.H + h;
+  if (p.incremental) {
+    const uint2 o = *reinterpret_cast<const uint2*>(yp);
+    acc[0] = acc[0] + bf16_to_f32((bf16_t)(o.x & 0xffffu));
+    acc[1] = acc[1] + bf16_to_f32((bf16_t)(o.x >> 16));
+    acc[2] = acc[2] + bf16_to_f32((bf16_t)(o.y & 0xffffu));
+    acc[3] = acc[3] + bf16_to_f32((bf16_t)(o.y >> 16));
+  }
+  const uint32_t lo = (uint32_t)f32_to_bf16(acc[0]) | ((uint32_t)f32_to_bf16(acc[1]) << 16);
+  const uint32_t hi = (uint32_t)f32_to_bf16(acc[2]) | ((uint32_t)f32_to_bf16(acc[3]) << 16);
+  *reinterpret_cast<uint2*>(yp) = make_uint2(lo, hi);
+}
+
+// =====================================================================================================
+// load-time: quantise bf16 rows (a7) and pack into the W tile layout
+// =====================================================================================================
+// One block per row.  fmt 0 (AMXINT4): d = float(double(amax)/112.0), q = round_4bit_s8(sat8(rne(w*(1/d)))).
+//                     fmt 1 (AMXINT8): d = amax/127,                 q = sat8(rne(w*(1/d))).
+__global__ __launch_bounds__(256) void quant_rows_kernel(const bf16_t* __restrict__ w, int K, int fmt,
+                                                         int8_t* __restrict__ q, float* __restrict__ d_out) {
+  __shared__ float s_red[4];
+  const int tid = threadIdx.x;
+  const size_t row = blockIdx.x;
+  const bf16_t* src = w + row * K;
+  float amax = 0.0f;
+  for (int j = tid; j < K; j += 256) amax = fmaxf(amax, fabsf(bf16_to_f32(src[j])));
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) s_red[tid >> 6] = amax;
+  __syncthreads();
+  amax = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  float d;
+  if (fmt == 0) d = (float)((double)amax / 112.0);
+  else d = amax / 127.0f;
+  const float id = d ? 1.0f / d : 0.0f;
+  for (int j = tid; j < K; j += 256) {
+    int v = quant_rne_sat8(bf16_to_f32(src[j]) * id);
+    if (fmt == 0) {  // round_4bit_s8 (amx_buffers.hpp:527-539): sign(i) * ((|i| + 8) & 0xF0)
+      int a = v < 0 ? -v : v;
+      a = (a + 8) & 0xF0;
+      v = v < 0 ? -a : a;
+    }
+    q[row * K + j] = (int8_t)v;
+  }
+  if (tid == 0) d_out[row] = d;
+}
+
+// q: int8 [N][K] row-major -> W4 tiles.  One thread per packed dword.
+__global__ void pack_w4_kernel(const int8_t* __restrict__ q, int N, int K, uint32_t* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;  // dword index
+  const size_t total = (size_t)N * K / 8;
+  if (idx >= total) return;
+  const int NKS = K / 128;
+  const size_t tile = idx / 256;
+  const int within = (int)(idx % 256);
+  const int lane = within / 4, P = within % 4;
+  const int strip = (int)(tile / NKS), ks = (int)(tile % NKS);
+  const int i = lane & 15, kc = lane >> 4, h = P >> 1, hi8 = (P & 1) * 8;
+  const int8_t* row = q + (size_t)(strip * 16 + i) * K + ks * 128 + kc * 32 + h * 16 + hi8;
+  uint32_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const uint32_t lo = ((uint32_t)(uint8_t)row[b] >> 4) & 0x0Fu;
+    const uint32_t hi = (uint32_t)(uint8_t)row[4 + b] & 0xF0u;
+    v |= (hi | lo) << (8 * b);
+  }
+  out[idx] = v;
+}
+
+// q: int8 [N][K] row-major -> W8 tiles.  One thread per dword.
+__global__ void pack_w8_kernel(const int8_t* __restrict__ q, int N, int K, uint32_t* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * K / 4;
+  if (idx >= total) return;
+  const int NKS = K / 128;
+  const size_t tile = idx / 512;
+  const int within = (int)(idx % 512);
+  const int h = within / 256, lane = (within % 256) / 4, dw = within % 4;
+  const int strip = (int)(tile / NKS), ks = (int)(tile % NKS);
+  const int i = lane & 15, kc = lane >> 4;
+  const int8_t* row = q + (size_t)(strip * 16 + i) * K + ks * 128 + kc * 32 + h * 16 + dw * 4;
+  out[idx] = (uint32_t)(uint8_t)row[0] | ((uint32_t)(uint8_t)row[1] << 8) | ((uint32_t)(uint8_t)row[2] << 16) |
+             ((uint32_t)(uint8_t)row[3] << 24);
+}
+
+// =====================================================================================================
+// host side
+// =====================================================================================================
+struct ktx_moe_s {
+  ktx_moe_config cfg;
+  int wbits;
+  size_t gu_stride, dn_stride;  // bytes per expert matrix
+  uint8_t *gate_w = nullptr, *up_w = nullptr, *down_w = nullptr;
+  float *gate_s = nullptr, *up_s = nullptr, *down_s = nullptr;
+  uint8_t* mask = nullptr;
+  // workspace
+  int8_t *x_q = nullptr, *a_q = nullptr;
+  float *x_d = nullptr, *a_d = nullptr;
+  bf16_t *a_buf = nullptr, *dn_buf = nullptr;
+  int32_t *row_of_pair = nullptr, *src_of_row = nullptr, *counters = nullptr;
+  Tile* tiles = nullptr;
+  int max_pairs = 0, max_tiles = 0;
+};
+
+static int pick_mt(int qlen, int k, int E) {
+  // tokens per expert on average; the MFMA N dimension is 16 tokens per M-tile
+  const double per = (double)qlen * k / std::max(1, E);
+  if (per <= 16.0) return 1;
+  if (per <= 48.0) return 2;
+  return 4;
+}
+
+extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
+  KTX_REQUIRE(cfg && out, "ktx_moe_create: null argument");
+  KTX_REQUIRE(cfg->format == KTX_FMT_AMXINT4 || cfg->format == KTX_FMT_AMXINT8,
+              "ktx_moe_create: format not supported by this build (AMXINT4, AMXINT8)");
+  KTX_REQUIRE(cfg->expert_num > 0 && cfg->expert_num <= KTX_EMAX, "ktx_moe_create: expert_num out of range (1..1024)");
+  KTX_REQUIRE(cfg->num_experts_per_tok > 0, "ktx_moe_create: num_experts_per_tok must be positive");
+  KTX_REQUIRE(cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0,
+              "ktx_moe_create: hidden_size and intermediate_size must be multiples of 128 (reference: K % 128 == 0)");
+  KTX_REQUIRE(cfg->max_len > 0, "ktx_moe_create: max_len must be positive");
+  KTX_HIP(hipSetDevice(cfg->device));
+  ktx_moe_s* h = new ktx_moe_s();
+  h->cfg = *cfg;
+  if (h->cfg.global_expert_num <= 0) h->cfg.global_expert_num = cfg->expert_num;
+  h->wbits = cfg->format == KTX_FMT_AMXINT4 ? 4 : 8;
+  const size_t E = cfg->expert_num, H = cfg->hidden_size, I = cfg->intermediate_size;
+  h->gu_stride = I * H * h->wbits / 8;
+  h->dn_stride = H * I * h->wbits / 8;
+  h->max_pairs = cfg->max_len * cfg->num_experts_per_tok;
+  h->max_tiles = std::min<int>(h->max_pairs, (int)E) + h->max_pairs / 16 + 1;
+  KTX_HIP(hipMalloc(&h->gate_w, E * h->gu_stride));
+  KTX_HIP(hipMalloc(&h->up_w, E * h->gu_stride));
+  KTX_HIP(hipMalloc(&h->down_w, E * h->dn_stride));
+  KTX_HIP(hipMalloc(&h->gate_s, E * I * sizeof(float)));
+  KTX_HIP(hipMalloc(&h->up_s, E * I * sizeof(float)));
+  KTX_HIP(hipMalloc(&h->down_s, E * H * sizeof(float)));
+  KTX_HIP(hipMalloc(&h->x_q, (size_t)cfg->max_len * H));
+  KTX_HIP(hipMalloc(&h->x_d, (size_t)cfg->max_len * sizeof(float)));
+  KTX_HIP(hipMalloc(&h->a_buf, (size_t)h->max_pairs * I * sizeof(bf16_t)));
+  KTX_HIP(hipMalloc(&h->a_q, (size_t)h->max_pairs * I));
+  KTX_HIP(hipMalloc(&h->a_d, (size_t)h->max_pairs * sizeof(float)));
+  KTX_HIP(hipMalloc(&h->dn_buf, (size_t)h->max_pairs * H * sizeof(bf16_t)));
+  KTX_HIP(hipMalloc(&h->row_of_pair, (size_t)h->max_pairs * sizeof(int32_t)));
+  KTX_HIP(hipMalloc(&h->src_of_row, (size_t)h->max_pairs * sizeof(int32_t)));
+  KTX_HIP(hipMalloc(&h->tiles, (size_t)h->max_tiles * sizeof(Tile)));
+  KTX_HIP(hipMalloc(&h->counters, 4 * sizeof(int32_t)));
+  KTX_HIP(hipMemset(h->counters, 0, 4 * sizeof(int32_t)));
+  *out = h;
+  return 0;
+}
+
+extern "C" int ktx_moe_destroy(ktx_moe_t h) {
+  if (!h) return 0;
+  hipSetDevice(h->cfg.device);
+  void* ptrs[] = {h->gate_w, h->up_w, h->down_w, h->gate_s, h->up_s, h->down_s, h->mask, h->x_q, h->a_q, h->x_d,
+                  h->a_d, h->a_buf, h->dn_buf, h->row_of_pair, h->src_of_row, h->counters, h->tiles};
+  for (void* p : ptrs)
+    if (p) hipFree(p);
+  delete h;
+  return 0;
+}
+
+extern "C" size_t ktx_moe_weight_bytes(ktx_moe_t h) {
+  if (!h) return 0;
+  const size_t E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  return E * (2 * h->gu_stride + h->dn_stride) + E * (2 * I + H) * sizeof(float);
+}
+
+static int pack_matrix(ktx_moe_s* h, const int8_t* d_q, int N, int K, uint8_t* d_dst, hipStream_t st) {
+  if (h->wbits == 4) {
+    const size_t total = (size_t)N * K / 8;
+    hipLaunchKernelGGL(pack_w4_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_q, N, K,
+                       reinterpret_cast<uint32_t*>(d_dst));
+  } else {
+    const size_t total = (size_t)N * K / 4;
+    hipLaunchKernelGGL(pack_w8_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d_q, N, K,
+                       reinterpret_cast<uint32_t*>(d_dst));
+  }
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down) {
+  KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_bf16: null argument");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  int8_t* tmp = nullptr;
+  KTX_HIP(hipMalloc(&tmp, (size_t)I * H));
+  const int fmt = h->cfg.format == KTX_FMT_AMXINT4 ? 0 : 1;
+  for (int e = 0; e < E; e++) {
+    const bf16_t* src[3] = {(const bf16_t*)d_gate + (size_t)e * I * H, (const bf16_t*)d_up + (size_t)e * I * H,
+                            (const bf16_t*)d_down + (size_t)e * H * I};
+    uint8_t* dst[3] = {h->gate_w + e * h->gu_stride, h->up_w + e * h->gu_stride, h->down_w + e * h->dn_stride};
+    float* sc[3] = {h->gate_s + (size_t)e * I, h->up_s + (size_t)e * I, h->down_s + (size_t)e * H};
+    const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
+    for (int m = 0; m < 3; m++) {
+      hipLaunchKernelGGL(quant_rows_kernel, dim3(Ns[m]), dim3(256), 0, 0, src[m], Ks[m], fmt, tmp, sc[m]);
+      if (pack_matrix(h, tmp, Ns[m], Ks[m], dst[m], 0)) { hipFree(tmp); return -1; }
+    }
+  }
+  KTX_HIP(hipDeviceSynchronize());
+  KTX_HIP(hipFree(tmp));
+  return 0;
+}
+
+extern "C" int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, const float* scale) {
+  KTX_REQUIRE(h && q && scale, "ktx_moe_load_quantized: null argument");
+  KTX_REQUIRE(expert >= 0 && expert < h->cfg.expert_num, "ktx_moe_load_quantized: expert out of range");
+  KTX_REQUIRE(which >= 0 && which <= 2, "ktx_moe_load_quantized: bad matrix selector");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  const int H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const int N = which == KTX_MAT_DOWN ? H : I, K = which == KTX_MAT_DOWN ? I : H;
+  uint8_t* dst = which == KTX_MAT_GATE ? h->gate_w + expert * h->gu_stride
+                 : which == KTX_MAT_UP ? h->up_w + expert * h->gu_stride
+                                       : h->down_w + expert * h->dn_stride;
+  float* sc = which == KTX_MAT_GATE ? h->gate_s + (size_t)expert * I
+              : which == KTX_MAT_UP ? h->up_s + (size_t)expert * I
+                                    : h->down_s + (size_t)expert * H;
+  int8_t* tmp = nullptr;
+  KTX_HIP(hipMalloc(&tmp, (size_t)N * K));
+  KTX_HIP(hipMemcpy(tmp, q, (size_t)N * K, hipMemcpyHostToDevice));
+  KTX_HIP(hipMemcpy(sc, scale, (size_t)N * sizeof(float), hipMemcpyHostToDevice));
+  if (pack_matrix(h, tmp, N, K, dst, 0)) { hipFree(tmp); return -1; }
+  KTX_HIP(hipDeviceSynchronize());
+  KTX_HIP(hipFree(tmp));
+  return 0;
+}
+
+extern "C" int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask) {
+  KTX_REQUIRE(h, "ktx_moe_set_expert_mask: null handle");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  if (!mask) {
+    if (h->mask) { KTX_HIP(hipFree(h->mask)); h->mask = nullptr; }
+    return 0;
+  }
+  if (!h->mask) KTX_HIP(hipMalloc(&h->mask, h->cfg.expert_num));
+  KTX_HIP(hipMemcpy(h->mask, mask, h->cfg.expert_num, hipMemcpyHostToDevice));
+  return 0;
+}
+
+extern "C" int ktx_moe_debug_ptrs(ktx_moe_t h, const void** act_bf16, const void** down_bf16,
+                                  const int32_t** row_of_pair) {
+  KTX_REQUIRE(h, "ktx_moe_debug_ptrs: null handle");
+  if (act_bf16) *act_bf16 = h->a_buf;
+  if (down_bf16) *down_bf16 = h->dn_buf;
+  if (row_of_pair) *row_of_pair = h->row_of_pair;
+  return 0;
+}
+
+template <int WBITS, int MT, int SPC, bool GATE_UP>
+static int launch_gemm(const GemmParams& p, int max_tiles, hipStream_t st) {
+  constexpr int BUF_BYTES = MT * (SPC * 128 / 16) * 256;
+  const size_t lds = 2 * BUF_BYTES + MT * 16 * 8;
+  auto kern = moe_gemm_kernel<WBITS, MT, SPC, GATE_UP>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                   (int)lds);
+  });
+  KTX_HIP(attr_err);
+  const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
+  hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int WBITS, bool GATE_UP>
+static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_t st) {
+  switch (mt) {
+    case 1: return launch_gemm<WBITS, 1, 4, GATE_UP>(p, max_tiles, st);
+    case 2: return launch_gemm<WBITS, 2, 4, GATE_UP>(p, max_tiles, st);
+    default: return launch_gemm<WBITS, 4, 2, GATE_UP>(p, max_tiles, st);
+  }
+}
+
+extern "C" int ktx_moe_forward(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                               const float* d_weights, const void* d_input, void* d_output, int incremental,
+                               ktx_stream_t stream) {
+  KTX_REQUIRE(h, "ktx_moe_forward: null handle");
+  KTX_REQUIRE(qlen > 0 && qlen <= h->cfg.max_len, "ktx_moe_forward: qlen exceeds max_len");
+  KTX_REQUIRE(k > 0 && k <= h->cfg.num_experts_per_tok, "ktx_moe_forward: k exceeds num_experts_per_tok");
+  KTX_REQUIRE(d_expert_ids && d_weights && d_input && d_output, "ktx_moe_forward: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const int mt = pick_mt(qlen, k, E);
+  const int npairs = qlen * k;
+  const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
+
+  PrepParams pp;
+  pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
+  pp.rows_per_tile = 16 * mt; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
+  pp.x_q = h->x_q; pp.x_d = h->x_d; pp.row_of_pair = h->row_of_pair; pp.src_of_row = h->src_of_row;
+  pp.tiles = h->tiles; pp.counters = h->counters;
+  hipLaunchKernelGGL(moe_prep_kernel, dim3(qlen + 1), dim3(1024), 0, st, pp);
+  KTX_HIP(hipGetLastError());
+
+  GemmParams g1;
+  g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = h->gate_s; g1.s1 = h->up_s; g1.expert_stride = h->gu_stride;
+  g1.N = I; g1.K = H; g1.act_q = h->x_q; g1.act_d = h->x_d; g1.row_src = h->src_of_row; g1.tiles = h->tiles;
+  g1.counters = h->counters; g1.out = h->a_buf;
+  int rc = h->wbits == 4 ? launch_gemm_mt<4, true>(mt, g1, max_tiles, st) : launch_gemm_mt<8, true>(mt, g1, max_tiles, st);
+  if (rc) return rc;
+
+  hipLaunchKernelGGL(moe_actquant_kernel, dim3(npairs), dim3(256), 0, st, h->a_buf, I, h->a_q, h->a_d, h->counters);
+  KTX_HIP(hipGetLastError());
+
+  GemmParams g2;
+  g2.w0 = h->down_w; g2.w1 = nullptr; g2.s0 = h->down_s; g2.s1 = nullptr; g2.expert_stride = h->dn_stride;
+  g2.N = H; g2.K = I; g2.act_q = h->a_q; g2.act_d = h->a_d; g2.row_src = nullptr; g2.tiles = h->tiles;
+  g2.counters = h->counters; g2.out = h->dn_buf;
+  rc = h->wbits == 4 ? launch_gemm_mt<4, false>(mt, g2, max_tiles, st) : launch_gemm_mt<8, false>(mt, g2, max_tiles, st);
+  if (rc) return rc;
+
+  CombineParams cp;
+  cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = h->dn_buf; cp.row_of_pair = h->row_of_pair;
+  cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = incremental;
+  hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
