@@ -6,11 +6,11 @@
  *   ---------------------------------------------------------  -----------------------------------------
  *   MOEConfig field bag   kt-kernel/ext_bindings.cpp:746-831   ktx_moe_config
  *   AMXInt4_MOE(config)   kt-kernel/ext_bindings.cpp:447-517   ktx_moe_create
- *   load_weights_task()   kt-kernel/ext_bindings.cpp:222-239   ktx_moe_load_bf16 / ktx_moe_load_quantized
+ *   load_weights_task()   kt-kernel/ext_bindings.cpp:196-219   ktx_moe_load_bf16 / ktx_moe_load_quantized
  *     (online bf16->int4: operators/amx/moe.hpp:352-387;
  *      pre-quantised:     operators/amx/moe.hpp:266-300)
  *   forward_task(bsz_ptr,k,ids,w,in,out,incremental)           ktx_moe_forward
- *                         kt-kernel/ext_bindings.cpp:240-251
+ *                         kt-kernel/ext_bindings.cpp:220-251
  *     -> TP_MOE::forward_binding  operators/moe-tp.hpp:195-199
  *   CPUInfer.submit_with_cuda_stream / sync_with_cuda_stream   (gone: the forward is enqueued on the caller's
  *                         cpu_backend/cpuinfer.h:87-120         hipStream_t; stream order IS the sync)
@@ -83,10 +83,26 @@ int ktx_moe_forward(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const in
                     const float* d_weights, const void* d_input, void* d_output, int incremental,
                     ktx_stream_t stream);
 
+/* Same, with flags.  KTX_FWD_PARTIAL_F32: d_output is float [qlen][H] and receives the un-rounded fp32 weighted sums of
+ * the experts this handle owns (ids outside [expert_begin, expert_begin+expert_num) contribute nothing) — the expert-
+ * parallel analogue of the reference's per-NUMA fp32 partials that merge_results sums before the single bf16 rounding
+ * (operators/amx/moe_base.hpp:749-791, operators/moe-tp.hpp:201-216). */
+enum { KTX_FWD_INCREMENTAL = 1, KTX_FWD_PARTIAL_F32 = 2 };
+int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                       const float* d_weights, const void* d_input, void* d_output, int flags, ktx_stream_t stream);
+
 /* Introspection for tests / bench: bytes of packed expert weights resident in HBM; debug taps (device pointers to
  * the last forward's intermediates in sorted-row order, plus the row of each (t,j) pair). */
 size_t ktx_moe_weight_bytes(ktx_moe_t h);
 int ktx_moe_debug_ptrs(ktx_moe_t h, const void** act_bf16, const void** down_bf16, const int32_t** row_of_pair);
+
+/* Measurement aid (bench.py roofline leg): when enabled, every ktx_moe_forward brackets each of its kernels with
+ * HIP events on the launch stream (slots: 0 prep, 1 gate/up GEMM, 2 act-quant, 3 down GEMM, 4 combine).  collect
+ * synchronises the device and returns summed elapsed ms + launch counts since the previous collect.  The reference's
+ * analogue is its FORWARD_TIME_PROFILE per-stage timers (operators/amx/moe_base.hpp:200-206,438-452).  Forwards
+ * issued while profiling is on are not graph-capturable. */
+int ktx_profile_enable(int on);
+int ktx_profile_collect(double* ms5, long long* count5);
 
 #ifdef __cplusplus
 }

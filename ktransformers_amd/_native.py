@@ -42,13 +42,29 @@ def _load() -> C.CDLL:
     lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
+    lib.ktx_moe_forward_ex.argtypes = lib.ktx_moe_forward.argtypes
     lib.ktx_moe_weight_bytes.argtypes = [C.c_void_p]
     lib.ktx_moe_weight_bytes.restype = C.c_size_t
     lib.ktx_moe_debug_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.ktx_profile_enable.argtypes = [C.c_int]
+    lib.ktx_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     return lib
 
 
 lib = _load()
+
+PROFILE_SLOTS = ("prep", "gate_up_gemm", "act_quant", "down_gemm", "combine")
+
+
+def profile_enable(on: bool) -> None:
+    check(lib.ktx_profile_enable(1 if on else 0))
+
+
+def profile_collect() -> dict:
+    ms = (C.c_double * 5)()
+    cnt = (C.c_longlong * 5)()
+    check(lib.ktx_profile_collect(ms, cnt))
+    return {name: (ms[i], int(cnt[i])) for i, name in enumerate(PROFILE_SLOTS)}
 
 
 def check(rc: int) -> None:
@@ -148,4 +164,22 @@ class MoEHandle:
             bsz_ptr = bsz_tensor.data_ptr()
         check(lib.ktx_moe_forward(self._h, bsz_ptr, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
                                   out.data_ptr(), 1 if incremental else 0, _stream_ptr(self.device)))
+        return out
+
+    def forward_partial(self, x: torch.Tensor, expert_ids: torch.Tensor, weights: torch.Tensor,
+                        out: torch.Tensor | None = None) -> torch.Tensor:
+        """Expert-parallel leg: fp32 [T,H] un-rounded weighted sums over the experts this handle owns."""
+        T, k = expert_ids.shape
+        if x.dtype != torch.bfloat16 or x.shape != (T, self.H) or not x.is_contiguous():
+            raise KtxError(f"forward_partial: x must be contiguous bf16 [{T},{self.H}]")
+        if expert_ids.dtype != torch.int64 or not expert_ids.is_contiguous():
+            raise KtxError("forward_partial: expert_ids must be contiguous int64 [T,k]")
+        if weights.dtype != torch.float32 or weights.shape != (T, k) or not weights.is_contiguous():
+            raise KtxError("forward_partial: weights must be contiguous fp32 [T,k]")
+        if out is None:
+            out = torch.empty((T, self.H), dtype=torch.float32, device=self.device)
+        elif out.dtype != torch.float32 or out.shape != (T, self.H) or not out.is_contiguous():
+            raise KtxError("forward_partial: out must be contiguous fp32 [T,H]")
+        check(lib.ktx_moe_forward_ex(self._h, None, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
+                                     out.data_ptr(), 2, _stream_ptr(self.device)))
         return out

@@ -434,8 +434,9 @@ struct CombineParams {
   const bf16_t* dn;            // [sorted rows][H]
   const int32_t* row_of_pair;  // [qlen*k]
   const float* weights;        // [qlen][k]
-  bf16_t* y;                   // [qlen][H]
+  bf16_t* y;                   // [qlen][H]  (float* when partial_f32)
   int incremental;
+  int partial_f32;
 };
 
 __global__ __launch_bounds__(256) void moe_combine_kernel(CombineParams p) {
@@ -455,6 +456,11 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(CombineParams p) {
     acc[1] = fmaf(bf16_to_f32((bf16_t)(v.x >> 16)), w, acc[1]);
     acc[2] = fmaf(bf16_to_f32((bf16_t)(v.y & 0xffffu)), w, acc[2]);
     acc[3] = fmaf(bf16_to_f32((bf16_t)(v.y >> 16)), w, acc[3]);
+  }
+  if (p.partial_f32) {  // expert-parallel partial: un-rounded fp32 sums, reduced across ranks by the caller
+    float* fp = reinterpret_cast<float*>(p.y) + (size_t)t * p.H + h;
+    *reinterpret_cast<float4*>(fp) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+    return;
   }
   bf16_t* yp = p.y + (size_t)t * p.H + h;
   if (p.incremental) {
@@ -543,6 +549,29 @@ __global__ void pack_w8_kernel(const int8_t* __restrict__ q, int N, int K, uint3
 // =====================================================================================================
 // host side
 // =====================================================================================================
+// Scratch for one forward.  Like the reference's shared_mem_buffer arena (cpu_backend/shared_mem_buffer.h:37-55) it is
+// shared by every MoE layer on a device: forwards of different layers are ordered on the caller's stream, so one
+// arena (grown to the largest request at create time, never inside forward) serves them all.
+struct Workspace {
+  int8_t *x_q = nullptr, *a_q = nullptr;
+  float *x_d = nullptr, *a_d = nullptr;
+  bf16_t *a_buf = nullptr, *dn_buf = nullptr;
+  int32_t *row_of_pair = nullptr, *src_of_row = nullptr, *counters = nullptr;
+  Tile* tiles = nullptr;
+  size_t cap[10] = {0};
+};
+static std::mutex g_ws_mu;
+static Workspace g_ws[64];
+
+template <class T>
+static hipError_t grow(T*& p, size_t& cap, size_t bytes) {
+  if (bytes <= cap) return hipSuccess;
+  if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; }
+  hipError_t e = hipMalloc(&p, bytes);
+  if (e == hipSuccess) cap = bytes;
+  return e;
+}
+
 struct ktx_moe_s {
   ktx_moe_config cfg;
   int wbits;
@@ -550,12 +579,7 @@ struct ktx_moe_s {
   uint8_t *gate_w = nullptr, *up_w = nullptr, *down_w = nullptr;
   float *gate_s = nullptr, *up_s = nullptr, *down_s = nullptr;
   uint8_t* mask = nullptr;
-  // workspace
-  int8_t *x_q = nullptr, *a_q = nullptr;
-  float *x_d = nullptr, *a_d = nullptr;
-  bf16_t *a_buf = nullptr, *dn_buf = nullptr;
-  int32_t *row_of_pair = nullptr, *src_of_row = nullptr, *counters = nullptr;
-  Tile* tiles = nullptr;
+  Workspace* ws = nullptr;
   int max_pairs = 0, max_tiles = 0;
 };
 
@@ -592,17 +616,27 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_HIP(hipMalloc(&h->gate_s, E * I * sizeof(float)));
   KTX_HIP(hipMalloc(&h->up_s, E * I * sizeof(float)));
   KTX_HIP(hipMalloc(&h->down_s, E * H * sizeof(float)));
-  KTX_HIP(hipMalloc(&h->x_q, (size_t)cfg->max_len * H));
-  KTX_HIP(hipMalloc(&h->x_d, (size_t)cfg->max_len * sizeof(float)));
-  KTX_HIP(hipMalloc(&h->a_buf, (size_t)h->max_pairs * I * sizeof(bf16_t)));
-  KTX_HIP(hipMalloc(&h->a_q, (size_t)h->max_pairs * I));
-  KTX_HIP(hipMalloc(&h->a_d, (size_t)h->max_pairs * sizeof(float)));
-  KTX_HIP(hipMalloc(&h->dn_buf, (size_t)h->max_pairs * H * sizeof(bf16_t)));
-  KTX_HIP(hipMalloc(&h->row_of_pair, (size_t)h->max_pairs * sizeof(int32_t)));
-  KTX_HIP(hipMalloc(&h->src_of_row, (size_t)h->max_pairs * sizeof(int32_t)));
-  KTX_HIP(hipMalloc(&h->tiles, (size_t)h->max_tiles * sizeof(Tile)));
-  KTX_HIP(hipMalloc(&h->counters, 4 * sizeof(int32_t)));
-  KTX_HIP(hipMemset(h->counters, 0, 4 * sizeof(int32_t)));
+  {
+    // Growing the arena frees the old blocks: only legal while no forward using them is in flight.
+    std::lock_guard<std::mutex> lk(g_ws_mu);
+    KTX_REQUIRE(cfg->device >= 0 && cfg->device < 64, "ktx_moe_create: device ordinal out of range");
+    Workspace* w = &g_ws[cfg->device];
+    KTX_HIP(hipDeviceSynchronize());
+    KTX_HIP(grow(w->x_q, w->cap[0], (size_t)cfg->max_len * H));
+    KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float)));
+    KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * sizeof(bf16_t)));
+    KTX_HIP(grow(w->a_q, w->cap[3], (size_t)h->max_pairs * I));
+    KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float)));
+    KTX_HIP(grow(w->dn_buf, w->cap[5], (size_t)h->max_pairs * H * sizeof(bf16_t)));
+    KTX_HIP(grow(w->row_of_pair, w->cap[6], (size_t)h->max_pairs * sizeof(int32_t)));
+    KTX_HIP(grow(w->src_of_row, w->cap[7], (size_t)h->max_pairs * sizeof(int32_t)));
+    KTX_HIP(grow(w->tiles, w->cap[8], (size_t)h->max_tiles * sizeof(Tile)));
+    if (!w->counters) {
+      KTX_HIP(grow(w->counters, w->cap[9], 4 * sizeof(int32_t)));
+      KTX_HIP(hipMemset(w->counters, 0, 4 * sizeof(int32_t)));
+    }
+    h->ws = w;
+  }
   *out = h;
   return 0;
 }
@@ -610,8 +644,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
 extern "C" int ktx_moe_destroy(ktx_moe_t h) {
   if (!h) return 0;
   hipSetDevice(h->cfg.device);
-  void* ptrs[] = {h->gate_w, h->up_w, h->down_w, h->gate_s, h->up_s, h->down_s, h->mask, h->x_q, h->a_q, h->x_d,
-                  h->a_d, h->a_buf, h->dn_buf, h->row_of_pair, h->src_of_row, h->counters, h->tiles};
+  void* ptrs[] = {h->gate_w, h->up_w, h->down_w, h->gate_s, h->up_s, h->down_s, h->mask};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete h;
@@ -699,9 +732,9 @@ extern "C" int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask) {
 extern "C" int ktx_moe_debug_ptrs(ktx_moe_t h, const void** act_bf16, const void** down_bf16,
                                   const int32_t** row_of_pair) {
   KTX_REQUIRE(h, "ktx_moe_debug_ptrs: null handle");
-  if (act_bf16) *act_bf16 = h->a_buf;
-  if (down_bf16) *down_bf16 = h->dn_buf;
-  if (row_of_pair) *row_of_pair = h->row_of_pair;
+  if (act_bf16) *act_bf16 = h->ws->a_buf;
+  if (down_bf16) *down_bf16 = h->ws->dn_buf;
+  if (row_of_pair) *row_of_pair = h->ws->row_of_pair;
   return 0;
 }
 
@@ -732,15 +765,72 @@ static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_
   }
 }
 
+// ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
+// Slots: 0 prep, 1 gate/up GEMM, 2 act-quant, 3 down GEMM, 4 combine.  Not graph-capturable; off by default.
+static bool g_prof_on = false;
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[5];
+static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
+
+extern "C" int ktx_profile_enable(int on) {
+  g_prof_on = on != 0;
+  return 0;
+}
+
+// Synchronises the device, then returns per slot the summed elapsed ms and the number of launches since the last call.
+extern "C" int ktx_profile_collect(double* ms5, long long* count5) {
+  KTX_HIP(hipDeviceSynchronize());
+  for (int s = 0; s < 5; s++) {
+    double tot = 0.0;
+    for (auto& pr : g_prof_ev[s]) {
+      float ms = 0.f;
+      KTX_HIP(hipEventElapsedTime(&ms, pr.first, pr.second));
+      tot += ms;
+      g_prof_free.push_back(pr);
+    }
+    if (ms5) ms5[s] = tot;
+    if (count5) count5[s] = (long long)g_prof_ev[s].size();
+    g_prof_ev[s].clear();
+  }
+  return 0;
+}
+
+struct ProfScope {
+  int slot;
+  hipStream_t st;
+  std::pair<hipEvent_t, hipEvent_t> ev;
+  bool on;
+  ProfScope(int slot_, hipStream_t st_) : slot(slot_), st(st_), on(g_prof_on) {
+    if (!on) return;
+    if (!g_prof_free.empty()) { ev = g_prof_free.back(); g_prof_free.pop_back(); }
+    else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
+    hipEventRecord(ev.first, st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    hipEventRecord(ev.second, st);
+    g_prof_ev[slot].push_back(ev);
+  }
+};
+
 extern "C" int ktx_moe_forward(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                                const float* d_weights, const void* d_input, void* d_output, int incremental,
                                ktx_stream_t stream) {
+  return ktx_moe_forward_ex(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output,
+                            incremental ? KTX_FWD_INCREMENTAL : 0, stream);
+}
+
+extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                                  const float* d_weights, const void* d_input, void* d_output, int flags,
+                                  ktx_stream_t stream) {
+  const int incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
   KTX_REQUIRE(h, "ktx_moe_forward: null handle");
+  KTX_REQUIRE(!((flags & KTX_FWD_PARTIAL_F32) && incremental), "ktx_moe_forward_ex: PARTIAL_F32 excludes INCREMENTAL");
   KTX_REQUIRE(qlen > 0 && qlen <= h->cfg.max_len, "ktx_moe_forward: qlen exceeds max_len");
   KTX_REQUIRE(k > 0 && k <= h->cfg.num_experts_per_tok, "ktx_moe_forward: k exceeds num_experts_per_tok");
   KTX_REQUIRE(d_expert_ids && d_weights && d_input && d_output, "ktx_moe_forward: null pointer");
   hipStream_t st = (hipStream_t)stream;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  Workspace* ws = h->ws;
   const int mt = pick_mt(qlen, k, E);
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
@@ -748,32 +838,49 @@ extern "C" int ktx_moe_forward(ktx_moe_t h, const int32_t* d_bsz, int qlen, int 
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
   pp.rows_per_tile = 16 * mt; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
-  pp.x_q = h->x_q; pp.x_d = h->x_d; pp.row_of_pair = h->row_of_pair; pp.src_of_row = h->src_of_row;
-  pp.tiles = h->tiles; pp.counters = h->counters;
-  hipLaunchKernelGGL(moe_prep_kernel, dim3(qlen + 1), dim3(1024), 0, st, pp);
+  pp.x_q = ws->x_q; pp.x_d = ws->x_d; pp.row_of_pair = ws->row_of_pair; pp.src_of_row = ws->src_of_row;
+  pp.tiles = ws->tiles; pp.counters = ws->counters;
+  {
+    ProfScope ps(0, st);
+    hipLaunchKernelGGL(moe_prep_kernel, dim3(qlen + 1), dim3(1024), 0, st, pp);
+  }
   KTX_HIP(hipGetLastError());
 
   GemmParams g1;
   g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = h->gate_s; g1.s1 = h->up_s; g1.expert_stride = h->gu_stride;
-  g1.N = I; g1.K = H; g1.act_q = h->x_q; g1.act_d = h->x_d; g1.row_src = h->src_of_row; g1.tiles = h->tiles;
-  g1.counters = h->counters; g1.out = h->a_buf;
-  int rc = h->wbits == 4 ? launch_gemm_mt<4, true>(mt, g1, max_tiles, st) : launch_gemm_mt<8, true>(mt, g1, max_tiles, st);
+  g1.N = I; g1.K = H; g1.act_q = ws->x_q; g1.act_d = ws->x_d; g1.row_src = ws->src_of_row; g1.tiles = ws->tiles;
+  g1.counters = ws->counters; g1.out = ws->a_buf;
+  int rc;
+  {
+    ProfScope ps(1, st);
+    rc = h->wbits == 4 ? launch_gemm_mt<4, true>(mt, g1, max_tiles, st) : launch_gemm_mt<8, true>(mt, g1, max_tiles, st);
+  }
   if (rc) return rc;
 
-  hipLaunchKernelGGL(moe_actquant_kernel, dim3(npairs), dim3(256), 0, st, h->a_buf, I, h->a_q, h->a_d, h->counters);
+  {
+    ProfScope ps(2, st);
+    hipLaunchKernelGGL(moe_actquant_kernel, dim3(npairs), dim3(256), 0, st, ws->a_buf, I, ws->a_q, ws->a_d, ws->counters);
+  }
   KTX_HIP(hipGetLastError());
 
   GemmParams g2;
   g2.w0 = h->down_w; g2.w1 = nullptr; g2.s0 = h->down_s; g2.s1 = nullptr; g2.expert_stride = h->dn_stride;
-  g2.N = H; g2.K = I; g2.act_q = h->a_q; g2.act_d = h->a_d; g2.row_src = nullptr; g2.tiles = h->tiles;
-  g2.counters = h->counters; g2.out = h->dn_buf;
-  rc = h->wbits == 4 ? launch_gemm_mt<4, false>(mt, g2, max_tiles, st) : launch_gemm_mt<8, false>(mt, g2, max_tiles, st);
+  g2.N = H; g2.K = I; g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.row_src = nullptr; g2.tiles = ws->tiles;
+  g2.counters = ws->counters; g2.out = ws->dn_buf;
+  {
+    ProfScope ps(3, st);
+    rc = h->wbits == 4 ? launch_gemm_mt<4, false>(mt, g2, max_tiles, st) : launch_gemm_mt<8, false>(mt, g2, max_tiles, st);
+  }
   if (rc) return rc;
 
   CombineParams cp;
-  cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = h->dn_buf; cp.row_of_pair = h->row_of_pair;
+  cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
   cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = incremental;
-  hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+  cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+  {
+    ProfScope ps(4, st);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+  }
   KTX_HIP(hipGetLastError());
   return 0;
 }

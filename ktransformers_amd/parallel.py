@@ -1,0 +1,109 @@
+"""Expert parallelism for the routed-expert path: one process per GPU, torch.distributed (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference has no GPU expert parallelism of its own for this path: its analogue is the NUMA tensor-parallel split
+of TP_MOE_Common::forward + merge_results (kt-kernel/operators/moe-tp.hpp:201-246, operators/amx/moe_base.hpp:749-791),
+where every part sees all tokens, computes an fp32 partial [T,H], and the partials are summed in fp32 before the single
+bf16 rounding.  Sharding by EXPERT instead of by intermediate column keeps exactly that reduce shape:
+
+  decode / small T ("replicate + reduce"): all-gather the ranks' token rows (x, ids, w — a few KiB),
+  every rank runs the experts it owns on all gathered tokens (ids outside its range are skipped inside the kernel),
+  reduce-scatter the fp32 partials so each rank receives the sum for its own tokens, round to bf16 once.
+
+The fp32 summation order across ranks differs from the single-GPU slot order j=0..k-1, so EP outputs match the
+single-GPU ones to fp32 rounding (<=1 bf16 ulp), not bit-for-bit; tests state that tolerance.
+"""
+from __future__ import annotations
+
+from typing import Callable
+
+import torch
+import torch.distributed as dist
+
+
+def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
+                      x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, group=None) -> torch.Tensor:
+    """x bf16 [T,H], ids int64 [T,k], w fp32 [T,k] (this rank's tokens) -> bf16 [T,H].
+
+    `local_partial(xg, idsg, wg) -> fp32 [world*T, H]` computes this rank's experts' contribution for all gathered
+    tokens (MoEHandle.forward_partial on GPU; the oracle in the gloo tests)."""
+    world = dist.get_world_size(group)
+    T, H = x.shape
+    k = ids.shape[1]
+    xg = torch.empty((world * T, H), dtype=x.dtype, device=x.device)
+    idsg = torch.empty((world * T, k), dtype=ids.dtype, device=ids.device)
+    wg = torch.empty((world * T, k), dtype=w.dtype, device=w.device)
+    dist.all_gather_into_tensor(xg, x.contiguous(), group=group)
+    dist.all_gather_into_tensor(idsg, ids.contiguous(), group=group)
+    dist.all_gather_into_tensor(wg, w.contiguous(), group=group)
+    part = local_partial(xg, idsg, wg)
+    out = torch.empty((T, H), dtype=torch.float32, device=x.device)
+    dist.reduce_scatter_tensor(out, part, op=dist.ReduceOp.SUM, group=group)
+    return out.to(torch.bfloat16)
+
+
+def expert_range(E: int, world: int, rank: int) -> tuple[int, int]:
+    """Contiguous expert shard [begin, begin+count) of rank `rank`."""
+    if E % world != 0:
+        raise ValueError(f"expert count {E} not divisible by world size {world}")
+    n = E // world
+    return rank * n, n
+
+
+class ExpertParallelMoE:
+    """One MoE layer sharded over the ranks of `group`; wraps a local MoEHandle created with
+    expert_begin/expert_num = expert_range(E, world, rank)."""
+
+    def __init__(self, handle, group=None):
+        self.handle = handle
+        self.group = group
+
+    def forward(self, x, ids, w):
+        return ep_decode_forward(self.handle.forward_partial, x, ids, w, self.group)
+
+    # ---- bench support ------------------------------------------------------------------------------------------
+    @staticmethod
+    def bench_runner(wl, layers, dev, world, rank, use_graph=True):
+        return _EPBenchRunner(wl, layers, dev, world, rank, use_graph)
+
+
+class _EPBenchRunner:
+    """Each rank decodes its own token stream (weak scaling); per layer all-gather + local experts + reduce-scatter."""
+
+    def __init__(self, wl, layers, dev, world, rank, use_graph, nsets=16):
+        E, k, L, H = wl["E"], wl["k"], wl["L"], wl["H"]
+        self.layers, self.dev, self.nsets = [ExpertParallelMoE(h) for h in layers], dev, nsets
+        g = torch.Generator(device=dev)
+        g.manual_seed(1234 + rank)
+        scores = torch.rand((nsets, L, 1, E), generator=g, device=dev)
+        self.ids_all = scores.topk(k, dim=-1).indices.to(torch.int64).contiguous()
+        self.w_all = torch.rand((nsets, L, 1, k), generator=g, device=dev, dtype=torch.float32).contiguous()
+        self.ids, self.w = self.ids_all[0].clone(), self.w_all[0].clone()
+        self.x = (torch.randn((1, H), generator=g, device=dev) / 100).to(torch.bfloat16)
+        self.graph = None
+        self._eager()
+        torch.cuda.synchronize(dev)
+        if use_graph:
+            try:
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    self._eager()
+                torch.cuda.synchronize(dev)
+                self.graph = gph
+            except Exception as e:  # collectives not capturable on this stack: stay eager, say so
+                import sys
+                print(f"[bench] EP graph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                self.graph = None
+
+    def _eager(self):
+        for li, m in enumerate(self.layers):
+            self.out = m.forward(self.x, self.ids[li], self.w[li])
+
+    def step(self, i):
+        s = i % self.nsets
+        self.ids.copy_(self.ids_all[s])
+        self.w.copy_(self.w_all[s])
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self._eager()
