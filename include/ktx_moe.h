@@ -102,6 +102,12 @@ int ktx_moe_debug_ptrs(ktx_moe_t h, const void** act_bf16, const void** down_bf1
  * analogue is its FORWARD_TIME_PROFILE per-stage timers (operators/amx/moe_base.hpp:200-206,438-452).  Forwards
  * issued while profiling is on are not graph-capturable. */
 int ktx_profile_enable(int on);
+/* Test hook: non-zero routes every batch through the grouped (bucket + M-tiled GEMM) path, including the small
+ * batches that normally take the two-launch decode path, so both implementations can be compared on one input. */
+int ktx_debug_force_generic(int on);
+/* Development knobs for timing experiments (never set by the product path): idx 0 = waves per workgroup of the decode
+ * gate/up kernel (0 = auto), idx 1 = ablation bits (bit0: skip the weight stream; results are then meaningless). */
+int ktx_debug_set(int idx, int val);
 int ktx_profile_collect(double* ms5, long long* count5);
 
 #ifdef __cplusplus

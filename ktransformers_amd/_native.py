@@ -47,6 +47,8 @@ def _load() -> C.CDLL:
     lib.ktx_moe_weight_bytes.restype = C.c_size_t
     lib.ktx_moe_debug_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
     lib.ktx_profile_enable.argtypes = [C.c_int]
+    lib.ktx_debug_force_generic.argtypes = [C.c_int]
+    lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
     lib.ktx_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     return lib
 
@@ -58,6 +60,10 @@ PROFILE_SLOTS = ("prep", "gate_up_gemm", "act_quant", "down_gemm", "combine")
 
 def profile_enable(on: bool) -> None:
     check(lib.ktx_profile_enable(1 if on else 0))
+
+
+def force_generic_path(on: bool) -> None:
+    check(lib.ktx_debug_force_generic(1 if on else 0))
 
 
 def profile_collect() -> dict:

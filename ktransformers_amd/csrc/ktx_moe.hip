@@ -426,6 +426,334 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
 }
 
 // =====================================================================================================
+// Decode fast path (qlen*k <= KTX_DEC_MAX_PAIRS): two launches per layer instead of five.
+//   moe_dec_gateup_kernel : one workgroup per ((t,j) pair, 4 strips); quantises x[t] itself (a6), streams the gate/up
+//                           strips of expert ids[t][j] through a D-deep register ring (every wave keeps D KiB-sized
+//                           loads in flight), MFMA, SiLU*up epilogue -> a_buf[pair]
+//   moe_dec_down_kernel   : one workgroup per (token, 16-row strip of H), wave j = slot j: quantises a_buf[t,j] itself
+//                           (a11), streams the down strip of its expert, then the weighted combine in slot order (a12)
+//                           and the merge/incremental/bf16 step (a4) happen in-workgroup through LDS.
+// Every column of the 16-wide MFMA B operand carries the same token, so no lane masking is needed.
+// =====================================================================================================
+#define KTX_DEC_MAX_PAIRS 64
+
+struct DecParams {
+  const int32_t* d_bsz;
+  int qlen, k, E, expert_begin, H, I;
+  const int64_t* ids;
+  const uint8_t* mask;
+  const bf16_t* x;
+  const float* weights;
+  const uint8_t *gate_w, *up_w, *down_w;
+  const float *gate_s, *up_s, *down_s;
+  size_t gu_stride, dn_stride;
+  bf16_t* a_buf;  // [qlen*k][I]
+  void* y;        // bf16 [qlen][H] or float when partial_f32
+  int incremental, partial_f32;
+  int ablate;  // dev knob: bit0 = skip the weight stream (timing experiments only)
+};
+
+template <int WBITS>
+__device__ __forceinline__ WFrag<WBITS> load_wfrag_nt(const uint8_t* __restrict__ tile_base, int lane) {
+  WFrag<WBITS> f;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  const u4v a = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(tile_base + lane * 16));
+  f.v[0] = make_uint4(a.x, a.y, a.z, a.w);
+  if constexpr (WBITS == 8) {
+    const u4v b = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(tile_base + 1024 + lane * 16));
+    f.v[1] = make_uint4(b.x, b.y, b.z, b.w);
+  }
+  return f;
+}
+
+// quantise 8 bf16 (one uint4) with inverse scale id -> 8 int8 packed in a uint2
+__device__ __forceinline__ uint2 quant8(const uint4& v, float id) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  uint32_t o[2] = {0, 0};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    const int a = quant_rne_sat8(bf16_to_f32((bf16_t)(w[q] & 0xffffu)) * id);
+    const int b = quant_rne_sat8(bf16_to_f32((bf16_t)(w[q] >> 16)) * id);
+    o[q >> 1] |= ((uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8)) << ((q & 1) * 16);
+  }
+  return make_uint2(o[0], o[1]);
+}
+__device__ __forceinline__ float amax8(const uint4& v, float m) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+  for (int q = 0; q < 4; q++) {
+    m = fmaxf(m, fabsf(bf16_to_f32((bf16_t)(w[q] & 0xffffu))));
+    m = fmaxf(m, fabsf(bf16_to_f32((bf16_t)(w[q] >> 16))));
+  }
+  return m;
+}
+
+// One k-step of the decode kernels: unpack one (gate, up) fragment pair and issue the four MFMAs.
+template <int WBITS>
+__device__ __forceinline__ void dec_step2(const WFrag<WBITS>& fg, const WFrag<WBITS>& fu, const v4i& b0, const v4i& b1,
+                                          v4i& accg, v4i& accu) {
+  v4i g0, g1, u0, u1;
+  unpack_wfrag<WBITS>(fg, g0, g1);
+  unpack_wfrag<WBITS>(fu, u0, u1);
+  accg = __builtin_amdgcn_mfma_i32_16x16x64_i8(g0, b0, accg, 0, 0, 0);
+  accu = __builtin_amdgcn_mfma_i32_16x16x64_i8(u0, b0, accu, 0, 0, 0);
+  accg = __builtin_amdgcn_mfma_i32_16x16x64_i8(g1, b1, accg, 0, 0, 0);
+  accu = __builtin_amdgcn_mfma_i32_16x16x64_i8(u1, b1, accu, 0, 0, 0);
+}
+
+// D = ring depth (k-steps in flight per wave).  EXACT: NKS is a multiple of D, so the hot loop is branch-free
+// straight-line code (the guarded variant costs ~2x in the loop: every predicate becomes an exec-mask branch that
+// fences the scheduler, exposing LDS and MFMA latency with one wave per SIMD).
+template <int WBITS, int D, int NW, bool EXACT>
+__global__ __launch_bounds__(NW * 64) void moe_dec_gateup_kernel(DecParams p) {
+  constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* xq = smem;                                              // [H + 128]
+  float* s_red = reinterpret_cast<float*>(smem + p.H + 128);       // [NW]
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int pair = blockIdx.y, t = pair / p.k;
+  if (t >= T) return;
+  const long long idl = p.ids[pair] - p.expert_begin;
+  if (idl < 0 || idl >= p.E || (p.mask && p.mask[idl])) return;
+  const int e = (int)idl;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform => scalar branches
+  const int strip = blockIdx.x * NW + wave;
+  const bool strip_ok = strip * 16 < p.I;
+  const int NKS = p.H / 128;
+
+  // ---- a6 part 1: this token's activations (issued first: vmcnt retires in order, and x is needed first) ----------
+  const bf16_t* xr = p.x + (size_t)t * p.H;
+  uint4 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = tid * 8 + i * NW * 512;
+    xv[i] = make_uint4(0, 0, 0, 0);
+    if (j < p.H) xv[i] = *reinterpret_cast<const uint4*>(xr + j);
+  }
+  // ---- weight ring: D k-steps of (gate, up) in flight --------------------------------------------------------------
+  const int strip_c = strip_ok ? strip : 0;
+  const uint8_t* wg = p.gate_w + (size_t)e * p.gu_stride + (size_t)strip_c * NKS * TILE_BYTES;
+  const uint8_t* wu = p.up_w + (size_t)e * p.gu_stride + (size_t)strip_c * NKS * TILE_BYTES;
+  WFrag<WBITS> ring[D][2];
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    if (EXACT || d < NKS) {
+      ring[d][0] = load_wfrag_nt<WBITS>(wg + (size_t)d * TILE_BYTES, lane);
+      ring[d][1] = load_wfrag_nt<WBITS>(wu + (size_t)d * TILE_BYTES, lane);
+    }
+  }
+  const int n0 = strip_c * 16 + (lane >> 4) * 4;
+  const float4 sg = *reinterpret_cast<const float4*>(p.gate_s + (size_t)e * p.I + n0);
+  const float4 su = *reinterpret_cast<const float4*>(p.up_s + (size_t)e * p.I + n0);
+
+  // ---- a6 part 2: per-row int8 quantisation into LDS (amx_buffers.hpp:47-98) ---------------------------------------
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) amax = amax8(xv[i], amax);
+  amax = wave_max(amax);
+  if constexpr (NW > 1) {
+    if (lane == 0) s_red[wave] = amax;
+    __syncthreads();
+    amax = s_red[0];
+#pragma unroll
+    for (int w = 1; w < NW; w++) amax = fmaxf(amax, s_red[w]);
+  }
+  const float xd = amax / 127.0f;
+  const float xid = xd ? 1.0f / xd : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = tid * 8 + i * NW * 512;
+    if (j < p.H) *reinterpret_cast<uint2*>(xq + j) = quant8(xv[i], xid);
+  }
+  __syncthreads();
+  if (!strip_ok) return;
+
+  v4i accg = {0, 0, 0, 0}, accu = {0, 0, 0, 0};
+  const uint8_t* bb = xq + (lane >> 4) * 32;
+  if constexpr (EXACT) {
+    const int G = NKS / D;
+    for (int g = 0; g < G - 1; g++) {
+      const uint8_t* bg = bb + g * D * 128;
+      const uint8_t* wgn = wg + (size_t)(g + 1) * D * TILE_BYTES;
+      const uint8_t* wun = wu + (size_t)(g + 1) * D * TILE_BYTES;
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const v4i b0 = *reinterpret_cast<const v4i*>(bg + d * 128);
+        const v4i b1 = *reinterpret_cast<const v4i*>(bg + d * 128 + 16);
+        dec_step2<WBITS>(ring[d][0], ring[d][1], b0, b1, accg, accu);
+        ring[d][0] = load_wfrag_nt<WBITS>(wgn + (size_t)d * TILE_BYTES, lane);
+        ring[d][1] = load_wfrag_nt<WBITS>(wun + (size_t)d * TILE_BYTES, lane);
+      }
+    }
+    const uint8_t* bg = bb + (G - 1) * D * 128;
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const v4i b0 = *reinterpret_cast<const v4i*>(bg + d * 128);
+      const v4i b1 = *reinterpret_cast<const v4i*>(bg + d * 128 + 16);
+      dec_step2<WBITS>(ring[d][0], ring[d][1], b0, b1, accg, accu);
+    }
+  } else {
+    for (int s0 = 0; s0 < NKS; s0 += D) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int ks = s0 + d;
+        if (ks < NKS) {
+          const v4i b0 = *reinterpret_cast<const v4i*>(bb + ks * 128);
+          const v4i b1 = *reinterpret_cast<const v4i*>(bb + ks * 128 + 16);
+          dec_step2<WBITS>(ring[d][0], ring[d][1], b0, b1, accg, accu);
+          if (ks + D < NKS) {
+            ring[d][0] = load_wfrag_nt<WBITS>(wg + (size_t)(ks + D) * TILE_BYTES, lane);
+            ring[d][1] = load_wfrag_nt<WBITS>(wu + (size_t)(ks + D) * TILE_BYTES, lane);
+          }
+        }
+      }
+    }
+  }
+  if ((lane & 15) == 0) {  // all 16 columns are the same token: column 0 stores
+    const float sgv[4] = {sg.x, sg.y, sg.z, sg.w}, suv[4] = {su.x, su.y, su.z, su.w};
+    bf16_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bf16_t g = f32_to_bf16((xd * sgv[r]) * (float)accg[r]);
+      const bf16_t u = f32_to_bf16((xd * suv[r]) * (float)accu[r]);
+      o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
+    }
+    *reinterpret_cast<uint2*>(p.a_buf + (size_t)pair * p.I + n0) =
+        make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+  }
+}
+
+template <int WBITS>
+__device__ __forceinline__ void dec_step1(const WFrag<WBITS>& f, const v4i& b0, const v4i& b1, v4i& acc0, v4i& acc1) {
+  v4i a0, a1;
+  unpack_wfrag<WBITS>(f, a0, a1);
+  acc0 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a0, b0, acc0, 0, 0, 0);  // two independent accumulators: the halves
+  acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1, 0, 0, 0);  // are summed (exactly, int32) at the end
+}
+
+template <int WBITS, int D, bool EXACT>
+__global__ __launch_bounds__(512) void moe_dec_down_kernel(DecParams p) {
+  constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // [k][I + 128] int8 activations | [k][16] fp32 down outputs | [k] valid flags | [k] routing weights
+  const int IP = p.I + 128;
+  uint8_t* aq_all = smem;
+  float* s_dn = reinterpret_cast<float*>(smem + (size_t)p.k * IP);
+  int* s_valid = reinterpret_cast<int*>(s_dn + p.k * 16);
+  float* s_wt = reinterpret_cast<float*>(s_valid + p.k);
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave j = routing slot j
+  const int pair = t * p.k + j, strip = blockIdx.x;
+  const long long idl = p.ids[pair] - p.expert_begin;
+  const bool valid = !(idl < 0 || idl >= p.E || (p.mask && p.mask[idl]));
+  const int e = valid ? (int)idl : 0;
+  const int NKS = p.I / 128;
+  const uint8_t* wd = p.down_w + (size_t)e * p.dn_stride + (size_t)strip * NKS * TILE_BYTES;
+  uint8_t* aq = aq_all + (size_t)j * IP;
+
+  float ad = 0.0f;
+  v4i acc0 = {0, 0, 0, 0}, acc1 = {0, 0, 0, 0};
+  if (valid) {
+    // ---- a11 part 1: the activated row of this (t,j) pair (issued before the weight ring: needed first) ----------
+    const bf16_t* ar = p.a_buf + (size_t)pair * p.I;
+    uint4 av[4];
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = lane * 8 + i * 512;
+      av[i] = make_uint4(0, 0, 0, 0);
+      if (c < p.I) av[i] = *reinterpret_cast<const uint4*>(ar + c);
+    }
+    WFrag<WBITS> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (EXACT || d < NKS) ring[d] = load_wfrag_nt<WBITS>(wd + (size_t)d * TILE_BYTES, lane);
+    const float4 sd = *reinterpret_cast<const float4*>(p.down_s + (size_t)e * p.H + strip * 16 + (lane >> 4) * 4);
+    const float wt = p.weights[pair];
+    // ---- a11 part 2: wave-local per-row int8 quantisation (moe_base.hpp:378-384 -> amx_buffers.hpp:47-98) ---------
+    float amax = 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) amax = amax8(av[i], amax);
+    amax = wave_max(amax);
+    ad = amax / 127.0f;
+    const float aid = ad ? 1.0f / ad : 0.0f;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < p.I) *reinterpret_cast<uint2*>(aq + c) = quant8(av[i], aid);
+    }
+    if (lane == 0) { s_valid[j] = 1; s_wt[j] = wt; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");  // the wave reads back its own LDS row: order only
+    __builtin_amdgcn_wave_barrier();
+
+    const uint8_t* bb = aq + (lane >> 4) * 32;
+    if constexpr (EXACT) {
+      const int G = NKS / D;
+      for (int g = 0; g < G - 1; g++) {
+        const uint8_t* bg = bb + g * D * 128;
+        const uint8_t* wn = wd + (size_t)(g + 1) * D * TILE_BYTES;
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+          const v4i b0 = *reinterpret_cast<const v4i*>(bg + d * 128);
+          const v4i b1 = *reinterpret_cast<const v4i*>(bg + d * 128 + 16);
+          dec_step1<WBITS>(ring[d], b0, b1, acc0, acc1);
+          ring[d] = load_wfrag_nt<WBITS>(wn + (size_t)d * TILE_BYTES, lane);
+        }
+      }
+      const uint8_t* bg = bb + (G - 1) * D * 128;
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const v4i b0 = *reinterpret_cast<const v4i*>(bg + d * 128);
+        const v4i b1 = *reinterpret_cast<const v4i*>(bg + d * 128 + 16);
+        dec_step1<WBITS>(ring[d], b0, b1, acc0, acc1);
+      }
+    } else {
+      for (int s0 = 0; s0 < NKS; s0 += D) {
+#pragma unroll
+        for (int d = 0; d < D; d++) {
+          const int ks = s0 + d;
+          if (ks < NKS) {
+            const v4i b0 = *reinterpret_cast<const v4i*>(bb + ks * 128);
+            const v4i b1 = *reinterpret_cast<const v4i*>(bb + ks * 128 + 16);
+            dec_step1<WBITS>(ring[d], b0, b1, acc0, acc1);
+            if (ks + D < NKS) ring[d] = load_wfrag_nt<WBITS>(wd + (size_t)(ks + D) * TILE_BYTES, lane);
+          }
+        }
+      }
+    }
+    if ((lane & 15) == 0) {
+      const int r0 = (lane >> 4) * 4;
+      const float sdv[4] = {sd.x, sd.y, sd.z, sd.w};
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+        s_dn[j * 16 + r0 + r] = bf16_to_f32(f32_to_bf16((ad * sdv[r]) * (float)(acc0[r] + acc1[r])));
+    }
+  } else if (lane == 0) {
+    s_valid[j] = 0;
+    s_wt[j] = 0.0f;
+  }
+  __syncthreads();
+  if (tid < 16) {  // a12: weighted combine in slot order, then a4
+    float acc = 0.0f;
+    for (int jj = 0; jj < p.k; jj++)
+      if (s_valid[jj]) acc = fmaf(s_dn[jj * 16 + tid], s_wt[jj], acc);
+    const size_t o = (size_t)t * p.H + strip * 16 + tid;
+    if (p.partial_f32) {
+      reinterpret_cast<float*>(p.y)[o] = acc;
+    } else {
+      bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + o;
+      if (p.incremental) acc = acc + bf16_to_f32(*yp);
+      *yp = f32_to_bf16(acc);
+    }
+  }
+}
+
+// =====================================================================================================
 // K3: weighted combine in slot order (a12) + merge/incremental + bf16 (a4)
 // =====================================================================================================
 struct CombineParams {
@@ -768,6 +1096,10 @@ static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
 // Slots: 0 prep, 1 gate/up GEMM, 2 act-quant, 3 down GEMM, 4 combine.  Not graph-capturable; off by default.
 static bool g_prof_on = false;
+static bool g_force_generic = false;  // tests: route small batches through the grouped (prefill) path too
+extern "C" int ktx_debug_force_generic(int on) { g_force_generic = on != 0; return 0; }
+static int g_dbg[8] = {0};  // dev knobs: [0] waves/workgroup override of the decode gate/up kernel, [1] ablation bits
+extern "C" int ktx_debug_set(int idx, int val) { if (idx >= 0 && idx < 8) g_dbg[idx] = val; return 0; }
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[5];
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
@@ -831,6 +1163,74 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   hipStream_t st = (hipStream_t)stream;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   Workspace* ws = h->ws;
+  if (qlen * k <= KTX_DEC_MAX_PAIRS && k <= 8 && H <= 8192 && I <= 2048 && !g_force_generic) {
+    DecParams dp;
+    dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
+    dp.ids = d_expert_ids; dp.mask = h->mask; dp.x = (const bf16_t*)d_input; dp.weights = d_weights;
+    dp.gate_w = h->gate_w; dp.up_w = h->up_w; dp.down_w = h->down_w;
+    dp.gate_s = h->gate_s; dp.up_s = h->up_s; dp.down_s = h->down_s;
+    dp.gu_stride = h->gu_stride; dp.dn_stride = h->dn_stride; dp.a_buf = ws->a_buf; dp.y = d_output;
+    dp.incremental = incremental; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+    dp.ablate = 0;
+    // waves per workgroup of the gate/up kernel: with few (pair, strip) work items use small workgroups so every CU
+    // gets work; the x-row register cache needs H <= NW*2048.
+    const int strips = I / 16;
+    int nw = 4;
+    if (H <= 2048 && (strips + 3) / 4 * qlen * k < 512) nw = 1;
+    else if (H <= 4096 && (strips + 3) / 4 * qlen * k < 512) nw = 2;
+    if (g_dbg[0] == 1 && H <= 2048) nw = 1;
+    if (g_dbg[0] == 2 && H <= 4096) nw = 2;
+    if (g_dbg[0] == 4) nw = 4;
+    const dim3 g1((strips + nw - 1) / nw, qlen * k), g2(H / 16, qlen);
+    const size_t lds1 = (size_t)H + 128 + 16;
+    const size_t lds2 = (size_t)k * (I + 128) + (size_t)k * 16 * sizeof(float) + (size_t)k * 2 * sizeof(int);
+    KTX_REQUIRE(lds2 <= 160 * 1024, "ktx_moe_forward: k*I too large for the decode path");
+    const int nks1 = H / 128, nks2 = I / 128;
+    const int only = g_dbg[2];
+#define KTX_LAUNCH_GU(WB, DD, EX)                                                                                   \
+    do {                                                                                                            \
+      if (nw == 1) hipLaunchKernelGGL((moe_dec_gateup_kernel<WB, DD, 1, EX>), g1, dim3(64), lds1, st, dp);          \
+      else if (nw == 2) hipLaunchKernelGGL((moe_dec_gateup_kernel<WB, DD, 2, EX>), g1, dim3(128), lds1, st, dp);    \
+      else hipLaunchKernelGGL((moe_dec_gateup_kernel<WB, DD, 4, EX>), g1, dim3(256), lds1, st, dp);                 \
+    } while (0)
+#define KTX_LAUNCH_DN(WB, DD, EX)                                                                                   \
+    do {                                                                                                            \
+      static std::once_flag once; static hipError_t err = hipSuccess;                                               \
+      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_down_kernel<WB, DD, EX>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+      KTX_HIP(err);                                                                                                 \
+      hipLaunchKernelGGL((moe_dec_down_kernel<WB, DD, EX>), g2, dim3(64 * k), lds2, st, dp);                        \
+    } while (0)
+    if (only != 2) {
+      ProfScope ps(1, st);
+      if (h->wbits == 4) {
+        if (nks1 % 16 == 0) KTX_LAUNCH_GU(4, 16, true);
+        else if (nks1 % 14 == 0) KTX_LAUNCH_GU(4, 14, true);
+        else if (nks1 % 11 == 0) KTX_LAUNCH_GU(4, 11, true);
+        else KTX_LAUNCH_GU(4, 16, false);
+      } else {
+        if (nks1 % 8 == 0) KTX_LAUNCH_GU(8, 8, true);
+        else if (nks1 % 7 == 0) KTX_LAUNCH_GU(8, 7, true);
+        else KTX_LAUNCH_GU(8, 8, false);
+      }
+    }
+    KTX_HIP(hipGetLastError());
+    if (only != 1) {
+      ProfScope ps(3, st);
+      if (h->wbits == 4) {
+        if (nks2 % 16 == 0) KTX_LAUNCH_DN(4, 16, true);
+        else if (nks2 % 14 == 0) KTX_LAUNCH_DN(4, 14, true);
+        else if (nks2 % 11 == 0) KTX_LAUNCH_DN(4, 11, true);
+        else KTX_LAUNCH_DN(4, 16, false);
+      } else {
+        if (nks2 % 8 == 0) KTX_LAUNCH_DN(8, 8, true);
+        else if (nks2 % 11 == 0) KTX_LAUNCH_DN(8, 11, true);
+        else KTX_LAUNCH_DN(8, 8, false);
+      }
+    }
+    KTX_HIP(hipGetLastError());
+    return 0;
+  }
   const int mt = pick_mt(qlen, k, E);
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
