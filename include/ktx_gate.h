@@ -1,0 +1,50 @@
+/* ktx_gate.h — C ABI of the MoE router (gate) kernels in libktx_hip.so.
+ *
+ * Replaces the ~10 small torch kernels of MoEGate.forward:
+ *   DeepSeek-V3 / Kimi-K2 (sigmoid + e_score_correction_bias, "noaux_tc" group-limited top-k)
+ *       archive/ktransformers/models/modeling_deepseek_v3.py:430-481
+ *   DeepSeek-V2 / V2-Lite (fp32 softmax, "greedy" or "group_limited_greedy")
+ *       archive/ktransformers/models/modeling_deepseek.py:413-455
+ * wrapped by KMoEGate (archive/ktransformers/operators/gate.py:91-127).
+ *
+ * Output order: the reference calls torch.topk(sorted=False), whose index order is implementation-defined; this
+ * library emits the selected experts in descending choice-score order (ties: lower index first), which is one of the
+ * orders torch may return.  Parity is therefore on the index SET (and the weight attached to each index).
+ * All pointers are DEVICE pointers; calls only enqueue on `stream` and are HIP-graph capturable.
+ */
+#ifndef KTX_GATE_H
+#define KTX_GATE_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum ktx_gate_scoring { KTX_GATE_SIGMOID = 0, KTX_GATE_SOFTMAX = 1 };
+enum ktx_gate_topk { KTX_GATE_GREEDY = 0, KTX_GATE_GROUP_LIMITED_GREEDY = 1, KTX_GATE_NOAUX_TC = 2 };
+
+typedef struct ktx_gate_config {
+  int32_t n_routed_experts;   /* config.n_routed_experts */
+  int32_t hidden_size;        /* config.hidden_size */
+  int32_t top_k;              /* config.num_experts_per_tok */
+  int32_t n_group;            /* config.n_group (1 = ungrouped) */
+  int32_t topk_group;         /* config.topk_group */
+  int32_t scoring;            /* enum ktx_gate_scoring  (config.scoring_func) */
+  int32_t topk_method;        /* enum ktx_gate_topk     (config.topk_method) */
+  int32_t norm_topk_prob;     /* config.norm_topk_prob */
+  float routed_scaling_factor;/* config.routed_scaling_factor */
+} ktx_gate_config;
+
+/* logits[t][e] = sum_h float(x[t][h]) * float(w[e][h])  (F.linear in fp32, modeling_deepseek_v3.py:434-437).
+ * x bf16 [qlen][H]; w bf16 [E][H]; logits fp32 [qlen][E]. */
+int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x, const void* d_w,
+                    float* d_logits, void* stream);
+
+/* scores -> (+bias) -> group selection -> top-k -> gather unbiased scores -> normalise / scale
+ * (modeling_deepseek_v3.py:438-481).  bias fp32 [E] or NULL.  topk_idx int64 [qlen][k], topk_weight fp32 [qlen][k]. */
+int ktx_gate_select(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const float* d_logits,
+                    const float* d_bias, int64_t* d_topk_idx, float* d_topk_weight, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

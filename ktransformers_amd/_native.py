@@ -22,6 +22,11 @@ class KtxError(RuntimeError):
     """Raised where the reference raises RuntimeError from a C++ std::runtime_error."""
 
 
+class _GateConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("n_routed_experts", "hidden_size", "top_k", "n_group", "topk_group", "scoring",
+                                         "topk_method", "norm_topk_prob")] + [("routed_scaling_factor", C.c_float)]
+
+
 class _MoeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
@@ -46,6 +51,9 @@ def _load() -> C.CDLL:
     lib.ktx_moe_weight_bytes.argtypes = [C.c_void_p]
     lib.ktx_moe_weight_bytes.restype = C.c_size_t
     lib.ktx_moe_debug_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
+    lib.ktx_gate_logits.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ktx_gate_select.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
+                                    C.c_void_p, C.c_void_p]
     lib.ktx_profile_enable.argtypes = [C.c_int]
     lib.ktx_debug_force_generic.argtypes = [C.c_int]
     lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
@@ -189,3 +197,48 @@ class MoEHandle:
         check(lib.ktx_moe_forward_ex(self._h, None, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
                                      out.data_ptr(), 2, _stream_ptr(self.device)))
         return out
+
+
+GATE_SCORING = {"sigmoid": 0, "softmax": 1}
+GATE_TOPK = {"greedy": 0, "group_limited_greedy": 1, "noaux_tc": 2}
+
+
+class GateHandle:
+    """Router parameters of one MoE layer + the two-launch HIP router (include/ktx_gate.h)."""
+
+    LOGITS_HIP_MAX_T = 64  # above this the fp32 logits GEMM goes to the BLAS library (a plain library GEMM)
+
+    def __init__(self, n_routed_experts: int, hidden_size: int, top_k: int, n_group: int = 1, topk_group: int = 1,
+                 scoring_func: str = "sigmoid", topk_method: str = "noaux_tc", norm_topk_prob: bool = True,
+                 routed_scaling_factor: float = 1.0):
+        if scoring_func not in GATE_SCORING:
+            raise KtxError(f"insupportable scoring function for MoE gating: {scoring_func}")
+        if topk_method not in GATE_TOPK:
+            raise KtxError(f"insupportable TopK function for MoE gating: {topk_method}")
+        self.cfg = _GateConfig(n_routed_experts, hidden_size, top_k, max(1, n_group or 1), max(1, topk_group or 1),
+                               GATE_SCORING[scoring_func], GATE_TOPK[topk_method], 1 if norm_topk_prob else 0,
+                               float(routed_scaling_factor))
+        self.E, self.H, self.k = n_routed_experts, hidden_size, top_k
+
+    def forward(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
+                bsz_tensor: torch.Tensor | None = None):
+        """x bf16 [T,H]; weight [E,H] (bf16 for the HIP GEMV; any float dtype for the library GEMM); bias fp32 [E]|None
+        -> (topk_idx int64 [T,k], topk_weight fp32 [T,k])."""
+        T = x.shape[0]
+        dev = x.device
+        st = _stream_ptr(dev)
+        bsz_ptr = bsz_tensor.data_ptr() if bsz_tensor is not None else None
+        if T <= self.LOGITS_HIP_MAX_T and weight.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+            logits = torch.empty((T, self.E), dtype=torch.float32, device=dev)
+            check(lib.ktx_gate_logits(C.byref(self.cfg), bsz_ptr, T, x.contiguous().data_ptr(),
+                                      weight.contiguous().data_ptr(), logits.data_ptr(), st))
+        else:  # F.linear in fp32, exactly the reference's expression (modeling_deepseek_v3.py:434-437)
+            logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
+        idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
+        w = torch.empty((T, self.k), dtype=torch.float32, device=dev)
+        b = None
+        if bias is not None:
+            b = bias.to(device=dev, dtype=torch.float32).contiguous()
+        check(lib.ktx_gate_select(C.byref(self.cfg), bsz_ptr, T, logits.data_ptr(), b.data_ptr() if b is not None else None,
+                                  idx.data_ptr(), w.data_ptr(), st))
+        return idx, w

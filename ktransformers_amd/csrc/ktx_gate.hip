@@ -1,0 +1,206 @@
+// ktx_gate.hip — MoE router for gfx950.  C ABI in include/ktx_gate.h.
+//
+// Restates MoEGate.forward (archive/ktransformers/models/modeling_deepseek_v3.py:430-481 and the V2 variant
+// archive/ktransformers/models/modeling_deepseek.py:413-455) as two launches: an HBM/L2-bound fp32 GEMV per (token,
+// expert) and a one-wavefront-per-token selection kernel that keeps all E scores in registers.
+#include <hip/hip_runtime.h>
+
+#include <string>
+
+#include "../../include/ktx_gate.h"
+#include "ktx_common.h"
+
+#define KTX_GATE_MAX_E 1024  // 16 scores per lane
+
+// ---- logits: one wavefront per (token, expert); 16-byte loads of both bf16 rows, fp32 FMA, butterfly reduce --------
+__global__ __launch_bounds__(256) void gate_logits_kernel(const int32_t* d_bsz, int qlen, int E, int H,
+                                                          const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                          float* __restrict__ logits) {
+  int T = qlen;
+  if (d_bsz) T = min(max(*d_bsz, 0), qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e >= E) return;
+  const bf16_t* xr = x + (size_t)t * H;
+  const bf16_t* wr = w + (size_t)e * H;
+  float acc = 0.0f;
+  for (int j = lane * 8; j < H; j += 512) {
+    const uint4 a = *reinterpret_cast<const uint4*>(xr + j);
+    const uint4 b = *reinterpret_cast<const uint4*>(wr + j);
+    const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      acc = fmaf(bf16_to_f32((bf16_t)(av[q] & 0xffffu)), bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
+      acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  if (lane == 0) logits[(size_t)t * E + e] = acc;
+}
+
+// ---- selection ---------------------------------------------------------------------------------------------------------
+// (value, index) argmax over the wave; ties -> lower index.  Every lane returns the winner.
+__device__ __forceinline__ void wave_argmax(float& v, int& i) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const float ov = __shfl_xor(v, o, 64);
+    const int oi = __shfl_xor(i, o, 64);
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+  }
+}
+
+template <int EPL>  // scores per lane: expert e lives on lane e % 64, slot e / 64 (E <= 64*EPL)
+__global__ __launch_bounds__(64) void gate_select_kernel(ktx_gate_config c, const int32_t* d_bsz, int qlen,
+                                                         const float* __restrict__ logits, const float* __restrict__ bias,
+                                                         int64_t* __restrict__ topk_idx, float* __restrict__ topk_w) {
+  int T = qlen;
+  if (d_bsz) T = min(max(*d_bsz, 0), qlen);
+  const int t = blockIdx.x;
+  if (t >= T) return;
+  const int lane = threadIdx.x;
+  const int E = c.n_routed_experts;
+  const float NEG = -__builtin_inff();
+  float score[EPL], choice[EPL];
+  // scores (modeling_deepseek_v3.py:438-444 sigmoid; modeling_deepseek.py:421-424 softmax in fp32)
+  float mx = NEG;
+#pragma unroll
+  for (int s = 0; s < EPL; s++) {
+    const int e = s * 64 + lane;
+    score[s] = e < E ? logits[(size_t)t * E + e] : NEG;
+    mx = fmaxf(mx, score[s]);
+  }
+  if (c.scoring == KTX_GATE_SOFTMAX) {
+    mx = wave_max(mx);
+    float sum = 0.0f;
+#pragma unroll
+    for (int s = 0; s < EPL; s++) {
+      score[s] = (s * 64 + lane < E) ? expf(score[s] - mx) : 0.0f;
+      sum += score[s];
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+#pragma unroll
+    for (int s = 0; s < EPL; s++) score[s] = score[s] / sum;
+  } else {
+#pragma unroll
+    for (int s = 0; s < EPL; s++) score[s] = 1.0f / (1.0f + expf(-score[s]));
+  }
+#pragma unroll
+  for (int s = 0; s < EPL; s++) {
+    const int e = s * 64 + lane;
+    choice[s] = e < E ? score[s] + ((bias && c.topk_method == KTX_GATE_NOAUX_TC) ? bias[e] : 0.0f) : NEG;
+  }
+
+  // group limitation (modeling_deepseek_v3.py:449-468 / modeling_deepseek.py:431-448)
+  if (c.topk_method != KTX_GATE_GREEDY && c.n_group > 1) {
+    const int gsz = E / c.n_group;
+    // group score: noaux_tc = sum of the group's top-2 choice scores; group_limited_greedy = group max
+    float gscore = NEG;  // lane g < n_group holds group g's score
+    for (int g = 0; g < c.n_group; g++) {
+      float v1 = NEG, v2 = NEG;  // per-lane top-2 inside group g
+#pragma unroll
+      for (int s = 0; s < EPL; s++) {
+        const int e = s * 64 + lane;
+        if (e < E && e / gsz == g) {
+          const float v = choice[s];
+          if (v > v1) { v2 = v1; v1 = v; } else if (v > v2) { v2 = v; }
+        }
+      }
+      // wave top-2 via two argmax passes
+      float m1 = v1; int i1 = lane;
+      wave_argmax(m1, i1);
+      float cand = (lane == i1) ? v2 : v1;
+      int i2 = lane;
+      wave_argmax(cand, i2);
+      const float gs = (c.topk_method == KTX_GATE_NOAUX_TC) ? (m1 + cand) : m1;
+      if (lane == g) gscore = gs;
+    }
+    // pick topk_group groups; everything outside them is masked out
+    unsigned long long keep = 0ull;
+    float gs = (lane < c.n_group) ? gscore : NEG;
+    for (int r = 0; r < c.topk_group; r++) {
+      float v = gs; int i = lane;
+      wave_argmax(v, i);
+      keep |= 1ull << i;
+      if (lane == i) gs = NEG;
+    }
+    const float masked = (c.topk_method == KTX_GATE_NOAUX_TC) ? NEG : 0.0f;  // V3 fills -inf, V2 fills 0.0
+#pragma unroll
+    for (int s = 0; s < EPL; s++) {
+      const int e = s * 64 + lane;
+      if (e < E && !((keep >> (e / gsz)) & 1ull)) choice[s] = masked;
+    }
+  }
+
+  // top-k experts, descending choice score, ties -> lower index
+  float wsum = 0.0f;
+  float myw = 0.0f;   // lane r keeps the weight of the r-th pick
+  int myi = 0;
+  for (int r = 0; r < c.top_k; r++) {
+    float bv = NEG; int bi = 0x7fffffff;
+#pragma unroll
+    for (int s = 0; s < EPL; s++) {
+      const int e = s * 64 + lane;
+      if (e < E && (choice[s] > bv || (choice[s] == bv && e < bi))) { bv = choice[s]; bi = e; }
+    }
+    wave_argmax(bv, bi);
+    // gather the UNBIASED score of the winner (modeling_deepseek_v3.py:472) and retire it
+    float sc = 0.0f;
+#pragma unroll
+    for (int s = 0; s < EPL; s++)
+      if (s * 64 + lane == bi) { sc = score[s]; choice[s] = NEG; }
+    sc = __shfl(sc, bi & 63, 64);
+    // V2 (modeling_deepseek.py:426-448) takes the weight straight from the (masked) score it ranked on; V3 gathers
+    // the unbiased score of the winner (modeling_deepseek_v3.py:472)
+    if (c.topk_method != KTX_GATE_NOAUX_TC) sc = bv;
+    wsum += sc;
+    if (lane == r) { myw = sc; myi = bi; }
+  }
+  if (lane < c.top_k) {
+    float wv = myw;
+    if (c.top_k > 1 && c.norm_topk_prob) {
+      wv = wv / (wsum + 1e-20f);
+      if (c.topk_method == KTX_GATE_NOAUX_TC) wv = wv * c.routed_scaling_factor;  // V3 always scales (:481)
+    } else {
+      wv = wv * c.routed_scaling_factor;  // V3 :481; V2 scales only when it does not normalise (:453-455)
+    }
+    topk_idx[(size_t)t * c.top_k + lane] = myi;
+    topk_w[(size_t)t * c.top_k + lane] = wv;
+  }
+}
+
+extern "C" int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x,
+                               const void* d_w, float* d_logits, void* stream) {
+  KTX_REQUIRE(cfg && d_x && d_w && d_logits && qlen > 0, "ktx_gate_logits: bad argument");
+  KTX_REQUIRE(cfg->hidden_size % 8 == 0, "ktx_gate_logits: hidden_size must be a multiple of 8");
+  const dim3 grid((cfg->n_routed_experts + 3) / 4, qlen);
+  hipLaunchKernelGGL(gate_logits_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_bsz, qlen, cfg->n_routed_experts,
+                     cfg->hidden_size, (const bf16_t*)d_x, (const bf16_t*)d_w, d_logits);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ktx_gate_select(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const float* d_logits,
+                               const float* d_bias, int64_t* d_topk_idx, float* d_topk_weight, void* stream) {
+  KTX_REQUIRE(cfg && d_logits && d_topk_idx && d_topk_weight && qlen > 0, "ktx_gate_select: bad argument");
+  const int E = cfg->n_routed_experts;
+  KTX_REQUIRE(E > 0 && E <= KTX_GATE_MAX_E, "ktx_gate_select: n_routed_experts out of range (1..1024)");
+  KTX_REQUIRE(cfg->top_k > 0 && cfg->top_k <= 64 && cfg->top_k <= E, "ktx_gate_select: top_k out of range");
+  KTX_REQUIRE(cfg->n_group >= 1 && cfg->n_group <= 64 && E % cfg->n_group == 0, "ktx_gate_select: bad n_group");
+  KTX_REQUIRE(cfg->topk_group >= 1 && cfg->topk_group <= cfg->n_group, "ktx_gate_select: bad topk_group");
+  hipStream_t st = (hipStream_t)stream;
+  const int epl = (E + 63) / 64;
+#define KTX_SEL(N) hipLaunchKernelGGL(gate_select_kernel<N>, dim3(qlen), dim3(64), 0, st, *cfg, d_bsz, qlen, d_logits, d_bias, d_topk_idx, d_topk_weight)
+  if (epl <= 1) KTX_SEL(1);
+  else if (epl <= 2) KTX_SEL(2);
+  else if (epl <= 4) KTX_SEL(4);
+  else if (epl <= 6) KTX_SEL(6);
+  else if (epl <= 8) KTX_SEL(8);
+  else KTX_SEL(16);
+#undef KTX_SEL
+  KTX_HIP(hipGetLastError());
+  return 0;
+}

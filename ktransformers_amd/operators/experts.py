@@ -1,0 +1,263 @@
+"""Routed-expert operators — mirror of archive/ktransformers/operators/experts.py for HBM-resident experts.
+
+Reference surface kept (file:line in archive/ktransformers/operators/experts.py):
+  KExpertsBase                :68-141   forward(input_tensor, expert_ids, weights) / load / unload / load_weights
+  KExpertsCPU                 :143-365  the op the YAML rules name for decode; here its role is taken by KExpertsHIP
+      .submit_for_one_decode / .sync_for_one_decode  :293-318  (fast path used by K*MoE.forward when capturing)
+  EXPERTS_MAP                 :680-684
+  KTransformersExperts        :686-757  prefill_op / generate_op switch, load / unload / set_inference_mode
+  KDeepseekV2MoE / KDeepseekV3MoE   :874-971 / :972-1012   gate -> routed experts (+ shared experts) orchestration
+
+What changed underneath: the reference copies hidden states to pinned host memory, runs the experts on the CPU
+(cpuinfer_ext MOE / AMX*_MOE) and copies the result back, ordered by cudaLaunchHostFunc; here the quantized experts
+live in HBM and the forward is a few HIP launches on the caller's stream (ktransformers_amd/_native.py ->
+include/ktx_moe.h), so submit/sync degenerate to "enqueue" and "nothing".  There is no CPU fallback.
+"""
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import torch
+from torch import nn
+
+from ktransformers_amd.operators.base_operator import BaseInjectedModule
+from ktransformers_amd.util.utils import InferenceState
+
+# reference backend names (KExpertsCPU(backend=...), experts.py:166,199-262; kt-kernel method table experts.py:316-360)
+_BACKEND_TO_METHOD = {
+    "AMXInt4": "AMXINT4", "AMXINT4": "AMXINT4", "int4": "AMXINT4",
+    "AMXInt8": "AMXINT8", "AMXINT8": "AMXINT8", "int8": "AMXINT8",
+}
+
+
+class KExpertsBase(ABC):
+    def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, device: str = "cuda", **kwargs):
+        self.key = key
+        self.gguf_loader = gguf_loader
+        self.config = config
+        self.device = device
+
+    @abstractmethod
+    def forward(self, input_tensor, expert_ids, weights):
+        ...
+
+    @abstractmethod
+    def load(self, w: dict | None = None, device: str | None = None, warmup: bool = False):
+        ...
+
+    @abstractmethod
+    def unload(self):
+        ...
+
+    def load_weights(self, override_key: list | None = None, device: str = "cpu") -> dict:
+        """{key: {"gate","up","down"}} from the loader; bf16 stacked per expert (reference :89-135 returns the GGUF
+        blobs + ggml types; the online-quant AMX backends require BF16 there — :226-228,246-248)."""
+        res = {}
+        for key in (override_key or [self.key]):
+            if hasattr(self.gguf_loader, "load_experts"):
+                res[key] = self.gguf_loader.load_experts(key, device=device)
+            else:
+                raise ValueError(f"Experts {key} not found in gguf_loader")
+        return res
+
+
+class KExpertsHIP(KExpertsBase):
+    """All routed experts of one layer, quantized and resident in HBM; forward = ktx_moe_forward on the current stream.
+
+    Registered in EXPERTS_MAP under its own name *and* under "KExpertsCPU"/"KExpertsTorch"/"KExpertsMarlin", so the
+    reference's unmodified optimize_rules (generate_op: "KExpertsCPU", prefill_op: "KExpertsTorch") select it."""
+
+    def __init__(self, key: str, gguf_loader, config, n_routed_experts: int, orig_module: nn.Module = None,
+                 device: str = "cuda", out_device: str = "cuda", **kwargs):
+        super().__init__(key, gguf_loader, config, orig_module, device, **kwargs)
+        self.n_routed_experts = n_routed_experts
+        self.out_device = out_device
+        backend = kwargs.get("backend", "AMXInt4")
+        if backend == "llamafile":  # the reference default; GGUF k-quants are a §8(f) row, int4 is this build's default
+            backend = "AMXInt4"
+        if backend not in _BACKEND_TO_METHOD:
+            raise ValueError(f"KExpertsHIP: unsupported backend {backend!r} (have {sorted(_BACKEND_TO_METHOD)})")
+        self.method = _BACKEND_TO_METHOD[backend]
+        self.max_len = int(kwargs.get("max_len", kwargs.get("chunk_size", 8192)))
+        self.expert_begin = int(kwargs.get("expert_begin", 0))
+        self.expert_count = int(kwargs.get("expert_count", n_routed_experts))
+        self.handle = None
+        self._decode_out = None
+
+    # the device the kernels run on: "cpu" in a reference YAML means "where KExpertsCPU ran" -> use out_device
+    def _hip_device(self) -> torch.device:
+        name = self.out_device if str(self.device).lower() == "cpu" else self.device
+        dev = torch.device(name)
+        if dev.type != "cuda":
+            raise RuntimeError(f"KExpertsHIP needs a HIP device, got {name!r}: there is no CPU path")
+        return torch.device("cuda", dev.index if dev.index is not None else torch.cuda.current_device())
+
+    def load(self, w: dict | None = None, device: str | None = None, warmup: bool = False):
+        from ktransformers_amd._native import MoEHandle
+
+        if self.handle is not None:
+            return
+        dev = self._hip_device()
+        if w is None:
+            w = self.load_weights(device=str(dev))[self.key]
+        cfg = self.config
+        inter = getattr(cfg, "moe_intermediate_size", None) or cfg.intermediate_size
+        h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=self.max_len,
+                      method=self.method, device=dev, expert_begin=self.expert_begin,
+                      global_expert_num=self.n_routed_experts)
+        sl = slice(self.expert_begin, self.expert_begin + self.expert_count)
+
+        def prep(t):
+            t = t if isinstance(t, torch.Tensor) else torch.as_tensor(t)
+            return t[sl].to(device=dev, dtype=torch.bfloat16).contiguous()
+
+        h.load_bf16(prep(w["gate"]), prep(w["up"]), prep(w["down"]))
+        self.handle = h
+        if warmup:
+            x = torch.zeros((1, cfg.hidden_size), dtype=torch.bfloat16, device=dev)
+            ids = torch.zeros((1, cfg.num_experts_per_tok), dtype=torch.int64, device=dev)
+            self.handle.forward(x, ids, torch.zeros((1, cfg.num_experts_per_tok), dtype=torch.float32, device=dev))
+
+    def unload(self):
+        if self.handle is not None:
+            self.handle.close()
+            self.handle = None
+
+    def forward(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0):
+        if self.handle is None:
+            raise RuntimeError("KExpertsHIP.forward before load()")
+        dev = self.handle.device
+        x = input_tensor.to(device=dev, dtype=torch.bfloat16).contiguous()
+        ids = expert_ids.to(device=dev, dtype=torch.int64).contiguous()
+        w = weights.to(device=dev, dtype=torch.float32).contiguous()
+        if x.dim() == 1:
+            x, ids, w = x.unsqueeze(0), ids.unsqueeze(0), w.unsqueeze(0)
+        out = self.handle.forward(x, ids, w, bsz_tensor=bsz_tensor)
+        return out.to(device=self.out_device if str(self.out_device) != "cuda" else dev)
+
+    # reference fast path (experts.py:293-318): enqueue on the capturing stream, result later.  On the GPU both halves
+    # are stream-ordered launches, so submit runs the forward and sync returns its output buffer.
+    def submit_for_one_decode(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0):
+        self._decode_out = self.forward(input_tensor.view(1, -1), expert_ids.view(1, -1), weights.view(1, -1),
+                                        bsz_tensor=bsz_tensor)
+
+    def sync_for_one_decode(self, cuda_graph_idx=0):
+        out, self._decode_out = self._decode_out, None
+        return out
+
+
+EXPERTS_MAP = {
+    "KExpertsHIP": KExpertsHIP,
+    # names used by the reference's rule files; all of them resolve to the HBM-resident implementation
+    "KExpertsCPU": KExpertsHIP,
+    "KExpertsTorch": KExpertsHIP,
+    "KExpertsMarlin": KExpertsHIP,
+}
+
+
+class KTransformersExperts(BaseInjectedModule, KExpertsBase):
+    """archive/ktransformers/operators/experts.py:686-757.  With one HBM-resident implementation serving both phases,
+    prefill_op and generate_op share a single KExpertsHIP instance when they name the same device."""
+
+    def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, prefill_device: str = "cuda",
+                 prefill_op: str | None = "KExpertsTorch", generate_device: str = "cpu",
+                 generate_op: str | None = "KExpertsCPU", **kwargs):
+        BaseInjectedModule.__init__(self, key, gguf_loader, config, orig_module, prefill_device, generate_device, **kwargs)
+        KExpertsBase.__init__(self, key, gguf_loader, config, orig_module, generate_device, **kwargs)
+        n = len(orig_module) if orig_module is not None and hasattr(orig_module, "__len__") else config.n_routed_experts
+        gen = EXPERTS_MAP[generate_op](key, gguf_loader, config, n, device=generate_device, **kwargs) \
+            if generate_op is not None else None
+        if prefill_op is not None and gen is not None and EXPERTS_MAP[prefill_op] is EXPERTS_MAP[generate_op]:
+            pre = gen
+        else:
+            pre = EXPERTS_MAP[prefill_op](key, gguf_loader, config, n, device=prefill_device, **kwargs) \
+                if prefill_op is not None else None
+        object.__setattr__(self, "generate_experts", gen)
+        object.__setattr__(self, "prefill_experts", pre)
+        object.__setattr__(self, "gpu_mlp_type", prefill_op)
+        object.__setattr__(self, "cpu_mlp_type", generate_op)
+        object.__setattr__(self, "mode", InferenceState.UNLOAD)
+
+    def load(self, w: dict = None, mode: InferenceState = None, warmup: bool = True):
+        if not mode:
+            mode = InferenceState.GENERATE
+        if mode == InferenceState.GENERATE:
+            if self.prefill_experts is not None and self.prefill_experts is not self.generate_experts:
+                self.prefill_experts.unload()
+            self.generate_experts.load(w, warmup=warmup)
+            self.device = self.generate_experts.device
+        elif mode == InferenceState.PREFILL:
+            if self.generate_experts is not None and self.prefill_experts is not self.generate_experts:
+                self.generate_experts.unload()
+            self.prefill_experts.load(w, warmup=warmup)
+            self.device = self.prefill_experts.device
+        elif mode == InferenceState.UNLOAD:
+            self.unload()
+        else:
+            raise ValueError("mode must be either InferenceState.GENERATE, InferenceState.PREFILL or InferenceState.UNLOAD")
+        self.mode = mode
+
+    def unload(self):
+        for e in (self.generate_experts, self.prefill_experts):
+            if e is not None:
+                e.unload()
+        if self.generate_experts is not None:
+            self.device = self.generate_experts.device
+
+    def forward(self, input_tensor, expert_ids, weights):
+        if self.mode == InferenceState.GENERATE:
+            assert self.generate_experts is not None, "generate_experts is None"
+            return self.generate_experts.forward(input_tensor, expert_ids, weights)
+        elif self.mode == InferenceState.PREFILL:
+            assert self.prefill_experts is not None, "prefill_experts is None"
+            return self.prefill_experts.forward(input_tensor, expert_ids, weights)
+        raise ValueError("load or set_inference_mode before forward")
+
+    def set_inference_mode(self, mode: InferenceState):
+        if mode in (InferenceState.GENERATE, InferenceState.PREFILL):
+            self.load(mode=mode, warmup=False)
+        elif mode == InferenceState.UNLOAD:
+            self.unload()
+        else:
+            raise ValueError("mode must be either InferenceState.GENERATE, InferenceState.PREFILL or InferenceState.UNLOAD")
+
+
+class _KMoEBlock(BaseInjectedModule):
+    """Shared orchestration of the model-specific MoE blocks: gate -> routed experts (+ shared experts)."""
+
+    def moe_kexperts(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weight: torch.Tensor) -> torch.Tensor:
+        return self.experts(x, topk_ids, topk_weight)
+
+    def forward(self, hidden_states):
+        identity = hidden_states
+        orig_shape = hidden_states.shape
+        sequence_length = orig_shape[1]
+        topk_idx, topk_weight = self.gate(hidden_states)
+        hidden_states = hidden_states.view(-1, hidden_states.shape[-1])
+        shared = getattr(self.config, "n_shared_experts", None) is not None
+
+        gen = getattr(self.experts, "generate_experts", None)
+        if (sequence_length == 1 and gen is not None and hasattr(gen, "submit_for_one_decode")
+                and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            gen.submit_for_one_decode(hidden_states[0], topk_idx[0], topk_weight[0])
+            if shared:
+                y_ = self.shared_experts(identity).squeeze(0)
+            y = gen.sync_for_one_decode().unsqueeze(0)
+            if shared:
+                y = y + y_
+            return y.reshape(*orig_shape)
+
+        if shared:
+            y_ = self.shared_experts(identity).squeeze(0)
+        y = self.moe_kexperts(hidden_states, topk_idx, topk_weight).view(*orig_shape).to(device=hidden_states.device)
+        if shared:
+            y = y + y_.view(*orig_shape)
+        return y
+
+
+class KDeepseekV2MoE(_KMoEBlock):
+    """archive/ktransformers/operators/experts.py:874-971."""
+
+
+class KDeepseekV3MoE(_KMoEBlock):
+    """archive/ktransformers/operators/experts.py:972-1012 ("V3 MoE" block; sigmoid noaux_tc gate in front)."""

@@ -1,0 +1,42 @@
+"""Generate tests/golden/moe_amx_golden.npz from the REFERENCE's own kernels (oracle/_ref, built from /root/reference).
+
+Run in the build container (needs /root/reference):   python tests/golden/make_golden.py
+The fixture stores the inputs (bf16 bits) and the reference outputs, so it travels to machines without the reference.
+Shapes are the smallest the reference accepts (K % 128 == 0, N % 32 == 0) to keep the file small.
+"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+from helpers import make_case  # noqa: E402
+from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, Reference  # noqa: E402
+
+E, k, H, I = 4, 2, 128, 128
+ref = Reference(threads=2)
+base = make_case(20260921, E, k, H, I, 1)
+out = dict(E=E, k=k, H=H, I=I, gate=base["gate"], up=base["up"], down=base["down"])
+cases = [("t1", 1, False), ("t7_invalid", 7, True), ("t33_prefill", 33, False)]
+for fmt, fname in ((FMT_AMXINT4, "int4"), (FMT_AMXINT8, "int8")):
+    moe = ref.make_moe(fmt, base["gate"], base["up"], base["down"], k=k, max_len=64)
+    for name, T, inv in cases:
+        c = make_case(1000 + T, E, k, H, I, T, invalid_ids=inv)
+        y = ref.moe_forward(moe, c["ids"], c["w"], c["x"])
+        y2 = ref.moe_forward(moe, c["ids"], c["w"], c["x"], y_prev=y)
+        out[f"{fname}_{name}_x"] = c["x"]
+        out[f"{fname}_{name}_ids"] = c["ids"]
+        out[f"{fname}_{name}_w"] = c["w"]
+        out[f"{fname}_{name}_y"] = y
+        out[f"{fname}_{name}_yinc"] = y2
+    ref.free_moe(moe)
+# the reference quantiser's own dequantised weights + scales for one matrix (BufferBInt4Impl::from_mat -> to_mat)
+deq, d = ref.quant_roundtrip_int4(base["gate"][0])
+out["int4_gate0_dequant"] = deq
+out["int4_gate0_scale"] = d
+path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "moe_amx_golden.npz")
+np.savez_compressed(path, **out)
+print("wrote", path, os.path.getsize(path), "bytes")

@@ -1,0 +1,76 @@
+"""Expert-parallel choreography on CPU: world_size 2, gloo.  Each rank owns half the experts and its own tokens; the
+local-expert compute is stood in by the oracle (tests only), so this exercises the all-gather / partial / reduce-scatter
+path of ktransformers_amd/parallel.py against the single-process oracle result."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from helpers import bf16_to_f32, make_case
+
+E, K, H, I, T = 8, 2, 256, 128, 3
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ktransformers_amd.parallel import ep_decode_forward, expert_range
+    from oracle.oracle import FMT_AMXINT4, Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    c = make_case(11, E, K, H, I, T * world)
+    moe = o.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"])
+    begin, cnt = expert_range(E, world, rank)
+    mask = np.ones(E, np.uint8)
+    mask[begin:begin + cnt] = 0           # everything this rank does NOT own is skipped
+    moe_local = dict(moe, mask=mask)
+
+    def local_partial(xg, idsg, wg):
+        # fp32 partial = un-rounded weighted sum over owned experts; the oracle rounds to bf16 at the end, so feed it
+        # one slot at a time and accumulate the (exactly representable) per-slot products in fp32 like the kernel does
+        xs = xg.view(torch.int16).numpy().view(np.uint16)
+        ids, w = idsg.numpy(), wg.numpy()
+        acc = np.zeros((xs.shape[0], H), np.float32)
+        for j in range(ids.shape[1]):
+            one = o.moe_forward(moe_local, ids[:, j:j + 1], np.ones((xs.shape[0], 1), np.float32), xs)
+            acc = np.float32(bf16_to_f32(one) * w[:, j:j + 1] + acc)
+        return torch.from_numpy(acc)
+
+    sl = slice(rank * T, (rank + 1) * T)
+    x = torch.from_numpy(c["x"][sl].view(np.int16).copy()).view(torch.bfloat16)
+    y = ep_decode_forward(local_partial, x, torch.from_numpy(c["ids"][sl]), torch.from_numpy(c["w"][sl]))
+    full = o.moe_forward(moe, c["ids"], c["w"], c["x"])
+    q.put((rank, y.view(torch.int16).numpy().view(np.uint16).copy(), full[sl].copy()))
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_decode_matches_single_process():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, want in res:
+        a, b = bf16_to_f32(got), bf16_to_f32(want)
+        # cross-rank fp32 summation order differs from slot order: <= 1 bf16 ulp
+        assert np.all(np.abs(a - b) <= np.abs(b) * 2.0 ** -7 + 1e-5 * np.abs(b).max()), f"rank {rank}"
+        assert (got != want).mean() < 0.05
+
+
+def test_expert_range():
+    from ktransformers_amd.parallel import expert_range
+    assert expert_range(256, 8, 3) == (96, 32)
+    with pytest.raises(ValueError):
+        expert_range(10, 4, 0)

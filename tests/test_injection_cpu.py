@@ -1,0 +1,96 @@
+"""Host logic of the drop-in boundary: YAML rule matching, injection, attribute fall-through, op registry
+(reference: archive/ktransformers/optimize/optimize.py:28-118, operators/base_operator.py:12-63, experts.py:680-757)."""
+import os
+
+import pytest
+import torch
+
+from toy_model import ToyConfig, ToyModel
+
+from ktransformers_amd.operators.base_operator import BaseInjectedModule
+from ktransformers_amd.operators.experts import (EXPERTS_MAP, KDeepseekV3MoE, KExpertsHIP, KTransformersExperts)
+from ktransformers_amd.operators.gate import KMoEGate
+from ktransformers_amd.optimize.optimize import gen_optimize_config, load_rules, optimize_and_load, resolve_class
+from ktransformers_amd.util.loader import DictLoader
+from ktransformers_amd.util.utils import InferenceState
+
+RULES = os.path.join(os.path.dirname(__file__), "toy_rules.yaml")
+
+
+@pytest.fixture()
+def injected():
+    cfg = ToyConfig()
+    with torch.device("meta"):
+        model = ToyModel(cfg)
+    loader = DictLoader({})
+    conf = optimize_and_load(model, RULES, loader, cfg, default_device="cuda:0", load=False)
+    return model, conf, cfg
+
+
+def test_reference_class_paths_resolve_to_the_mirror():
+    assert resolve_class("ktransformers.operators.experts.KTransformersExperts") is KTransformersExperts
+    assert resolve_class("ktransformers.operators.gate.KMoEGate") is KMoEGate
+    with pytest.raises(ImportError):
+        resolve_class("ktransformers.operators.nope.Missing")
+
+
+def test_rules_pick_first_match_and_respect_recursive(injected):
+    model, conf, _ = injected
+    assert conf["model.layers.1.mlp"]["class"].endswith("KDeepseekV3MoE")
+    assert conf["model.layers.0.mlp"]["class"] == "default"          # dense layer: not a ToyMoE
+    assert conf["model.layers.1.mlp.experts"]["class"].endswith("KTransformersExperts")
+    assert "model.layers.1.mlp.experts.0" not in conf                # recursive: False stops the descent
+    assert conf["lm_head"]["class"] == "default" and conf["lm_head"]["kwargs"]["generate_device"] == "cuda"
+    assert conf["model.layers.2.mlp.gate"]["kwargs"]["generate_device"] == "cuda:0"
+
+
+def test_injected_module_types_and_fallthrough(injected):
+    model, _, cfg = injected
+    mlp = model.model.layers[1].mlp
+    assert isinstance(mlp, KDeepseekV3MoE) and isinstance(mlp, BaseInjectedModule)
+    assert isinstance(mlp.experts, KTransformersExperts)
+    assert isinstance(mlp.gate, KMoEGate)
+    assert mlp.key == "model.layers.1.mlp" and mlp.experts.key == "model.layers.1.mlp.experts"
+    # attribute fall-through to the replaced module
+    assert mlp.gate.top_k == cfg.num_experts_per_tok
+    assert mlp.gate.orig_module.weight.shape == (cfg.n_routed_experts, cfg.hidden_size)
+    assert mlp.config is cfg
+    # writes to unknown attributes land on the original module (base_operator.py:52-56)
+    mlp.gate.some_flag = 7
+    assert mlp.gate.orig_module.some_flag == 7
+
+
+def test_experts_registry_and_modes(injected):
+    model, _, _ = injected
+    ex = model.model.layers[2].mlp.experts
+    assert EXPERTS_MAP["KExpertsCPU"] is KExpertsHIP and EXPERTS_MAP["KExpertsTorch"] is KExpertsHIP
+    assert isinstance(ex.generate_experts, KExpertsHIP) and ex.prefill_experts is ex.generate_experts
+    assert ex.generate_experts.n_routed_experts == 8 and ex.generate_experts.method == "AMXINT4"
+    assert ex.mode == InferenceState.UNLOAD
+    with pytest.raises(ValueError):
+        ex.forward(torch.zeros(1, 256), torch.zeros(1, 2, dtype=torch.long), torch.zeros(1, 2))
+    with pytest.raises(ValueError):
+        ex.set_inference_mode("bogus")
+
+
+def test_unknown_backend_is_rejected():
+    with pytest.raises(ValueError):
+        KExpertsHIP("k", DictLoader({}), ToyConfig(), 8, backend="Q2_K")
+
+
+def test_kexperts_hip_has_no_cpu_path():
+    e = KExpertsHIP("k", DictLoader({}), ToyConfig(), 8, device="cpu", out_device="cpu")
+    with pytest.raises(RuntimeError):
+        e.load({"gate": torch.zeros(8, 128, 256), "up": torch.zeros(8, 128, 256), "down": torch.zeros(8, 256, 128)})
+
+
+def test_rule_without_match_keys_raises():
+    with pytest.raises(Exception):
+        gen_optimize_config(ToyModel(ToyConfig()), {}, [{"match": {}, "replace": {"class": "default"}}])
+
+
+def test_shipped_rule_files_parse():
+    d = os.path.join(os.path.dirname(os.path.dirname(__file__)), "ktransformers_amd", "optimize", "optimize_rules")
+    for f in os.listdir(d):
+        rules = load_rules(os.path.join(d, f))
+        assert isinstance(rules, list) and all("match" in r and "replace" in r for r in rules)

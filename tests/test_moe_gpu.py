@@ -1,0 +1,260 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the oracle on identical seeded inputs, against the
+reference-generated golden fixtures, and size-independent properties at full model shapes.  Bit-exact: every rounding
+step of the reference is reproduced and all accumulations are either exact (int32) or in the reference's order."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from helpers import bf16_to_f32, f32_to_bf16, make_case, numpy_u16, torch_bf16
+from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "moe_amx_golden.npz")
+FMT = {"AMXINT4": FMT_AMXINT4, "AMXINT8": FMT_AMXINT8}
+
+
+@pytest.fixture(scope="module")
+def dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda", 0)
+
+
+def make_handle(method, c, E, k, H, I, max_len, dev, **kw):
+    from ktransformers_amd._native import MoEHandle
+    h = MoEHandle(E, k, H, I, max_len=max_len, method=method, device=0, **kw)
+    h.load_bf16(torch_bf16(c["gate"], dev), torch_bf16(c["up"], dev), torch_bf16(c["down"], dev))
+    return h
+
+
+def run(h, c, dev, **kw):
+    y = h.forward(torch_bf16(c["x"], dev), torch.from_numpy(c["ids"]).to(dev), torch.from_numpy(c["w"]).to(dev), **kw)
+    torch.cuda.synchronize()
+    return numpy_u16(y)
+
+
+@pytest.mark.parametrize("method", ["AMXINT4", "AMXINT8"])
+@pytest.mark.parametrize("shape", [
+    (8, 2, 512, 256, 1),      # decode path, one token
+    (8, 2, 512, 256, 5),      # decode path, ragged routing with invalid ids
+    (8, 6, 2048, 1408, 1),    # DeepSeek-V2-Lite layer shape (K=1408 -> 11 k-steps)
+    (16, 8, 7168, 2048, 2),   # DeepSeek-V3 layer shape, 16 of the 256 experts
+    (8, 2, 256, 512, 40),     # grouped path, MT=1
+    (8, 2, 256, 512, 300),    # grouped path, MT=4, several tiles per expert
+    (4, 2, 256, 256, 700),    # grouped path, ragged last tiles
+])
+def test_parity_with_oracle_both_paths(oracle, dev, method, shape):
+    from ktransformers_amd import _native
+    E, k, H, I, T = shape
+    c = make_case(1, E, k, H, I, T, invalid_ids=T >= 5)
+    mo = oracle.make_moe(FMT[method], c["gate"], c["up"], c["down"])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+    h = make_handle(method, c, E, k, H, I, max(T, 8), dev)
+    try:
+        for force_generic in (False, True):
+            _native.force_generic_path(force_generic)
+            got = run(h, c, dev)
+            assert np.array_equal(got, want), f"{int((got != want).sum())} bf16 outputs differ (generic={force_generic})"
+            got_inc = run(h, c, dev, out=torch_bf16(want, dev), incremental=True)
+            assert np.array_equal(got_inc, want_inc)
+    finally:
+        _native.force_generic_path(False)
+        h.close()
+
+
+@pytest.mark.parametrize("fname,method", [("int4", "AMXINT4"), ("int8", "AMXINT8")])
+@pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
+def test_parity_with_reference_golden(dev, fname, method, case):
+    g = np.load(GOLDEN)
+    E, k, H, I = int(g["E"]), int(g["k"]), int(g["H"]), int(g["I"])
+    c = dict(gate=g["gate"], up=g["up"], down=g["down"], x=g[f"{fname}_{case}_x"], ids=g[f"{fname}_{case}_ids"],
+             w=g[f"{fname}_{case}_w"])
+    h = make_handle(method, c, E, k, H, I, 64, dev)
+    try:
+        got = run(h, c, dev)
+        assert np.array_equal(got, g[f"{fname}_{case}_y"]), "HIP path differs from the reference kernels' own output"
+        got_inc = run(h, c, dev, out=torch_bf16(g[f"{fname}_{case}_y"], dev), incremental=True)
+        assert np.array_equal(got_inc, g[f"{fname}_{case}_yinc"])
+    finally:
+        h.close()
+
+
+def test_prequantised_load_equals_online_quant(oracle, dev):
+    """load_quantized(host q, scale) (reference pre-quantised branch, moe.hpp:266-300) == load_bf16 (online quant)."""
+    from ktransformers_amd._native import MAT_DOWN, MAT_GATE, MAT_UP, MoEHandle
+    E, k, H, I, T = 4, 2, 256, 128, 6
+    c = make_case(9, E, k, H, I, T)
+    mo = oracle.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"])
+    h1 = make_handle("AMXINT4", c, E, k, H, I, 8, dev)
+    h2 = MoEHandle(E, k, H, I, max_len=8, method="AMXINT4", device=0)
+    for e in range(E):
+        h2.load_quantized(e, MAT_GATE, mo["gate_q"][e], mo["gate_d"][e])
+        h2.load_quantized(e, MAT_UP, mo["up_q"][e], mo["up_d"][e])
+        h2.load_quantized(e, MAT_DOWN, mo["down_q"][e], mo["down_d"][e])
+    try:
+        assert np.array_equal(run(h1, c, dev), run(h2, c, dev))
+    finally:
+        h1.close(); h2.close()
+
+
+def test_expert_mask_and_bsz_tensor(oracle, dev):
+    E, k, H, I, T = 8, 2, 256, 256, 6
+    c = make_case(4, E, k, H, I, T)
+    mask = np.zeros(E, np.uint8); mask[[1, 5]] = 1
+    mo = oracle.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"], mask=mask)
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = make_handle("AMXINT4", c, E, k, H, I, 8, dev)
+    try:
+        h.set_expert_mask(mask)
+        assert np.array_equal(run(h, c, dev), want)
+        # masking an expert == routing to an invalid id (should_skip_expert, common.hpp:256-258)
+        h.set_expert_mask(None)
+        c2 = dict(c, ids=np.where(np.isin(c["ids"], [1, 5]), -1, c["ids"]))
+        assert np.array_equal(run(h, c2, dev), want)
+        # device-side batch size (moe-tp.hpp:209): only the first bsz tokens are touched
+        bsz = torch.tensor([4], dtype=torch.int32, device=dev)
+        sentinel = f32_to_bf16(np.full((T, H), 7.0, np.float32))
+        out = torch_bf16(sentinel, dev)
+        got = run(h, c, dev, out=out, bsz_tensor=bsz)
+        full = oracle.moe_forward(oracle.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"]), c["ids"], c["w"], c["x"])
+        assert np.array_equal(got[:4], full[:4]) and np.array_equal(got[4:], sentinel[4:])
+    finally:
+        h.close()
+
+
+def test_expert_parallel_partials_sum_to_the_whole(oracle, dev):
+    """Two handles owning half the experts each: fp32 partials add up to the single-handle result (<= 1 bf16 ulp)."""
+    from ktransformers_amd._native import MoEHandle
+    E, k, H, I, T = 8, 4, 256, 256, 5
+    c = make_case(12, E, k, H, I, T)
+    whole = make_handle("AMXINT4", c, E, k, H, I, 8, dev)
+    parts = []
+    for r in range(2):
+        h = MoEHandle(E // 2, k, H, I, max_len=8, method="AMXINT4", device=0, expert_begin=r * E // 2, global_expert_num=E)
+        sl = slice(r * E // 2, (r + 1) * E // 2)
+        h.load_bf16(torch_bf16(c["gate"][sl], dev), torch_bf16(c["up"][sl], dev), torch_bf16(c["down"][sl], dev))
+        parts.append(h)
+    try:
+        x, ids, w = torch_bf16(c["x"], dev), torch.from_numpy(c["ids"]).to(dev), torch.from_numpy(c["w"]).to(dev)
+        s = parts[0].forward_partial(x, ids, w) + parts[1].forward_partial(x, ids, w)
+        ref = bf16_to_f32(run(whole, c, dev))
+        got = s.to(torch.bfloat16).float().cpu().numpy()
+        assert np.all(np.abs(got - ref) <= np.abs(ref) * 2.0 ** -7 + 1e-5 * np.abs(ref).max())
+    finally:
+        whole.close(); [p.close() for p in parts]
+
+
+# ---- size-independent properties at full layer shapes ------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(64, 6, 2048, 1408), (32, 8, 7168, 2048)])  # V2-Lite full layer; V3 shape, 32 experts
+def test_properties_full_shapes(dev, shape):
+    from ktransformers_amd import _native
+    from ktransformers_amd._native import MoEHandle
+    E, k, H, I = shape
+    g = torch.Generator(device=dev); g.manual_seed(3)
+    gate = (torch.randn((E, I, H), generator=g, device=dev) / 10).to(torch.bfloat16)
+    up = (torch.randn((E, I, H), generator=g, device=dev) / 10).to(torch.bfloat16)
+    down = (torch.randn((E, H, I), generator=g, device=dev) / 10).to(torch.bfloat16)
+    T = 24
+    h = MoEHandle(E, k, H, I, max_len=T, method="AMXINT4", device=0)
+    h.load_bf16(gate, up, down)
+    del gate, up, down
+    try:
+        x = (torch.randn((T, H), generator=g, device=dev) / 100).to(torch.bfloat16)
+        ids = torch.rand((T, E), generator=g, device=dev).topk(k, dim=-1).indices.to(torch.int64).contiguous()
+        w = torch.rand((T, k), generator=g, device=dev)
+        y = h.forward(x, ids, w)                                 # grouped path (T*k > 64)
+        # (1) every row equals the same token pushed alone through the decode path
+        for t in (0, 7, T - 1):
+            y1 = h.forward(x[t:t + 1].contiguous(), ids[t:t + 1].contiguous(), w[t:t + 1].contiguous())
+            assert torch.equal(y1[0], y[t]), f"token {t}: batched and single-token results differ"
+        # (2) token permutation equivariance
+        perm = torch.randperm(T, generator=torch.Generator().manual_seed(0)).to(dev)
+        yp = h.forward(x[perm].contiguous(), ids[perm].contiguous(), w[perm].contiguous())
+        assert torch.equal(yp, y[perm])
+        # (3) scaling the routing weights by 2 scales the output by exactly 2 (power of two: no rounding change)
+        y2 = h.forward(x, ids, (w * 2).contiguous())
+        assert torch.equal(y2.float(), y.float() * 2)
+        # (4) slot-order permutation of one token changes at most fp32 summation order: <= 1 bf16 ulp
+        idsr, wr = ids.flip(-1).contiguous(), w.flip(-1).contiguous()
+        yr = h.forward(x, idsr, wr).float()
+        # (a different fp32 order changes the sum by ~1e-7 of the largest partial sum, then at most one bf16 ulp)
+        yf = y.float()
+        assert torch.all((yr - yf).abs() <= yf.abs() * 2.0 ** -7 + 1e-5 * yf.abs().max())
+        # (5) incremental == previous + new, rounded once
+        yi = h.forward(x, ids, w, out=y.clone(), incremental=True)
+        assert torch.all((yi.float() - 2 * yf).abs() <= (2 * yf).abs() * 2.0 ** -7 + 1e-5 * yf.abs().max())
+        # (6) both implementations agree on the same small batch
+        xs, idss, ws = x[:4].contiguous(), ids[:4].contiguous(), w[:4].contiguous()
+        a = h.forward(xs, idss, ws)
+        _native.force_generic_path(True)
+        b = h.forward(xs, idss, ws)
+        _native.force_generic_path(False)
+        assert torch.equal(a, b)
+    finally:
+        _native.force_generic_path(False)
+        h.close()
+
+
+def test_full_v2lite_layer_vs_oracle(oracle, dev):
+    """One full DeepSeek-V2-Lite MoE layer shape, 8 of the 64 experts routed, against the CPU oracle."""
+    E, k, H, I, T = 8, 6, 2048, 1408, 3
+    c = make_case(21, E, k, H, I, T)
+    mo = oracle.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = make_handle("AMXINT4", c, E, k, H, I, 8, dev)
+    try:
+        assert np.array_equal(run(h, c, dev), want)
+    finally:
+        h.close()
+
+
+def test_hip_graph_capture_and_variable_batch(oracle, dev):
+    """The forward is capturable and the captured graph honours a device-side batch size (reference: CUDAGraphRunner +
+    bsz_tensor, experts.py:293-318)."""
+    E, k, H, I, T = 8, 2, 256, 256, 4
+    c = make_case(2, E, k, H, I, T)
+    mo = oracle.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = make_handle("AMXINT4", c, E, k, H, I, 8, dev)
+    try:
+        x, ids, w = torch_bf16(c["x"], dev), torch.from_numpy(c["ids"]).to(dev), torch.from_numpy(c["w"]).to(dev)
+        out = torch.zeros_like(x)
+        bsz = torch.tensor([T], dtype=torch.int32, device=dev)
+        h.forward(x, ids, w, out=out, bsz_tensor=bsz)
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            h.forward(x, ids, w, out=out, bsz_tensor=bsz)
+        out.zero_()
+        g.replay(); torch.cuda.synchronize()
+        assert np.array_equal(numpy_u16(out), want)
+        out.zero_(); bsz.fill_(2)
+        g.replay(); torch.cuda.synchronize()
+        got = numpy_u16(out)
+        assert np.array_equal(got[:2], want[:2]) and not got[2:].any()
+    finally:
+        h.close()
+
+
+def test_error_behaviour(dev):
+    from ktransformers_amd._native import KtxError, MoEHandle
+    h = MoEHandle(4, 2, 256, 128, max_len=4, method="AMXINT4", device=0)
+    try:
+        x = torch.zeros((8, 256), dtype=torch.bfloat16, device=dev)
+        with pytest.raises(KtxError):   # qlen > max_len
+            h.forward(x, torch.zeros((8, 2), dtype=torch.int64, device=dev), torch.zeros((8, 2), device=dev))
+        with pytest.raises(KtxError):   # wrong dtype
+            h.forward(x[:2].float(), torch.zeros((2, 2), dtype=torch.int64, device=dev), torch.zeros((2, 2), device=dev))
+        with pytest.raises(KtxError):
+            MoEHandle(4, 2, 200, 128, max_len=4, method="AMXINT4", device=0)
+        with pytest.raises(KtxError):
+            MoEHandle(4, 2, 256, 128, max_len=4, method="Q9_9", device=0)
+    finally:
+        h.close()
+
+
+def test_smoke_entry():
+    import __graft_entry__
+    __graft_entry__.smoke()
