@@ -1,0 +1,56 @@
+/* ktx_mla.h — C ABI of the MLA compressed-KV paged attention (absorbed form) in libktx_hip.so.
+ *
+ * Replaces, for KDeepseekV2Attention.forward_linux_flashinfer (archive/ktransformers/operators/attention.py:349-523)
+ * and flashinfer_attn.forward (archive/ktransformers/operators/balance_serve_attention.py:66-118):
+ *   flashinfer.mla.BatchMLAPagedAttentionWrapper.plan / .run       call sites archive/.../flashinfer_wrapper.py:103-161
+ *   Triton decode_attention_fwd_grouped                              archive/.../triton_attention.py:358-385
+ *   StaticCache.update / KDeepSeekV3Cache.update (latent append)    archive/ktransformers/models/custom_cache.py:147-199,414-447
+ *
+ * Semantics (= attention_ref_torch, flashinfer_wrapper.py:30-76, with K = [ckv | k_pe], V = ckv shared by all heads):
+ *   s[h][n] = sm_scale * ( q_nope[h] . ckv[n] + q_pe[h] . k_pe[n] ),  n <= kv_len - qo_len + i   (causal)
+ *   out[h]  = softmax_n(s[h]) @ ckv                                     fp32 softmax / accumulation, bf16 in/out
+ * All pointers are DEVICE pointers; calls only enqueue on `stream` and are HIP-graph capturable (batch size and the
+ * page tables are read on the device).
+ */
+#ifndef KTX_MLA_H
+#define KTX_MLA_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ktx_mla_config {
+  int32_t num_heads;      /* query heads (128 V3, 64 K2, 16 V2-Lite); multiple of 16 */
+  int32_t head_dim_ckv;   /* kv_lora_rank = 512 */
+  int32_t head_dim_kpe;   /* qk_rope_head_dim = 64 */
+  int32_t page_size;      /* tokens per page (64 single-request cache, 256 server cache) */
+  float sm_scale;         /* softmax_scale = q_head_dim^-0.5 * mscale^2 (modeling_deepseek_v3.py:697-703) */
+  int32_t max_splits;     /* upper bound on KV splits the workspace was sized for (>=1) */
+} ktx_mla_config;
+
+/* bytes of scratch needed for `max_q_tokens` query tokens (fp32 partial outputs + softmax stats per KV split) */
+size_t ktx_mla_workspace_bytes(const ktx_mla_config* cfg, int max_q_tokens);
+
+/* run(q_nope[T,Hq,512], q_pe[T,Hq,64], ckv[pages,page,512], k_pe[pages,page,64]) -> out[T,Hq,512]
+ * (BatchMLAPagedAttentionWrapper.run; the plan() arguments are passed here as device arrays):
+ *   qo_indptr int32 [batch+1], kv_indptr int32 [batch+1], kv_indices int32 [*] (page ids), kv_len_arr int32 [batch];
+ *   d_bsz int32* or NULL: number of live requests (<= batch), read on the device;
+ *   ckv_token_stride / kpe_token_stride: elements between consecutive tokens of a page (576 for the fused cache view);
+ *   lse float [T,Hq] or NULL (natural-log sum-exp * log2(e), like flashinfer's return_lse). */
+int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, const void* d_ckv,
+                   const void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride, const int32_t* d_qo_indptr,
+                   const int32_t* d_kv_indptr, const int32_t* d_kv_indices, const int32_t* d_kv_len_arr,
+                   const int32_t* d_bsz, int batch, int total_q_tokens, void* d_out, float* d_lse, void* d_workspace,
+                   size_t workspace_bytes, void* stream);
+
+/* cache.update(): scatter T new latent rows [ckv(512) | k_pe(64)] to cache[page_idx[t]][page_offset[t]]
+ * (custom_cache.py:189-195 / :433-441).  kv_cache bf16 [pages][page_size][token_stride]. */
+int ktx_mla_cache_append(const ktx_mla_config* cfg, void* d_kv_cache, int64_t token_stride, const void* d_ckv_new,
+                         const void* d_kpe_new, const int32_t* d_page_idx, const int32_t* d_page_offset,
+                         const int32_t* d_ntokens, int max_tokens, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

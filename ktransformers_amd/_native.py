@@ -27,6 +27,11 @@ class _GateConfig(C.Structure):
                                          "topk_method", "norm_topk_prob")] + [("routed_scaling_factor", C.c_float)]
 
 
+class _MlaConfig(C.Structure):
+    _fields_ = [("num_heads", C.c_int32), ("head_dim_ckv", C.c_int32), ("head_dim_kpe", C.c_int32),
+                ("page_size", C.c_int32), ("sm_scale", C.c_float), ("max_splits", C.c_int32)]
+
+
 class _MoeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
@@ -54,6 +59,12 @@ def _load() -> C.CDLL:
     lib.ktx_gate_logits.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_gate_select.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]
+    lib.ktx_mla_workspace_bytes.argtypes = [C.POINTER(_MlaConfig), C.c_int]
+    lib.ktx_mla_workspace_bytes.restype = C.c_size_t
+    lib.ktx_mla_decode.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
+        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.ktx_mla_cache_append.argtypes = [C.POINTER(_MlaConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_profile_enable.argtypes = [C.c_int]
     lib.ktx_debug_force_generic.argtypes = [C.c_int]
     lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
@@ -230,8 +241,8 @@ class GateHandle:
         bsz_ptr = bsz_tensor.data_ptr() if bsz_tensor is not None else None
         if T <= self.LOGITS_HIP_MAX_T and weight.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
             logits = torch.empty((T, self.E), dtype=torch.float32, device=dev)
-            check(lib.ktx_gate_logits(C.byref(self.cfg), bsz_ptr, T, x.contiguous().data_ptr(),
-                                      weight.contiguous().data_ptr(), logits.data_ptr(), st))
+            xc, wc = x.contiguous(), weight.contiguous()
+            check(lib.ktx_gate_logits(C.byref(self.cfg), bsz_ptr, T, xc.data_ptr(), wc.data_ptr(), logits.data_ptr(), st))
         else:  # F.linear in fp32, exactly the reference's expression (modeling_deepseek_v3.py:434-437)
             logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
         idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
@@ -242,3 +253,82 @@ class GateHandle:
         check(lib.ktx_gate_select(C.byref(self.cfg), bsz_ptr, T, logits.data_ptr(), b.data_ptr() if b is not None else None,
                                   idx.data_ptr(), w.data_ptr(), st))
         return idx, w
+
+
+class MLAWrapper:
+    """plan()/run() facade with the reference's MLAWrapper signature (archive/ktransformers/operators/
+    flashinfer_wrapper.py:78-161) over ktx_mla_decode.  plan() only records the (device) index arrays: there is no host
+    planning step, so a captured graph stays valid when their contents change."""
+
+    def __init__(self, max_batch_size: int, max_pages: int, use_cuda_graph: bool = True, device="cuda",
+                 max_q_tokens: int | None = None, max_splits: int = 64):
+        self.device = torch.device(device) if not isinstance(device, torch.device) else device
+        if self.device.type != "cuda":
+            raise KtxError("MLAWrapper needs a HIP device; there is no CPU path")
+        if self.device.index is None:
+            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.max_batch_size, self.max_pages, self.max_splits = max_batch_size, max_pages, max_splits
+        self.max_q_tokens = max_q_tokens or max(256, max_batch_size)
+        self.cfg = None
+        self.workspace = None
+        if max_batch_size == 1:  # single-request defaults like the reference wrapper (:88-93)
+            self.qo_indptr_buf = torch.arange(0, 2, dtype=torch.int32, device=self.device)
+            self.kv_indptr_buf = torch.tensor([0, max_pages], dtype=torch.int32, device=self.device)
+            self.kv_indices_buf = torch.arange(0, max_pages, dtype=torch.int32, device=self.device)
+            self.batch_size_tensor_buf = torch.tensor([1], dtype=torch.int32, device=self.device)
+        self.need_plan = True
+
+    def plan(self, qo_indptr, kv_indptr, kv_indices, kv_len_arr, bsz_tensor, num_heads, head_dim_ckv, head_dim_kpe,
+             page_size, sm_scale, q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16):
+        if q_data_type != torch.bfloat16 or kv_data_type != torch.bfloat16:
+            raise KtxError("MLAWrapper: bf16 q/kv only")
+        self.qo_indptr = qo_indptr if qo_indptr is not None else self.qo_indptr_buf
+        self.kv_indptr = kv_indptr if kv_indptr is not None else self.kv_indptr_buf
+        self.kv_indices = kv_indices if kv_indices is not None else self.kv_indices_buf
+        self.bsz_tensor = bsz_tensor if bsz_tensor is not None else getattr(self, "batch_size_tensor_buf", None)
+        self.kv_len_arr = kv_len_arr
+        self.cfg = _MlaConfig(num_heads, head_dim_ckv, head_dim_kpe, page_size, float(sm_scale), self.max_splits)
+        need = int(lib.ktx_mla_workspace_bytes(C.byref(self.cfg), self.max_q_tokens))
+        if self.workspace is None or self.workspace.numel() < need:
+            self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
+        self.need_plan = False
+
+    def run(self, q_nope, q_pe, ckv, k_pe, return_lse: bool = False):
+        if self.cfg is None:
+            raise KtxError("MLAWrapper.run before plan()")
+        T, Hq, dc = q_nope.shape
+        if T > self.max_q_tokens:
+            raise KtxError(f"MLAWrapper.run: {T} query tokens exceed max_q_tokens={self.max_q_tokens}")
+        for t in (q_nope, q_pe):
+            if t.dtype != torch.bfloat16 or not t.is_contiguous():
+                raise KtxError("MLAWrapper.run: q tensors must be contiguous bf16")
+        if ckv.stride(-1) != 1 or k_pe.stride(-1) != 1 or ckv.dtype != torch.bfloat16:
+            raise KtxError("MLAWrapper.run: kv tensors must be bf16 with unit inner stride")
+        ckv_ts, kpe_ts = ckv.stride(-2), k_pe.stride(-2)
+        if ckv.stride(0) != ckv_ts * self.cfg.page_size or k_pe.stride(0) != kpe_ts * self.cfg.page_size:
+            raise KtxError("MLAWrapper.run: pages must be contiguous runs of page_size tokens")
+        out = torch.empty((T, Hq, dc), dtype=torch.bfloat16, device=q_nope.device)
+        lse = torch.empty((T, Hq), dtype=torch.float32, device=q_nope.device) if return_lse else None
+        batch = self.qo_indptr.numel() - 1
+        check(lib.ktx_mla_decode(C.byref(self.cfg), q_nope.data_ptr(), q_pe.data_ptr(), ckv.data_ptr(), k_pe.data_ptr(),
+                                 ckv_ts, kpe_ts, self.qo_indptr.data_ptr(), self.kv_indptr.data_ptr(),
+                                 self.kv_indices.data_ptr(), self.kv_len_arr.data_ptr(),
+                                 self.bsz_tensor.data_ptr() if self.bsz_tensor is not None else None, batch, T,
+                                 out.data_ptr(), lse.data_ptr() if lse is not None else None, self.workspace.data_ptr(),
+                                 self.workspace.numel(), _stream_ptr(q_nope.device)))
+        return (out, lse) if return_lse else out
+
+
+def mla_cache_append(kv_cache: torch.Tensor, ckv_new: torch.Tensor, kpe_new: torch.Tensor, page_idx: torch.Tensor,
+                     page_offset: torch.Tensor, ntokens: torch.Tensor | None = None) -> None:
+    """kv_cache bf16 [pages, page_size, (1,) 576]; scatter T rows (StaticCache.update, custom_cache.py:189-195)."""
+    page_size = kv_cache.shape[1]
+    ts = kv_cache.stride(1)
+    cfg = _MlaConfig(16, 512, 64, page_size, 1.0, 1)
+    T = ckv_new.shape[0]
+    # keep the converted temporaries alive until the launch is enqueued (stream-ordered allocator reuse is then safe)
+    c, r = ckv_new.contiguous(), kpe_new.contiguous()
+    pi, po = page_idx.to(torch.int32).contiguous(), page_offset.to(torch.int32).contiguous()
+    check(lib.ktx_mla_cache_append(C.byref(cfg), kv_cache.data_ptr(), ts, c.data_ptr(), r.data_ptr(), pi.data_ptr(),
+                                   po.data_ptr(), ntokens.data_ptr() if ntokens is not None else None, T,
+                                   _stream_ptr(kv_cache.device)))

@@ -1,0 +1,81 @@
+"""MLA paged attention against the reference's own torch oracle, at the shapes and tolerance of the reference's
+self-test (archive/ktransformers/operators/flashinfer_wrapper.py:254-395: Hq=128, page 64, kv_len 4023 decode and
+2 x (q_len 128, kv_len 512) causal prefill, assert_close rtol=atol=5e-3 in bf16), plus V2-Lite/K2 head counts, ragged
+batches, non-identity page tables and the latent-cache append."""
+import numpy as np
+import pytest
+import torch
+
+from oracle.mla_ref import mla_paged_ref
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def run_case(Hq, page_size, kv_lens, q_lens, seed=0, shuffle_pages=False, max_splits=64, rtol=5e-3):
+    from ktransformers_amd._native import MLAWrapper
+    g = torch.Generator().manual_seed(seed)
+    B = len(kv_lens)
+    pages_per = [(n + page_size - 1) // page_size for n in kv_lens]
+    max_pages = sum(pages_per) + 3
+    kv_buf = torch.randn((max_pages, page_size, 576), generator=g).to(torch.bfloat16)
+    T = sum(q_lens)
+    q_nope = torch.randn((T, Hq, 512), generator=g).to(torch.bfloat16)
+    q_pe = torch.randn((T, Hq, 64), generator=g).to(torch.bfloat16)
+    perm = torch.randperm(max_pages, generator=g) if shuffle_pages else torch.arange(max_pages)
+    kv_indices = perm[:sum(pages_per)].to(torch.int32)
+    kv_indptr = torch.tensor([0] + list(np.cumsum(pages_per)), dtype=torch.int32)
+    qo_indptr = torch.tensor([0] + list(np.cumsum(q_lens)), dtype=torch.int32)
+    kv_len_arr = torch.tensor(kv_lens, dtype=torch.int32)
+    sm_scale = 192 ** (-0.5)
+    ref, lse_ref = mla_paged_ref(q_nope, q_pe, kv_buf, qo_indptr, kv_indptr, kv_indices, kv_len_arr, sm_scale)
+
+    w = MLAWrapper(B, max_pages, device=DEV, max_q_tokens=T, max_splits=max_splits)
+    kvd = kv_buf.to(DEV)
+    ckv, k_pe = torch.split(kvd, [512, 64], dim=-1)
+    w.plan(qo_indptr.to(DEV), kv_indptr.to(DEV), kv_indices.to(DEV), kv_len_arr.to(DEV),
+           torch.tensor([B], dtype=torch.int32, device=DEV), Hq, 512, 64, page_size, sm_scale, torch.bfloat16, torch.bfloat16)
+    out, lse = w.run(q_nope.to(DEV), q_pe.to(DEV), ckv, k_pe, return_lse=True)
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=rtol, atol=5e-3)
+    torch.testing.assert_close(lse.cpu(), lse_ref, rtol=2e-3, atol=2e-3)
+
+
+def test_reference_selftest_decode_shape():
+    run_case(128, 64, [4023], [1])
+
+
+def test_reference_selftest_prefill_shape():
+    run_case(128, 64, [512, 512], [128, 128], seed=1)
+
+
+@pytest.mark.parametrize("Hq", [16, 64, 128])      # V2-Lite, Kimi-K2, V3
+@pytest.mark.parametrize("kv_len", [1, 31, 32, 33, 1000])
+def test_decode_head_counts_and_ragged_lengths(Hq, kv_len):
+    run_case(Hq, 64, [kv_len], [1], seed=kv_len, rtol=5e-3 if kv_len >= 1000 else 2.0 ** -7)
+
+
+def test_ragged_batch_shuffled_pages_page256():
+    # kv_len 5 averages only a handful of unit-variance rows, so |out| reaches ~2 where one bf16 ulp (2^-7 relative)
+    # exceeds the reference's 5e-3: allow exactly one ulp there
+    run_case(128, 256, [700, 5, 2049], [1, 3, 2], seed=3, shuffle_pages=True, rtol=2.0 ** -7)
+
+
+def test_single_split_equals_many():
+    run_case(16, 64, [3000], [1], seed=4, max_splits=1)
+
+
+def test_cache_append():
+    from ktransformers_amd._native import mla_cache_append
+    g = torch.Generator().manual_seed(0)
+    cache = torch.zeros((8, 64, 1, 576), dtype=torch.bfloat16, device=DEV)
+    T = 5
+    ckv = torch.randn((T, 512), generator=g).to(torch.bfloat16).to(DEV)
+    kpe = torch.randn((T, 64), generator=g).to(torch.bfloat16).to(DEV)
+    pos = torch.tensor([0, 63, 64, 200, 511])
+    mla_cache_append(cache, ckv, kpe, (pos // 64).to(DEV), (pos % 64).to(DEV))
+    torch.cuda.synchronize()
+    want = torch.zeros_like(cache)
+    want[pos // 64, pos % 64, 0, :512] = ckv          # StaticCache.update (custom_cache.py:189-195)
+    want[pos // 64, pos % 64, 0, 512:] = kpe
+    assert torch.equal(cache, want)
