@@ -29,9 +29,13 @@ import torch  # noqa: E402
 
 WORKLOADS = {
     # name: (H, I, E, k, L_moe, description)
-    "v2lite-int4": dict(H=2048, I=1408, E=64, k=6, L=26, method="AMXINT4",
+    "v2lite-int4": dict(H=2048, I=1408, E=64, k=6, L=26, method="AMXINT4", heads=16, attn_layers=27,
+                        gate=dict(n_group=1, topk_group=1, scoring_func="softmax", topk_method="greedy",
+                                  norm_topk_prob=False, routed_scaling_factor=1.0, bias=False),
                         desc="DeepSeek-V2-Lite 16B routed experts AMXINT4, 26 MoE layers, decode bs=1"),
-    "v3-int4-layers": dict(H=7168, I=2048, E=256, k=8, L=8, method="AMXINT4",
+    "v3-int4-layers": dict(H=7168, I=2048, E=256, k=8, L=8, method="AMXINT4", heads=128, attn_layers=8,
+                           gate=dict(n_group=8, topk_group=4, scoring_func="sigmoid", topk_method="noaux_tc",
+                                     norm_topk_prob=True, routed_scaling_factor=2.5, bias=True),
                            desc="DeepSeek-V3 routed experts AMXINT4, layer subset (8 distinct resident layers), decode bs=1"),
 }
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
@@ -113,6 +117,70 @@ class DecodeRunner:
 
     def step(self, i):
         self.set_step(i)
+        if self.graph is not None:
+            self.graph.replay()
+        else:
+            self.step_eager()
+
+
+class FullDecodeRunner:
+    """One token through the WHOLE hot path of every layer, one HIP graph:
+         MLA: latent-cache append + absorbed paged attention over `ctx` cached tokens        (a14/a15, every attention layer)
+         MoE: router (logits + group-limited top-k) -> routed experts                        (a1, a5-a12, every MoE layer)
+    The hidden state fed to router and experts changes every step (nsets pre-generated rows), so routing changes too."""
+
+    def __init__(self, wl, layers, dev, ctx=4096, nsets=16, seed=3):
+        from ktransformers_amd._native import GateHandle, MLAWrapper
+
+        self.wl, self.layers, self.dev, self.nsets = wl, layers, dev, nsets
+        H, E, k, L = wl["H"], wl["E"], wl["k"], wl["L"]
+        gc = wl["gate"]
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        self.x_all = (torch.randn((nsets, 1, H), generator=g, device=dev) / 100).to(torch.bfloat16)
+        self.x = self.x_all[0].clone()
+        self.y = [torch.empty_like(self.x) for _ in range(2)]
+        self.gate = GateHandle(E, H, k, gc["n_group"], gc["topk_group"], gc["scoring_func"], gc["topk_method"],
+                               gc["norm_topk_prob"], gc["routed_scaling_factor"])
+        self.gate_w = [(torch.randn((E, H), generator=g, device=dev) * H ** -0.5).to(torch.bfloat16) for _ in range(L)]
+        self.gate_b = [(torch.randn((E,), generator=g, device=dev) * 0.1) if gc["bias"] else None for _ in range(L)]
+        # MLA state: page 64 single-request cache like StaticCache (custom_cache.py:81)
+        self.heads, self.ctx, self.nattn = wl["heads"], ctx, wl["attn_layers"]
+        pages = (ctx + 1 + 63) // 64
+        self.kv = [torch.randn((pages, 64, 576), generator=g, device=dev).to(torch.bfloat16) for _ in range(self.nattn)]
+        self.qn = (torch.randn((1, self.heads, 512), generator=g, device=dev)).to(torch.bfloat16)
+        self.qp = (torch.randn((1, self.heads, 64), generator=g, device=dev)).to(torch.bfloat16)
+        self.new_ckv = torch.randn((1, 512), generator=g, device=dev).to(torch.bfloat16)
+        self.new_kpe = torch.randn((1, 64), generator=g, device=dev).to(torch.bfloat16)
+        self.page_idx = torch.tensor([ctx // 64], dtype=torch.int32, device=dev)
+        self.page_off = torch.tensor([ctx % 64], dtype=torch.int32, device=dev)
+        self.mla = MLAWrapper(1, pages, device=dev, max_q_tokens=1)
+        self.kv_len = torch.tensor([ctx + 1], dtype=torch.int32, device=dev)
+        self.mla.plan(None, None, None, self.kv_len, None, self.heads, 512, 64, 64, 192 ** -0.5, max_kv_len=ctx + 1)
+        self.graph = None
+
+    def step_eager(self):
+        from ktransformers_amd._native import mla_cache_append
+
+        for a in range(self.nattn):
+            mla_cache_append(self.kv[a], self.new_ckv, self.new_kpe, self.page_idx, self.page_off)
+            ckv, k_pe = torch.split(self.kv[a], [512, 64], dim=-1)
+            self.attn_out = self.mla.run(self.qn, self.qp, ckv, k_pe)
+            li = a - (self.nattn - len(self.layers))
+            if li >= 0:
+                ids, w = self.gate.forward(self.x, self.gate_w[li], self.gate_b[li])
+                self.layers[li].forward(self.x, ids, w, out=self.y[li & 1])
+
+    def capture(self):
+        self.step_eager()
+        torch.cuda.synchronize(self.dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph):
+            self.step_eager()
+        torch.cuda.synchronize(self.dev)
+
+    def step(self, i):
+        self.x.copy_(self.x_all[i % self.nsets])
         if self.graph is not None:
             self.graph.replay()
         else:
@@ -218,6 +286,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--hot-path", default="full", choices=["full", "moe"],
+                    help="full: MLA attention + router + routed experts per layer; moe: routed experts only")
+    ap.add_argument("--ctx", type=int, default=4096, help="cached tokens the MLA decode attends over")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(WORKLOADS[args.workload])), flush=True)
@@ -257,7 +328,7 @@ def main():
         step = runner.step
         tokens_per_step = world  # one token per rank per step
     else:
-        r = DecodeRunner(wl, layers, T=1, dev=dev)
+        r = FullDecodeRunner(wl, layers, dev, ctx=args.ctx) if args.hot_path == "full" else DecodeRunner(wl, layers, T=1, dev=dev)
         if not args.no_graph:
             r.capture()
         step = r.step
@@ -267,13 +338,16 @@ def main():
     decode_tps = tokens_per_step * args.steps / dt
 
     out = {
-        "metric": "decode tokens/s (routed-expert MoE hot path, int4 experts resident in HBM)",
+        "metric": "decode tokens/s (MoE + MLA hot path, int4 experts resident in HBM)",
         "value": round(decode_tps, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8xint4->int32 (bf16 io)", "data": "synthetic",
         "config": {"workload": wl["desc"], "hidden": H, "intermediate": I, "experts": E, "top_k": k, "moe_layers": L,
                    "batch_per_gpu": 1, "parallelism": f"ep{world}" if dist_on else "single",
-                   "hip_graph": not args.no_graph},
+                   "hip_graph": not args.no_graph,
+                   "step": ("MLA cache-append + absorbed paged attention (ctx %d, %d heads, %d layers) + router + routed "
+                            "experts (%d layers)" % (args.ctx, wl["heads"], wl["attn_layers"], L))
+                   if (args.hot_path == "full" and not dist_on) else "router-less routed experts only"},
     }
 
     if not dist_on:
@@ -301,6 +375,12 @@ def main():
             _native.lib.ktx_debug_set(2, 0)
             return tot / (R * L) * 1e3
 
+        # routed-experts-only decode rate, for continuity with earlier profiles
+        rm = DecodeRunner(wl, layers, T=1, dev=dev)
+        rm.capture()
+        dtm = timed(rm.step, max(50, args.steps // 2), 10, dev, False)
+        out["moe_only"] = {"value": round(max(50, args.steps // 2) / dtm, 2), "unit": "tok/s",
+                           "ms_per_step": round(dtm / max(50, args.steps // 2) * 1e3, 4)}
         gu_us = kernel_only_us(1)
         dn_us = kernel_only_us(2)
         gu_bytes = k * 2 * I * H * 0.5 + k * 2 * I * 4 + H * 2  # packed gate+up of k experts + fp32 row scales + bf16 x row

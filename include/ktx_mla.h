@@ -27,6 +27,7 @@ typedef struct ktx_mla_config {
   int32_t page_size;      /* tokens per page (64 single-request cache, 256 server cache) */
   float sm_scale;         /* softmax_scale = q_head_dim^-0.5 * mscale^2 (modeling_deepseek_v3.py:697-703) */
   int32_t max_splits;     /* upper bound on KV splits the workspace was sized for (>=1) */
+  int32_t kv_len_hint;    /* host-side upper bound of the context length (0 = unknown): only steers the split count */
 } ktx_mla_config;
 
 /* bytes of scratch needed for `max_q_tokens` query tokens (fp32 partial outputs + softmax stats per KV split) */

@@ -29,7 +29,7 @@ class _GateConfig(C.Structure):
 
 class _MlaConfig(C.Structure):
     _fields_ = [("num_heads", C.c_int32), ("head_dim_ckv", C.c_int32), ("head_dim_kpe", C.c_int32),
-                ("page_size", C.c_int32), ("sm_scale", C.c_float), ("max_splits", C.c_int32)]
+                ("page_size", C.c_int32), ("sm_scale", C.c_float), ("max_splits", C.c_int32), ("kv_len_hint", C.c_int32)]
 
 
 class _MoeConfig(C.Structure):
@@ -261,7 +261,7 @@ class MLAWrapper:
     planning step, so a captured graph stays valid when their contents change."""
 
     def __init__(self, max_batch_size: int, max_pages: int, use_cuda_graph: bool = True, device="cuda",
-                 max_q_tokens: int | None = None, max_splits: int = 64):
+                 max_q_tokens: int | None = None, max_splits: int = 256):
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
         if self.device.type != "cuda":
             raise KtxError("MLAWrapper needs a HIP device; there is no CPU path")
@@ -279,7 +279,7 @@ class MLAWrapper:
         self.need_plan = True
 
     def plan(self, qo_indptr, kv_indptr, kv_indices, kv_len_arr, bsz_tensor, num_heads, head_dim_ckv, head_dim_kpe,
-             page_size, sm_scale, q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16):
+             page_size, sm_scale, q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16, max_kv_len: int = 0):
         if q_data_type != torch.bfloat16 or kv_data_type != torch.bfloat16:
             raise KtxError("MLAWrapper: bf16 q/kv only")
         self.qo_indptr = qo_indptr if qo_indptr is not None else self.qo_indptr_buf
@@ -287,7 +287,8 @@ class MLAWrapper:
         self.kv_indices = kv_indices if kv_indices is not None else self.kv_indices_buf
         self.bsz_tensor = bsz_tensor if bsz_tensor is not None else getattr(self, "batch_size_tensor_buf", None)
         self.kv_len_arr = kv_len_arr
-        self.cfg = _MlaConfig(num_heads, head_dim_ckv, head_dim_kpe, page_size, float(sm_scale), self.max_splits)
+        self.cfg = _MlaConfig(num_heads, head_dim_ckv, head_dim_kpe, page_size, float(sm_scale), self.max_splits,
+                              int(max_kv_len))
         need = int(lib.ktx_mla_workspace_bytes(C.byref(self.cfg), self.max_q_tokens))
         if self.workspace is None or self.workspace.numel() < need:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
@@ -324,7 +325,7 @@ def mla_cache_append(kv_cache: torch.Tensor, ckv_new: torch.Tensor, kpe_new: tor
     """kv_cache bf16 [pages, page_size, (1,) 576]; scatter T rows (StaticCache.update, custom_cache.py:189-195)."""
     page_size = kv_cache.shape[1]
     ts = kv_cache.stride(1)
-    cfg = _MlaConfig(16, 512, 64, page_size, 1.0, 1)
+    cfg = _MlaConfig(16, 512, 64, page_size, 1.0, 1, 0)
     T = ckv_new.shape[0]
     # keep the converted temporaries alive until the launch is enqueued (stream-ordered allocator reuse is then safe)
     c, r = ckv_new.contiguous(), kpe_new.contiguous()

@@ -7,9 +7,10 @@
 //
 // Workgroup = NWV waves; each wave owns 16 heads (Q fragments and the 16x512 fp32 output tile live in registers), all
 // waves share one staged 32-token KV tile in LDS:
-//   Kt [32][576+8]  bf16 row-major (pad 16 B)  -> B operand of S = Q K^T  (16-byte reads, token = lane&15)
-//   Vt [512][32+8]  bf16 transposed            -> B operand of O += P V   (16-byte reads, dim = lane&15)
-//   Pt [NWV][16][32] bf16                      -> P re-laid from the MFMA C layout to the A layout (wave-private)
+//   Kt [32][576+8]  bf16 row-major (pad 16 B), ckv rows land by LDS-DMA (global_load_lds, 1 KiB per wave-instruction)
+//        -> B operand of S = Q K^T   : ds_read_b128, token = lane&15
+//        -> B operand of O += P V    : ds_read_b64_tr_b16 x2 (hardware transpose: 8 tokens of one dim per lane)
+//   Pt [NWV][16][32] bf16            : P re-laid from the MFMA C layout to the A layout (wave-private)
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -23,8 +24,7 @@ typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 #define MLA_TILE 32
 #define MLA_DC 512
 #define MLA_DR 64
-#define MLA_KROW (MLA_DC + MLA_DR + 8)   // 584 elements = 1168 B
-#define MLA_VROW (MLA_TILE + 8)          // 40 elements = 80 B
+#define MLA_KROW (MLA_DC + MLA_DR + 8)   // 584 elements = 1168 B (73 x 16 B: rows rotate through the 16-B bank slots)
 
 struct MlaParams {
   const bf16_t *q_nope, *q_pe, *ckv, *k_pe;
@@ -36,19 +36,34 @@ struct MlaParams {
   float* part_ml;  // [total_q][Hq][nsplit][2]
 };
 
+typedef short v4s16 __attribute__((ext_vector_type(4)));
+
 __device__ __forceinline__ v8bf as_v8bf(const uint4& u) {
   union { uint4 u; v8bf v; } c;
   c.u = u;
   return c.v;
 }
 
+// B operand of O += P V straight from the row-major K tile: two hardware-transposed LDS reads (ds_read_b64_tr_b16).
+// Within a 16-lane group, lane i supplies the address of a 4-element chunk (row i/4, cols (i%4)*4..+3) of a
+// [4 tokens][16 dims] block and receives column i of it, i.e. 4 consecutive tokens of one dim (probed on gfx950:
+// scripts/tr_probe.hip).  base points at [token (lane>>4)*8 + ((lane&15)>>2)][dim0 + (lane&3)*4].
+__device__ __forceinline__ v8bf load_v_frag(const bf16_t* base) {
+  typedef __attribute__((address_space(3))) v4s16 lds_v4;
+  const v4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base));
+  const v4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base + 4 * MLA_KROW));
+  union { v4s16 h[2]; v8bf v; } c;
+  c.h[0] = lo;
+  c.h[1] = hi;
+  return c.v;
+}
+
 template <int NWV>
 __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [32][584]
-  bf16_t* Vt = Kt + MLA_TILE * MLA_KROW;                               // [512][40]
-  bf16_t* Pt = Vt + MLA_DC * MLA_VROW;                                 // [NWV][16][32]
-  __shared__ int s_req[4];  // request id, kv_end, page base, first tile / tile count packed below
+  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [32][584] row-major [ckv | k_pe | pad]
+  bf16_t* Pt = Kt + MLA_TILE * MLA_KROW;                               // [NWV][16][32]
+  int* s_req = reinterpret_cast<int*>(Pt + NWV * 16 * MLA_TILE);       // [4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, hb = blockIdx.y, qt = blockIdx.z;
@@ -80,98 +95,106 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
   const int per = (ntiles + p.nsplit - 1) / p.nsplit;
   const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
 
-  // ---- Q fragments: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope) ------------
-  v8bf qf[18];
-  {
-    const int h = head0 + (lane & 15);
-    const bf16_t* qn = p.q_nope + ((size_t)qt * p.Hq + h) * MLA_DC + (lane >> 4) * 8;
-    const bf16_t* qr = p.q_pe + ((size_t)qt * p.Hq + h) * MLA_DR + (lane >> 4) * 8;
-#pragma unroll
-    for (int s = 0; s < 16; s++) qf[s] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
-#pragma unroll
-    for (int s = 0; s < 2; s++) qf[16 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
-  }
-
   v4f o[32];
 #pragma unroll
   for (int i = 0; i < 32; i++) o[i] = v4f{0.f, 0.f, 0.f, 0.f};
   float m_run[4], l_run[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) { m_run[r] = -__builtin_inff(); l_run[r] = 0.f; }
-  bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
 
-  for (int tile = t_begin; tile < t_end; tile++) {
-    const int tok0 = tile * MLA_TILE;
-    __syncthreads();  // previous tile fully consumed
-    // ---- stage the tile: 32 tokens x (512 + 64) bf16; each thread moves 16-byte pieces ----------------------------
-    for (int u = tid; u < MLA_TILE * 72; u += NWV * 64) {  // 72 = 576/8 pieces per token
-      const int tk = u / 72, piece = u % 72;
-      const int pos = tok0 + tk;
-      uint4 v = make_uint4(0, 0, 0, 0);
-      if (pos < kv_end) {
-        const int page = p.kv_indices[page_base + pos / p.page_size];
-        const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
-        if (piece < 64) v = *reinterpret_cast<const uint4*>(p.ckv + trow * p.ckv_ts + piece * 8);
-        else v = *reinterpret_cast<const uint4*>(p.k_pe + trow * p.kpe_ts + (piece - 64) * 8);
-      }
-      *reinterpret_cast<uint4*>(Kt + tk * MLA_KROW + piece * 8) = v;
-      if (piece < 64) {  // transposed copy for the PV GEMM
-        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  if (t_begin < t_end) {
+    // ---- Q fragments: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope) ----------
+    v8bf qf[18];
+    {
+      const int h = head0 + (lane & 15);
+      const bf16_t* qn = p.q_nope + ((size_t)qt * p.Hq + h) * MLA_DC + (lane >> 4) * 8;
+      const bf16_t* qr = p.q_pe + ((size_t)qt * p.Hq + h) * MLA_DR + (lane >> 4) * 8;
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          Vt[(piece * 8 + 2 * q) * MLA_VROW + tk] = (bf16_t)(w[q] & 0xffffu);
-          Vt[(piece * 8 + 2 * q + 1) * MLA_VROW + tk] = (bf16_t)(w[q] >> 16);
+      for (int s = 0; s < 16; s++) qf[s] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
+#pragma unroll
+      for (int s = 0; s < 2; s++) qf[16 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
+    }
+    bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
+    // a tile never straddles a page when page_size is a multiple of the tile; otherwise look every row up
+    const bool tile_in_page = (p.page_size % MLA_TILE) == 0;
+
+    for (int tile = t_begin; tile < t_end; tile++) {
+      const int tok0 = tile * MLA_TILE;
+      const int ntok = min(MLA_TILE, kv_end - tok0);
+      const int page0 = p.kv_indices[page_base + tok0 / p.page_size];   // one lookup per tile in the common case
+      __syncthreads();  // previous tile fully consumed
+      // ---- stage 32 token rows.  ckv: one 1-KiB row per wave-instruction, straight into LDS (global_load_lds) -----
+      for (int r = wave; r < MLA_TILE; r += NWV) {
+        if (r < ntok) {
+          const int pos = tok0 + r;
+          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
+          const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
+          __builtin_amdgcn_global_load_lds(
+              (const __attribute__((address_space(1))) void*)(p.ckv + trow * p.ckv_ts + lane * 8),
+              (__attribute__((address_space(3))) void*)(Kt + r * MLA_KROW), 16, 0, 0);
+        } else {  // rows past the end must be finite: P is 0 there and 0 * NaN would poison the output
+          *reinterpret_cast<uint4*>(Kt + r * MLA_KROW + lane * 8) = make_uint4(0, 0, 0, 0);
         }
       }
-    }
-    __syncthreads();
+      for (int u = tid; u < MLA_TILE * 8; u += NWV * 64) {  // k_pe: 32 rows x 8 pieces of 16 B through registers
+        const int r = u >> 3, piece = u & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (r < ntok) {
+          const int pos = tok0 + r;
+          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
+          v = *reinterpret_cast<const uint4*>(p.k_pe + ((size_t)page * p.page_size + pos % p.page_size) * p.kpe_ts + piece * 8);
+        }
+        *reinterpret_cast<uint4*>(Kt + r * MLA_KROW + MLA_DC + piece * 8) = v;
+      }
+      __syncthreads();  // (drains the LDS-DMA: the compiler emits vmcnt(0) ahead of the barrier)
 
-    // ---- S = Q K^T for 2 x 16 tokens ---------------------------------------------------------------------------------
-    v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-    const bf16_t* kb0 = Kt + (lane & 15) * MLA_KROW + (lane >> 4) * 8;
-    const bf16_t* kb1 = kb0 + 16 * MLA_KROW;
+      // ---- S = Q K^T for 2 x 16 tokens -----------------------------------------------------------------------------
+      v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+      const bf16_t* kb0 = Kt + (lane & 15) * MLA_KROW + (lane >> 4) * 8;
+      const bf16_t* kb1 = kb0 + 16 * MLA_KROW;
 #pragma unroll
-    for (int s = 0; s < 18; s++) {
-      const v8bf b0 = as_v8bf(*reinterpret_cast<const uint4*>(kb0 + s * 32));
-      const v8bf b1 = as_v8bf(*reinterpret_cast<const uint4*>(kb1 + s * 32));
-      s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b0, s0, 0, 0, 0);
-      s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b1, s1, 0, 0, 0);
-    }
-    // lane holds S[head = (lane>>4)*4 + r][token = tok0 + (lane&15) (+16)]
-    const bool v0 = tok0 + (lane & 15) < kv_end, v1 = tok0 + 16 + (lane & 15) < kv_end;
-    float alpha[4];
+      for (int s = 0; s < 18; s++) {
+        const v8bf b0 = as_v8bf(*reinterpret_cast<const uint4*>(kb0 + s * 32));
+        const v8bf b1 = as_v8bf(*reinterpret_cast<const uint4*>(kb1 + s * 32));
+        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b0, s0, 0, 0, 0);
+        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b1, s1, 0, 0, 0);
+      }
+      // lane holds S[head = (lane>>4)*4 + r][token = tok0 + (lane&15) (+16)]
+      const bool v0 = (lane & 15) < ntok, v1 = 16 + (lane & 15) < ntok;
+      float alpha[4];
 #pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const float a = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
-      const float b = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
-      float mx = fmaxf(a, b);
+      for (int r = 0; r < 4; r++) {
+        const float a = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
+        const float b = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
+        float mx = fmaxf(a, b);
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
-      const float m_new = fmaxf(m_run[r], mx);        // finite: every processed tile has >= 1 visible token
-      const float pa = __expf(a - m_new), pb = __expf(b - m_new);
-      float sum = pa + pb;
+        for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float m_new = fmaxf(m_run[r], mx);        // finite: every processed tile has >= 1 visible token
+        const float pa = __expf(a - m_new), pb = __expf(b - m_new);
+        float sum = pa + pb;
 #pragma unroll
-      for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
-      alpha[r] = __expf(m_run[r] - m_new);
-      l_run[r] = l_run[r] * alpha[r] + sum;
-      m_run[r] = m_new;
-      // P to LDS in [head][token] order for the A-operand re-read
-      const int hrow = (lane >> 4) * 4 + r;
-      Pw[hrow * MLA_TILE + (lane & 15)] = f32_to_bf16(pa);
-      Pw[hrow * MLA_TILE + 16 + (lane & 15)] = f32_to_bf16(pb);
-    }
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
-    __builtin_amdgcn_wave_barrier();
-    const v8bf pf = as_v8bf(*reinterpret_cast<const uint4*>(Pw + (lane & 15) * MLA_TILE + (lane >> 4) * 8));
+        for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        alpha[r] = __expf(m_run[r] - m_new);
+        l_run[r] = l_run[r] * alpha[r] + sum;
+        m_run[r] = m_new;
+        // P to LDS in [head][token] order for the A-operand re-read
+        const int hrow = (lane >> 4) * 4 + r;
+        Pw[hrow * MLA_TILE + (lane & 15)] = f32_to_bf16(pa);
+        Pw[hrow * MLA_TILE + 16 + (lane & 15)] = f32_to_bf16(pb);
+      }
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+      __builtin_amdgcn_wave_barrier();
+      const v8bf pf = as_v8bf(*reinterpret_cast<const uint4*>(Pw + (lane & 15) * MLA_TILE + (lane >> 4) * 8));
 
-    // ---- O = O*alpha + P V --------------------------------------------------------------------------------------------
-    const bf16_t* vb = Vt + (lane & 15) * MLA_VROW + (lane >> 4) * 8;
+      // ---- O = O*alpha + P V ; V fragments by transposed reads of the same K tile ------------------------------------
+      const bf16_t* vb = Kt + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * MLA_KROW + (lane & 3) * 4;
 #pragma unroll
-    for (int i = 0; i < 32; i++) {
+      for (int i = 0; i < 32; i++) {
 #pragma unroll
-      for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
-      const v8bf b = as_v8bf(*reinterpret_cast<const uint4*>(vb + i * 16 * MLA_VROW));
-      o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
+        for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
+        const v8bf b = load_v_frag(vb + i * 16);
+        o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
+      }
     }
   }
 
@@ -179,48 +202,88 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int hrow = (lane >> 4) * 4 + r;
-    float* po = p.part_o + (pidx + (size_t)hrow * p.nsplit) * MLA_DC;
-#pragma unroll
-    for (int i = 0; i < 32; i++) po[i * 16 + (lane & 15)] = o[i][r];
     if ((lane & 15) == 0) {
       float* ml = p.part_ml + (pidx + (size_t)hrow * p.nsplit) * 2;
       ml[0] = m_run[r];
       ml[1] = l_run[r];
     }
+    if (t_begin < t_end) {
+      float* po = p.part_o + (pidx + (size_t)hrow * p.nsplit) * MLA_DC;
+#pragma unroll
+      for (int i = 0; i < 32; i++) po[i * 16 + (lane & 15)] = o[i][r];
+    }
   }
 }
 
-// merge the KV splits: one wave per (query token, head); lane handles 8 of the 512 output dims
-__global__ __launch_bounds__(64) void mla_merge_kernel(MlaParams p, bf16_t* out, float* lse) {
-  const int qt = blockIdx.y, h = blockIdx.x, lane = threadIdx.x;
+// merge the KV splits: one 256-thread workgroup per (query token, head).  Softmax statistics are combined split-parallel,
+// the weights are parked in LDS, then wave w accumulates splits w, w+4, ... (8 of the 512 dims per lane) with
+// unconditional, independent loads (a dead split's load is redirected to a live one and weighted by 0), and the four
+// partial sums meet in LDS.
+__global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p, bf16_t* out, float* lse) {
+  __shared__ float s_w[1024];
+  __shared__ float s_red[8];
+  __shared__ int s_live;
+  __shared__ float s_acc[4][MLA_DC];
+  const int qt = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int B = p.batch;
   if (p.d_bsz) B = min(max(*p.d_bsz, 0), p.batch);
   if (qt >= p.qo_indptr[B]) return;
   const size_t base = ((size_t)qt * p.Hq + h) * p.nsplit;
+  if (tid == 0) s_live = 0x7fffffff;
+  __syncthreads();
   float mstar = -__builtin_inff();
-  for (int s = 0; s < p.nsplit; s++) {
-    const float l = p.part_ml[(base + s) * 2 + 1];
-    if (l > 0.f) mstar = fmaxf(mstar, p.part_ml[(base + s) * 2]);
+  int live = 0x7fffffff;
+  for (int s = tid; s < p.nsplit; s += 256) {
+    const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + (base + s) * 2);
+    if (ml.y > 0.f) { mstar = fmaxf(mstar, ml.x); live = min(live, s); }
   }
-  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  mstar = wave_max(mstar);
+  if (lane == 0) s_red[wave] = mstar;
+  if (live != 0x7fffffff) atomicMin(&s_live, live);
+  __syncthreads();
+  mstar = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   float lsum = 0.f;
-  for (int s = 0; s < p.nsplit; s++) {
-    const float l = p.part_ml[(base + s) * 2 + 1];
-    if (!(l > 0.f)) continue;
-    const float w = __expf(p.part_ml[(base + s) * 2] - mstar);
-    lsum += l * w;
-    const float* po = p.part_o + (base + s) * MLA_DC + lane * 8;
-    const float4 a = *reinterpret_cast<const float4*>(po), b = *reinterpret_cast<const float4*>(po + 4);
-    acc[0] += a.x * w; acc[1] += a.y * w; acc[2] += a.z * w; acc[3] += a.w * w;
-    acc[4] += b.x * w; acc[5] += b.y * w; acc[6] += b.z * w; acc[7] += b.w * w;
+  for (int s = tid; s < p.nsplit; s += 256) {
+    const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + (base + s) * 2);
+    const float w = ml.y > 0.f ? __expf(ml.x - mstar) : 0.f;
+    s_w[s] = w;
+    lsum += ml.y * w;
   }
-  const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-  uint32_t w[4];
 #pragma unroll
-  for (int q = 0; q < 4; q++)
-    w[q] = (uint32_t)f32_to_bf16(acc[2 * q] * inv) | ((uint32_t)f32_to_bf16(acc[2 * q + 1] * inv) << 16);
-  *reinterpret_cast<uint4*>(out + ((size_t)qt * p.Hq + h) * MLA_DC + lane * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-  if (lse && lane == 0) lse[(size_t)qt * p.Hq + h] = lsum > 0.f ? (mstar + __logf(lsum)) * 1.44269504089f : -__builtin_inff();
+  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+  if (lane == 0) s_red[4 + wave] = lsum;
+  __syncthreads();
+  lsum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
+  const int live0 = s_live;
+  float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (live0 != 0x7fffffff) {
+    const float* po = p.part_o + base * MLA_DC + lane * 8;
+#pragma unroll 4
+    for (int s = wave; s < p.nsplit; s += 4) {
+      const float w = s_w[s];
+      const int ss = w > 0.f ? s : live0;
+      const float4 a = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC);
+      const float4 b = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC + 4);
+      acc[0] += a.x * w; acc[1] += a.y * w; acc[2] += a.z * w; acc[3] += a.w * w;
+      acc[4] += b.x * w; acc[5] += b.y * w; acc[6] += b.z * w; acc[7] += b.w * w;
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < 8; q++) s_acc[wave][lane * 8 + q] = acc[q];
+  __syncthreads();
+  if (wave == 0) {
+    const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+    uint32_t w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const int d0 = lane * 8 + 2 * q;
+      const float v0 = (s_acc[0][d0] + s_acc[1][d0]) + (s_acc[2][d0] + s_acc[3][d0]);
+      const float v1 = (s_acc[0][d0 + 1] + s_acc[1][d0 + 1]) + (s_acc[2][d0 + 1] + s_acc[3][d0 + 1]);
+      w[q] = (uint32_t)f32_to_bf16(v0 * inv) | ((uint32_t)f32_to_bf16(v1 * inv) << 16);
+    }
+    *reinterpret_cast<uint4*>(out + ((size_t)qt * p.Hq + h) * MLA_DC + lane * 8) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (lse && lane == 0) lse[(size_t)qt * p.Hq + h] = lsum > 0.f ? (mstar + __logf(lsum)) * 1.44269504089f : -__builtin_inff();
+  }
 }
 
 __global__ void mla_cache_append_kernel(bf16_t* cache, long long ts, int page_size, const bf16_t* ckv, const bf16_t* kpe,
@@ -238,7 +301,11 @@ __global__ void mla_cache_append_kernel(bf16_t* cache, long long ts, int page_si
 
 extern "C" size_t ktx_mla_workspace_bytes(const ktx_mla_config* cfg, int max_q_tokens) {
   if (!cfg || max_q_tokens <= 0) return 0;
-  const size_t n = (size_t)max_q_tokens * cfg->num_heads * std::max(1, cfg->max_splits);
+  // one (O[512], m, l) record per (token, head, split).  The launcher never uses more than ~2048 workgroups, so beyond
+  // that the split count shrinks as the token count grows; it also clamps the split count to what the buffer holds.
+  const size_t per_split = (size_t)max_q_tokens * cfg->num_heads;
+  const size_t cap = (size_t)2048 * 64 + per_split;
+  const size_t n = std::max(per_split, std::min(per_split * (size_t)std::max(1, cfg->max_splits), cap));
   return n * (MLA_DC + 2) * sizeof(float);
 }
 
@@ -257,9 +324,13 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
   const int Hq = cfg->num_heads;
   const int nwv = (Hq % 64 == 0) ? 4 : 1;
   const int hblocks = Hq / (16 * nwv);
-  // enough workgroups to cover the chip a few times over, bounded by the workspace
-  int nsplit = std::max(1, 1024 / std::max(1, hblocks * total_q_tokens));
-  nsplit = std::min(nsplit, std::max(1, cfg->max_splits));
+  // KV splits: enough workgroups to cover the chip a few times over, one tile of 32 tokens per split when the caller
+  // gives a context-length hint (every extra split costs the merge kernel a partial to read), bounded by the workspace
+  int nsplit = std::max(1, 2048 / std::max(1, hblocks * total_q_tokens));
+  if (cfg->kv_len_hint > 0) nsplit = std::min(nsplit, std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE));
+  nsplit = std::min(nsplit, std::min(1024, std::max(1, cfg->max_splits)));
+  nsplit = (int)std::min<size_t>((size_t)nsplit, workspace_bytes / ((size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float)));
+  KTX_REQUIRE(nsplit >= 1, "ktx_mla_decode: workspace too small");
   const size_t need = (size_t)total_q_tokens * Hq * nsplit * (MLA_DC + 2) * sizeof(float);
   KTX_REQUIRE(workspace_bytes >= need, "ktx_mla_decode: workspace too small");
   MlaParams p;
@@ -270,7 +341,7 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
   p.sm_scale = cfg->sm_scale;
   p.part_o = (float*)d_workspace;
   p.part_ml = p.part_o + (size_t)total_q_tokens * Hq * nsplit * MLA_DC;
-  const size_t lds = (size_t)(MLA_TILE * MLA_KROW + MLA_DC * MLA_VROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t);
+  const size_t lds = (size_t)(MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
   const dim3 grid(nsplit, hblocks, total_q_tokens);
   if (nwv == 4) {
     static hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<4>),
@@ -284,7 +355,7 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
     hipLaunchKernelGGL(mla_decode_kernel<1>, grid, dim3(64), lds, st, p);
   }
   KTX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(mla_merge_kernel, dim3(Hq, total_q_tokens), dim3(64), 0, st, p, (bf16_t*)d_out, d_lse);
+  hipLaunchKernelGGL(mla_merge_kernel, dim3(Hq, total_q_tokens), dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
   KTX_HIP(hipGetLastError());
   return 0;
 }
