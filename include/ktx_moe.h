@@ -73,6 +73,13 @@ int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_up, const v
  * Mirrors the pre-quantised branch of load_weights (operators/amx/moe.hpp:266-300). Synchronous. */
 int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, const float* scale);
 
+/* FP8 (DeepSeek block-fp8) experts: e4m3 bytes gate/up [expert_num][I][H], down [expert_num][H][I] and fp32
+ * scale_inv [expert_num][N/128][K/128] per matrix, DEVICE pointers — the "native weight" load of AMX_FP8_MOE_TP
+ * (operators/amx/fp8-moe.hpp:180-240; layout of BufferBFP8Impl, amx/la/amx_raw_buffers.hpp:285-330).  For KTX_FMT_BF16
+ * handles ktx_moe_load_bf16 stores the weights as they are (re-tiled).  Synchronous. */
+int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, const float* d_gate_scale,
+                     const float* d_up_scale, const float* d_down_scale);
+
 /* should_skip_expert mask (operators/common.hpp:241-258): mask[e] != 0 => expert e contributes nothing. HOST ptr, may be NULL. */
 int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask);
 

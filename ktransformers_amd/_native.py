@@ -49,6 +49,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_destroy.argtypes = [C.c_void_p]
     lib.ktx_moe_load_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_moe_load_quantized.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ktx_moe_load_fp8.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -140,6 +141,23 @@ class MoEHandle:
                 raise KtxError(f"load_bf16: expected contiguous bf16 {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
         torch.cuda.synchronize(self.device)
         check(lib.ktx_moe_load_bf16(self._h, gate.data_ptr(), up.data_ptr(), down.data_ptr()))
+
+    def load_fp8(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_scale: torch.Tensor,
+                 up_scale: torch.Tensor, down_scale: torch.Tensor) -> None:
+        """DeepSeek block-fp8 experts: uint8/float8_e4m3fn [E,I,H]/[E,I,H]/[E,H,I] + fp32 scale_inv [E,N/128,K/128]."""
+        ws = []
+        for t, shape in ((gate, (self.E, self.I, self.H)), (up, (self.E, self.I, self.H)), (down, (self.E, self.H, self.I))):
+            if t.element_size() != 1 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
+                raise KtxError(f"load_fp8: expected contiguous 1-byte {shape} on {self.device}")
+            ws.append(t)
+        ss = []
+        for t, (n, kk) in ((gate_scale, (self.I, self.H)), (up_scale, (self.I, self.H)), (down_scale, (self.H, self.I))):
+            if t.dtype != torch.float32 or tuple(t.shape) != (self.E, n // 128, kk // 128) or not t.is_contiguous() or t.device != self.device:
+                raise KtxError("load_fp8: scale_inv must be contiguous fp32 [E, N/128, K/128] on the handle's device")
+            ss.append(t)
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_moe_load_fp8(self._h, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ss[0].data_ptr(),
+                                   ss[1].data_ptr(), ss[2].data_ptr()))
 
     def load_quantized(self, expert: int, which: int, q, scale) -> None:
         """One expert matrix from host int8 [N,K] multiplicands + fp32 [N] scales (numpy arrays)."""

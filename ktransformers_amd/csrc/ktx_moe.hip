@@ -875,6 +875,244 @@ __global__ void pack_w8_kernel(const int8_t* __restrict__ q, int N, int K, uint3
 }
 
 // =====================================================================================================
+// FP8 (DeepSeek e4m3, 128x128 block scale_inv) and BF16 experts: bf16 activations, bf16 MFMA, fp32 accumulation.
+// Reference: AMX_FP8_MOE_TP / AMX_BF16_MOE_TP (operators/amx/fp8-moe.hpp:93-108, bf16-moe.hpp) over
+// GemmKernel224FP8 / GemmKernel224BF16 (operators/amx/la/amx_raw_kernels.hpp:17-566): weights are widened to bf16
+// exactly, activations are NOT quantised, products accumulate in fp32 (per 128-K group for FP8, then
+// c = fma(group_sum, scale_inv[n/128][k/128], c)), every stage output is rounded to bf16.
+// The reference's fp32 summation order inside a group is a sequential VDPBF16PS chain (and differs again on its AMX tile
+// path); the MFMA sums the same exact products in a different order, so outputs agree to fp32 rounding of the group
+// sums (tests: <= 1 bf16 ulp on a small fraction of elements), not bit-for-bit.
+//
+// W tile layout for these formats (k-step = 128, four 16x16x32 MFMAs j = 0..3; fragment element e <-> k = ks*128 +
+// kc*32 + j*8 + e):  FP8: tile 2048 B, lane l owns bytes [l*16, +16) of each of two 1 KiB halves (elements 0..15, 16..31
+// of its 32-k run);  BF16: tile 4096 B, four 1 KiB quarters, quarter j = the lane's fragment for MFMA j.
+// Activations are staged per 256-k chunk as [mt][col = 32][tok = 16][16 B] (same conflict-free scheme as the int path).
+// =====================================================================================================
+typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
+
+__device__ __forceinline__ v8bf u4_as_v8bf(const uint4& u) {
+  union { uint4 u; v8bf v; } c;
+  c.u = u;
+  return c.v;
+}
+
+// 4 e4m3 bytes -> 4 bf16 (two dwords): v_cvt_pk_f32_fp8 is exact, and every e4m3 value is exact in bf16, so taking the
+// upper halves of the fp32 results is exact (OCP e4m3fn on gfx950; 0x7F/0xFF are NaN here, +-480 in the reference's LUT).
+__device__ __forceinline__ uint2 fp8x4_to_bf16x4(uint32_t v) {
+  typedef float v2f __attribute__((ext_vector_type(2)));
+  const v2f lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false);
+  const v2f hi = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
+  const uint32_t a = __float_as_uint(lo[0]), b = __float_as_uint(lo[1]), c = __float_as_uint(hi[0]), d = __float_as_uint(hi[1]);
+  return make_uint2((a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u));
+}
+
+struct FpGemmParams {
+  const uint8_t *w0, *w1;     // tiled weights (gate | down, up)
+  const float *s0, *s1;       // FP8: scale_inv [E][N/128][K/128]; BF16: nullptr
+  size_t expert_stride;       // bytes per expert matrix
+  size_t scale_stride;        // floats per expert
+  int N, K;
+  const bf16_t* act;          // [src rows][K] bf16
+  const int32_t* row_src;     // sorted row -> source row (nullptr: identity)
+  const Tile* tiles;
+  const int32_t* counters;
+  bf16_t* out;                // [sorted rows][N]
+};
+
+template <bool FP8, int MT, bool GATE_UP>
+__global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
+  constexpr int NMAT = GATE_UP ? 2 : 1;
+  constexpr int SPC = 2;                      // k-steps per chunk
+  constexpr int COLS = SPC * 16;              // 16-byte columns per chunk (128 bf16 = 256 B per step)
+  constexpr int BUF_BYTES = MT * COLS * 256;
+  constexpr int GROUPS = MT * COLS / 4;       // staging groups of (16 tok x 4 cols)
+  constexpr int UPT = (GROUPS + 3) / 4;
+  constexpr int TILE_BYTES = FP8 ? 2048 : 4096;
+  constexpr int NQ = FP8 ? 2 : 4;             // uint4 per lane per k-step per matrix
+
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* Bs = smem;                                            // [2][BUF_BYTES]
+  int* s_src = reinterpret_cast<int*>(smem + 2 * BUF_BYTES);     // [MT*16]
+
+  const int tile_idx = blockIdx.y;
+  if (tile_idx >= p.counters[0]) return;
+  const Tile tile = p.tiles[tile_idx];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = blockIdx.x * 4 + wave;
+  const int NKS = p.K / 128;
+  const int NC = (NKS + SPC - 1) / SPC;
+  const bool strip_ok = strip * 16 < p.N;
+
+  if (tid < MT * 16) s_src[tid] = tid < tile.nrows ? (p.row_src ? p.row_src[tile.row0 + tid] : tile.row0 + tid) : -1;
+  __syncthreads();
+
+  const uint8_t* wbase[NMAT];
+  const float* sbase[NMAT];
+  wbase[0] = p.w0 + (size_t)tile.expert * p.expert_stride + (size_t)strip * NKS * TILE_BYTES;
+  sbase[0] = FP8 ? p.s0 + (size_t)tile.expert * p.scale_stride + (size_t)(strip * 16 / 128) * NKS : nullptr;
+  if constexpr (GATE_UP) {
+    wbase[1] = p.w1 + (size_t)tile.expert * p.expert_stride + (size_t)strip * NKS * TILE_BYTES;
+    sbase[1] = FP8 ? p.s1 + (size_t)tile.expert * p.scale_stride + (size_t)(strip * 16 / 128) * NKS : nullptr;
+  }
+
+  v4f acc[NMAT][MT];
+#pragma unroll
+  for (int m = 0; m < NMAT; m++)
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[m][t] = v4f{0.f, 0.f, 0.f, 0.f};
+
+  uint4 wA[SPC][NMAT][NQ], wB[SPC][NMAT][NQ];
+  uint4 breg[UPT];
+
+  auto load_w = [&](uint4(&dst)[SPC][NMAT][NQ], int c) {
+#pragma unroll
+    for (int s = 0; s < SPC; s++) {
+      const int ks = c * SPC + s;
+      if (strip_ok && ks < NKS) {
+#pragma unroll
+        for (int m = 0; m < NMAT; m++)
+#pragma unroll
+          for (int q = 0; q < NQ; q++)
+            dst[s][m][q] = *reinterpret_cast<const uint4*>(wbase[m] + (size_t)ks * TILE_BYTES + q * 1024 + lane * 16);
+      }
+    }
+  };
+  auto load_b = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < UPT; it++) {
+      const int g = it * 4 + wave;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (g < GROUPS) {
+        const int mt = g / (COLS / 4), col = (g % (COLS / 4)) * 4 + (lane >> 4);
+        const int src = s_src[mt * 16 + (lane & 15)];
+        const int kb = c * SPC * 128 + col * 8;   // bf16 element index of this 16-byte column
+        if (src >= 0 && kb < p.K) v = *reinterpret_cast<const uint4*>(p.act + (size_t)src * p.K + kb);
+      }
+      breg[it] = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+#pragma unroll
+    for (int it = 0; it < UPT; it++) {
+      const int g = it * 4 + wave;
+      if (g < GROUPS) {
+        const int mt = g / (COLS / 4), col = (g % (COLS / 4)) * 4 + (lane >> 4);
+        *reinterpret_cast<uint4*>(Bs + buf * BUF_BYTES + ((mt * COLS + col) * 16 + (lane & 15)) * 16) = breg[it];
+      }
+    }
+  };
+  auto compute = [&](uint4(&w)[SPC][NMAT][NQ], int c, int buf) {
+    if (!strip_ok) return;
+    // B fragment of MFMA j in step s: column s*16 + kc*4 + j, token lane&15
+    const uint8_t* bb = Bs + buf * BUF_BYTES + ((lane >> 4) * 4 * 16 + (lane & 15)) * 16;
+#pragma unroll
+    for (int s = 0; s < SPC; s++) {
+      const int ks = c * SPC + s;
+      if (ks < NKS) {
+        v8bf a[NMAT][4];
+#pragma unroll
+        for (int m = 0; m < NMAT; m++) {
+          if constexpr (FP8) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+              const uint2 e0 = fp8x4_to_bf16x4(w[s][m][q].x), e1 = fp8x4_to_bf16x4(w[s][m][q].y);
+              const uint2 e2 = fp8x4_to_bf16x4(w[s][m][q].z), e3 = fp8x4_to_bf16x4(w[s][m][q].w);
+              a[m][q * 2] = u4_as_v8bf(make_uint4(e0.x, e0.y, e1.x, e1.y));
+              a[m][q * 2 + 1] = u4_as_v8bf(make_uint4(e2.x, e2.y, e3.x, e3.y));
+            }
+          } else {
+#pragma unroll
+            for (int j = 0; j < 4; j++) a[m][j] = u4_as_v8bf(w[s][m][j]);
+          }
+        }
+        float sc[NMAT];
+#pragma unroll
+        for (int m = 0; m < NMAT; m++) sc[m] = FP8 ? sbase[m][ks] : 1.0f;
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+          v4f tmp[NMAT];
+#pragma unroll
+          for (int m = 0; m < NMAT; m++) tmp[m] = FP8 ? v4f{0.f, 0.f, 0.f, 0.f} : acc[m][t];
+#pragma unroll
+          for (int j = 0; j < 4; j++) {
+            const v8bf b = u4_as_v8bf(*reinterpret_cast<const uint4*>(bb + ((t * COLS + s * 16 + j) * 16) * 16));
+#pragma unroll
+            for (int m = 0; m < NMAT; m++) tmp[m] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[m][j], b, tmp[m], 0, 0, 0);
+          }
+#pragma unroll
+          for (int m = 0; m < NMAT; m++) {
+            if constexpr (FP8) {
+#pragma unroll
+              for (int r = 0; r < 4; r++) acc[m][t][r] = fmaf(tmp[m][r], sc[m], acc[m][t][r]);  // apply_scale_kgroup
+            } else {
+              acc[m][t] = tmp[m];
+            }
+          }
+        }
+      }
+    }
+  };
+
+  load_w(wA, 0);
+  load_b(0);
+  store_b(0);
+  __syncthreads();
+  for (int c = 0; c < NC; c += 2) {
+    if (c + 1 < NC) { load_b(c + 1); load_w(wB, c + 1); }
+    compute(wA, c, 0);
+    if (c + 1 < NC) store_b(1);
+    __syncthreads();
+    if (c + 1 < NC) {
+      if (c + 2 < NC) { load_b(c + 2); load_w(wA, c + 2); }
+      compute(wB, c + 1, 1);
+      if (c + 2 < NC) store_b(0);
+      __syncthreads();
+    }
+  }
+
+  if (!strip_ok) return;
+  const int tok = lane & 15;
+  const int n0 = strip * 16 + (lane >> 4) * 4;
+#pragma unroll
+  for (int t = 0; t < MT; t++) {
+    const int row = t * 16 + tok;
+    if (row < tile.nrows) {
+      bf16_t o[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const bf16_t g = f32_to_bf16(acc[0][t][r]);
+        if constexpr (GATE_UP) {
+          const bf16_t u = f32_to_bf16(acc[1][t][r]);
+          o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
+        } else {
+          o[r] = g;
+        }
+      }
+      *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * p.N + n0) =
+          make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+    }
+  }
+}
+
+// row-major [N][K] (fp8 bytes or bf16) -> W tiles of the fp formats; one thread per 16-byte piece
+__global__ void pack_wfp_kernel(const uint8_t* __restrict__ src, int N, int K, int fp8, uint4* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int esz = fp8 ? 1 : 2, nq = fp8 ? 2 : 4, per16 = 16 / esz;   // elements per 16-byte piece
+  const size_t total = (size_t)N * K * esz / 16;
+  if (idx >= total) return;
+  const int NKS = K / 128;
+  const size_t tile = idx / (64 * nq);
+  const int within = (int)(idx % (64 * nq));
+  const int q = within / 64, lane = within % 64;
+  const int strip = (int)(tile / NKS), ks = (int)(tile % NKS);
+  const int i = lane & 15, kc = lane >> 4;
+  const size_t k0 = (size_t)ks * 128 + kc * 32 + q * per16;
+  out[idx] = *reinterpret_cast<const uint4*>(src + ((size_t)(strip * 16 + i) * K + k0) * esz);
+}
+
+// =====================================================================================================
 // host side
 // =====================================================================================================
 // Scratch for one forward.  Like the reference's shared_mem_buffer arena (cpu_backend/shared_mem_buffer.h:37-55) it is
@@ -921,8 +1159,11 @@ static int pick_mt(int qlen, int k, int E) {
 
 extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_REQUIRE(cfg && out, "ktx_moe_create: null argument");
-  KTX_REQUIRE(cfg->format == KTX_FMT_AMXINT4 || cfg->format == KTX_FMT_AMXINT8,
-              "ktx_moe_create: format not supported by this build (AMXINT4, AMXINT8)");
+  KTX_REQUIRE(cfg->format == KTX_FMT_AMXINT4 || cfg->format == KTX_FMT_AMXINT8 || cfg->format == KTX_FMT_FP8 ||
+                  cfg->format == KTX_FMT_BF16,
+              "ktx_moe_create: format not supported by this build (AMXINT4, AMXINT8, FP8, BF16)");
+  KTX_REQUIRE(cfg->format != KTX_FMT_FP8 || cfg->group_size == 0 || cfg->group_size == 128,
+              "ktx_moe_create: FP8 supports 128x128 block scales only");
   KTX_REQUIRE(cfg->expert_num > 0 && cfg->expert_num <= KTX_EMAX, "ktx_moe_create: expert_num out of range (1..1024)");
   KTX_REQUIRE(cfg->num_experts_per_tok > 0, "ktx_moe_create: num_experts_per_tok must be positive");
   KTX_REQUIRE(cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0,
@@ -932,7 +1173,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   ktx_moe_s* h = new ktx_moe_s();
   h->cfg = *cfg;
   if (h->cfg.global_expert_num <= 0) h->cfg.global_expert_num = cfg->expert_num;
-  h->wbits = cfg->format == KTX_FMT_AMXINT4 ? 4 : 8;
+  h->wbits = cfg->format == KTX_FMT_AMXINT4 ? 4 : (cfg->format == KTX_FMT_BF16 ? 16 : 8);
   const size_t E = cfg->expert_num, H = cfg->hidden_size, I = cfg->intermediate_size;
   h->gu_stride = I * H * h->wbits / 8;
   h->dn_stride = H * I * h->wbits / 8;
@@ -1003,6 +1244,22 @@ extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_
   KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_bf16: null argument");
   KTX_HIP(hipSetDevice(h->cfg.device));
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  KTX_REQUIRE(h->cfg.format != KTX_FMT_FP8, "ktx_moe_load_bf16: FP8 handles take pre-quantised weights (ktx_moe_load_fp8)");
+  if (h->cfg.format == KTX_FMT_BF16) {  // no quantisation: re-tile only (BufferBBF16Impl::from_mat is a re-layout too)
+    const size_t pieces = (size_t)I * H * 2 / 16;
+    for (int e = 0; e < E; e++) {
+      const uint8_t* src[3] = {(const uint8_t*)d_gate + (size_t)e * I * H * 2, (const uint8_t*)d_up + (size_t)e * I * H * 2,
+                               (const uint8_t*)d_down + (size_t)e * H * I * 2};
+      uint8_t* dst[3] = {h->gate_w + e * h->gu_stride, h->up_w + e * h->gu_stride, h->down_w + e * h->dn_stride};
+      const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
+      for (int m = 0; m < 3; m++)
+        hipLaunchKernelGGL(pack_wfp_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, 0, src[m], Ns[m], Ks[m], 0,
+                           reinterpret_cast<uint4*>(dst[m]));
+    }
+    KTX_HIP(hipGetLastError());
+    KTX_HIP(hipDeviceSynchronize());
+    return 0;
+  }
   int8_t* tmp = nullptr;
   KTX_HIP(hipMalloc(&tmp, (size_t)I * H));
   const int fmt = h->cfg.format == KTX_FMT_AMXINT4 ? 0 : 1;
@@ -1025,6 +1282,8 @@ extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_
 extern "C" int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, const float* scale) {
   KTX_REQUIRE(h && q && scale, "ktx_moe_load_quantized: null argument");
   KTX_REQUIRE(expert >= 0 && expert < h->cfg.expert_num, "ktx_moe_load_quantized: expert out of range");
+  KTX_REQUIRE(h->wbits == 4 || (h->wbits == 8 && h->cfg.format == KTX_FMT_AMXINT8),
+              "ktx_moe_load_quantized: integer formats only");
   KTX_REQUIRE(which >= 0 && which <= 2, "ktx_moe_load_quantized: bad matrix selector");
   KTX_HIP(hipSetDevice(h->cfg.device));
   const int H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
@@ -1042,6 +1301,30 @@ extern "C" int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const 
   if (pack_matrix(h, tmp, N, K, dst, 0)) { hipFree(tmp); return -1; }
   KTX_HIP(hipDeviceSynchronize());
   KTX_HIP(hipFree(tmp));
+  return 0;
+}
+
+extern "C" int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down,
+                                const float* d_gate_scale, const float* d_up_scale, const float* d_down_scale) {
+  KTX_REQUIRE(h && d_gate && d_up && d_down && d_gate_scale && d_up_scale && d_down_scale, "ktx_moe_load_fp8: null argument");
+  KTX_REQUIRE(h->cfg.format == KTX_FMT_FP8, "ktx_moe_load_fp8: handle was not created with KTX_FMT_FP8");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const size_t pieces = (size_t)I * H / 16, nsc = (size_t)(I / 128) * (H / 128);
+  for (int e = 0; e < E; e++) {
+    const uint8_t* src[3] = {(const uint8_t*)d_gate + (size_t)e * I * H, (const uint8_t*)d_up + (size_t)e * I * H,
+                             (const uint8_t*)d_down + (size_t)e * H * I};
+    uint8_t* dst[3] = {h->gate_w + e * h->gu_stride, h->up_w + e * h->gu_stride, h->down_w + e * h->dn_stride};
+    const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
+    for (int m = 0; m < 3; m++)
+      hipLaunchKernelGGL(pack_wfp_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, 0, src[m], Ns[m], Ks[m], 1,
+                         reinterpret_cast<uint4*>(dst[m]));
+  }
+  KTX_HIP(hipGetLastError());
+  KTX_HIP(hipMemcpy(h->gate_s, d_gate_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipMemcpy(h->up_s, d_up_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipMemcpy(h->down_s, d_down_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipDeviceSynchronize());
   return 0;
 }
 
@@ -1092,6 +1375,28 @@ static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_
     default: return launch_gemm<WBITS, 4, 2, GATE_UP>(p, max_tiles, st);
   }
 }
+
+template <bool FP8, bool GATE_UP>
+static int launch_gemm_fp(int mt, const FpGemmParams& p, int max_tiles, hipStream_t st) {
+  const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
+#define KTX_FP_LAUNCH(MT)                                                                                              \
+  do {                                                                                                                 \
+    constexpr size_t lds = 2 * (MT * 32 * 256) + MT * 16 * sizeof(int);                                                \
+    static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp_kernel<FP8, MT, GATE_UP>),   \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
+    KTX_HIP(err);                                                                                                      \
+    hipLaunchKernelGGL((moe_gemm_fp_kernel<FP8, MT, GATE_UP>), grid, dim3(256), lds, st, p);                           \
+  } while (0)
+  if (mt == 1) KTX_FP_LAUNCH(1);
+  else if (mt == 2) KTX_FP_LAUNCH(2);
+  else KTX_FP_LAUNCH(4);
+#undef KTX_FP_LAUNCH
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                      const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st);
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
 // Slots: 0 prep, 1 gate/up GEMM, 2 act-quant, 3 down GEMM, 4 combine.  Not graph-capturable; off by default.
@@ -1163,6 +1468,7 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   hipStream_t st = (hipStream_t)stream;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   Workspace* ws = h->ws;
+  if (!(h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_BF16))
   if (qlen * k <= KTX_DEC_MAX_PAIRS && k <= 8 && H <= 8192 && I <= 2048 && !g_force_generic) {
     DecParams dp;
     dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
@@ -1231,6 +1537,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     KTX_HIP(hipGetLastError());
     return 0;
   }
+  if (h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_BF16)
+    return forward_fp(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   const int mt = pick_mt(qlen, k, E);
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
@@ -1276,6 +1584,59 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   CombineParams cp;
   cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
   cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = incremental;
+  cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+  {
+    ProfScope ps(4, st);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+  }
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+
+// FP8 / BF16: bucket -> gate/up GEMM (+SiLU*up) -> down GEMM -> combine; activations stay bf16 (no quantisation launch).
+static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                      const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st) {
+  Workspace* ws = h->ws;
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const bool fp8 = h->cfg.format == KTX_FMT_FP8;
+  const int mt = pick_mt(qlen, k, E);
+  const int npairs = qlen * k;
+  const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
+
+  PrepParams pp;
+  pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
+  pp.rows_per_tile = 16 * mt; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
+  pp.x_q = ws->x_q; pp.x_d = ws->x_d; pp.row_of_pair = ws->row_of_pair; pp.src_of_row = ws->src_of_row;
+  pp.tiles = ws->tiles; pp.counters = ws->counters;
+  {
+    ProfScope ps(0, st);
+    hipLaunchKernelGGL(moe_prep_kernel, dim3(1), dim3(1024), 0, st, pp);  // block 0 only: bucketing, no quantisation
+  }
+  KTX_HIP(hipGetLastError());
+
+  FpGemmParams g1;
+  g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = h->gate_s; g1.s1 = h->up_s; g1.expert_stride = h->gu_stride;
+  g1.scale_stride = (size_t)(I / 128) * (H / 128); g1.N = I; g1.K = H; g1.act = (const bf16_t*)d_input;
+  g1.row_src = ws->src_of_row; g1.tiles = ws->tiles; g1.counters = ws->counters; g1.out = ws->a_buf;
+  int rc;
+  {
+    ProfScope ps(1, st);
+    rc = fp8 ? launch_gemm_fp<true, true>(mt, g1, max_tiles, st) : launch_gemm_fp<false, true>(mt, g1, max_tiles, st);
+  }
+  if (rc) return rc;
+  FpGemmParams g2;
+  g2.w0 = h->down_w; g2.w1 = nullptr; g2.s0 = h->down_s; g2.s1 = nullptr; g2.expert_stride = h->dn_stride;
+  g2.scale_stride = (size_t)(H / 128) * (I / 128); g2.N = H; g2.K = I; g2.act = ws->a_buf; g2.row_src = nullptr;
+  g2.tiles = ws->tiles; g2.counters = ws->counters; g2.out = ws->dn_buf;
+  {
+    ProfScope ps(3, st);
+    rc = fp8 ? launch_gemm_fp<true, false>(mt, g2, max_tiles, st) : launch_gemm_fp<false, false>(mt, g2, max_tiles, st);
+  }
+  if (rc) return rc;
+  CombineParams cp;
+  cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
+  cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
   cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
   {
     ProfScope ps(4, st);

@@ -183,6 +183,9 @@ typedef struct {
   const int8_t* up_q;   const float* up_d;
   const int8_t* down_q; const float* down_d;
   const uint8_t* gpu_experts_mask; /* optional [E]; common.hpp:256-258 should_skip_expert */
+  /* FP8: gate_q/up_q/down_q point at e4m3 bytes [E][N][K], *_d at fp32 scale_inv [E][N/128][K/128].
+   * BF16: *_q point at bf16 bits [E][N][K] (as uint16), *_d unused. */
+  int dp_even_first; /* test knob: order of the two FMAs inside one VDPBF16PS (0 = odd element first) */
 } ktxo_moe;
 
 static inline int skip_expert(const ktxo_moe* m, int64_t id) {
@@ -258,6 +261,107 @@ int ktxo_moe_forward(const ktxo_moe* m, int T, int k, const int64_t* ids, const 
     }
   }
   free(xq); free(aq); free(g); free(u); free(dn); free(acc);
+  return 0;
+}
+
+/* ------------------------------------------------------------------------------------------------ */
+/* FP8 (DeepSeek 128x128 block scales) and BF16 experts: bf16 activations, fp32 FMA chains            */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* GemmKernel224FP8::fp8x64_to_bf16x64 byte LUTs (operators/amx/la/amx_raw_kernels.hpp:290-340): plain e4m3 decode
+ * (bias 7, denormals exact, 0x7F/0xFF decode to +-480 — no NaN special case); every value is exact in bf16. */
+float ktxo_e4m3_to_f32(uint8_t v) {
+  const int s = v >> 7, e = (v >> 3) & 15, m = v & 7;
+  float f = e == 0 ? ldexpf((float)m, -9) : ldexpf(1.0f + (float)m / 8.0f, e - 7);
+  return s ? -f : f;
+}
+
+/* One VDPBF16PS lane as issued by avx_kernel(_4) (amx_raw_kernels.hpp:334-505, 154-256): two fp32 FMAs. */
+static inline float dpbf16(float c, float a0, float b0, float a1, float b1, int mode) {
+  if (mode == 1) { c = fmaf(a0, b0, c); c = fmaf(a1, b1, c); return c; }
+  if (mode == 2) {  /* both products added with a single rounding */
+    return (float)((double)c + ((double)a0 * (double)b0 + (double)a1 * (double)b1));
+  }
+  c = fmaf(a1, b1, c); c = fmaf(a0, b0, c);
+  return c;
+}
+
+/* float_mat_vec_kgroup + avx_kernel + apply_scale_kgroup (amx_raw_kernels.hpp:334-566): per 128-K group a sequential
+ * fp32 chain r over the group's k pairs, then c = fma(r, scale_inv[n/128][g], c). */
+static void gemv_fp8(const uint16_t* a_bf16, const uint8_t* w, const float* scale, int N, int K, int even_first,
+                     uint16_t* out) {
+  const int G = 128, kg = K / G;
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; n++) {
+    const uint8_t* row = w + (size_t)n * K;
+    float c = 0.0f;
+    for (int g = 0; g < kg; g++) {
+      float r = 0.0f;
+      for (int j = g * G; j < (g + 1) * G; j += 2)
+        r = dpbf16(r, ktxo_bf16_to_f32(a_bf16[j]), ktxo_e4m3_to_f32(row[j]), ktxo_bf16_to_f32(a_bf16[j + 1]),
+                   ktxo_e4m3_to_f32(row[j + 1]), even_first);
+      /* apply_scale_kgroup writes mul then add with intrinsics; g++ (-ffp-contract=fast, the GNU default, which is what
+       * the reference's CMake build and oracle/_ref both use) contracts the pair into one FMA — verified against _ref. */
+      c = fmaf(r, scale[(size_t)(n / G) * kg + g], c);
+    }
+    out[n] = ktxo_f32_to_bf16(c);
+  }
+}
+
+/* GemmKernel224BF16::avx_kernel(_4) (amx_raw_kernels.hpp:93-256): one fp32 chain over the whole K. */
+static void gemv_bf16(const uint16_t* a_bf16, const uint16_t* w, int N, int K, int even_first, uint16_t* out) {
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; n++) {
+    const uint16_t* row = w + (size_t)n * K;
+    float c = 0.0f;
+    for (int j = 0; j < K; j += 2)
+      c = dpbf16(c, ktxo_bf16_to_f32(a_bf16[j]), ktxo_bf16_to_f32(row[j]), ktxo_bf16_to_f32(a_bf16[j + 1]),
+                 ktxo_bf16_to_f32(row[j + 1]), even_first);
+    out[n] = ktxo_f32_to_bf16(c);
+  }
+}
+
+/* The same frame as ktxo_moe_forward with QA = identity: activations stay bf16 between stages
+ * (AMX_FP8_MOE_TP / AMX_BF16_MOE_TP: operators/amx/fp8-moe.hpp:93-108, bf16-moe.hpp; BufferABF16Impl::from_mat copies). */
+int ktxo_moe_forward_fp(const ktxo_moe* m, int T, int k, const int64_t* ids, const float* w, const uint16_t* x,
+                        uint16_t* y, int incremental) {
+  if (m->fmt != KTXO_FMT_FP8 && m->fmt != KTXO_FMT_BF16) return -1;
+  const int H = m->H, I = m->I, ef = m->dp_even_first;
+  const int fp8 = m->fmt == KTXO_FMT_FP8;
+  uint16_t* g = (uint16_t*)malloc(sizeof(uint16_t) * I);
+  uint16_t* u = (uint16_t*)malloc(sizeof(uint16_t) * I);
+  uint16_t* dn = (uint16_t*)malloc(sizeof(uint16_t) * H);
+  float* acc = (float*)malloc(sizeof(float) * H);
+  const size_t esz = fp8 ? 1 : 2;
+  const size_t sgu = (size_t)(I / 128) * (H / 128), sdn = (size_t)(H / 128) * (I / 128);
+  for (int t = 0; t < T; t++) {
+    const uint16_t* xt = x + (size_t)t * H;
+    for (int e = 0; e < H; e++) acc[e] = 0.0f;
+    for (int j = 0; j < k; j++) {
+      int64_t id = ids[(size_t)t * k + j];
+      if (skip_expert(m, id)) continue;
+      const size_t wo = (size_t)id * I * H * esz;
+      if (fp8) {
+        gemv_fp8(xt, (const uint8_t*)m->gate_q + wo, m->gate_d + id * sgu, I, H, ef, g);
+        gemv_fp8(xt, (const uint8_t*)m->up_q + wo, m->up_d + id * sgu, I, H, ef, u);
+      } else {
+        gemv_bf16(xt, (const uint16_t*)((const uint8_t*)m->gate_q + wo), I, H, ef, g);
+        gemv_bf16(xt, (const uint16_t*)((const uint8_t*)m->up_q + wo), I, H, ef, u);
+      }
+      for (int i = 0; i < I; i++) g[i] = ktxo_f32_to_bf16(ktxo_act_fn(ktxo_bf16_to_f32(g[i]), ktxo_bf16_to_f32(u[i])));
+      if (fp8) gemv_fp8(g, (const uint8_t*)m->down_q + wo, m->down_d + id * sdn, H, I, ef, dn);
+      else gemv_bf16(g, (const uint16_t*)((const uint8_t*)m->down_q + wo), H, I, ef, dn);
+      const float wt = w[(size_t)t * k + j];
+      for (int e = 0; e < H; e++) acc[e] = fmaf(ktxo_bf16_to_f32(dn[e]), wt, acc[e]);
+    }
+    uint16_t* yt = y + (size_t)t * H;
+    for (int e = 0; e < H; e++) {
+      float v = acc[e];
+      if (incremental) v = v + ktxo_bf16_to_f32(yt[e]);
+      yt[e] = ktxo_f32_to_bf16(v);
+    }
+  }
+  free(g); free(u); free(dn); free(acc);
   return 0;
 }
 

@@ -68,7 +68,7 @@ class _KtxoMoe(C.Structure):
         ("gate_q", C.c_void_p), ("gate_d", C.c_void_p),
         ("up_q", C.c_void_p), ("up_d", C.c_void_p),
         ("down_q", C.c_void_p), ("down_d", C.c_void_p),
-        ("gpu_experts_mask", C.c_void_p),
+        ("gpu_experts_mask", C.c_void_p), ("dp_even_first", C.c_int),
     ]
 
 
@@ -135,10 +135,18 @@ class Oracle:
         x_bf16 = np.ascontiguousarray(x_bf16, dtype=np.uint16)
         y = np.zeros((T, H), np.uint16) if y_prev is None else np.ascontiguousarray(y_prev, dtype=np.uint16).copy()
         s = _KtxoMoe(moe["fmt"], moe["E"], H, I, 0,
-                     moe["gate_q"].ctypes.data, moe["gate_d"].ctypes.data,
-                     moe["up_q"].ctypes.data, moe["up_d"].ctypes.data,
-                     moe["down_q"].ctypes.data, moe["down_d"].ctypes.data,
-                     moe["mask"].ctypes.data if moe.get("mask") is not None else None)
+                     moe["gate_q"].ctypes.data, moe["gate_d"].ctypes.data if moe["gate_d"] is not None else None,
+                     moe["up_q"].ctypes.data, moe["up_d"].ctypes.data if moe["up_d"] is not None else None,
+                     moe["down_q"].ctypes.data, moe["down_d"].ctypes.data if moe["down_d"] is not None else None,
+                     moe["mask"].ctypes.data if moe.get("mask") is not None else None, int(moe.get("dp_even_first", 0)))
+        if moe["fmt"] in (FMT_FP8, FMT_BF16):
+            if trace:
+                raise NotImplementedError("traces are only kept for the integer formats")
+            rc = self.lib.ktxo_moe_forward_fp(C.byref(s), C.c_int(T), C.c_int(k), _p(ids), _p(weights), _p(x_bf16), _p(y),
+                                              C.c_int(0 if y_prev is None else 1))
+            if rc != 0:
+                raise RuntimeError("ktxo_moe_forward_fp failed")
+            return y
         tr = None
         if trace:
             tr = dict(gate=np.zeros((T, k, I), np.uint16), up=np.zeros((T, k, I), np.uint16),
@@ -150,6 +158,26 @@ class Oracle:
         if rc != 0:
             raise RuntimeError("ktxo_moe_forward: unsupported format")
         return (y, tr) if trace else y
+
+    def make_moe_fp8(self, gate_fp8, up_fp8, down_fp8, gate_s, up_s, down_s, mask=None, dp_even_first=0):
+        """e4m3 bytes gate/up [E,I,H], down [E,H,I]; fp32 scale_inv [E, N/128, K/128]."""
+        E, I, H = gate_fp8.shape
+        c = np.ascontiguousarray
+        return dict(fmt=FMT_FP8, E=E, H=H, I=I, gate_q=c(gate_fp8, dtype=np.uint8), up_q=c(up_fp8, dtype=np.uint8),
+                    down_q=c(down_fp8, dtype=np.uint8), gate_d=c(gate_s, dtype=np.float32), up_d=c(up_s, dtype=np.float32),
+                    down_d=c(down_s, dtype=np.float32), mask=mask, dp_even_first=dp_even_first)
+
+    def make_moe_bf16(self, gate, up, down, mask=None, dp_even_first=0):
+        E, I, H = gate.shape
+        c = np.ascontiguousarray
+        return dict(fmt=FMT_BF16, E=E, H=H, I=I, gate_q=c(gate, dtype=np.uint16), up_q=c(up, dtype=np.uint16),
+                    down_q=c(down, dtype=np.uint16), gate_d=None, up_d=None, down_d=None, mask=mask,
+                    dp_even_first=dp_even_first)
+
+    def e4m3_to_f32(self, b: np.ndarray) -> np.ndarray:
+        self.lib.ktxo_e4m3_to_f32.restype = C.c_float
+        lut = np.array([self.lib.ktxo_e4m3_to_f32(C.c_uint8(i)) for i in range(256)], np.float32)
+        return lut[np.asarray(b, dtype=np.uint8)]
 
     def bucket(self, E: int, ids: np.ndarray, mask=None):
         T, k = ids.shape

@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from helpers import make_case  # noqa: E402
-from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, Reference  # noqa: E402
+from helpers import bf16_to_f32, fp8_block_quant, make_case  # noqa: E402
+from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, Reference  # noqa: E402
 
 E, k, H, I = 4, 2, 128, 128
 ref = Reference(threads=2)
@@ -33,6 +33,20 @@ for fmt, fname in ((FMT_AMXINT4, "int4"), (FMT_AMXINT8, "int8")):
         out[f"{fname}_{name}_y"] = y
         out[f"{fname}_{name}_yinc"] = y2
     ref.free_moe(moe)
+# FP8 (block scales) and BF16 experts: same weights; fp8 codes/scales are stored so the fixture is self-contained
+gq, gs = fp8_block_quant(bf16_to_f32(base["gate"]))
+uq, us = fp8_block_quant(bf16_to_f32(base["up"]))
+dq, ds = fp8_block_quant(bf16_to_f32(base["down"]))
+out.update(fp8_gate=gq, fp8_up=uq, fp8_down=dq, fp8_gate_s=gs, fp8_up_s=us, fp8_down_s=ds)
+moe8 = ref.make_moe_quant(FMT_FP8, E, H, I, k, gq, uq, dq, gs, us, ds, max_len=64, group_size=128)
+moeb = ref.make_moe(FMT_BF16, base["gate"], base["up"], base["down"], k=k, max_len=64)
+for fname, moe in (("fp8", moe8), ("bf16", moeb)):
+    for name, T, inv in cases:
+        c = make_case(1000 + T, E, k, H, I, T, invalid_ids=inv)
+        y = ref.moe_forward(moe, c["ids"], c["w"], c["x"])
+        out[f"{fname}_{name}_y"] = y
+        out[f"{fname}_{name}_yinc"] = ref.moe_forward(moe, c["ids"], c["w"], c["x"], y_prev=y)
+
 # the reference quantiser's own dequantised weights + scales for one matrix (BufferBInt4Impl::from_mat -> to_mat)
 deq, d = ref.quant_roundtrip_int4(base["gate"][0])
 out["int4_gate0_dequant"] = deq

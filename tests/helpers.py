@@ -27,3 +27,36 @@ def torch_bf16(a_u16, device):
 def numpy_u16(t):
     import torch
     return t.detach().cpu().contiguous().view(torch.int16).numpy().view(np.uint16)
+
+
+_E4M3_LUT = None
+
+
+def e4m3_lut():
+    """float value of every e4m3 byte exactly as the reference's LUT decodes it (0x7F/0xFF -> +-480)."""
+    global _E4M3_LUT
+    if _E4M3_LUT is None:
+        v = np.zeros(256, np.float32)
+        for b in range(256):
+            e, m = (b >> 3) & 15, b & 7
+            f = m * 2.0 ** -9 if e == 0 else (1 + m / 8.0) * 2.0 ** (e - 7)
+            v[b] = -f if b & 0x80 else f
+        _E4M3_LUT = v
+    return _E4M3_LUT
+
+
+def fp8_block_quant(w_f32):
+    """[E,N,K] fp32 -> (e4m3 bytes [E,N,K], fp32 scale_inv [E,N/128,K/128]); scale = amax/448 per 128x128 block, nearest
+    e4m3 (the scheme of kt-kernel/test/per_commit/test_moe_avx2_accuracy_fp8.py:28-63).  Codes 0x7F/0xFF (NaN in OCP
+    e4m3fn, 480 in the reference's table) are never produced."""
+    E, N, K = w_f32.shape
+    grid = e4m3_lut()[:127].astype(np.float32)          # non-negative finite codes 0..126 (max 448)
+    wb = w_f32.reshape(E, N // 128, 128, K // 128, 128)
+    amax = np.abs(wb).max(axis=(2, 4), keepdims=True)
+    scale = (amax / 448.0).astype(np.float32)
+    scale[scale == 0] = 1
+    v = (wb / scale).astype(np.float32)
+    mid = (grid[1:] + grid[:-1]) / 2
+    idx = np.searchsorted(mid, np.abs(v)).astype(np.uint8)
+    q = idx | ((v < 0).astype(np.uint8) << 7)
+    return q.reshape(E, N, K), scale.reshape(E, N // 128, K // 128).astype(np.float32)

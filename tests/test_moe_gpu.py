@@ -258,3 +258,59 @@ def test_error_behaviour(dev):
 def test_smoke_entry():
     import __graft_entry__
     __graft_entry__.smoke()
+
+
+# ---- FP8 (DeepSeek block scales) and BF16 experts ----------------------------------------------------------------------
+# The reference accumulates each 128-K group as a sequential fp32 VDPBF16PS chain (and in tile order on its AMX path);
+# the MFMA adds the same exact products in another order.  Outputs therefore agree to fp32 rounding of the partial
+# sums: the test allows one bf16 ulp (2^-7 relative) plus 2^-9 of the row scale, on a small fraction of elements,
+# and requires the aggregate relative error (the reference tests' own metric) to be far below north_star's 1e-3.
+def _check_fp(got_u16, want_u16):
+    a, b = bf16_to_f32(got_u16), bf16_to_f32(want_u16)
+    assert np.all(np.abs(a - b) <= np.abs(b) * 2.0 ** -7 + 2.0 ** -9 * np.abs(b).max())
+    assert (got_u16 != want_u16).mean() < 0.05
+    assert np.abs(a - b).mean() / max(np.abs(b).mean(), 1e-30) < 1e-3
+
+
+@pytest.mark.parametrize("fmt", ["FP8", "BF16"])
+@pytest.mark.parametrize("shape", [(8, 2, 512, 256, 1), (8, 2, 512, 256, 5), (8, 6, 2048, 1408, 2), (8, 2, 256, 512, 40),
+                                   (8, 2, 256, 512, 300), (4, 2, 256, 256, 700)])
+def test_fp_formats_against_oracle(oracle, dev, fmt, shape):
+    from helpers import fp8_block_quant
+    from ktransformers_amd._native import MoEHandle
+    E, k, H, I, T = shape
+    c = make_case(6, E, k, H, I, T, invalid_ids=T >= 5)
+    h = MoEHandle(E, k, H, I, max_len=max(T, 8), method=fmt, device=0, group_size=128 if fmt == "FP8" else 0)
+    try:
+        if fmt == "FP8":
+            q = [fp8_block_quant(bf16_to_f32(c[n])) for n in ("gate", "up", "down")]
+            mo = oracle.make_moe_fp8(q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1])
+            h.load_fp8(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch.from_numpy(x[1]).to(dev) for x in q])
+        else:
+            mo = oracle.make_moe_bf16(c["gate"], c["up"], c["down"])
+            h.load_bf16(torch_bf16(c["gate"], dev), torch_bf16(c["up"], dev), torch_bf16(c["down"], dev))
+        want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+        _check_fp(run(h, c, dev), want)
+        want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+        _check_fp(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
+    finally:
+        h.close()
+
+
+@pytest.mark.parametrize("fname,fmt", [("fp8", "FP8"), ("bf16", "BF16")])
+@pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
+def test_fp_formats_against_reference_golden(dev, fname, fmt, case):
+    from ktransformers_amd._native import MoEHandle
+    g = np.load(GOLDEN)
+    E, k, H, I = int(g["E"]), int(g["k"]), int(g["H"]), int(g["I"])
+    c = dict(x=g[f"int4_{case}_x"], ids=g[f"int4_{case}_ids"], w=g[f"int4_{case}_w"])
+    h = MoEHandle(E, k, H, I, max_len=64, method=fmt, device=0, group_size=128 if fmt == "FP8" else 0)
+    try:
+        if fmt == "FP8":
+            h.load_fp8(*[torch.from_numpy(g[f"fp8_{n}"]).to(dev) for n in ("gate", "up", "down")],
+                       *[torch.from_numpy(g[f"fp8_{n}_s"]).to(dev) for n in ("gate", "up", "down")])
+        else:
+            h.load_bf16(torch_bf16(g["gate"], dev), torch_bf16(g["up"], dev), torch_bf16(g["down"], dev))
+        _check_fp(run(h, c, dev), g[f"{fname}_{case}_y"])
+    finally:
+        h.close()

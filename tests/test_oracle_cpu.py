@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import bf16_to_f32, f32_to_bf16, make_case
-from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, Reference, reference_available
+from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, Reference, reference_available
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "moe_amx_golden.npz")
 
@@ -26,6 +26,37 @@ def test_oracle_matches_reference_golden(oracle, golden, fname, fmt, case):
     assert np.array_equal(y, g[f"{fname}_{case}_y"]), "oracle differs from the reference kernels' golden output"
     y2 = oracle.moe_forward(moe, ids, w, x, y_prev=y)
     assert np.array_equal(y2, g[f"{fname}_{case}_yinc"]), "incremental merge differs from the reference"
+
+
+@pytest.mark.parametrize("fname", ["fp8", "bf16"])
+@pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
+def test_oracle_fp_formats_match_reference_golden(oracle, golden, fname, case):
+    g = golden
+    if fname == "fp8":
+        moe = oracle.make_moe_fp8(g["fp8_gate"], g["fp8_up"], g["fp8_down"], g["fp8_gate_s"], g["fp8_up_s"], g["fp8_down_s"])
+    else:
+        moe = oracle.make_moe_bf16(g["gate"], g["up"], g["down"])
+    x, ids, w = g[f"int4_{case}_x"], g[f"int4_{case}_ids"], g[f"int4_{case}_w"]   # same seeded inputs for all formats
+    y = oracle.moe_forward(moe, ids, w, x)
+    assert np.array_equal(y, g[f"{fname}_{case}_y"])
+    assert np.array_equal(oracle.moe_forward(moe, ids, w, x, y_prev=y), g[f"{fname}_{case}_yinc"])
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref not built or host lacks AVX512-VNNI/BF16")
+@pytest.mark.parametrize("shape", [(8, 2, 512, 256, 40), (8, 2, 1024, 512, 3)])
+def test_oracle_fp_formats_match_live_reference(oracle, shape):
+    from helpers import fp8_block_quant
+    E, k, H, I, T = shape
+    c = make_case(3, E, k, H, I, T)
+    ref = Reference(threads=4)
+    gq, gs = fp8_block_quant(bf16_to_f32(c["gate"])); uq, us = fp8_block_quant(bf16_to_f32(c["up"]))
+    dq, ds = fp8_block_quant(bf16_to_f32(c["down"]))
+    mr = ref.make_moe_quant(FMT_FP8, E, H, I, k, gq, uq, dq, gs, us, ds, max_len=64, group_size=128)
+    assert np.array_equal(oracle.moe_forward(oracle.make_moe_fp8(gq, uq, dq, gs, us, ds), c["ids"], c["w"], c["x"]),
+                          ref.moe_forward(mr, c["ids"], c["w"], c["x"]))
+    mb = ref.make_moe(FMT_BF16, c["gate"], c["up"], c["down"], k=k, max_len=64)
+    assert np.array_equal(oracle.moe_forward(oracle.make_moe_bf16(c["gate"], c["up"], c["down"]), c["ids"], c["w"], c["x"]),
+                          ref.moe_forward(mb, c["ids"], c["w"], c["x"]))
 
 
 def test_oracle_int4_quantiser_matches_reference_golden(oracle, golden):
