@@ -80,6 +80,13 @@ int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, 
 int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, const float* d_gate_scale,
                      const float* d_up_scale, const float* d_down_scale);
 
+/* RAWINT4 (Kimi-K2 native / compressed-tensors int4): packed nibbles gate/up [expert_num][I][H/2], down
+ * [expert_num][H][I/2] (byte = ((q1+8)<<4)|(q0+8), even k in the low nibble) and bf16 scales [expert_num][N][K/32],
+ * DEVICE pointers — what AMX_K2_MOE_TP::load_weights consumes (operators/amx/k2-moe.hpp:124-191;
+ * kt-kernel/python/utils/loader.py:683-777 `weight_packed` / `weight_scale`).  Synchronous. */
+int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, const void* d_gate_scale,
+                         const void* d_up_scale, const void* d_down_scale);
+
 /* should_skip_expert mask (operators/common.hpp:241-258): mask[e] != 0 => expert e contributes nothing. HOST ptr, may be NULL. */
 int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask);
 

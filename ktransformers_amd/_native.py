@@ -50,6 +50,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_load_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_moe_load_quantized.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.ktx_moe_load_fp8.argtypes = [C.c_void_p] * 7
+    lib.ktx_moe_load_rawint4.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -158,6 +159,20 @@ class MoEHandle:
         torch.cuda.synchronize(self.device)
         check(lib.ktx_moe_load_fp8(self._h, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ss[0].data_ptr(),
                                    ss[1].data_ptr(), ss[2].data_ptr()))
+
+    def load_rawint4(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_scale: torch.Tensor,
+                     up_scale: torch.Tensor, down_scale: torch.Tensor) -> None:
+        """Kimi-K2 native int4: uint8 nibbles [E,I,H/2]/[E,I,H/2]/[E,H,I/2] + bf16 scales [E,N,K/32]."""
+        for t, shape in ((gate, (self.E, self.I, self.H // 2)), (up, (self.E, self.I, self.H // 2)),
+                         (down, (self.E, self.H, self.I // 2))):
+            if t.dtype != torch.uint8 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
+                raise KtxError(f"load_rawint4: expected contiguous uint8 {shape} on {self.device}")
+        for t, (n, kk) in ((gate_scale, (self.I, self.H)), (up_scale, (self.I, self.H)), (down_scale, (self.H, self.I))):
+            if t.dtype != torch.bfloat16 or tuple(t.shape) != (self.E, n, kk // 32) or not t.is_contiguous() or t.device != self.device:
+                raise KtxError("load_rawint4: scales must be contiguous bf16 [E, N, K/32] on the handle's device")
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_moe_load_rawint4(self._h, gate.data_ptr(), up.data_ptr(), down.data_ptr(), gate_scale.data_ptr(),
+                                       up_scale.data_ptr(), down_scale.data_ptr()))
 
     def load_quantized(self, expert: int, which: int, q, scale) -> None:
         """One expert matrix from host int8 [N,K] multiplicands + fp32 [N] scales (numpy arrays)."""

@@ -1113,6 +1113,228 @@ __global__ void pack_wfp_kernel(const uint8_t* __restrict__ src, int N, int K, i
 }
 
 // =====================================================================================================
+// RAWINT4 (Kimi-K2 compressed-tensors int4, group 32, bf16 scales): bit-exact restatement of
+// GemmKernel224Int4SmallKGroup (operators/amx/la/amx_kernels.hpp:3344-3597) on v_mfma_i32_4x4x4i8.
+//
+// The reference keeps, per output, SIXTEEN fp32 lane accumulators: AVX lane L owns k = 64*kb + 4L..4L+3 of every 64-K
+// block, adds fma(as[g]*bs[g], float(dot4), s_L) block after block (g = 2kb + (L>=8)), and only at the end reduces the
+// 16 lanes with _mm512_reduce_add_ps' fixed tree and divides by 16.  A 64-deep MFMA cannot reproduce that association,
+// but the 16-block 4x4x4 int8 MFMA computes exactly those dot4 partial sums: block b = AVX lane L, A rows = 4 tokens,
+// B columns = 4 weight rows, K = the lane's 4 k (layout probed: scripts/mfma4_probe.hip).  GPU lane (L, j) therefore
+// holds s_L for weight row j and tokens r = 0..3, and the final butterfly over lane bits 5,4,3,2 is the reference's tree.
+//
+// RAW tile layout: weight rows in groups of 4, k in steps of 512 (8 blocks of 64): tile (rg, step) = 1 KiB, lane
+// l = L*4 + j owns 16 B = dwords P[0..3]; byte b of P[p]: low nibble = q[row j][64*(8*step+2p) + 4L + b],
+// high nibble = q[row j][64*(8*step+2p+1) + 4L + b] (two's complement nibbles), so ((P<<4)&0xF0F0F0F0, P&0xF0F0F0F0)
+// are the two B operands (multiplicand 16q, as in the reference).  Scales stay bf16: [rg][step][row j][h][8 blocks].
+// =====================================================================================================
+struct RawGemmParams {
+  const uint8_t *w0, *w1;      // RAW tiles (gate | down, up)
+  const bf16_t *s0, *s1;       // bf16 scales in the tile order above
+  size_t expert_stride;        // bytes of weights per expert matrix
+  size_t scale_stride;         // bf16 elements of scales per expert matrix
+  int N, K;
+  const int8_t* act_q;         // [src rows][K]
+  const float* act_d;          // [src rows][K/32]
+  const int32_t* row_src;
+  const Tile* tiles;           // <= 4 rows per tile
+  const int32_t* counters;
+  bf16_t* out;                 // [sorted rows][N]
+};
+
+template <int NT, bool GATE_UP>
+__global__ __launch_bounds__(256) void moe_rawint4_gemm_kernel(RawGemmParams p) {
+  constexpr int NMAT = GATE_UP ? 2 : 1;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int KP = p.K + 32;                                        // padded activation row (bank spread of the 4 tokens)
+  int8_t* xq = reinterpret_cast<int8_t*>(smem);                   // [4][K+32]
+  float* as_l = reinterpret_cast<float*>(smem + 4 * KP);          // [K/32][4]
+  __shared__ int s_src[4];
+
+  const int tile_idx = blockIdx.y;
+  if (tile_idx >= p.counters[0]) return;
+  const Tile tile = p.tiles[tile_idx];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = blockIdx.x * 4 + wave;
+  const bool strip_ok = strip * 16 < p.N;
+  const int NS = p.K / 512, G = p.K / 32;
+  const int L = lane >> 2, j = lane & 3, hsel = L >> 3;
+
+  if (tid < 4) s_src[tid] = tid < tile.nrows ? (p.row_src ? p.row_src[tile.row0 + tid] : tile.row0 + tid) : -1;
+  __syncthreads();
+  for (int u = tid; u < 4 * (p.K / 16); u += 256) {
+    const int r = u / (p.K / 16), piece = u % (p.K / 16);
+    uint4 v = make_uint4(0, 0, 0, 0);
+    if (s_src[r] >= 0) v = *reinterpret_cast<const uint4*>(p.act_q + (size_t)s_src[r] * p.K + piece * 16);
+    *reinterpret_cast<uint4*>(xq + r * KP + piece * 16) = v;
+  }
+  for (int u = tid; u < 4 * G; u += 256) {
+    const int g = u >> 2, r = u & 3;
+    as_l[u] = s_src[r] >= 0 ? p.act_d[(size_t)s_src[r] * G + g] : 0.0f;
+  }
+  __syncthreads();
+  if (!strip_ok) return;
+
+  float acc[NMAT][4][NT];
+#pragma unroll
+  for (int m = 0; m < NMAT; m++)
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+      for (int r = 0; r < NT; r++) acc[m][rg][r] = 0.0f;
+
+  const uint8_t* wb[NMAT];
+  const bf16_t* sb[NMAT];
+  wb[0] = p.w0 + (size_t)tile.expert * p.expert_stride + (size_t)(strip * 4) * NS * 1024 + lane * 16;
+  sb[0] = p.s0 + (size_t)tile.expert * p.scale_stride + (size_t)(strip * 4) * NS * 64 + (j * 2 + hsel) * 8;
+  if constexpr (GATE_UP) {
+    wb[1] = p.w1 + (size_t)tile.expert * p.expert_stride + (size_t)(strip * 4) * NS * 1024 + lane * 16;
+    sb[1] = p.s1 + (size_t)tile.expert * p.scale_stride + (size_t)(strip * 4) * NS * 64 + (j * 2 + hsel) * 8;
+  }
+  const int8_t* xa = xq + j * KP + 4 * L;   // A operand: lane (L, i = j) supplies token i's 4 int8 of AVX lane L
+
+  uint4 wcur[NMAT][4], scur[NMAT][4], wnxt[NMAT][4], snxt[NMAT][4];
+  auto load_step = [&](uint4(&w)[NMAT][4], uint4(&sc)[NMAT][4], int st) {
+#pragma unroll
+    for (int m = 0; m < NMAT; m++)
+#pragma unroll
+      for (int rg = 0; rg < 4; rg++) {
+        w[m][rg] = *reinterpret_cast<const uint4*>(wb[m] + ((size_t)rg * NS + st) * 1024);
+        sc[m][rg] = *reinterpret_cast<const uint4*>(sb[m] + ((size_t)rg * NS + st) * 64);
+      }
+  };
+  auto compute_step = [&](uint4(&w)[NMAT][4], uint4(&sc)[NMAT][4], int st) {
+#pragma unroll
+    for (int kb8 = 0; kb8 < 8; kb8++) {
+      const int kb = st * 8 + kb8;
+      const int a_op = *reinterpret_cast<const int*>(xa + 64 * kb);
+      const float4 as4 = *reinterpret_cast<const float4*>(as_l + (2 * kb + hsel) * 4);
+      const float asv[4] = {as4.x, as4.y, as4.z, as4.w};
+#pragma unroll
+      for (int m = 0; m < NMAT; m++)
+#pragma unroll
+        for (int rg = 0; rg < 4; rg++) {
+          const uint32_t P = kb8 < 2 ? w[m][rg].x : kb8 < 4 ? w[m][rg].y : kb8 < 6 ? w[m][rg].z : w[m][rg].w;
+          const int b_op = (kb8 & 1) ? (int)(P & 0xF0F0F0F0u) : (int)((P << 4) & 0xF0F0F0F0u);
+          const uint32_t S = kb8 < 2 ? sc[m][rg].x : kb8 < 4 ? sc[m][rg].y : kb8 < 6 ? sc[m][rg].z : sc[m][rg].w;
+          const float bs = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
+          const v4i d = __builtin_amdgcn_mfma_i32_4x4x4i8(a_op, b_op, v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+          for (int r = 0; r < NT; r++) acc[m][rg][r] = fmaf(asv[r] * bs, (float)d[r], acc[m][rg][r]);
+        }
+    }
+  };
+
+  load_step(wcur, scur, 0);
+  for (int st = 0; st < NS; st += 2) {
+    if (st + 1 < NS) load_step(wnxt, snxt, st + 1);
+    compute_step(wcur, scur, st);
+    if (st + 1 < NS) {
+      if (st + 2 < NS) load_step(wcur, scur, st + 2);
+      compute_step(wnxt, snxt, st + 1);
+    }
+  }
+
+  // _mm512_reduce_add_ps tree over the 16 AVX lanes (lane bits 5,4,3,2), then /16 (amx_kernels.hpp:3385-3450)
+#pragma unroll
+  for (int m = 0; m < NMAT; m++)
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++)
+#pragma unroll
+      for (int r = 0; r < NT; r++) {
+        float v = acc[m][rg][r];
+        v = v + __shfl_xor(v, 32, 64);
+        v = v + __shfl_xor(v, 16, 64);
+        v = v + __shfl_xor(v, 8, 64);
+        v = v + __shfl_xor(v, 4, 64);
+        acc[m][rg][r] = v / 16.0f;
+      }
+  if (L == 0) {
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const int n = strip * 16 + rg * 4 + j;
+#pragma unroll
+      for (int r = 0; r < NT; r++) {
+        if (r < tile.nrows) {
+          const bf16_t g = f32_to_bf16(acc[0][rg][r]);
+          bf16_t o = g;
+          if constexpr (GATE_UP) {
+            const bf16_t u = f32_to_bf16(acc[1][rg][r]);
+            o = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
+          }
+          p.out[(size_t)(tile.row0 + r) * p.N + n] = o;
+        }
+      }
+    }
+  }
+}
+
+// per-(row, 32-group) int8 quantisation (BufferASmallKGroupImpl::from_mat, amx_buffers.hpp:431-495): one block per row,
+// 8 elements per thread, a group = 4 adjacent lanes
+__device__ __forceinline__ void quant_row_kgroup_block(const bf16_t* __restrict__ src, int K, int8_t* __restrict__ dst,
+                                                       float* __restrict__ d_out) {
+  for (int c = threadIdx.x * 8; c < K; c += blockDim.x * 8) {
+    const uint4 v = *reinterpret_cast<const uint4*>(src + c);
+    float amax = amax8(v, 0.0f);
+    amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+    amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+    const float d = amax / 127.0f;
+    const float id = d ? 1.0f / d : 0.0f;
+    *reinterpret_cast<uint2*>(dst + c) = quant8(v, id);
+    if ((threadIdx.x & 3) == 0) d_out[c >> 5] = d;
+  }
+}
+
+__global__ __launch_bounds__(256) void moe_actquant_kgroup_kernel(const bf16_t* __restrict__ a, int K,
+                                                                  int8_t* __restrict__ a_q, float* __restrict__ a_d,
+                                                                  const int32_t* counters, const int32_t* d_bsz, int qlen,
+                                                                  int rows_are_tokens) {
+  const int row = blockIdx.x;
+  if (rows_are_tokens) {
+    int T = qlen;
+    if (d_bsz) T = min(max(*d_bsz, 0), qlen);
+    if (row >= T) return;
+  } else if (row >= counters[1]) {
+    return;
+  }
+  quant_row_kgroup_block(a + (size_t)row * K, K, a_q + (size_t)row * K, a_d + (size_t)row * (K / 32));
+}
+
+// raw row-major nibbles [N][K/2] (byte = ((q1+8)<<4)|(q0+8), even k low) -> RAW tiles; one thread per packed dword
+__global__ void pack_rawint4_kernel(const uint8_t* __restrict__ src, int N, int K, uint32_t* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)N * K / 8;
+  if (idx >= total) return;
+  const int NS = K / 512;
+  const size_t tile = idx / 256;
+  const int within = (int)(idx % 256), lane = within / 4, pp = within % 4;
+  const int rg = (int)(tile / NS), st = (int)(tile % NS);
+  const int L = lane >> 2, jrow = lane & 3;
+  const uint8_t* row = src + (size_t)(rg * 4 + jrow) * (K / 2);
+  uint32_t v = 0;
+#pragma unroll
+  for (int b = 0; b < 4; b++) {
+    const int k_lo = 64 * (8 * st + 2 * pp) + 4 * L + b, k_hi = k_lo + 64;
+    const uint32_t n_lo = ((k_lo & 1) ? (row[k_lo >> 1] >> 4) : (row[k_lo >> 1] & 15)) ^ 8u;
+    const uint32_t n_hi = ((k_hi & 1) ? (row[k_hi >> 1] >> 4) : (row[k_hi >> 1] & 15)) ^ 8u;
+    v |= ((n_hi << 4) | n_lo) << (8 * b);
+  }
+  out[idx] = v;
+}
+
+// bf16 scales [N][K/32] -> tile order [rg][step][row j][h][8 blocks]; one thread per element
+__global__ void pack_rawint4_scales_kernel(const bf16_t* __restrict__ src, int N, int K, bf16_t* __restrict__ out) {
+  const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int G = K / 32, NS = K / 512;
+  if (idx >= (size_t)N * G) return;
+  const int kb8 = (int)(idx % 8), h = (int)((idx / 8) % 2), jrow = (int)((idx / 16) % 4);
+  const size_t t = idx / 64;
+  const int st = (int)(t % NS), rg = (int)(t / NS);
+  out[idx] = src[(size_t)(rg * 4 + jrow) * G + 2 * (8 * st + kb8) + h];
+}
+
+// =====================================================================================================
 // host side
 // =====================================================================================================
 // Scratch for one forward.  Like the reference's shared_mem_buffer arena (cpu_backend/shared_mem_buffer.h:37-55) it is
@@ -1159,9 +1381,11 @@ static int pick_mt(int qlen, int k, int E) {
 
 extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_REQUIRE(cfg && out, "ktx_moe_create: null argument");
-  KTX_REQUIRE(cfg->format == KTX_FMT_AMXINT4 || cfg->format == KTX_FMT_AMXINT8 || cfg->format == KTX_FMT_FP8 ||
-                  cfg->format == KTX_FMT_BF16,
-              "ktx_moe_create: format not supported by this build (AMXINT4, AMXINT8, FP8, BF16)");
+  KTX_REQUIRE(cfg->format >= KTX_FMT_AMXINT4 && cfg->format <= KTX_FMT_BF16, "ktx_moe_create: unknown format");
+  KTX_REQUIRE(cfg->format != KTX_FMT_RAWINT4 || cfg->group_size == 32,
+              "ktx_moe_create: RAWINT4 supports group_size 32 (Kimi-K2 native int4) only");
+  KTX_REQUIRE(cfg->format != KTX_FMT_RAWINT4 || (cfg->hidden_size % 512 == 0 && cfg->intermediate_size % 512 == 0),
+              "ktx_moe_create: RAWINT4 needs hidden_size and intermediate_size to be multiples of 512");
   KTX_REQUIRE(cfg->format != KTX_FMT_FP8 || cfg->group_size == 0 || cfg->group_size == 128,
               "ktx_moe_create: FP8 supports 128x128 block scales only");
   KTX_REQUIRE(cfg->expert_num > 0 && cfg->expert_num <= KTX_EMAX, "ktx_moe_create: expert_num out of range (1..1024)");
@@ -1173,18 +1397,21 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   ktx_moe_s* h = new ktx_moe_s();
   h->cfg = *cfg;
   if (h->cfg.global_expert_num <= 0) h->cfg.global_expert_num = cfg->expert_num;
-  h->wbits = cfg->format == KTX_FMT_AMXINT4 ? 4 : (cfg->format == KTX_FMT_BF16 ? 16 : 8);
+  h->wbits = (cfg->format == KTX_FMT_AMXINT4 || cfg->format == KTX_FMT_RAWINT4) ? 4 : (cfg->format == KTX_FMT_BF16 ? 16 : 8);
   const size_t E = cfg->expert_num, H = cfg->hidden_size, I = cfg->intermediate_size;
   h->gu_stride = I * H * h->wbits / 8;
   h->dn_stride = H * I * h->wbits / 8;
   h->max_pairs = cfg->max_len * cfg->num_experts_per_tok;
-  h->max_tiles = std::min<int>(h->max_pairs, (int)E) + h->max_pairs / 16 + 1;
+  h->max_tiles = std::min<int>(h->max_pairs, (int)E) + h->max_pairs / (cfg->format == KTX_FMT_RAWINT4 ? 4 : 16) + 1;
   KTX_HIP(hipMalloc(&h->gate_w, E * h->gu_stride));
   KTX_HIP(hipMalloc(&h->up_w, E * h->gu_stride));
   KTX_HIP(hipMalloc(&h->down_w, E * h->dn_stride));
-  KTX_HIP(hipMalloc(&h->gate_s, E * I * sizeof(float)));
-  KTX_HIP(hipMalloc(&h->up_s, E * I * sizeof(float)));
-  KTX_HIP(hipMalloc(&h->down_s, E * H * sizeof(float)));
+  // scales: fp32 per row (int formats) | fp32 per 128x128 block (FP8) | bf16 per (row, 32-group) (RAWINT4)
+  size_t gu_sbytes = E * I * sizeof(float), dn_sbytes = E * H * sizeof(float);
+  if (cfg->format == KTX_FMT_RAWINT4) gu_sbytes = dn_sbytes = E * I * (H / 32) * sizeof(bf16_t);
+  KTX_HIP(hipMalloc(&h->gate_s, gu_sbytes));
+  KTX_HIP(hipMalloc(&h->up_s, gu_sbytes));
+  KTX_HIP(hipMalloc(&h->down_s, dn_sbytes));
   {
     // Growing the arena frees the old blocks: only legal while no forward using them is in flight.
     std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -1192,10 +1419,10 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
     Workspace* w = &g_ws[cfg->device];
     KTX_HIP(hipDeviceSynchronize());
     KTX_HIP(grow(w->x_q, w->cap[0], (size_t)cfg->max_len * H));
-    KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float)));
+    KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? H / 32 : 1)));
     KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * sizeof(bf16_t)));
     KTX_HIP(grow(w->a_q, w->cap[3], (size_t)h->max_pairs * I));
-    KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float)));
+    KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? I / 32 : 1)));
     KTX_HIP(grow(w->dn_buf, w->cap[5], (size_t)h->max_pairs * H * sizeof(bf16_t)));
     KTX_HIP(grow(w->row_of_pair, w->cap[6], (size_t)h->max_pairs * sizeof(int32_t)));
     KTX_HIP(grow(w->src_of_row, w->cap[7], (size_t)h->max_pairs * sizeof(int32_t)));
@@ -1244,7 +1471,8 @@ extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_
   KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_bf16: null argument");
   KTX_HIP(hipSetDevice(h->cfg.device));
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
-  KTX_REQUIRE(h->cfg.format != KTX_FMT_FP8, "ktx_moe_load_bf16: FP8 handles take pre-quantised weights (ktx_moe_load_fp8)");
+  KTX_REQUIRE(h->cfg.format != KTX_FMT_FP8 && h->cfg.format != KTX_FMT_RAWINT4,
+              "ktx_moe_load_bf16: FP8 / RAWINT4 handles take pre-quantised weights (ktx_moe_load_fp8 / ktx_moe_load_rawint4)");
   if (h->cfg.format == KTX_FMT_BF16) {  // no quantisation: re-tile only (BufferBBF16Impl::from_mat is a re-layout too)
     const size_t pieces = (size_t)I * H * 2 / 16;
     for (int e = 0; e < E; e++) {
@@ -1282,8 +1510,8 @@ extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_
 extern "C" int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, const float* scale) {
   KTX_REQUIRE(h && q && scale, "ktx_moe_load_quantized: null argument");
   KTX_REQUIRE(expert >= 0 && expert < h->cfg.expert_num, "ktx_moe_load_quantized: expert out of range");
-  KTX_REQUIRE(h->wbits == 4 || (h->wbits == 8 && h->cfg.format == KTX_FMT_AMXINT8),
-              "ktx_moe_load_quantized: integer formats only");
+  KTX_REQUIRE(h->cfg.format == KTX_FMT_AMXINT4 || h->cfg.format == KTX_FMT_AMXINT8,
+              "ktx_moe_load_quantized: AMXINT4 / AMXINT8 handles only");
   KTX_REQUIRE(which >= 0 && which <= 2, "ktx_moe_load_quantized: bad matrix selector");
   KTX_HIP(hipSetDevice(h->cfg.device));
   const int H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
@@ -1324,6 +1552,33 @@ extern "C" int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_u
   KTX_HIP(hipMemcpy(h->gate_s, d_gate_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
   KTX_HIP(hipMemcpy(h->up_s, d_up_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
   KTX_HIP(hipMemcpy(h->down_s, d_down_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+extern "C" int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down,
+                                    const void* d_gate_scale, const void* d_up_scale, const void* d_down_scale) {
+  KTX_REQUIRE(h && d_gate && d_up && d_down && d_gate_scale && d_up_scale && d_down_scale, "ktx_moe_load_rawint4: null argument");
+  KTX_REQUIRE(h->cfg.format == KTX_FMT_RAWINT4, "ktx_moe_load_rawint4: handle was not created with KTX_FMT_RAWINT4");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const size_t dwords = (size_t)I * H / 8, nsc = (size_t)I * (H / 32);
+  for (int e = 0; e < E; e++) {
+    const uint8_t* src[3] = {(const uint8_t*)d_gate + (size_t)e * I * H / 2, (const uint8_t*)d_up + (size_t)e * I * H / 2,
+                             (const uint8_t*)d_down + (size_t)e * H * I / 2};
+    const bf16_t* ssrc[3] = {(const bf16_t*)d_gate_scale + e * nsc, (const bf16_t*)d_up_scale + e * nsc,
+                             (const bf16_t*)d_down_scale + e * nsc};
+    uint8_t* dst[3] = {h->gate_w + e * h->gu_stride, h->up_w + e * h->gu_stride, h->down_w + e * h->dn_stride};
+    bf16_t* sdst[3] = {(bf16_t*)h->gate_s + e * nsc, (bf16_t*)h->up_s + e * nsc, (bf16_t*)h->down_s + e * nsc};
+    const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
+    for (int m = 0; m < 3; m++) {
+      hipLaunchKernelGGL(pack_rawint4_kernel, dim3((unsigned)((dwords + 255) / 256)), dim3(256), 0, 0, src[m], Ns[m], Ks[m],
+                         reinterpret_cast<uint32_t*>(dst[m]));
+      hipLaunchKernelGGL(pack_rawint4_scales_kernel, dim3((unsigned)((nsc + 255) / 256)), dim3(256), 0, 0, ssrc[m], Ns[m],
+                         Ks[m], sdst[m]);
+    }
+  }
+  KTX_HIP(hipGetLastError());
   KTX_HIP(hipDeviceSynchronize());
   return 0;
 }
@@ -1397,6 +1652,8 @@ static int launch_gemm_fp(int mt, const FpGemmParams& p, int max_tiles, hipStrea
 
 static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                       const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st);
+static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                           const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st);
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
 // Slots: 0 prep, 1 gate/up GEMM, 2 act-quant, 3 down GEMM, 4 combine.  Not graph-capturable; off by default.
@@ -1468,7 +1725,7 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   hipStream_t st = (hipStream_t)stream;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   Workspace* ws = h->ws;
-  if (!(h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_BF16))
+  if (h->cfg.format == KTX_FMT_AMXINT4 || h->cfg.format == KTX_FMT_AMXINT8)
   if (qlen * k <= KTX_DEC_MAX_PAIRS && k <= 8 && H <= 8192 && I <= 2048 && !g_force_generic) {
     DecParams dp;
     dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
@@ -1539,6 +1796,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   }
   if (h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_BF16)
     return forward_fp(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
+  if (h->cfg.format == KTX_FMT_RAWINT4)
+    return forward_rawint4(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   const int mt = pick_mt(qlen, k, E);
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
@@ -1632,6 +1891,76 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
   {
     ProfScope ps(3, st);
     rc = fp8 ? launch_gemm_fp<true, false>(mt, g2, max_tiles, st) : launch_gemm_fp<false, false>(mt, g2, max_tiles, st);
+  }
+  if (rc) return rc;
+  CombineParams cp;
+  cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
+  cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
+  cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+  {
+    ProfScope ps(4, st);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+  }
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+
+template <int NT, bool GATE_UP>
+static int launch_rawint4(const RawGemmParams& p, int max_tiles, hipStream_t st) {
+  const size_t lds = 4 * (size_t)(p.K + 32) + (size_t)(p.K / 32) * 16;
+  static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_rawint4_gemm_kernel<NT, GATE_UP>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  KTX_HIP(err);
+  KTX_REQUIRE(lds <= 96 * 1024, "ktx_moe_forward: K too large for the RAWINT4 kernel");
+  hipLaunchKernelGGL((moe_rawint4_gemm_kernel<NT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+// RAWINT4: bucket (4-row tiles) -> per-group activation quant -> gate/up -> per-group requant -> down -> combine
+static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                           const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st) {
+  Workspace* ws = h->ws;
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const int npairs = qlen * k;
+  const int max_tiles = std::min(npairs, E) + npairs / 4;
+  PrepParams pp;
+  pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
+  pp.rows_per_tile = 4; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
+  pp.x_q = ws->x_q; pp.x_d = ws->x_d; pp.row_of_pair = ws->row_of_pair; pp.src_of_row = ws->src_of_row;
+  pp.tiles = ws->tiles; pp.counters = ws->counters;
+  {
+    ProfScope ps(0, st);
+    hipLaunchKernelGGL(moe_prep_kernel, dim3(1), dim3(1024), 0, st, pp);
+    hipLaunchKernelGGL(moe_actquant_kgroup_kernel, dim3(qlen), dim3(256), 0, st, (const bf16_t*)d_input, H, ws->x_q, ws->x_d,
+                       ws->counters, d_bsz, qlen, 1);
+  }
+  KTX_HIP(hipGetLastError());
+  const size_t nsc_gu = (size_t)I * (H / 32), nsc_dn = (size_t)H * (I / 32);
+  RawGemmParams g1;
+  g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = (const bf16_t*)h->gate_s; g1.s1 = (const bf16_t*)h->up_s;
+  g1.expert_stride = h->gu_stride; g1.scale_stride = nsc_gu; g1.N = I; g1.K = H; g1.act_q = ws->x_q; g1.act_d = ws->x_d;
+  g1.row_src = ws->src_of_row; g1.tiles = ws->tiles; g1.counters = ws->counters; g1.out = ws->a_buf;
+  int rc;
+  {
+    ProfScope ps(1, st);
+    rc = qlen == 1 ? launch_rawint4<1, true>(g1, max_tiles, st) : launch_rawint4<4, true>(g1, max_tiles, st);
+  }
+  if (rc) return rc;
+  {
+    ProfScope ps(2, st);
+    hipLaunchKernelGGL(moe_actquant_kgroup_kernel, dim3(npairs), dim3(256), 0, st, ws->a_buf, I, ws->a_q, ws->a_d, ws->counters,
+                       d_bsz, qlen, 0);
+  }
+  KTX_HIP(hipGetLastError());
+  RawGemmParams g2;
+  g2.w0 = h->down_w; g2.w1 = nullptr; g2.s0 = (const bf16_t*)h->down_s; g2.s1 = nullptr; g2.expert_stride = h->dn_stride;
+  g2.scale_stride = nsc_dn; g2.N = H; g2.K = I; g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.row_src = nullptr;
+  g2.tiles = ws->tiles; g2.counters = ws->counters; g2.out = ws->dn_buf;
+  {
+    ProfScope ps(3, st);
+    rc = qlen == 1 ? launch_rawint4<1, false>(g2, max_tiles, st) : launch_rawint4<4, false>(g2, max_tiles, st);
   }
   if (rc) return rc;
   CombineParams cp;

@@ -27,7 +27,11 @@ from ktransformers_amd.util.utils import InferenceState
 _BACKEND_TO_METHOD = {
     "AMXInt4": "AMXINT4", "AMXINT4": "AMXINT4", "int4": "AMXINT4",
     "AMXInt8": "AMXINT8", "AMXINT8": "AMXINT8", "int8": "AMXINT8",
+    "AMXBF16": "BF16", "BF16": "BF16",
+    "FP8": "FP8",                       # DeepSeek block-fp8 (weight + weight_scale_inv)
+    "RAWINT4": "RAWINT4",               # Kimi-K2 native int4 (weight_packed + weight_scale, group 32)
 }
+_GROUP_SIZE = {"FP8": 128, "RAWINT4": 32}
 
 
 class KExpertsBase(ABC):
@@ -104,14 +108,25 @@ class KExpertsHIP(KExpertsBase):
         inter = getattr(cfg, "moe_intermediate_size", None) or cfg.intermediate_size
         h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=self.max_len,
                       method=self.method, device=dev, expert_begin=self.expert_begin,
-                      global_expert_num=self.n_routed_experts)
+                      global_expert_num=self.n_routed_experts, group_size=_GROUP_SIZE.get(self.method, 0))
         sl = slice(self.expert_begin, self.expert_begin + self.expert_count)
 
-        def prep(t):
+        def prep(t, dtype=None):
             t = t if isinstance(t, torch.Tensor) else torch.as_tensor(t)
-            return t[sl].to(device=dev, dtype=torch.bfloat16).contiguous()
+            t = t[sl].to(device=dev)
+            return (t.to(dtype) if dtype is not None else t).contiguous()
 
-        h.load_bf16(prep(w["gate"]), prep(w["up"]), prep(w["down"]))
+        if self.method in ("AMXINT4", "AMXINT8", "BF16"):
+            # bf16 source weights; the integer formats are quantised online exactly like the reference's AMX backends
+            h.load_bf16(prep(w["gate"], torch.bfloat16), prep(w["up"], torch.bfloat16), prep(w["down"], torch.bfloat16))
+        elif self.method == "FP8":
+            h.load_fp8(prep(w["gate"]).view(torch.uint8), prep(w["up"]).view(torch.uint8), prep(w["down"]).view(torch.uint8),
+                       prep(w["gate_scale"], torch.float32), prep(w["up_scale"], torch.float32),
+                       prep(w["down_scale"], torch.float32))
+        else:  # RAWINT4
+            h.load_rawint4(prep(w["gate"]).view(torch.uint8), prep(w["up"]).view(torch.uint8), prep(w["down"]).view(torch.uint8),
+                           prep(w["gate_scale"], torch.bfloat16), prep(w["up_scale"], torch.bfloat16),
+                           prep(w["down_scale"], torch.bfloat16))
         self.handle = h
         if warmup:
             x = torch.zeros((1, cfg.hidden_size), dtype=torch.bfloat16, device=dev)

@@ -25,7 +25,7 @@ class DictLoader:
         return self.state[name].to(device)
 
     def get_expert_count(self, key: str) -> int:
-        pat = re.compile(re.escape(key) + r"\.(\d+)\.gate_proj\.weight$")
+        pat = re.compile(re.escape(key) + r"\.(\d+)\.gate_proj\.weight(_packed)?$")
         ids = [int(m.group(1)) for k in self.state for m in [pat.match(k)] if m]
         return max(ids) + 1 if ids else 0
 
@@ -36,6 +36,16 @@ class DictLoader:
         out = {}
         for proj in ("gate", "up", "down"):
             out[proj] = torch.stack([self.state[f"{key}.{e}.{proj}_proj.weight"] for e in range(n)]).to(device)
+            # DeepSeek block-fp8 checkpoints carry weight_scale_inv (kt-kernel/python/utils/loader.py:296-508); Kimi-K2
+            # compressed-tensors int4 carries weight_packed + weight_scale (:683-777)
+            for suffix in ("weight_scale_inv", "weight_scale"):
+                k0 = f"{key}.0.{proj}_proj.{suffix}"
+                if k0 in self.state:
+                    out[proj + "_scale"] = torch.stack(
+                        [self.state[f"{key}.{e}.{proj}_proj.{suffix}"] for e in range(n)]).to(device)
+            kp = f"{key}.0.{proj}_proj.weight_packed"
+            if kp in self.state:
+                out[proj] = torch.stack([self.state[f"{key}.{e}.{proj}_proj.weight_packed"] for e in range(n)]).to(device)
         return out
 
 

@@ -365,6 +365,93 @@ int ktxo_moe_forward_fp(const ktxo_moe* m, int T, int k, const int64_t* ids, con
   return 0;
 }
 
+/* ------------------------------------------------------------------------------------------------ */
+/* RAWINT4 (Kimi-K2 compressed-tensors int4, group 32): a6', a8'                                     */
+/* ------------------------------------------------------------------------------------------------ */
+
+/* GemmKernel224Int4SmallKGroup::integer_mat_vec_kgroup / integer_mat_mat_kgroup
+ * (operators/amx/la/amx_kernels.hpp:3385-3455 and :3453-3597) for one (row m, output n):
+ *   weights: byte = ((q1+8)<<4) | (q0+8), even k in the low nibble; int8 multiplicand = (nibble ^ 8) << 4 = 16*q
+ *   per 64-K block kb and AVX lane L (k = 64kb + 4L .. +3):  dot4 = sum a_q*w8  (exact int32)
+ *   lane accumulator  s_L = fma(as[g]*bs[g], float(dot4), s_L),  g = 2kb + (L >= 8)     (g++ contracts add(mul))
+ *   result = reduce_add(s_0..s_15) / 16  with _mm512_reduce_add_ps' tree: r_i = s_i + s_{i+8}; t_i = r_i + r_{i+4};
+ *            u0 = t0 + t2, u1 = t1 + t3; u0 + u1.
+ * use_fma selects the contracted form (what the g++-built reference executes). */
+static float rawint4_dot(const int8_t* aq, const float* as, const uint8_t* wrow, const float* bs, int K, int use_fma) {
+  float s[16];
+  for (int L = 0; L < 16; L++) s[L] = 0.0f;
+  for (int kb = 0; kb < K / 64; kb++) {
+    for (int L = 0; L < 16; L++) {
+      int32_t d = 0;
+      for (int i = 0; i < 4; i++) {
+        const int kk = kb * 64 + L * 4 + i;
+        const uint8_t byte = wrow[kk >> 1];
+        const int nib = (kk & 1) ? (byte >> 4) : (byte & 15);
+        const int8_t w8 = (int8_t)(((nib ^ 8) << 4) & 0xF0);
+        d += (int32_t)aq[kk] * (int32_t)w8;
+      }
+      const int g = kb * 2 + (L >= 8);
+      const float sc = as[g] * bs[g];
+      if (use_fma) s[L] = fmaf(sc, (float)d, s[L]);
+      else { float t = sc * (float)d; s[L] = s[L] + t; }
+    }
+  }
+  float r[8], t[4];
+  for (int i = 0; i < 8; i++) r[i] = s[i] + s[i + 8];
+  for (int i = 0; i < 4; i++) t[i] = r[i] + r[i + 4];
+  const float u0 = t[0] + t[2], u1 = t[1] + t[3];
+  return (u0 + u1) / 16.0f;
+}
+
+static void gemv_rawint4(const int8_t* aq, const float* as, const uint8_t* w, const float* bs, int N, int K, int use_fma,
+                         uint16_t* out) {
+  const int G = K / 32;
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; n++)
+    out[n] = ktxo_f32_to_bf16(rawint4_dot(aq, as, w + (size_t)n * (K / 2), bs + (size_t)n * G, K, use_fma));
+}
+
+/* AMX_K2_MOE_TP (operators/amx/k2-moe.hpp:88-191) inside the common frame of moe_base.hpp: QA = per (row, 32-group) int8.
+ * gate_q/up_q/down_q: packed nibbles [E][N][K/2]; *_d: fp32 scales [E][N][K/32] (bf16 in the checkpoint, widened at load,
+ * k2-moe.hpp:172-187). */
+int ktxo_moe_forward_rawint4(const ktxo_moe* m, int T, int k, const int64_t* ids, const float* w, const uint16_t* x,
+                             uint16_t* y, int incremental) {
+  if (m->fmt != KTXO_FMT_RAWINT4 || m->group != 32) return -1;
+  const int H = m->H, I = m->I, fm = !m->dp_even_first;   /* knob reused: 0 = contracted (reference build) */
+  int8_t* xq = (int8_t*)malloc((size_t)H);
+  float* xs = (float*)malloc(sizeof(float) * (H / 32));
+  int8_t* aq = (int8_t*)malloc((size_t)I);
+  float* as = (float*)malloc(sizeof(float) * (I / 32));
+  uint16_t* g = (uint16_t*)malloc(sizeof(uint16_t) * I);
+  uint16_t* u = (uint16_t*)malloc(sizeof(uint16_t) * I);
+  uint16_t* dn = (uint16_t*)malloc(sizeof(uint16_t) * H);
+  float* acc = (float*)malloc(sizeof(float) * H);
+  for (int t = 0; t < T; t++) {
+    ktxo_quant_act_row_kgroup(x + (size_t)t * H, H, 32, xq, xs);
+    for (int e = 0; e < H; e++) acc[e] = 0.0f;
+    for (int j = 0; j < k; j++) {
+      int64_t id = ids[(size_t)t * k + j];
+      if (skip_expert(m, id)) continue;
+      const size_t wo = (size_t)id * I * H / 2;
+      gemv_rawint4(xq, xs, (const uint8_t*)m->gate_q + wo, m->gate_d + (size_t)id * I * (H / 32), I, H, fm, g);
+      gemv_rawint4(xq, xs, (const uint8_t*)m->up_q + wo, m->up_d + (size_t)id * I * (H / 32), I, H, fm, u);
+      for (int i = 0; i < I; i++) g[i] = ktxo_f32_to_bf16(ktxo_act_fn(ktxo_bf16_to_f32(g[i]), ktxo_bf16_to_f32(u[i])));
+      ktxo_quant_act_row_kgroup(g, I, 32, aq, as);
+      gemv_rawint4(aq, as, (const uint8_t*)m->down_q + wo, m->down_d + (size_t)id * H * (I / 32), H, I, fm, dn);
+      const float wt = w[(size_t)t * k + j];
+      for (int e = 0; e < H; e++) acc[e] = fmaf(ktxo_bf16_to_f32(dn[e]), wt, acc[e]);
+    }
+    uint16_t* yt = y + (size_t)t * H;
+    for (int e = 0; e < H; e++) {
+      float v = acc[e];
+      if (incremental) v = v + ktxo_bf16_to_f32(yt[e]);
+      yt[e] = ktxo_f32_to_bf16(v);
+    }
+  }
+  free(xq); free(xs); free(aq); free(as); free(g); free(u); free(dn); free(acc);
+  return 0;
+}
+
 /* a5 — token->expert bucketing, operators/amx/moe_base.hpp:208-227: per-expert histogram m_local_num_[e],
  * arrival rank m_local_pos_[t][j] (token-major, slot-minor), compacted list of active experts in ascending id.
  * pos[t*k+j] = -1 for skipped slots.  Returns the number of active experts. */

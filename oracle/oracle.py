@@ -134,11 +134,17 @@ class Oracle:
         weights = np.ascontiguousarray(weights, dtype=np.float32)
         x_bf16 = np.ascontiguousarray(x_bf16, dtype=np.uint16)
         y = np.zeros((T, H), np.uint16) if y_prev is None else np.ascontiguousarray(y_prev, dtype=np.uint16).copy()
-        s = _KtxoMoe(moe["fmt"], moe["E"], H, I, 0,
+        s = _KtxoMoe(moe["fmt"], moe["E"], H, I, int(moe.get("group", 0)),
                      moe["gate_q"].ctypes.data, moe["gate_d"].ctypes.data if moe["gate_d"] is not None else None,
                      moe["up_q"].ctypes.data, moe["up_d"].ctypes.data if moe["up_d"] is not None else None,
                      moe["down_q"].ctypes.data, moe["down_d"].ctypes.data if moe["down_d"] is not None else None,
                      moe["mask"].ctypes.data if moe.get("mask") is not None else None, int(moe.get("dp_even_first", 0)))
+        if moe["fmt"] == FMT_RAWINT4:
+            rc = self.lib.ktxo_moe_forward_rawint4(C.byref(s), C.c_int(T), C.c_int(k), _p(ids), _p(weights), _p(x_bf16),
+                                                   _p(y), C.c_int(0 if y_prev is None else 1))
+            if rc != 0:
+                raise RuntimeError("ktxo_moe_forward_rawint4 failed")
+            return y
         if moe["fmt"] in (FMT_FP8, FMT_BF16):
             if trace:
                 raise NotImplementedError("traces are only kept for the integer formats")
@@ -166,6 +172,17 @@ class Oracle:
         return dict(fmt=FMT_FP8, E=E, H=H, I=I, gate_q=c(gate_fp8, dtype=np.uint8), up_q=c(up_fp8, dtype=np.uint8),
                     down_q=c(down_fp8, dtype=np.uint8), gate_d=c(gate_s, dtype=np.float32), up_d=c(up_s, dtype=np.float32),
                     down_d=c(down_s, dtype=np.float32), mask=mask, dp_even_first=dp_even_first)
+
+    def make_moe_rawint4(self, gate_p, up_p, down_p, gate_s, up_s, down_s, mask=None, uncontracted=0):
+        """packed nibbles gate/up [E,I,H/2], down [E,H,I/2] uint8; scales bf16 bits (uint16) or fp32 [E,N,K/32]."""
+        E, I, H2 = gate_p.shape
+        c = np.ascontiguousarray
+
+        def sc(a):
+            return c(bf16_to_f32(a) if a.dtype == np.uint16 else a, dtype=np.float32)
+        return dict(fmt=FMT_RAWINT4, E=E, H=H2 * 2, I=I, group=32, gate_q=c(gate_p, dtype=np.uint8), up_q=c(up_p, dtype=np.uint8),
+                    down_q=c(down_p, dtype=np.uint8), gate_d=sc(gate_s), up_d=sc(up_s), down_d=sc(down_s), mask=mask,
+                    dp_even_first=uncontracted)
 
     def make_moe_bf16(self, gate, up, down, mask=None, dp_even_first=0):
         E, I, H = gate.shape

@@ -60,3 +60,19 @@ def fp8_block_quant(w_f32):
     idx = np.searchsorted(mid, np.abs(v)).astype(np.uint8)
     q = idx | ((v < 0).astype(np.uint8) << 7)
     return q.reshape(E, N, K), scale.reshape(E, N // 128, K // 128).astype(np.float32)
+
+
+def rawint4_quantize(w_f32, group=32):
+    """[E,N,K] fp32 -> (packed uint8 [E,N,K/2] with byte = ((q1+8)<<4)|(q0+8), bf16 scale bits uint16 [E,N,K/group]),
+    vectorised form of rawint4_quantize in kt-kernel/test/per_commit/test_moe_rawint4_accuracy.py:69-94
+    (scale = amax/7 or 1, stored as bf16; q = clamp(round(w/scale)+8, 0, 15) with Python's round-half-even on the
+    fp32/fp64 quotient)."""
+    E, N, K = w_f32.shape
+    wg = w_f32.reshape(E, N, K // group, group).astype(np.float32)
+    amax = np.abs(wg).max(-1, keepdims=True).astype(np.float64)
+    scale = np.where(amax > 0, amax / 7.0, 1.0)
+    sb = f32_to_bf16(scale.astype(np.float32))                     # the test stores the scale in a bf16 tensor...
+    q = np.clip(np.rint(wg.astype(np.float64) / scale) + 8, 0, 15).astype(np.uint8)   # ...but divides by the fp64 one
+    q = q.reshape(E, N, K)
+    packed = (q[..., 1::2] << 4) | q[..., 0::2]
+    return np.ascontiguousarray(packed), np.ascontiguousarray(sb.reshape(E, N, K // group))

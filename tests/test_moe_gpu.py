@@ -314,3 +314,25 @@ def test_fp_formats_against_reference_golden(dev, fname, fmt, case):
         _check_fp(run(h, c, dev), g[f"{fname}_{case}_y"])
     finally:
         h.close()
+
+
+# ---- RAWINT4 (Kimi-K2 native int4, group 32): bit-exact --------------------------------------------------------------------
+@pytest.mark.parametrize("shape", [(8, 2, 512, 512, 1), (8, 2, 512, 512, 5), (8, 3, 1024, 512, 2), (16, 8, 7168, 2048, 1),
+                                   (8, 2, 512, 1024, 40), (4, 2, 512, 512, 300)])
+def test_rawint4_bit_exact(oracle, dev, shape):
+    from helpers import rawint4_quantize
+    from ktransformers_amd._native import MoEHandle
+    E, k, H, I, T = shape
+    c = make_case(8, E, k, H, I, T, invalid_ids=T >= 5)
+    q = [rawint4_quantize(bf16_to_f32(c[n])) for n in ("gate", "up", "down")]
+    mo = oracle.make_moe_rawint4(q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = MoEHandle(E, k, H, I, max_len=max(T, 8), method="RAWINT4", device=0, group_size=32)
+    try:
+        h.load_rawint4(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch_bf16(x[1], dev) for x in q])
+        got = run(h, c, dev)
+        assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ"
+        want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+        assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
+    finally:
+        h.close()
