@@ -154,18 +154,16 @@ class FullDecodeRunner:
         self.new_kpe = torch.randn((1, 64), generator=g, device=dev).to(torch.bfloat16)
         self.page_idx = torch.tensor([ctx // 64], dtype=torch.int32, device=dev)
         self.page_off = torch.tensor([ctx % 64], dtype=torch.int32, device=dev)
-        self.mla = MLAWrapper(1, pages, device=dev, max_q_tokens=1)
+        self.mla = MLAWrapper(1, pages, device=dev, max_q_tokens=1, max_splits=int(os.environ.get('KTX_MLA_SPLITS', '256')))
         self.kv_len = torch.tensor([ctx + 1], dtype=torch.int32, device=dev)
         self.mla.plan(None, None, None, self.kv_len, None, self.heads, 512, 64, 64, 192 ** -0.5, max_kv_len=ctx + 1)
         self.graph = None
 
     def step_eager(self):
-        from ktransformers_amd._native import mla_cache_append
-
         for a in range(self.nattn):
-            mla_cache_append(self.kv[a], self.new_ckv, self.new_kpe, self.page_idx, self.page_off)
             ckv, k_pe = torch.split(self.kv[a], [512, 64], dim=-1)
-            self.attn_out = self.mla.run(self.qn, self.qp, ckv, k_pe)
+            # latent-cache append of the new token is fused into the attention launch
+            self.attn_out = self.mla.run(self.qn, self.qp, ckv, k_pe, new_ckv=self.new_ckv, new_kpe=self.new_kpe)
             li = a - (self.nattn - len(self.layers))
             if li >= 0:
                 ids, w = self.gate.forward(self.x, self.gate_w[li], self.gate_b[li])

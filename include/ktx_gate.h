@@ -44,6 +44,13 @@ int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, 
 int ktx_gate_select(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const float* d_logits,
                     const float* d_bias, int64_t* d_topk_idx, float* d_topk_weight, void* stream);
 
+/* Both steps in ONE launch for decode-sized batches (bf16 x and w): the last workgroup of each token to finish its
+ * logits performs the selection.  d_counters: int32 [qlen], zero-initialised once by the caller (the kernel leaves them
+ * zero again).  d_logits fp32 [qlen][E] is scratch that also receives the logits. */
+int ktx_gate_forward(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x, const void* d_w,
+                     const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
+                     float* d_topk_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

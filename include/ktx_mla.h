@@ -45,6 +45,15 @@ int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, const void* 
                    const int32_t* d_bsz, int batch, int total_q_tokens, void* d_out, float* d_lse, void* d_workspace,
                    size_t workspace_bytes, void* stream);
 
+/* Decode step with the cache append fused in (one launch less per layer): for every request with exactly one query token,
+ * the newest position kv_len-1 is read from d_new_ckv [batch][512] / d_new_kpe [batch][64] instead of the cache and is
+ * written into the cache page by the kernel (StaticCache.update + run in one call).  NULL/NULL = plain ktx_mla_decode. */
+int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv, void* d_k_pe,
+                          int64_t ckv_token_stride, int64_t kpe_token_stride, const int32_t* d_qo_indptr,
+                          const int32_t* d_kv_indptr, const int32_t* d_kv_indices, const int32_t* d_kv_len_arr,
+                          const int32_t* d_bsz, int batch, int total_q_tokens, const void* d_new_ckv, const void* d_new_kpe,
+                          void* d_out, float* d_lse, void* d_workspace, size_t workspace_bytes, void* stream);
+
 /* cache.update(): scatter T new latent rows [ckv(512) | k_pe(64)] to cache[page_idx[t]][page_offset[t]]
  * (custom_cache.py:189-195 / :433-441).  kv_cache bf16 [pages][page_size][token_stride]. */
 int ktx_mla_cache_append(const ktx_mla_config* cfg, void* d_kv_cache, int64_t token_stride, const void* d_ckv_new,

@@ -61,10 +61,13 @@ def _load() -> C.CDLL:
     lib.ktx_gate_logits.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_gate_select.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]
+    lib.ktx_gate_forward.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int] + [C.c_void_p] * 8
     lib.ktx_mla_workspace_bytes.argtypes = [C.POINTER(_MlaConfig), C.c_int]
     lib.ktx_mla_workspace_bytes.restype = C.c_size_t
     lib.ktx_mla_decode.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.ktx_mla_decode_append.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
+        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.ktx_mla_cache_append.argtypes = [C.POINTER(_MlaConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_profile_enable.argtypes = [C.c_int]
@@ -263,6 +266,7 @@ class GateHandle:
                                GATE_SCORING[scoring_func], GATE_TOPK[topk_method], 1 if norm_topk_prob else 0,
                                float(routed_scaling_factor))
         self.E, self.H, self.k = n_routed_experts, hidden_size, top_k
+        self._counters: dict = {}
 
     def forward(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
                 bsz_tensor: torch.Tensor | None = None):
@@ -273,9 +277,21 @@ class GateHandle:
         st = _stream_ptr(dev)
         bsz_ptr = bsz_tensor.data_ptr() if bsz_tensor is not None else None
         if T <= self.LOGITS_HIP_MAX_T and weight.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
+            # one launch: logits GEMV, then the last workgroup of each token selects (include/ktx_gate.h)
             logits = torch.empty((T, self.E), dtype=torch.float32, device=dev)
+            idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
+            wt = torch.empty((T, self.k), dtype=torch.float32, device=dev)
+            cnt = self._counters.get(dev)
+            if cnt is None:
+                cnt = self._counters[dev] = torch.zeros(self.LOGITS_HIP_MAX_T, dtype=torch.int32, device=dev)
             xc, wc = x.contiguous(), weight.contiguous()
-            check(lib.ktx_gate_logits(C.byref(self.cfg), bsz_ptr, T, xc.data_ptr(), wc.data_ptr(), logits.data_ptr(), st))
+            b = bias.to(device=dev, dtype=torch.float32).contiguous() if bias is not None else None
+            check(lib.ktx_gate_forward(C.byref(self.cfg), bsz_ptr, T, xc.data_ptr(), wc.data_ptr(),
+                                       b.data_ptr() if b is not None else None, logits.data_ptr(), cnt.data_ptr(),
+                                       idx.data_ptr(), wt.data_ptr(), st))
+            return idx, wt
+        if False:
+            pass
         else:  # F.linear in fp32, exactly the reference's expression (modeling_deepseek_v3.py:434-437)
             logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
         idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
@@ -327,7 +343,9 @@ class MLAWrapper:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self.need_plan = False
 
-    def run(self, q_nope, q_pe, ckv, k_pe, return_lse: bool = False):
+    def run(self, q_nope, q_pe, ckv, k_pe, return_lse: bool = False, new_ckv=None, new_kpe=None):
+        """new_ckv [batch,512] / new_kpe [batch,64]: fuse StaticCache.update of the current decode token into the launch
+        (the kernel reads position kv_len-1 from these buffers and stores it into the cache pages)."""
         if self.cfg is None:
             raise KtxError("MLAWrapper.run before plan()")
         T, Hq, dc = q_nope.shape
@@ -344,12 +362,18 @@ class MLAWrapper:
         out = torch.empty((T, Hq, dc), dtype=torch.bfloat16, device=q_nope.device)
         lse = torch.empty((T, Hq), dtype=torch.float32, device=q_nope.device) if return_lse else None
         batch = self.qo_indptr.numel() - 1
-        check(lib.ktx_mla_decode(C.byref(self.cfg), q_nope.data_ptr(), q_pe.data_ptr(), ckv.data_ptr(), k_pe.data_ptr(),
-                                 ckv_ts, kpe_ts, self.qo_indptr.data_ptr(), self.kv_indptr.data_ptr(),
-                                 self.kv_indices.data_ptr(), self.kv_len_arr.data_ptr(),
-                                 self.bsz_tensor.data_ptr() if self.bsz_tensor is not None else None, batch, T,
-                                 out.data_ptr(), lse.data_ptr() if lse is not None else None, self.workspace.data_ptr(),
-                                 self.workspace.numel(), _stream_ptr(q_nope.device)))
+        if (new_ckv is None) != (new_kpe is None):
+            raise KtxError("MLAWrapper.run: pass both new_ckv and new_kpe or neither")
+        if new_ckv is not None and (new_ckv.dtype != torch.bfloat16 or not new_ckv.is_contiguous() or not new_kpe.is_contiguous()):
+            raise KtxError("MLAWrapper.run: new_ckv/new_kpe must be contiguous bf16")
+        check(lib.ktx_mla_decode_append(C.byref(self.cfg), q_nope.data_ptr(), q_pe.data_ptr(), ckv.data_ptr(), k_pe.data_ptr(),
+                                        ckv_ts, kpe_ts, self.qo_indptr.data_ptr(), self.kv_indptr.data_ptr(),
+                                        self.kv_indices.data_ptr(), self.kv_len_arr.data_ptr(),
+                                        self.bsz_tensor.data_ptr() if self.bsz_tensor is not None else None, batch, T,
+                                        new_ckv.data_ptr() if new_ckv is not None else None,
+                                        new_kpe.data_ptr() if new_kpe is not None else None,
+                                        out.data_ptr(), lse.data_ptr() if lse is not None else None, self.workspace.data_ptr(),
+                                        self.workspace.numel(), _stream_ptr(q_nope.device)))
         return (out, lse) if return_lse else out
 
 

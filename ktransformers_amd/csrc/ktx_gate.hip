@@ -53,14 +53,9 @@ __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 }
 
 template <int EPL>  // scores per lane: expert e lives on lane e % 64, slot e / 64 (E <= 64*EPL)
-__global__ __launch_bounds__(64) void gate_select_kernel(ktx_gate_config c, const int32_t* d_bsz, int qlen,
-                                                         const float* __restrict__ logits, const float* __restrict__ bias,
-                                                         int64_t* __restrict__ topk_idx, float* __restrict__ topk_w) {
-  int T = qlen;
-  if (d_bsz) T = min(max(*d_bsz, 0), qlen);
-  const int t = blockIdx.x;
-  if (t >= T) return;
-  const int lane = threadIdx.x;
+__device__ __forceinline__ void gate_select_token(const ktx_gate_config& c, int t, int lane, const float* __restrict__ logits,
+                                                  const float* __restrict__ bias, int64_t* __restrict__ topk_idx,
+                                                  float* __restrict__ topk_w) {
   const int E = c.n_routed_experts;
   const float NEG = -__builtin_inff();
   float score[EPL], choice[EPL];
@@ -172,6 +167,72 @@ __global__ __launch_bounds__(64) void gate_select_kernel(ktx_gate_config c, cons
   }
 }
 
+template <int EPL>
+__global__ __launch_bounds__(64) void gate_select_kernel(ktx_gate_config c, const int32_t* d_bsz, int qlen,
+                                                         const float* __restrict__ logits, const float* __restrict__ bias,
+                                                         int64_t* __restrict__ topk_idx, float* __restrict__ topk_w) {
+  int T = qlen;
+  if (d_bsz) T = min(max(*d_bsz, 0), qlen);
+  const int t = blockIdx.x;
+  if (t >= T) return;
+  gate_select_token<EPL>(c, t, threadIdx.x, logits, bias, topk_idx, topk_w);
+}
+
+// ---- fused router for decode-sized batches: logits GEMV + selection in ONE launch -----------------------------------------
+// Every workgroup computes 4 experts' logits for one token; the last workgroup of a token to finish (arrival ticket on a
+// per-token counter) performs the selection.  Hand-off = the placement-independent recipe of cdna_hip_programming.md §6
+// G16: plain stores -> __syncthreads -> one-lane agent-scope release -> counter; last arriver: one-lane agent-scope
+// acquire -> __syncthreads -> plain loads.  No workgroup ever waits, so residency does not matter.  The counter is reset by
+// the last arriver (zeroed at allocation), keeping the launch graph-replayable without a memset node.
+template <int EPL>
+__global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, const int32_t* d_bsz, int qlen,
+                                                         const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ logits,
+                                                         int32_t* __restrict__ counters, int64_t* __restrict__ topk_idx,
+                                                         float* __restrict__ topk_w) {
+  __shared__ int s_last;
+  int T = qlen;
+  if (d_bsz) T = min(max(*d_bsz, 0), qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int E = c.n_routed_experts, H = c.hidden_size;
+  const int lane = threadIdx.x & 63;
+  const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (e < E) {
+    const bf16_t* xr = x + (size_t)t * H;
+    const bf16_t* wr = w + (size_t)e * H;
+    float acc = 0.0f;
+    for (int j = lane * 8; j < H; j += 512) {
+      const uint4 a = *reinterpret_cast<const uint4*>(xr + j);
+      const uint4 b = *reinterpret_cast<const uint4*>(wr + j);
+      const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        acc = fmaf(bf16_to_f32((bf16_t)(av[q] & 0xffffu)), bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
+        acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
+      }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    if (lane == 0) logits[(size_t)t * E + e] = acc;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == (int)gridDim.x - 1;
+    if (last) {
+      __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    }
+    s_last = last;
+  }
+  __syncthreads();
+  if (s_last && threadIdx.x < 64) gate_select_token<EPL>(c, t, threadIdx.x, logits, bias, topk_idx, topk_w);
+}
+
 extern "C" int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x,
                                const void* d_w, float* d_logits, void* stream) {
   KTX_REQUIRE(cfg && d_x && d_w && d_logits && qlen > 0, "ktx_gate_logits: bad argument");
@@ -179,6 +240,31 @@ extern "C" int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz,
   const dim3 grid((cfg->n_routed_experts + 3) / 4, qlen);
   hipLaunchKernelGGL(gate_logits_kernel, grid, dim3(256), 0, (hipStream_t)stream, d_bsz, qlen, cfg->n_routed_experts,
                      cfg->hidden_size, (const bf16_t*)d_x, (const bf16_t*)d_w, d_logits);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ktx_gate_forward(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x, const void* d_w,
+                                const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
+                                float* d_topk_weight, void* stream) {
+  KTX_REQUIRE(cfg && d_x && d_w && d_logits && d_counters && d_topk_idx && d_topk_weight && qlen > 0, "ktx_gate_forward: bad argument");
+  const int E = cfg->n_routed_experts;
+  KTX_REQUIRE(cfg->hidden_size % 8 == 0, "ktx_gate_forward: hidden_size must be a multiple of 8");
+  KTX_REQUIRE(E > 0 && E <= KTX_GATE_MAX_E, "ktx_gate_forward: n_routed_experts out of range (1..1024)");
+  KTX_REQUIRE(cfg->top_k > 0 && cfg->top_k <= 64 && cfg->top_k <= E, "ktx_gate_forward: top_k out of range");
+  KTX_REQUIRE(cfg->n_group >= 1 && cfg->n_group <= 64 && E % cfg->n_group == 0, "ktx_gate_forward: bad n_group");
+  KTX_REQUIRE(cfg->topk_group >= 1 && cfg->topk_group <= cfg->n_group, "ktx_gate_forward: bad topk_group");
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((E + 3) / 4, qlen);
+  const int epl = (E + 63) / 64;
+#define KTX_FUSED(N) hipLaunchKernelGGL(gate_fused_kernel<N>, grid, dim3(256), 0, st, *cfg, d_bsz, qlen, (const bf16_t*)d_x, (const bf16_t*)d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight)
+  if (epl <= 1) KTX_FUSED(1);
+  else if (epl <= 2) KTX_FUSED(2);
+  else if (epl <= 4) KTX_FUSED(4);
+  else if (epl <= 6) KTX_FUSED(6);
+  else if (epl <= 8) KTX_FUSED(8);
+  else KTX_FUSED(16);
+#undef KTX_FUSED
   KTX_HIP(hipGetLastError());
   return 0;
 }

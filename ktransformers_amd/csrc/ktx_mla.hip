@@ -34,6 +34,9 @@ struct MlaParams {
   float sm_scale;
   float* part_o;   // [total_q][Hq][nsplit][512]
   float* part_ml;  // [total_q][Hq][nsplit][2]
+  // optional fused cache append for decode (one new token per request): latent rows [batch][512], [batch][64]
+  const bf16_t *app_ckv, *app_kpe;
+  bf16_t *ckv_w, *kpe_w;
 };
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
@@ -58,11 +61,17 @@ __device__ __forceinline__ v8bf load_v_frag(const bf16_t* base) {
   return c.v;
 }
 
-template <int NWV>
-__global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
+// Workgroup = HBW head blocks (16 heads each) x DSPLIT slices of the 512 output dims: wave (hbw, ds) computes the full
+// S = Q K^T of its head block (redundantly across ds: 36 cheap MFMAs) but only 512/DSPLIT dims of O += P V, which divides
+// the fp32 accumulator registers — the 128-VGPR O tile of the undivided form left one wave per SIMD running a serial
+// chain of LDS reads and MFMAs (~7 us per 32-token tile).
+template <int HBW, int DSPLIT>
+__global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams p) {
+  constexpr int NWV = HBW * DSPLIT;
+  constexpr int NDT = 32 / DSPLIT;   // 16-dim output tiles per wave
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [32][584] row-major [ckv | k_pe | pad]
-  bf16_t* Pt = Kt + MLA_TILE * MLA_KROW;                               // [NWV][16][32]
+  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584] row-major [ckv | k_pe | pad]
+  bf16_t* Pt = Kt + 2 * MLA_TILE * MLA_KROW;                           // [NWV][16][32]
   int* s_req = reinterpret_cast<int*>(Pt + NWV * 16 * MLA_TILE);       // [4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -75,19 +84,23 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
     int b = -1;
     for (int i = 0; i < B; i++)
       if (qt >= p.qo_indptr[i] && qt < p.qo_indptr[i + 1]) { b = i; break; }
-    int kv_end = 0;
+    int kv_end = 0, app = -1;
     if (b >= 0) {
       const int qo_len = p.qo_indptr[b + 1] - p.qo_indptr[b];
       kv_end = p.kv_len[b] - qo_len + (qt - p.qo_indptr[b]) + 1;   // causal: positions < kv_end are visible
       kv_end = max(kv_end, 0);
+      // fused cache append (decode: one new token per request): the newest position is taken from the append buffers
+      if (p.app_ckv && qo_len == 1) app = p.kv_len[b] - 1;
     }
     s_req[0] = b;
     s_req[1] = kv_end;
     s_req[2] = b >= 0 ? p.kv_indptr[b] : 0;
+    s_req[3] = app;
   }
   __syncthreads();
-  const int req = s_req[0], kv_end = s_req[1], page_base = s_req[2];
-  const int head0 = hb * NWV * 16 + wave * 16;
+  const int req = s_req[0], kv_end = s_req[1], page_base = s_req[2], app_pos = s_req[3];
+  const int hbw = wave / DSPLIT, ds = wave % DSPLIT;
+  const int head0 = (hb * HBW + hbw) * 16;
   const size_t pidx = ((size_t)qt * p.Hq + head0) * p.nsplit + split;  // + head*nsplit per head
   if (req < 0) return;
 
@@ -95,14 +108,75 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
   const int per = (ntiles + p.nsplit - 1) / p.nsplit;
   const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
 
-  v4f o[32];
+  v4f o[NDT];
 #pragma unroll
-  for (int i = 0; i < 32; i++) o[i] = v4f{0.f, 0.f, 0.f, 0.f};
+  for (int i = 0; i < NDT; i++) o[i] = v4f{0.f, 0.f, 0.f, 0.f};
   float m_run[4], l_run[4];
 #pragma unroll
   for (int r = 0; r < 4; r++) { m_run[r] = -__builtin_inff(); l_run[r] = 0.f; }
 
   if (t_begin < t_end) {
+    const bool tile_in_page = (p.page_size % MLA_TILE) == 0;
+    constexpr int KPE_PER_THREAD = (MLA_TILE * 8 + NWV * 64 - 1) / (NWV * 64);
+    uint4 kreg[KPE_PER_THREAD];
+
+    // ckv rows: one 1-KiB row per wave-instruction straight into LDS (global_load_lds); rows past the end are zeroed
+    // (P is 0 there and 0 * NaN would poison the output); the appended token comes from the append buffer and the
+    // workgroup (hb 0) that owns its tile also writes it into the cache (StaticCache.update, custom_cache.py:189-195)
+    auto stage_ckv = [&](int tile, bf16_t* dst) {
+      const int tok0 = tile * MLA_TILE;
+      const int ntok = min(MLA_TILE, kv_end - tok0);
+      const int page0 = p.kv_indices[page_base + tok0 / p.page_size];
+      for (int r = wave; r < MLA_TILE; r += NWV) {
+        if (r < ntok) {
+          const int pos = tok0 + r;
+          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
+          const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
+          const bf16_t* src = p.ckv + trow * p.ckv_ts;
+          if (pos == app_pos) {
+            src = p.app_ckv + (size_t)req * MLA_DC;
+            if (hb == 0) *reinterpret_cast<uint4*>(p.ckv_w + trow * p.ckv_ts + lane * 8) = *reinterpret_cast<const uint4*>(src + lane * 8);
+          }
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
+                                           (__attribute__((address_space(3))) void*)(dst + r * MLA_KROW), 16, 0, 0);
+        } else {
+          *reinterpret_cast<uint4*>(dst + r * MLA_KROW + lane * 8) = make_uint4(0, 0, 0, 0);
+        }
+      }
+    };
+    auto load_kpe = [&](int tile) {   // k_pe: 32 rows x 8 pieces of 16 B through registers
+      const int tok0 = tile * MLA_TILE;
+      const int ntok = min(MLA_TILE, kv_end - tok0);
+      const int page0 = p.kv_indices[page_base + tok0 / p.page_size];
+#pragma unroll
+      for (int i = 0; i < KPE_PER_THREAD; i++) {
+        const int u = tid + i * NWV * 64, r = u >> 3, piece = u & 7;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (u < MLA_TILE * 8 && r < ntok) {
+          const int pos = tok0 + r;
+          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
+          const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
+          if (pos == app_pos) {
+            v = *reinterpret_cast<const uint4*>(p.app_kpe + (size_t)req * MLA_DR + piece * 8);
+            if (hb == 0) *reinterpret_cast<uint4*>(p.kpe_w + trow * p.kpe_ts + piece * 8) = v;
+          } else {
+            v = *reinterpret_cast<const uint4*>(p.k_pe + trow * p.kpe_ts + piece * 8);
+          }
+        }
+        kreg[i] = v;
+      }
+    };
+    auto store_kpe = [&](bf16_t* dst) {
+#pragma unroll
+      for (int i = 0; i < KPE_PER_THREAD; i++) {
+        const int u = tid + i * NWV * 64;
+        if (u < MLA_TILE * 8) *reinterpret_cast<uint4*>(dst + (u >> 3) * MLA_KROW + MLA_DC + (u & 7) * 8) = kreg[i];
+      }
+    };
+
+    // first tile in flight while the Q fragments arrive
+    stage_ckv(t_begin, Kt);
+    load_kpe(t_begin);
     // ---- Q fragments: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope) ----------
     v8bf qf[18];
     {
@@ -114,43 +188,24 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
 #pragma unroll
       for (int s = 0; s < 2; s++) qf[16 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
     }
+    store_kpe(Kt);
     bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
-    // a tile never straddles a page when page_size is a multiple of the tile; otherwise look every row up
-    const bool tile_in_page = (p.page_size % MLA_TILE) == 0;
 
     for (int tile = t_begin; tile < t_end; tile++) {
+      const int cur = (tile - t_begin) & 1;
+      bf16_t* Kc = Kt + cur * MLA_TILE * MLA_KROW;
+      bf16_t* Kn = Kt + (cur ^ 1) * MLA_TILE * MLA_KROW;
       const int tok0 = tile * MLA_TILE;
       const int ntok = min(MLA_TILE, kv_end - tok0);
-      const int page0 = p.kv_indices[page_base + tok0 / p.page_size];   // one lookup per tile in the common case
-      __syncthreads();  // previous tile fully consumed
-      // ---- stage 32 token rows.  ckv: one 1-KiB row per wave-instruction, straight into LDS (global_load_lds) -----
-      for (int r = wave; r < MLA_TILE; r += NWV) {
-        if (r < ntok) {
-          const int pos = tok0 + r;
-          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
-          const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
-          __builtin_amdgcn_global_load_lds(
-              (const __attribute__((address_space(1))) void*)(p.ckv + trow * p.ckv_ts + lane * 8),
-              (__attribute__((address_space(3))) void*)(Kt + r * MLA_KROW), 16, 0, 0);
-        } else {  // rows past the end must be finite: P is 0 there and 0 * NaN would poison the output
-          *reinterpret_cast<uint4*>(Kt + r * MLA_KROW + lane * 8) = make_uint4(0, 0, 0, 0);
-        }
-      }
-      for (int u = tid; u < MLA_TILE * 8; u += NWV * 64) {  // k_pe: 32 rows x 8 pieces of 16 B through registers
-        const int r = u >> 3, piece = u & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (r < ntok) {
-          const int pos = tok0 + r;
-          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
-          v = *reinterpret_cast<const uint4*>(p.k_pe + ((size_t)page * p.page_size + pos % p.page_size) * p.kpe_ts + piece * 8);
-        }
-        *reinterpret_cast<uint4*>(Kt + r * MLA_KROW + MLA_DC + piece * 8) = v;
-      }
-      __syncthreads();  // (drains the LDS-DMA: the compiler emits vmcnt(0) ahead of the barrier)
+      // One barrier per tile: it drains this tile's LDS-DMA (the compiler emits vmcnt(0) ahead of it), publishes the k_pe
+      // stores, and proves every wave is done reading the other buffer, which the next tile's DMA may now overwrite.
+      __syncthreads();
+      const bool more = tile + 1 < t_end;
+      if (more) { stage_ckv(tile + 1, Kn); load_kpe(tile + 1); }
 
       // ---- S = Q K^T for 2 x 16 tokens -----------------------------------------------------------------------------
       v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-      const bf16_t* kb0 = Kt + (lane & 15) * MLA_KROW + (lane >> 4) * 8;
+      const bf16_t* kb0 = Kc + (lane & 15) * MLA_KROW + (lane >> 4) * 8;
       const bf16_t* kb1 = kb0 + 16 * MLA_KROW;
 #pragma unroll
       for (int s = 0; s < 18; s++) {
@@ -187,14 +242,15 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
       const v8bf pf = as_v8bf(*reinterpret_cast<const uint4*>(Pw + (lane & 15) * MLA_TILE + (lane >> 4) * 8));
 
       // ---- O = O*alpha + P V ; V fragments by transposed reads of the same K tile ------------------------------------
-      const bf16_t* vb = Kt + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * MLA_KROW + (lane & 3) * 4;
+      const bf16_t* vb = Kc + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * MLA_KROW + (lane & 3) * 4 + ds * NDT * 16;
 #pragma unroll
-      for (int i = 0; i < 32; i++) {
+      for (int i = 0; i < NDT; i++) {
 #pragma unroll
         for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
         const v8bf b = load_v_frag(vb + i * 16);
         o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
       }
+      if (more) store_kpe(Kn);
     }
   }
 
@@ -202,29 +258,30 @@ __global__ __launch_bounds__(NWV * 64) void mla_decode_kernel(MlaParams p) {
 #pragma unroll
   for (int r = 0; r < 4; r++) {
     const int hrow = (lane >> 4) * 4 + r;
-    if ((lane & 15) == 0) {
+    if ((lane & 15) == 0 && ds == 0) {
       float* ml = p.part_ml + (pidx + (size_t)hrow * p.nsplit) * 2;
       ml[0] = m_run[r];
       ml[1] = l_run[r];
     }
     if (t_begin < t_end) {
-      float* po = p.part_o + (pidx + (size_t)hrow * p.nsplit) * MLA_DC;
+      float* po = p.part_o + (pidx + (size_t)hrow * p.nsplit) * MLA_DC + ds * NDT * 16;
 #pragma unroll
-      for (int i = 0; i < 32; i++) po[i * 16 + (lane & 15)] = o[i][r];
+      for (int i = 0; i < NDT; i++) po[i * 16 + (lane & 15)] = o[i][r];
     }
   }
 }
 
-// merge the KV splits: one 256-thread workgroup per (query token, head).  Softmax statistics are combined split-parallel,
-// the weights are parked in LDS, then wave w accumulates splits w, w+4, ... (8 of the 512 dims per lane) with
-// unconditional, independent loads (a dead split's load is redirected to a live one and weighted by 0), and the four
-// partial sums meet in LDS.
+// merge the KV splits: one 256-thread workgroup per (query token, head, quarter of the 512 output dims) — a workgroup
+// pulls cross-XCD data at only ~65 GB/s (MI355X_MICROARCH.md handoff-payload), so the partials of one head are spread
+// over four workgroups.  Every workgroup recomputes the (tiny) softmax statistics split-parallel and parks the weights in
+// LDS; thread (sl, dg) then accumulates splits sl, sl+16, ... for 8 dims with unconditional, independent loads (a dead
+// split's load is redirected to a live one and weighted by 0); the 16 split-lanes meet in LDS.
 __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p, bf16_t* out, float* lse) {
   __shared__ float s_w[1024];
   __shared__ float s_red[8];
   __shared__ int s_live;
-  __shared__ float s_acc[4][MLA_DC];
-  const int qt = blockIdx.y, h = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  __shared__ float s_acc[16][128 + 4];
+  const int qt = blockIdx.y, h = blockIdx.x, quarter = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int B = p.batch;
   if (p.d_bsz) B = min(max(*p.d_bsz, 0), p.batch);
   if (qt >= p.qo_indptr[B]) return;
@@ -255,34 +312,40 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p, bf16_t* out
   __syncthreads();
   lsum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
   const int live0 = s_live;
+  const int dg = tid & 15, sl = tid >> 4;   // 16 dim groups of 8 dims x 16 split lanes
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
   if (live0 != 0x7fffffff) {
-    const float* po = p.part_o + base * MLA_DC + lane * 8;
-#pragma unroll 4
-    for (int s = wave; s < p.nsplit; s += 4) {
-      const float w = s_w[s];
-      const int ss = w > 0.f ? s : live0;
-      const float4 a = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC);
-      const float4 b = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC + 4);
-      acc[0] += a.x * w; acc[1] += a.y * w; acc[2] += a.z * w; acc[3] += a.w * w;
-      acc[4] += b.x * w; acc[5] += b.y * w; acc[6] += b.z * w; acc[7] += b.w * w;
+    const float* po = p.part_o + base * MLA_DC + quarter * 128 + dg * 8;
+    for (int s0 = sl; s0 < p.nsplit; s0 += 64) {
+      float wv[4];
+      float4 va[4], vb[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        const int s = s0 + 16 * u;
+        wv[u] = s < p.nsplit ? s_w[s] : 0.f;
+        const int ss = wv[u] > 0.f ? s : live0;
+        va[u] = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC);
+        vb[u] = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC + 4);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; u++) {
+        acc[0] += va[u].x * wv[u]; acc[1] += va[u].y * wv[u]; acc[2] += va[u].z * wv[u]; acc[3] += va[u].w * wv[u];
+        acc[4] += vb[u].x * wv[u]; acc[5] += vb[u].y * wv[u]; acc[6] += vb[u].z * wv[u]; acc[7] += vb[u].w * wv[u];
+      }
     }
   }
 #pragma unroll
-  for (int q = 0; q < 8; q++) s_acc[wave][lane * 8 + q] = acc[q];
+  for (int q = 0; q < 8; q++) s_acc[sl][dg * 8 + q] = acc[q];
   __syncthreads();
-  if (wave == 0) {
+  if (tid < 64) {   // 128 dims: two per thread
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-    uint32_t w[4];
+    float v0 = 0.f, v1 = 0.f;
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      const int d0 = lane * 8 + 2 * q;
-      const float v0 = (s_acc[0][d0] + s_acc[1][d0]) + (s_acc[2][d0] + s_acc[3][d0]);
-      const float v1 = (s_acc[0][d0 + 1] + s_acc[1][d0 + 1]) + (s_acc[2][d0 + 1] + s_acc[3][d0 + 1]);
-      w[q] = (uint32_t)f32_to_bf16(v0 * inv) | ((uint32_t)f32_to_bf16(v1 * inv) << 16);
-    }
-    *reinterpret_cast<uint4*>(out + ((size_t)qt * p.Hq + h) * MLA_DC + lane * 8) = make_uint4(w[0], w[1], w[2], w[3]);
-    if (lse && lane == 0) lse[(size_t)qt * p.Hq + h] = lsum > 0.f ? (mstar + __logf(lsum)) * 1.44269504089f : -__builtin_inff();
+    for (int i = 0; i < 16; i++) { v0 += s_acc[i][2 * tid]; v1 += s_acc[i][2 * tid + 1]; }
+    const uint32_t w = (uint32_t)f32_to_bf16(v0 * inv) | ((uint32_t)f32_to_bf16(v1 * inv) << 16);
+    *reinterpret_cast<uint32_t*>(out + ((size_t)qt * p.Hq + h) * MLA_DC + quarter * 128 + 2 * tid) = w;
+    if (lse && tid == 0 && quarter == 0)
+      lse[(size_t)qt * p.Hq + h] = lsum > 0.f ? (mstar + __logf(lsum)) * 1.44269504089f : -__builtin_inff();
   }
 }
 
@@ -314,6 +377,18 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
                               const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
                               const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
                               void* d_out, float* d_lse, void* d_workspace, size_t workspace_bytes, void* stream) {
+  return ktx_mla_decode_append(cfg, d_q_nope, d_q_pe, const_cast<void*>(d_ckv), const_cast<void*>(d_k_pe), ckv_token_stride,
+                               kpe_token_stride, d_qo_indptr, d_kv_indptr, d_kv_indices, d_kv_len_arr, d_bsz, batch,
+                               total_q_tokens, nullptr, nullptr, d_out, d_lse, d_workspace, workspace_bytes, stream);
+}
+
+extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
+                                     void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
+                                     const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
+                                     const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
+                                     const void* d_new_ckv, const void* d_new_kpe, void* d_out, float* d_lse,
+                                     void* d_workspace, size_t workspace_bytes, void* stream) {
+  KTX_REQUIRE((d_new_ckv == nullptr) == (d_new_kpe == nullptr), "ktx_mla_decode_append: give both new_ckv and new_kpe or neither");
   KTX_REQUIRE(cfg && d_q_nope && d_q_pe && d_ckv && d_k_pe && d_out && d_workspace, "ktx_mla_decode: null pointer");
   KTX_REQUIRE(d_qo_indptr && d_kv_indptr && d_kv_indices && d_kv_len_arr, "ktx_mla_decode: null index array");
   KTX_REQUIRE(cfg->head_dim_ckv == MLA_DC && cfg->head_dim_kpe == MLA_DR, "ktx_mla_decode: only kv_lora_rank 512 + rope 64");
@@ -322,10 +397,12 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
   KTX_REQUIRE(ckv_token_stride % 8 == 0 && kpe_token_stride % 8 == 0, "ktx_mla_decode: token strides must be multiples of 8 elements");
   hipStream_t st = (hipStream_t)stream;
   const int Hq = cfg->num_heads;
-  const int nwv = (Hq % 64 == 0) ? 4 : 1;
-  const int hblocks = Hq / (16 * nwv);
-  // KV splits: enough workgroups to cover the chip a few times over, one tile of 32 tokens per split when the caller
-  // gives a context-length hint (every extra split costs the merge kernel a partial to read), bounded by the workspace
+  // workgroup shape: (head blocks x dim slices) = 4x2 for head counts that are multiples of 64, 1x4 otherwise
+  const bool wide = (Hq % 64 == 0);
+  const int hbw = wide ? 4 : 1, nwv = wide ? 8 : 4;
+  const int hblocks = Hq / (16 * hbw);
+  // KV splits: one 32-token tile per workgroup whenever the grid stays under ~2048 workgroups (measured: extra tiles per
+  // workgroup cost more than the extra partials cost the merge kernel), bounded by the workspace
   int nsplit = std::max(1, 2048 / std::max(1, hblocks * total_q_tokens));
   if (cfg->kv_len_hint > 0) nsplit = std::min(nsplit, std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE));
   nsplit = std::min(nsplit, std::min(1024, std::max(1, cfg->max_splits)));
@@ -341,21 +418,22 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
   p.sm_scale = cfg->sm_scale;
   p.part_o = (float*)d_workspace;
   p.part_ml = p.part_o + (size_t)total_q_tokens * Hq * nsplit * MLA_DC;
-  const size_t lds = (size_t)(MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
+  p.app_ckv = (const bf16_t*)d_new_ckv; p.app_kpe = (const bf16_t*)d_new_kpe; p.ckv_w = (bf16_t*)d_ckv; p.kpe_w = (bf16_t*)d_k_pe;
+  const size_t lds = (size_t)(2 * MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
   const dim3 grid(nsplit, hblocks, total_q_tokens);
-  if (nwv == 4) {
-    static hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<4>),
+  if (wide) {
+    static hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<4, 2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     KTX_HIP(e4);
-    hipLaunchKernelGGL(mla_decode_kernel<4>, grid, dim3(256), lds, st, p);
+    hipLaunchKernelGGL((mla_decode_kernel<4, 2>), grid, dim3(512), lds, st, p);
   } else {
-    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<1>),
+    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<1, 4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     KTX_HIP(e1);
-    hipLaunchKernelGGL(mla_decode_kernel<1>, grid, dim3(64), lds, st, p);
+    hipLaunchKernelGGL((mla_decode_kernel<1, 4>), grid, dim3(256), lds, st, p);
   }
   KTX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(mla_merge_kernel, dim3(Hq, total_q_tokens), dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+  hipLaunchKernelGGL(mla_merge_kernel, dim3(Hq, total_q_tokens, 4), dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
   KTX_HIP(hipGetLastError());
   return 0;
 }

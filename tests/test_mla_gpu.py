@@ -79,3 +79,37 @@ def test_cache_append():
     want[pos // 64, pos % 64, 0, :512] = ckv          # StaticCache.update (custom_cache.py:189-195)
     want[pos // 64, pos % 64, 0, 512:] = kpe
     assert torch.equal(cache, want)
+
+
+def test_decode_with_fused_cache_append():
+    """run(new_ckv, new_kpe) == cache_append followed by run, and the cache ends up updated."""
+    from ktransformers_amd._native import MLAWrapper
+    g = torch.Generator().manual_seed(9)
+    Hq, page, B = 16, 64, 3
+    kv_lens = [130, 64, 1]                               # position kv_len-1 is the token being appended
+    pages_per = [(n + page - 1) // page for n in kv_lens]
+    kv_buf = torch.randn((sum(pages_per) + 1, page, 576), generator=g).to(torch.bfloat16)
+    q_nope = torch.randn((B, Hq, 512), generator=g).to(torch.bfloat16)
+    q_pe = torch.randn((B, Hq, 64), generator=g).to(torch.bfloat16)
+    new_ckv = torch.randn((B, 512), generator=g).to(torch.bfloat16)
+    new_kpe = torch.randn((B, 64), generator=g).to(torch.bfloat16)
+    kv_indices = torch.arange(sum(pages_per), dtype=torch.int32)
+    kv_indptr = torch.tensor([0] + list(np.cumsum(pages_per)), dtype=torch.int32)
+    qo_indptr = torch.arange(B + 1, dtype=torch.int32)
+    kv_len_arr = torch.tensor(kv_lens, dtype=torch.int32)
+    ref_buf = kv_buf.clone()
+    for b in range(B):
+        pos = kv_lens[b] - 1
+        pg = int(kv_indices[int(kv_indptr[b]) + pos // page])
+        ref_buf[pg, pos % page, :512] = new_ckv[b]
+        ref_buf[pg, pos % page, 512:] = new_kpe[b]
+    ref, _ = mla_paged_ref(q_nope, q_pe, ref_buf, qo_indptr, kv_indptr, kv_indices, kv_len_arr, 192 ** -0.5)
+    w = MLAWrapper(B, kv_buf.shape[0], device=DEV, max_q_tokens=B)
+    kvd = kv_buf.to(DEV)
+    ckv, k_pe = torch.split(kvd, [512, 64], dim=-1)
+    w.plan(qo_indptr.to(DEV), kv_indptr.to(DEV), kv_indices.to(DEV), kv_len_arr.to(DEV),
+           torch.tensor([B], dtype=torch.int32, device=DEV), Hq, 512, 64, page, 192 ** -0.5)
+    out = w.run(q_nope.to(DEV), q_pe.to(DEV), ckv, k_pe, new_ckv=new_ckv.to(DEV), new_kpe=new_kpe.to(DEV))
+    torch.cuda.synchronize()
+    torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2.0 ** -7, atol=5e-3)
+    assert torch.equal(kvd.cpu(), ref_buf), "the kernel must leave the appended rows in the cache"
