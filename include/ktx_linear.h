@@ -1,0 +1,92 @@
+/* ktx_linear.h — C ABI of the quantised dense linears around the MoE/MLA hot path (libktx_hip.so).
+ *
+ * Replaces what the reference's injected linear operators call:
+ *
+ *   reference (NVIDIA GPU)                                               this library (gfx950)
+ *   -------------------------------------------------------------------  -----------------------------------------
+ *   KLinearMarlin.load: marlin_quantize(w, 4, 64, act_order=False)       ktx_linear_load_bf16 (format W4) — the
+ *     archive/ktransformers/operators/linear.py:633-677                    quantiser of quant_utils.py:36-98 restated
+ *     .../custom_marlin/quantize/utils/{marlin_utils.py:79-114,            on the GPU (same q and bf16 scales), or
+ *       quant_utils.py:36-98}                                              ktx_linear_load_w4 (pre-quantised q + s)
+ *   KLinearMarlin.forward: KTransformersOps.gptq_marlin_gemm(...)        ktx_linear_forward
+ *     linear.py:679-711 (un-vendored CUDA; W4A16, fp32 accumulate)
+ *   KLinearFP8.load / forward: act_quant(x,128) + fp8_gemm(...)          ktx_linear_load_fp8 / ktx_linear_forward
+ *     linear.py:408-429, ktransformers_ext/triton/fp8gemm.py:10-193
+ *   KLinearTorch.forward: x @ W (+ bias)    linear.py:173-183            ktx_linear_load_bf16 (format BF16) / forward
+ *
+ * Conventions as in ktx_moe.h: DEVICE pointers, kernels are only enqueued on `stream` (graph capturable, no
+ * allocation inside forward), 0 = success, ktx_last_error() holds the message.  Activations and outputs are bf16
+ * row-major [T][in_features] / [T][out_features].  The reference pads Marlin shapes to K%128, N%64 with zero weights
+ * (linear.py:622-630, 655-658); here any in_features%8==0 and any out_features work and the padding is internal.
+ */
+#ifndef KTX_LINEAR_H
+#define KTX_LINEAR_H
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct ktx_linear_s* ktx_linear_t;
+#ifndef KTX_MOE_H
+typedef void* ktx_stream_t; /* hipStream_t */
+const char* ktx_last_error(void);
+#endif
+
+enum ktx_linear_format {
+  KTX_LIN_BF16 = 0, /* dense bf16 weights (KLinearTorch) */
+  KTX_LIN_W4 = 1,   /* Marlin/GPTQ symmetric uint4, zero point 8, bf16 scale per (group of `group_size` inputs, output) */
+  KTX_LIN_FP8 = 2,  /* e4m3 weights + fp32 scale_inv per 128x128 block; activations quantised to e4m3 per 128 inputs */
+};
+
+typedef struct ktx_linear_config {
+  int32_t in_features;  /* K (KLinearBase.in_features, linear.py:76-84) */
+  int32_t out_features; /* N */
+  int32_t format;       /* enum ktx_linear_format */
+  int32_t group_size;   /* W4: 32, 64 (KLinearMarlin default, linear.py:607) or 128; FP8: 128; BF16: 0 */
+  int32_t max_len;      /* largest T of one forward */
+  int32_t device;       /* HIP device ordinal */
+  int32_t batch;        /* 0/1: one matrix; B > 1: B independent [N][K] matrices (per-head absorb bmm, attention.py:414-418,467) */
+} ktx_linear_config;
+
+int ktx_linear_create(const ktx_linear_config* cfg, ktx_linear_t* out);
+int ktx_linear_destroy(ktx_linear_t h);
+
+/* d_w: bf16 [batch][out_features][in_features] (the nn.Linear weight; KLinearMarlin transposes it itself, linear.py:645),
+ * d_bias: bf16 [out_features] or NULL.  BF16 handles keep the weights (re-tiled); W4 handles quantise on the GPU with
+ * the arithmetic of quantize_weights (quant_utils.py:61-67) evaluated as torch evaluates it on bf16 tensors:
+ * s = bf16(max|w| * (2/15)), q = clamp(rint(bf16(w / s)) + 8, 0, 15).  Synchronous. */
+int ktx_linear_load_bf16(ktx_linear_t h, const void* d_w, const void* d_bias);
+
+/* Pre-quantised Marlin-semantics weights, DEVICE pointers: d_q uint8 [in_features][out_features] with values 0..15
+ * (quantize_weights' q_w, before the Marlin tile permutation), d_s bf16 [in_features/group_size][out_features]
+ * (its `s`).  Synchronous. */
+int ktx_linear_load_w4(ktx_linear_t h, const uint8_t* d_q, const void* d_s, const void* d_bias);
+
+/* DeepSeek block-fp8: d_w e4m3 bytes [out_features][in_features], d_scale_inv fp32 [ceil(N/128)][ceil(K/128)]
+ * (`weight`, `weight_scale_inv` of the checkpoint; KLinearFP8.load, linear.py:416-429).  in_features % 128 == 0.
+ * Synchronous. */
+int ktx_linear_load_fp8(ktx_linear_t h, const void* d_w, const float* d_scale_inv, const void* d_bias);
+
+/* y[t] = x[t] · W^T (+ bias) for t < min(T, *d_bsz) (d_bsz may be NULL = T rows); rows beyond are left untouched.
+ * Mirrors KLinear*.forward(x, bsz_tensor) (linear.py:174,409,679). */
+int ktx_linear_forward(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y, ktx_stream_t stream);
+
+/* Batched form for the per-head absorb products of MLA (torch.matmul(q_nope, q_absorb) / matmul(attn, out_absorb.mT),
+ * archive/ktransformers/operators/attention.py:414-418,465-468): batch b uses weight matrix b ([batch][N][K] at load)
+ * and reads x[t*ldx + b*x_batch_stride + k], writes y[t*ldy + b*y_batch_stride + n] (strides in elements). */
+int ktx_linear_forward_batched(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, int64_t ldx,
+                               int64_t x_batch_stride, void* d_y, int64_t ldy, int64_t y_batch_stride,
+                               ktx_stream_t stream);
+
+/* bytes of HBM held for the weights (tiles + scales) — the algorithmic bytes one decode launch streams */
+size_t ktx_linear_weight_bytes(ktx_linear_t h);
+
+/* tests only: read back the quantiser's result in the layout of ktx_linear_load_w4 (HOST pointers). */
+int ktx_linear_debug_get_w4(ktx_linear_t h, uint8_t* q, uint16_t* s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

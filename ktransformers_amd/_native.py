@@ -32,6 +32,10 @@ class _MlaConfig(C.Structure):
                 ("page_size", C.c_int32), ("sm_scale", C.c_float), ("max_splits", C.c_int32), ("kv_len_hint", C.c_int32)]
 
 
+class _LinearConfig(C.Structure):
+    _fields_ = [(n, C.c_int32) for n in ("in_features", "out_features", "format", "group_size", "max_len", "device", "batch")]
+
+
 class _MoeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
@@ -70,6 +74,24 @@ def _load() -> C.CDLL:
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.ktx_mla_cache_append.argtypes = [C.POINTER(_MlaConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    lib.ktx_linear_create.argtypes = [C.POINTER(_LinearConfig), C.POINTER(C.c_void_p)]
+    lib.ktx_linear_destroy.argtypes = [C.c_void_p]
+    lib.ktx_linear_load_bf16.argtypes = [C.c_void_p] * 3
+    lib.ktx_linear_load_w4.argtypes = [C.c_void_p] * 4
+    lib.ktx_linear_load_fp8.argtypes = [C.c_void_p] * 4
+    lib.ktx_linear_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ktx_linear_forward_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                               C.c_int64, C.c_int64, C.c_void_p]
+    lib.ktx_linear_weight_bytes.argtypes = [C.c_void_p]
+    lib.ktx_linear_weight_bytes.restype = C.c_size_t
+    lib.ktx_linear_debug_get_w4.argtypes = [C.c_void_p] * 3
+    lib.ktx_linear_debug_force_gemm.argtypes = [C.c_int]
+    lib.ktx_rmsnorm.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_float, C.c_int,
+                                C.c_void_p, C.c_void_p]
+    lib.ktx_fused_add_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
+    lib.ktx_silu_mul.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ktx_mla_prep.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
+                                                 C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.ktx_profile_enable.argtypes = [C.c_int]
     lib.ktx_debug_force_generic.argtypes = [C.c_int]
     lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
@@ -250,6 +272,120 @@ GATE_SCORING = {"sigmoid": 0, "softmax": 1}
 GATE_TOPK = {"greedy": 0, "group_limited_greedy": 1, "noaux_tc": 2}
 
 
+LIN_FMT = {"BF16": 0, "W4": 1, "FP8": 2}
+
+
+class LinearHandle:
+    """Owner of one ktx_linear_t (include/ktx_linear.h): tiled weights of one dense linear on one GPU."""
+
+    def __init__(self, in_features: int, out_features: int, fmt: str = "W4", group_size: int = 64, max_len: int = 4096,
+                 device: int | torch.device = 0, batch: int = 1):
+        dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if dev.type != "cuda":
+            raise KtxError("LinearHandle needs a HIP device; there is no CPU path")
+        if fmt not in LIN_FMT:
+            raise KtxError(f"unknown linear format {fmt!r}")
+        self.device, self.fmt, self.K, self.N, self.max_len = dev, fmt, in_features, out_features, max_len
+        self.group_size = {"BF16": 0, "FP8": 128}.get(fmt, group_size)
+        self.batch = max(int(batch), 1)
+        cfg = _LinearConfig(in_features, out_features, LIN_FMT[fmt], self.group_size, max_len, dev.index or 0, self.batch)
+        h = C.c_void_p()
+        check(lib.ktx_linear_create(C.byref(cfg), C.byref(h)))
+        self._h = h
+
+    def close(self) -> None:
+        if getattr(self, "_h", None):
+            lib.ktx_linear_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _chk(self, t: torch.Tensor, dtype, shape, what: str) -> torch.Tensor:
+        if t.dtype != dtype or tuple(t.shape) != tuple(shape) or t.device != self.device:
+            raise KtxError(f"{what}: expected {dtype} {tuple(shape)} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        return t.contiguous()
+
+    def _bias(self, bias):
+        return None if bias is None else self._chk(bias, torch.bfloat16, (self.N,), "bias")
+
+    def load_bf16(self, weight: torch.Tensor, bias: torch.Tensor | None = None) -> None:
+        """weight: bf16 [out, in] (nn.Linear layout). W4 handles quantise with quantize_weights' arithmetic."""
+        shape = (self.N, self.K) if self.batch == 1 else (self.batch, self.N, self.K)
+        w = self._chk(weight, torch.bfloat16, shape, "load_bf16")
+        b = self._bias(bias)
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_linear_load_bf16(self._h, w.data_ptr(), b.data_ptr() if b is not None else None))
+
+    def load_w4(self, q: torch.Tensor, s: torch.Tensor, bias: torch.Tensor | None = None) -> None:
+        """q: uint8 [in, out] in 0..15, s: bf16 [in/group, out] — the (q_w, s) of quantize_weights."""
+        q = self._chk(q, torch.uint8, (self.K, self.N), "load_w4 q")
+        s = self._chk(s, torch.bfloat16, (self.K // self.group_size, self.N), "load_w4 s")
+        b = self._bias(bias)
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_linear_load_w4(self._h, q.data_ptr(), s.data_ptr(), b.data_ptr() if b is not None else None))
+
+    def load_fp8(self, weight: torch.Tensor, scale_inv: torch.Tensor, bias: torch.Tensor | None = None) -> None:
+        """weight: float8_e4m3fn (or its uint8 bytes) [out, in]; scale_inv fp32 [ceil(out/128), ceil(in/128)]."""
+        if weight.dtype == torch.float8_e4m3fn:
+            weight = weight.view(torch.uint8)
+        w = self._chk(weight, torch.uint8, (self.N, self.K), "load_fp8 weight")
+        sc = self._chk(scale_inv, torch.float32, ((self.N + 127) // 128, (self.K + 127) // 128), "load_fp8 scale_inv")
+        b = self._bias(bias)
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_linear_load_fp8(self._h, w.data_ptr(), sc.data_ptr(), b.data_ptr() if b is not None else None))
+
+    def weight_bytes(self) -> int:
+        return int(lib.ktx_linear_weight_bytes(self._h))
+
+    def debug_get_w4(self):
+        import numpy as np
+        q = np.empty((self.K, self.N), dtype=np.uint8)
+        s = np.empty((self.K // self.group_size, self.N), dtype=np.uint16)
+        check(lib.ktx_linear_debug_get_w4(self._h, q.ctypes.data, s.ctypes.data))
+        return q, s
+
+    def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+        """x: bf16 [..., in] -> bf16 [..., out] on the current stream."""
+        if x.dtype != torch.bfloat16 or x.shape[-1] != self.K or x.device != self.device:
+            raise KtxError(f"forward: expected bf16 [..., {self.K}] on {self.device}, got {x.dtype} {tuple(x.shape)} on {x.device}")
+        x2 = x.reshape(-1, self.K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        if out is None:
+            out = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
+                torch.zeros((T, self.N), dtype=torch.bfloat16, device=self.device)
+        bsz = None
+        if bsz_tensor is not None:
+            if bsz_tensor.dtype != torch.int32 or bsz_tensor.device != self.device:
+                raise KtxError("forward: bsz_tensor must be int32 on the handle's device")
+            bsz = bsz_tensor.data_ptr()
+        check(lib.ktx_linear_forward(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+        return out.reshape(*x.shape[:-1], self.N)
+
+
+    def forward_batched(self, x: torch.Tensor, out: torch.Tensor | None = None, bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
+        """x: bf16 [T, batch, in] (any row / batch strides that are multiples of 8, unit stride along `in`) ->
+        bf16 [T, batch, out]: y[t, b] = x[t, b] @ W[b]^T — the per-head absorb products of MLA."""
+        if x.dtype != torch.bfloat16 or x.dim() != 3 or x.shape[1] != self.batch or x.shape[2] != self.K or x.stride(2) != 1:
+            raise KtxError(f"forward_batched: expected bf16 [T, {self.batch}, {self.K}] with unit inner stride, got {tuple(x.shape)}")
+        T = x.shape[0]
+        if out is None:
+            out = torch.empty((T, self.batch, self.N), dtype=torch.bfloat16, device=self.device)
+        bsz = bsz_tensor.data_ptr() if bsz_tensor is not None else None
+        check(lib.ktx_linear_forward_batched(self._h, bsz, T, x.data_ptr(), x.stride(0), x.stride(1), out.data_ptr(),
+                                             out.stride(0), out.stride(1), _stream_ptr(self.device)))
+        return out
+
+
+def linear_force_gemm(on: bool) -> None:
+    check(lib.ktx_linear_debug_force_gemm(1 if on else 0))
+
+
 class GateHandle:
     """Router parameters of one MoE layer + the two-launch HIP router (include/ktx_gate.h)."""
 
@@ -390,3 +526,75 @@ def mla_cache_append(kv_cache: torch.Tensor, ckv_new: torch.Tensor, kpe_new: tor
     check(lib.ktx_mla_cache_append(C.byref(cfg), kv_cache.data_ptr(), ts, c.data_ptr(), r.data_ptr(), pi.data_ptr(),
                                    po.data_ptr(), ntokens.data_ptr() if ntokens is not None else None, T,
                                    _stream_ptr(kv_cache.device)))
+
+
+# ---- small fused ops (include/ktx_ops.h) ---------------------------------------------------------------------------
+def _bf16_rows(t: torch.Tensor, what: str) -> torch.Tensor:
+    if t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(-1) != 1:
+        raise KtxError(f"{what}: expected a bf16 device tensor with unit inner stride, got {t.dtype} on {t.device}")
+    return t
+
+
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, native_rounding: bool = True,
+            bsz_tensor: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
+    """RMSNorm over the last dim of a bf16 [..., dim] tensor (layernorm.py:79-87 when native_rounding)."""
+    _bf16_rows(x, "rmsnorm")
+    dim = x.shape[-1]
+    x2 = x.reshape(-1, dim)
+    if out is None:
+        out = torch.empty((x2.shape[0], dim), dtype=torch.bfloat16, device=x.device)
+    o2 = out.reshape(-1, dim)
+    check(lib.ktx_rmsnorm(x2.data_ptr(), x2.stride(0), weight.data_ptr(), o2.data_ptr(), o2.stride(0), x2.shape[0], dim,
+                          float(eps), 1 if native_rounding else 0, bsz_tensor.data_ptr() if bsz_tensor is not None else None,
+                          _stream_ptr(x.device)))
+    return out.reshape(x.shape)
+
+
+def fused_add_rmsnorm(x: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                      bsz_tensor: torch.Tensor | None = None) -> None:
+    """In place: residual += x; x = rmsnorm(residual) (flashinfer.norm.fused_add_rmsnorm, layernorm.py:69)."""
+    _bf16_rows(x, "fused_add_rmsnorm")
+    dim = x.shape[-1]
+    if not (x.is_contiguous() and residual.is_contiguous()) or residual.shape != x.shape or residual.dtype != torch.bfloat16:
+        raise KtxError("fused_add_rmsnorm: x and residual must be contiguous bf16 tensors of the same shape")
+    check(lib.ktx_fused_add_rmsnorm(x.data_ptr(), residual.data_ptr(), weight.data_ptr(), x.numel() // dim, dim, float(eps),
+                                    bsz_tensor.data_ptr() if bsz_tensor is not None else None, _stream_ptr(x.device)))
+
+
+def silu_mul(gate_up: torch.Tensor, bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
+    """gate_up: bf16 [T, 2*I] = [gate | up] -> bf16 [T, I] = silu(gate) * up."""
+    _bf16_rows(gate_up, "silu_mul")
+    g2 = gate_up.reshape(-1, gate_up.shape[-1])
+    inter = g2.shape[1] // 2
+    out = torch.empty((g2.shape[0], inter), dtype=torch.bfloat16, device=g2.device)
+    check(lib.ktx_silu_mul(g2.data_ptr(), g2.stride(0), out.data_ptr(), g2.shape[0], inter,
+                           bsz_tensor.data_ptr() if bsz_tensor is not None else None, _stream_ptr(g2.device)))
+    return out.reshape(*gate_up.shape[:-1], inter)
+
+
+def mla_prep(q: torch.Tensor | None, kv: torch.Tensor | None, kv_norm_weight: torch.Tensor | None, eps: float,
+             positions: torch.Tensor, inv_freq: torch.Tensor, mscale: float, num_heads: int, nope_dim: int, rope_dim: int,
+             kv_lora: int):
+    """q: bf16 [T, num_heads*(nope+rope)] (or None), kv: bf16 [T, kv_lora+rope] (or None), positions int64 [T].
+    Returns (q_pe [T,H,rope] | None, ckv [T,kv_lora] | None, k_pe [T,rope] | None)."""
+    T = positions.numel()
+    dev = positions.device
+    if positions.dtype != torch.int64 or inv_freq.dtype != torch.float32:
+        raise KtxError("mla_prep: positions must be int64 and inv_freq fp32")
+    q_pe = ckv = kpe = None
+    if q is not None:
+        _bf16_rows(q, "mla_prep q")
+        q = q.reshape(T, -1)
+        q_pe = torch.empty((T, num_heads, rope_dim), dtype=torch.bfloat16, device=dev)
+    if kv is not None:
+        _bf16_rows(kv, "mla_prep kv")
+        kv = kv.reshape(T, -1)
+        ckv = torch.empty((T, kv_lora), dtype=torch.bfloat16, device=dev)
+        kpe = torch.empty((T, rope_dim), dtype=torch.bfloat16, device=dev)
+    check(lib.ktx_mla_prep(T, num_heads, nope_dim, rope_dim, kv_lora, q.data_ptr() if q is not None else None,
+                           q.stride(0) if q is not None else 0, q_pe.data_ptr() if q is not None else None,
+                           kv.data_ptr() if kv is not None else None, kv.stride(0) if kv is not None else 0,
+                           kv_norm_weight.data_ptr() if kv is not None else None, float(eps),
+                           ckv.data_ptr() if kv is not None else None, kpe.data_ptr() if kv is not None else None,
+                           positions.data_ptr(), inv_freq.data_ptr(), float(mscale), _stream_ptr(dev)))
+    return q_pe, ckv, kpe

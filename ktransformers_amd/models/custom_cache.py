@@ -1,0 +1,82 @@
+"""Paged latent KV cache for MLA — mirror of the MLA branch of archive/ktransformers/models/custom_cache.py:26-215
+(StaticCache): one `[max_pages, page_size, 1, kv_lora_rank + qk_rope_head_dim]` bf16 tensor per layer, pages of 64
+tokens, an identity page table, `update()` scatters the new `[ckv | k_pe]` rows at `cache_position`.
+
+The scatter itself is `mla_cache_append_kernel` (csrc/ktx_mla.hip); the decode path of KDeepseekV2Attention does not even
+call update(): the MLA kernel stores the new row while it reads it (ktx_mla_decode_append)."""
+from __future__ import annotations
+
+from typing import Any, Dict, Optional, Tuple
+
+import torch
+
+
+class StaticCache:
+    def __init__(self, config, max_batch_size: int, max_cache_len: Optional[int], device, dtype=None) -> None:
+        self._max_batch_size = max_batch_size
+        self._max_cache_len = config.max_position_embeddings if max_cache_len is None else max_cache_len
+        self.dtype = dtype if dtype is not None else torch.bfloat16
+        if self.dtype != torch.bfloat16:
+            raise ValueError("the HIP MLA kernels read a bf16 latent cache")
+        self.page_size = 64                                                      # custom_cache.py:81
+        self.max_pages = (self._max_cache_len + self.page_size - 1) // self.page_size
+        self.kv_lora_rank = config.kv_lora_rank
+        self.qk_rope_head_dim = config.qk_rope_head_dim
+        self.num_hidden_layers = config.num_hidden_layers
+        self.is_MLA, self.is_page = True, True
+        latent_shape = (self.max_pages, self.page_size, 1, self.kv_lora_rank + self.qk_rope_head_dim)
+        self.key_cache, self.value_cache, self.page_table_list, self.past_tokens = [], [], [], []
+        self.page_table_map: Dict[Any, torch.Tensor] = {}
+        for idx in range(self.num_hidden_layers):
+            dev = device[f"blk.{idx}.self_attn"]["generate_device"] if isinstance(device, dict) else device
+            if dev not in self.page_table_map:                                   # custom_cache.py:99-104
+                pt = torch.arange(max_batch_size * self.max_pages, dtype=torch.int32, device=dev)
+                self.page_table_map[dev] = pt.view(max_batch_size, self.max_pages)
+            self.page_table_list.append(self.page_table_map[dev])
+            self.key_cache.append(torch.zeros(latent_shape, dtype=self.dtype, device=dev))
+            self.value_cache.append(None)
+            self.past_tokens.append(0)
+
+    @property
+    def max_batch_size(self):
+        return self._max_batch_size
+
+    @property
+    def max_cache_len(self):
+        return self._max_cache_len
+
+    def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int,
+               cache_kwargs: Optional[Dict[str, Any]] = None) -> Tuple[torch.Tensor, torch.Tensor]:
+        """key_states = compressed_kv [.., T, 1, kv_lora], value_states = k_pe [.., T, 1, rope] (custom_cache.py:147-199)."""
+        from ktransformers_amd._native import mla_cache_append
+
+        cache_position = cache_kwargs.get("cache_position")
+        k_out = self.key_cache[layer_idx]
+        self.past_tokens[layer_idx] += cache_position.size(0)
+        page_idx = cache_position // self.page_size
+        page_offset = cache_position % self.page_size
+        mla_cache_append(k_out, key_states.reshape(-1, self.kv_lora_rank), value_states.reshape(-1, self.qk_rope_head_dim),
+                         page_idx, page_offset)
+        return k_out, self.page_table_list[layer_idx]
+
+    def note_appended(self, layer_idx: int, n: int) -> None:
+        """Bookkeeping for rows the attention kernel appended itself."""
+        self.past_tokens[layer_idx] += n
+
+    def get_seq_length(self, layer_idx: Optional[int] = 0) -> int:
+        return self.past_tokens[layer_idx]
+
+    def get_usable_length(self, kv_seq_len: int, layer_idx: Optional[int] = 0) -> int:
+        return self.past_tokens[layer_idx]
+
+    def change_seq_length(self, bias: Optional[int] = 0) -> None:
+        for i in range(self.num_hidden_layers):
+            self.past_tokens[i] += bias
+
+    def get_max_length(self) -> Optional[int]:
+        return self._max_cache_len
+
+    def reset(self):
+        for i in range(self.num_hidden_layers):
+            self.key_cache[i].zero_()
+            self.past_tokens[i] = 0

@@ -1,0 +1,151 @@
+"""MLA attention operator — mirror of archive/ktransformers/operators/attention.py:47-75,349-523
+(KDeepseekV2Attention.forward_linux_flashinfer; "V3 MLA is same to V2").
+
+HF call signature and return `(attn_output, None, past_key_value)`; the replaced module supplies the sub-modules
+(q_proj | q_a_proj+q_a_layernorm+q_b_proj, kv_a_proj_with_mqa, kv_a_layernorm, kv_b_proj, o_proj, rotary_emb) which the
+rule file may itself have replaced by KTransformersLinear / RMSNorm / YarnRotaryEmbeddingV3.  One forward is
+
+    q, kv_a projections            KLinear* (csrc/ktx_linear.hip)
+    latent RMSNorm + RoPE(q_pe, k_pe)   one launch, ktx_mla_prep (csrc/ktx_ops.hip)
+    q_nope · W_UK  (absorb)        batched bf16 linear, one launch over heads
+    paged MQA over the latent + cache append     ktx_mla_decode_append (csrc/ktx_mla.hip)
+    attn · W_UV^T                  batched bf16 linear
+    o_proj                         KLinear*
+
+The reference switches to a non-absorbed flash-attention path for prompts unless `absorb_for_prefill` is set
+(attention.py:393,470-523); here the absorbed path serves every q_len (same math, the latent never leaves its 576-wide
+form) — `absorb_for_prefill` is accepted and ignored."""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+from torch import nn
+
+from ktransformers_amd.operators.base_operator import BaseInjectedModule
+from ktransformers_amd.operators.RoPE import yarn_get_mscale
+
+
+class KDeepseekV2Attention(BaseInjectedModule):
+    def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, prefill_device: str = "cuda",
+                 generate_device: str = "cuda", chunck_size: int = 1000, absorb_for_prefill: bool = False, **kwargs):
+        BaseInjectedModule.__init__(self, key, gguf_loader, config, orig_module, prefill_device, generate_device, **kwargs)
+        c = config
+        for name, val in (("chunck_size", chunck_size), ("absorb_for_prefill", absorb_for_prefill), ("mla_wrapper", None),
+                          ("_absorb", None), ("_decode_plan", None)):
+            object.__setattr__(self, name, val)
+        for name in ("num_heads", "q_lora_rank", "qk_rope_head_dim", "kv_lora_rank", "v_head_dim", "qk_nope_head_dim",
+                     "q_head_dim", "layer_idx"):
+            if not hasattr(orig_module, name):
+                derived = {"num_heads": getattr(c, "num_attention_heads", None),
+                           "q_head_dim": c.qk_nope_head_dim + c.qk_rope_head_dim,
+                           "layer_idx": None}.get(name, getattr(c, name, None))
+                setattr(orig_module, name, derived)
+        if not hasattr(orig_module, "softmax_scale"):                      # modeling_deepseek_v3.py:697-703
+            scale = orig_module.q_head_dim ** (-0.5)
+            rs = getattr(c, "rope_scaling", None)
+            if rs is not None and rs.get("mscale_all_dim", 0):
+                m = yarn_get_mscale(rs["factor"], rs["mscale_all_dim"])
+                scale = scale * m * m
+            orig_module.softmax_scale = scale
+
+    # ---- absorbed kv_b_proj (attention.py:67-74): W_UK [H, nope, lora] used as q_nope @ W_UK, W_UV [H, v, lora] --------
+    def get_absorbed(self):
+        if self._absorb is None:
+            from ktransformers_amd._native import LinearHandle
+
+            H, nope, v, lora = self.num_heads, self.qk_nope_head_dim, self.v_head_dim, self.kv_lora_rank
+            w = self.kv_b_proj.weight
+            if w.shape[0] != H * (nope + v):                               # KLinearTorch exposes the transposed weight
+                w = w.T
+            kv_b = w.reshape(H, nope + v, lora).to(torch.bfloat16)
+            dev = kv_b.device
+            q_absorb = kv_b[:, :nope, :]                                   # [H, nope, lora]
+            out_absorb = kv_b[:, nope:, :]                                 # [H, v, lora]
+            qa = LinearHandle(nope, lora, "BF16", 0, self._max_len(), dev, batch=H)
+            qa.load_bf16(q_absorb.transpose(1, 2).contiguous())            # y[lora] = sum_nope x[nope] * W_UK[nope, lora]
+            oa = LinearHandle(lora, v, "BF16", 0, self._max_len(), dev, batch=H)
+            oa.load_bf16(out_absorb.contiguous())                          # y[v] = sum_lora x[lora] * W_UV[v, lora]
+            object.__setattr__(self, "_absorb", (qa, oa))
+            object.__setattr__(self, "q_absorb", q_absorb)
+            object.__setattr__(self, "out_absorb", out_absorb)
+        return self._absorb
+
+    def _max_len(self) -> int:
+        return int(getattr(self.config, "max_position_embeddings", 4096) or 4096)
+
+    def _rope_params(self, device):
+        rope = self.rotary_emb
+        inv = getattr(rope, "inv_freq", None)
+        if inv is None and hasattr(rope, "load"):
+            rope.load()
+            inv = rope.inv_freq
+        inv = inv.to(device=device, dtype=torch.float32).contiguous()
+        return inv, float(getattr(rope, "_mscale", 1.0))
+
+    def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
+                position_ids: Optional[torch.Tensor] = None, past_key_value=None, output_attentions: bool = False,
+                use_cache: bool = False, cache_position: Optional[torch.Tensor] = None, **kwargs
+                ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
+        from ktransformers_amd._native import MLAWrapper, mla_prep, rmsnorm
+
+        bsz, q_len, _ = hidden_states.size()
+        if bsz != 1:
+            raise ValueError("KDeepseekV2Attention: the single-request engine path runs bsz == 1 (attention.py:421-422)")
+        if past_key_value is None:
+            raise ValueError("KDeepseekV2Attention needs the paged latent cache (past_key_value)")
+        dev = hidden_states.device
+        H, nope, rope, lora = self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim, self.kv_lora_rank
+        x = hidden_states.reshape(q_len, -1)
+
+        if self.q_lora_rank is None:
+            q = self.q_proj(x)
+        else:
+            qa = self.q_a_proj(x)
+            ln = self.q_a_layernorm                                        # DeepseekV3RMSNorm.forward (native rounding)
+            q = self.q_b_proj(rmsnorm(qa, ln.weight.to(torch.bfloat16), ln.variance_epsilon, native_rounding=True))
+        kv = self.kv_a_proj_with_mqa(x)
+        q = q.reshape(q_len, H * (nope + rope))
+
+        inv_freq, mscale = self._rope_params(dev)
+        pos = position_ids.reshape(-1).to(torch.int64)
+        kln = self.kv_a_layernorm
+        q_pe, ckv_new, kpe_new = mla_prep(q, kv, kln.weight.to(torch.bfloat16), kln.variance_epsilon, pos, inv_freq, mscale,
+                                          H, nope, rope, lora)
+
+        qabs, oabs = self.get_absorbed()
+        q3 = q.view(q_len, H, nope + rope)
+        q_nope = qabs.forward_batched(q3[:, :, :nope])                     # [T, H, lora]
+
+        Hp = (H + 15) // 16 * 16          # the MLA kernel tiles heads by 16 (every shipped model: 16 / 64 / 128 heads)
+        if Hp != H:
+            q_nope = torch.cat([q_nope, q_nope.new_zeros(q_len, Hp - H, lora)], dim=1)
+            q_pe = torch.cat([q_pe, q_pe.new_zeros(q_len, Hp - H, rope)], dim=1)
+        cache = past_key_value.key_cache[self.layer_idx]                   # [pages, page, 1, lora + rope]
+        ckv_pages = cache[:, :, 0, :lora]
+        kpe_pages = cache[:, :, 0, lora:]
+        if self.mla_wrapper is None:
+            object.__setattr__(self, "mla_wrapper", MLAWrapper(1, past_key_value.max_pages, use_cuda_graph=True, device=dev,
+                                                               max_q_tokens=self._max_len()))
+        if q_len == 1:
+            # kv_len is read on the device: positions + 1 (attention.py:430-433); the kernel appends the new row itself
+            kv_len = (pos + 1).to(torch.int32)
+            self.mla_wrapper.plan(None, None, None, kv_len, None, Hp, lora, rope, past_key_value.page_size,
+                                  self.softmax_scale, torch.bfloat16, torch.bfloat16)
+            attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
+            past_key_value.note_appended(self.layer_idx, 1)
+            object.__setattr__(self, "_decode_plan", kv_len)
+        else:
+            cp = cache_position if cache_position is not None else pos
+            past_key_value.update(ckv_new, kpe_new, self.layer_idx, {"cache_position": cp})
+            qo_indptr = torch.tensor([0, q_len], dtype=torch.int32, device=dev)
+            kv_len = (pos[-1:] + 1).to(torch.int32)
+            self.mla_wrapper.plan(qo_indptr, None, None, kv_len, None, Hp, lora, rope, past_key_value.page_size,
+                                  self.softmax_scale, torch.bfloat16, torch.bfloat16)
+            attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
+        out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
+        out = self.o_proj(out.reshape(q_len, H * self.v_head_dim))
+        return out.reshape(bsz, q_len, -1), None, past_key_value
+
+
+KDeepseekV3Attention = KDeepseekV2Attention

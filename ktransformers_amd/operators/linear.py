@@ -1,0 +1,239 @@
+"""Injected linear operators — mirror of archive/ktransformers/operators/linear.py.
+
+Same class names, constructor kwargs, `load / unload / forward(x, bsz_tensor)` lifecycle and `LINEAR_MAP` registry as the
+reference, so its YAML rules (`class: ktransformers.operators.linear.KTransformersLinear`, kwargs `generate_op:
+"KLinearMarlin"`, `prefill_op: "KLinearTorch"`) resolve unchanged.  The compute is the HIP library (include/ktx_linear.h):
+
+  KLinearMarlin (linear.py:595-720)  -> W4 g=64 handle; weights quantised on the GPU with quantize_weights' arithmetic
+  KLinearFP8    (linear.py:388-436)  -> block-fp8 handle (e4m3 weight + weight_scale_inv; e4m3 activations per 128)
+  KLinearTorch  (linear.py:158-216)  -> dense bf16 handle
+  VLinearMarlin / KLinearQ8 / KLinearCPUInfer / KLinearIPEXLLM are vendor back-ends of the same contract; their names map
+  to the closest of the three above so a rule file written for another box still loads.
+
+One deliberate difference: the reference keeps a *prefill* and a *generate* copy (bf16 for KLinearTorch prefill, Marlin
+for decode) and swaps them on `set_inference_mode` because the Marlin kernel is slow for long prompts; here one
+quantised copy serves every T (the same handle runs a GEMV kernel for T <= 4 and an MFMA-tiled GEMM above), so when
+both ops name a quantised format only one handle is built.
+"""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from ktransformers_amd.operators.base_operator import BaseInjectedModule
+from ktransformers_amd.util.utils import InferenceState
+
+
+class KLinearBase(nn.Module):
+    """linear.py:57-155 — shape discovery and weight fetch through the loader."""
+    FMT = "BF16"
+
+    def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module = None, device: str = "cuda", **kwargs):
+        nn.Module.__init__(self)
+        self.key, self.gguf_loader, self.device, self.config = key, gguf_loader, device, config
+        self.has_bias = False
+        self.dtype = torch.get_default_dtype()
+        if orig_module is not None:
+            self.in_features, self.out_features = orig_module.in_features, orig_module.out_features
+        else:
+            shape = gguf_loader.load_tensor(key + ".weight").shape      # [out, in]
+            self.out_features, self.in_features = int(shape[0]), int(shape[1])
+        self.loaded = False
+        self.max_len = int(kwargs.get("max_len", getattr(config, "max_position_embeddings", 4096) or 4096))
+        self._h = None
+        self.weight = None
+
+    def load_weight(self, override_key: str | None = None, device: str | None = None):
+        """linear.py:92-141 for the safetensors branch: weight (+ weight_scale_inv) (+ bias)."""
+        key = override_key or self.key
+        ld = self.gguf_loader
+        if not ld.has_tensor(key + ".weight"):
+            raise FileNotFoundError(f"Weight file not found for key {key}")
+        w = ld.load_tensor(key + ".weight", device=device or "cpu")
+        bias = ld.load_tensor(key + ".bias", device=device or "cpu") if ld.has_tensor(key + ".bias") else None
+        if ld.has_tensor(key + ".weight_scale_inv"):
+            return nn.Parameter(w, requires_grad=False), nn.Parameter(
+                ld.load_tensor(key + ".weight_scale_inv", device=device or "cpu"), requires_grad=False)
+        if bias is not None:
+            return nn.Parameter(w, requires_grad=False), nn.Parameter(bias, requires_grad=False)
+        return nn.Parameter(w, requires_grad=False)
+
+    def _make_handle(self, group_size: int = 0):
+        from ktransformers_amd._native import LinearHandle
+        return LinearHandle(self.in_features, self.out_features, self.FMT, group_size, self.max_len, torch.device(self.device))
+
+    def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor = None, **kwargs) -> torch.Tensor:
+        if self._h is None:
+            raise RuntimeError(f"{type(self).__name__}({self.key}): forward before load()")
+        dtype, dev = x.dtype, x.device
+        y = self._h.forward(x.to(device=self.device, dtype=torch.bfloat16), bsz_tensor)
+        return y.to(dtype=dtype, device=dev)
+
+    def unload(self):
+        if self._h is not None:
+            self._h.close()
+        self._h = None
+        self.weight = None
+        self.loaded = False
+
+
+def _split(w):
+    """(weight, second) from the load() argument forms of linear.py:185-205."""
+    if isinstance(w, nn.Parameter) or isinstance(w, torch.Tensor):
+        return w, None
+    if isinstance(w, tuple):
+        return w[0], w[1]
+    raise ValueError("Invalid weight type")
+
+
+class KLinearTorch(KLinearBase):
+    """Dense bf16: x @ W^T (+ bias) — linear.py:158-216."""
+    FMT = "BF16"
+
+    def load(self, w=None, device: str | None = None):
+        if self.loaded:
+            return
+        if device is not None:
+            self.device = device
+        if w is None:
+            w = self.load_weight(device=self.device)
+        weight, bias = _split(w)
+        weight = weight.data.to(self.device, torch.bfloat16).view(self.out_features, self.in_features).contiguous()
+        self.has_bias = bias is not None
+        self._h = self._make_handle()
+        self._h.load_bf16(weight, bias.data.to(self.device, torch.bfloat16) if bias is not None else None)
+        self.weight = weight.T                                     # modeling code may read linear.weight (linear.py:196)
+        self.loaded = True
+
+
+class KLinearMarlin(KLinearBase):
+    """W4A16, group 64 — linear.py:595-720.  `num_bits`, `group_size`, `act_order`, `is_k_full` as in the reference;
+    only num_bits=4 without act_order is implemented (the only configuration the reference's rule files use)."""
+    FMT = "W4"
+
+    def __init__(self, key, gguf_loader, config, orig_module=None, device: str = "cuda", num_bits: int = 4,
+                 group_size: int = 64, act_order: bool = False, is_k_full=True, **kwargs):
+        assert device.lower() != "cpu", "Marlin quantized linear only supports GPU device"
+        super().__init__(key, gguf_loader, config, orig_module, device, **kwargs)
+        if num_bits != 4 or act_order:
+            raise NotImplementedError("KLinearMarlin here: num_bits=4, act_order=False")
+        self.num_bits, self.group_size, self.act_order, self.is_k_full = num_bits, group_size, act_order, is_k_full
+        self.k, self.n = self.in_features, self.out_features
+
+    def load(self, w=None, device: str | None = None):
+        if self.loaded:
+            return
+        if device is not None:
+            self.device = device
+        assert self.device.lower() != "cpu", "Marlin quantized linear only supports GPU device"
+        if w is None:
+            w = self.load_weight(device=self.device)
+        weight, bias = _split(w)
+        weight = weight.data.to(self.device, torch.bfloat16).view(self.out_features, self.in_features).contiguous()
+        self.has_bias = bias is not None
+        g = self.in_features if self.group_size == -1 else self.group_size
+        self._h = self._make_handle(g)
+        self._h.load_bf16(weight, bias.data.to(self.device, torch.bfloat16) if bias is not None else None)
+        # the reference exposes marlin_q_w here and consumers only use it for shape/device: no bf16 copy is kept
+        self.weight = torch.empty((self.in_features, self.out_features), dtype=torch.bfloat16, device="meta")
+        self.loaded = True
+
+
+class KLinearFP8(KLinearBase):
+    """DeepSeek block-fp8 — linear.py:388-436.  Needs (weight e4m3, weight_scale_inv)."""
+    FMT = "FP8"
+
+    def __init__(self, key, gguf_loader, config, orig_module=None, device: str = "cuda", block_size: int = 128, **kwargs):
+        super().__init__(key, gguf_loader, config, orig_module, device, **kwargs)
+        self.block_size = block_size
+
+    def load(self, w=None, device: str | None = None):
+        if self.loaded:
+            return
+        if device is not None:
+            self.device = device
+        if w is None:
+            w = self.load_weight(device=self.device)
+        if not isinstance(w, tuple):
+            raise ValueError("Invalid weight type")              # linear.py:426
+        weight, scale_inv = w[0].data, w[1].data
+        self._h = self._make_handle(self.block_size)
+        self._h.load_fp8(weight.to(self.device).contiguous(), scale_inv.to(self.device, torch.float32).contiguous())
+        self.weight, self.weight_scale_inv = weight, scale_inv
+        self.loaded = True
+
+
+LINEAR_MAP = {
+    "KLinearMarlin": KLinearMarlin,
+    "KLinearTorch": KLinearTorch,
+    "KLinearFP8": KLinearFP8,
+    # other vendors' back-ends of the same contract (linear.py:896-904)
+    "VLinearMarlin": KLinearMarlin,
+    "KLinearQ8": KLinearMarlin,
+    "KLinearCPUInfer": KLinearTorch,
+    "KLinearIPEXLLM": KLinearTorch,
+}
+
+
+class KTransformersLinear(BaseInjectedModule):
+    """linear.py:906-990: picks the prefill / generate operator by inference mode."""
+
+    def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, generate_device: str = "cuda",
+                 generate_op: str | None = "KLinearMarlin", prefill_device: str = "cuda",
+                 prefill_op: str | None = "KLinearTorch", **kwargs):
+        BaseInjectedModule.__init__(self, key, gguf_loader, config, orig_module, prefill_device, generate_device, **kwargs)
+        for op in (prefill_op, generate_op):
+            assert op is None or op in LINEAR_MAP, f"linear_type {op} not supported"
+        object.__setattr__(self, "in_features", orig_module.in_features)
+        object.__setattr__(self, "out_features", orig_module.out_features)
+        gen = LINEAR_MAP[generate_op](key, gguf_loader, config, orig_module, generate_device, **kwargs) if generate_op else None
+        # one quantised copy serves prefill too unless the rule asks for a different *format* on a different device
+        if prefill_op is None:
+            pre = None
+        elif gen is not None and (LINEAR_MAP[prefill_op] is type(gen) or prefill_device == generate_device):
+            pre = gen
+        else:
+            pre = LINEAR_MAP[prefill_op](key, gguf_loader, config, orig_module, prefill_device, **kwargs)
+        object.__setattr__(self, "generate_linear", gen)
+        object.__setattr__(self, "prefill_linear", pre)
+        object.__setattr__(self, "mode", InferenceState.UNLOAD)
+        object.__setattr__(self, "weight", None)
+
+    def forward(self, x, bsz_tensor=None):
+        if self.mode == InferenceState.PREFILL:
+            assert self.prefill_linear is not None, "cpu linear is not initialized"
+            return self.prefill_linear.forward(x, bsz_tensor)
+        assert self.generate_linear is not None, "gpu linear is not initialized"
+        return self.generate_linear.forward(x, bsz_tensor)
+
+    def load(self, w=None, mode: InferenceState = InferenceState.GENERATE):
+        if not mode:
+            mode = InferenceState.GENERATE
+        if mode == InferenceState.UNLOAD:
+            return self.unload()
+        if mode not in (InferenceState.GENERATE, InferenceState.PREFILL):
+            raise ValueError("mode must be either InferenceState.GENERATE, InferenceState.PREFILL or InferenceState.UNLOAD")
+        op = self.prefill_linear if mode == InferenceState.PREFILL else self.generate_linear
+        other = self.generate_linear if mode == InferenceState.PREFILL else self.prefill_linear
+        if other is not None and other is not op:
+            other.unload()
+        op.load(w=w)
+        object.__setattr__(self, "device", op.device)
+        object.__setattr__(self, "weight", op.weight)
+        object.__setattr__(self, "mode", mode)
+
+    def unload(self):
+        for op in (self.prefill_linear, self.generate_linear):
+            if op is not None:
+                op.unload()
+        object.__setattr__(self, "mode", InferenceState.UNLOAD)
+
+    def set_inference_mode(self, mode: InferenceState):
+        if not mode:
+            mode = InferenceState.GENERATE
+        if mode in (InferenceState.GENERATE, InferenceState.PREFILL):
+            self.load(mode=mode)
+        elif mode == InferenceState.UNLOAD:
+            self.unload()
+        else:
+            raise ValueError("mode must be either InferenceState.GENERATE, InferenceState.PREFILL or InferenceState.UNLOAD")

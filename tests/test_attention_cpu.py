@@ -1,0 +1,39 @@
+"""CPU: the restated absorbed-MLA attention operator (oracle/attention_ref.py) agrees with the reference's own eager
+DeepseekV3Attention on the committed golden vectors (tests/golden/make_attention_golden.py).  The two compute the same
+function with different op orders (absorbed vs materialised K/V) in bf16, so the bound is bf16 noise:
+norm-wise <= 2e-2 against the reference's fp32 run (the reference's own bf16 run sits at ~1e-2 from it)."""
+import pytest
+import torch
+
+from attn_helpers import load_golden
+from oracle.attention_ref import mla_attention_ref, rope_tables, softmax_scale
+
+
+@pytest.mark.parametrize("name", ["v3", "v2lite"])
+def test_oracle_matches_reference_eager_attention(name):
+    cfg, w, x, y_bf16, y_f32 = load_golden(name)
+    T = x.shape[0]
+    out, rows = mla_attention_ref(cfg, w, x, torch.arange(T), torch.zeros(0, 576, dtype=torch.bfloat16))
+    rel = float((out.float() - y_f32).norm() / y_f32.norm())
+    ref_rel = float((y_bf16.float() - y_f32).norm() / y_f32.norm())
+    assert rel < 2e-2, (rel, ref_rel)
+    assert rows.shape == (T, 576)
+    # token-by-token decode with a growing history reproduces the prompt pass
+    hist = torch.zeros(0, 576, dtype=torch.bfloat16)
+    outs = []
+    for t in range(T):
+        o, r = mla_attention_ref(cfg, w, x[t:t + 1], torch.tensor([t]), hist)
+        hist = torch.cat([hist, r], 0)
+        outs.append(o)
+    dec = torch.cat(outs, 0)
+    assert float((dec.float() - out.float()).norm() / out.float().norm()) < 1e-2
+    assert torch.equal(hist, rows)
+
+
+def test_yarn_tables_and_scale():
+    cfg, *_ = load_golden("v3")
+    cos, sin, inv_freq, mscale = rope_tables(cfg, torch.arange(8), torch.float32)
+    assert cos.shape == (8, 64) and inv_freq.shape == (32,)
+    assert mscale == pytest.approx(1.0)                       # mscale == mscale_all_dim
+    assert torch.allclose(cos[0], torch.ones(64)) and torch.allclose(sin[0], torch.zeros(64))
+    assert softmax_scale(cfg) == pytest.approx(192 ** -0.5 * (0.1 * torch.log(torch.tensor(40.0)).item() + 1.0) ** 2)

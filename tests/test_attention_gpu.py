@@ -1,0 +1,104 @@
+"""GPU: KDeepseekV2Attention (operators/attention.py) against the reference's eager attention (golden fixture) and the
+restated absorbed operator (oracle/attention_ref.py).  bf16 pipeline, fp32 accumulation: the bound is bf16 noise —
+norm-wise <= 2e-2 vs the reference's fp32 run (its own bf16 run is ~1e-2 away), <= 1.5e-2 vs the bf16 oracle; the latent
+rows written to the cache are compared against the oracle to 1 bf16 ulp."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from attn_helpers import ToyAttention, load_golden, make_cfg  # noqa: E402
+from oracle.attention_ref import mla_attention_ref  # noqa: E402
+
+
+def build(cfg, w, linear_op=None):
+    from ktransformers_amd.models.custom_cache import StaticCache
+    from ktransformers_amd.operators.attention import KDeepseekV2Attention
+    from ktransformers_amd.operators.linear import KTransformersLinear
+    from ktransformers_amd.operators.RoPE import YarnRotaryEmbeddingV3
+    from ktransformers_amd.util.loader import DictLoader
+    from ktransformers_amd.util.utils import InferenceState
+
+    dev = "cuda:0"
+    orig = ToyAttention(cfg, w, dev)
+    loader = DictLoader({f"attn.{k}.weight": v for k, v in w.items()})
+    rope = YarnRotaryEmbeddingV3("attn.rotary_emb", loader, cfg, orig.rotary_emb, dev, dev)
+    rope.load()
+    orig.rotary_emb = rope
+    if linear_op is not None:
+        for name in ("q_proj", "q_a_proj", "q_b_proj", "kv_a_proj_with_mqa", "o_proj"):
+            if hasattr(orig, name):
+                lin = KTransformersLinear(f"attn.{name}", loader, cfg, getattr(orig, name), dev, linear_op, dev, linear_op)
+                lin.load(mode=InferenceState.GENERATE)
+                setattr(orig, name, lin)
+    attn = KDeepseekV2Attention("attn", loader, cfg, orig, dev, dev, absorb_for_prefill=True)
+    cache = StaticCache(cfg, 1, 4096, dev, torch.bfloat16)
+    return attn, cache
+
+
+def rows_close(rows, ref):
+    """cache rows vs the oracle: 1 bf16 ulp, plus the absolute slack of a rope sum that cancels (|a|+|b| ~ 4)."""
+    d = (rows - ref).abs()
+    bad = d > 2.0 ** -7 * ref.abs() + 2.0 ** -6
+    assert not bad.any(), f"{int(bad.sum())} of {bad.numel()} cache elements off, max diff {float(d.max())} at {bad.nonzero()[:4].tolist()}"
+
+
+def rel(a, b):
+    return float((a.float().cpu() - b.float()).norm() / b.float().norm())
+
+
+@pytest.mark.parametrize("name", ["v3", "v2lite"])
+@pytest.mark.parametrize("linear_op", [None, "KLinearTorch"])
+def test_prefill_and_decode_match_reference(name, linear_op):
+    cfg, w, x, y_bf16, y_f32 = load_golden(name)
+    T = x.shape[0]
+    oracle_out, oracle_rows = mla_attention_ref(cfg, w, x, torch.arange(T), torch.zeros(0, 576, dtype=torch.bfloat16))
+    attn, cache = build(cfg, w, linear_op)
+    xg = x.cuda()
+    pos = torch.arange(T, device="cuda")
+    out, _, _ = attn(xg[None], position_ids=pos[None], past_key_value=cache, cache_position=pos)
+    assert out.shape == (1, T, cfg.hidden_size)
+    assert rel(out[0], y_f32) < 2e-2
+    assert rel(out[0], oracle_out) < 1.5e-2
+    rows = cache.key_cache[0].reshape(-1, 576)[:T].float().cpu()
+    rows_close(rows, oracle_rows.float())
+    assert cache.get_seq_length(0) == T
+    # token-by-token decode (kernel-appended cache rows) reproduces the prompt pass
+    cache.reset()
+    outs = []
+    for t in range(T):
+        o, _, _ = attn(xg[None, t:t + 1], position_ids=pos[None, t:t + 1], past_key_value=cache, cache_position=pos[t:t + 1])
+        outs.append(o[0])
+    dec = torch.cat(outs, 0)
+    assert rel(dec, y_f32) < 2e-2
+    assert rel(dec, oracle_out) < 1.5e-2
+    rows2 = cache.key_cache[0].reshape(-1, 576)[:T].float().cpu()
+    rows_close(rows2, oracle_rows.float())
+
+
+def test_marlin_linears_track_the_quantised_oracle():
+    """With KLinearMarlin projections the operator follows the oracle evaluated on the de-quantised weights."""
+    from oracle.linear_ref import dequant_w4, quantize_weights_ref
+
+    cfg, w, x, _, _ = load_golden("v3")
+    wq = dict(w)
+    for name in ("q_a_proj", "q_b_proj", "kv_a_proj_with_mqa", "o_proj"):
+        if w[name].shape[1] % 64 == 0:
+            q, s = quantize_weights_ref(w[name].T.contiguous(), 64)
+            wq[name] = dequant_w4(q, s, 64, False).T.contiguous().to(torch.bfloat16)
+    T = 5
+    oracle_out, _ = mla_attention_ref(cfg, wq, x[:T], torch.arange(T), torch.zeros(0, 576, dtype=torch.bfloat16))
+    attn, cache = build(cfg, w, "KLinearMarlin")
+    pos = torch.arange(T, device="cuda")
+    out, _, _ = attn(x[:T].cuda()[None], position_ids=pos[None], past_key_value=cache, cache_position=pos)
+    assert rel(out[0], oracle_out) < 2e-2
+
+
+def test_requires_cache_and_single_request():
+    cfg, w, x, _, _ = load_golden("v2lite")
+    attn, cache = build(cfg, w)
+    with pytest.raises(ValueError):
+        attn(x[None, :1].cuda(), position_ids=torch.zeros(1, 1, dtype=torch.long, device="cuda"), past_key_value=None)
+    with pytest.raises(ValueError):
+        attn(x[None, :1].cuda().repeat(2, 1, 1), position_ids=torch.zeros(2, 1, dtype=torch.long, device="cuda"),
+             past_key_value=cache)

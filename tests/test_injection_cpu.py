@@ -94,3 +94,27 @@ def test_shipped_rule_files_parse():
     for f in os.listdir(d):
         rules = load_rules(os.path.join(d, f))
         assert isinstance(rules, list) and all("match" in r and "replace" in r for r in rules)
+
+
+def test_linear_injection_and_registry(injected):
+    from ktransformers_amd.operators.linear import (LINEAR_MAP, KLinearFP8, KLinearMarlin, KLinearTorch,
+                                                     KTransformersLinear)
+    model, conf, cfg = injected
+    assert resolve_class("ktransformers.operators.linear.KTransformersLinear") is KTransformersLinear
+    lin = model.model.layers[0].mlp.gate_proj
+    assert isinstance(lin, KTransformersLinear) and lin.key == "model.layers.0.mlp.gate_proj"
+    assert conf["model.layers.0.mlp.down_proj"]["kwargs"]["generate_op"] == "KLinearMarlin"
+    assert isinstance(lin.generate_linear, KLinearMarlin) and lin.generate_linear.group_size == 64
+    assert lin.prefill_linear is lin.generate_linear            # one quantised copy serves prefill and decode
+    assert (lin.in_features, lin.out_features) == (cfg.hidden_size, cfg.intermediate_size)
+    assert lin.mode == InferenceState.UNLOAD
+    assert LINEAR_MAP["VLinearMarlin"] is KLinearMarlin and LINEAR_MAP["KLinearFP8"] is KLinearFP8
+    assert LINEAR_MAP["KLinearCPUInfer"] is KLinearTorch
+    with pytest.raises(RuntimeError):
+        lin.generate_linear.forward(torch.zeros(1, cfg.hidden_size))     # no silent fallback before load()
+    with pytest.raises(AssertionError):
+        KTransformersLinear("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), generate_op="Nope")
+    with pytest.raises(NotImplementedError):
+        KLinearMarlin("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), num_bits=8)
+    with pytest.raises(ValueError):
+        lin.set_inference_mode("bogus")

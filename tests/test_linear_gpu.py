@@ -1,0 +1,150 @@
+"""GPU parity of the quantised linears (include/ktx_linear.h) against oracle/linear_ref.py, through the C ABI.
+
+Tolerances (floating point path, fp32 accumulation in a different order than the un-vendored CUDA/Triton kernels):
+  W4/BF16: |y - ref| <= 2^-7*|ref| + 2e-3*max|ref|  (one bf16 ulp of the output + accumulation-order noise);
+           norm-wise relative error <= 1e-3 against exact (q-8)*s math in fp64.
+  FP8    : same bound; activations that sit on an e4m3 rounding tie after x/s may quantise one step apart, which the
+           norm-wise bound (2e-3) absorbs.
+The quantiser is integer work: bit-exact against the reference's own quantize_weights (golden fixture)."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle.linear_ref import linear_bf16_ref, linear_fp8_ref, linear_w4_ref, quantize_weights_ref  # noqa: E402
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "linear_w4_golden.npz")
+
+
+def native():
+    from ktransformers_amd import _native
+    return _native
+
+
+def close(y, ref, rel=1e-3):
+    y, ref = y.float().cpu(), ref.float()
+    tol = 2.0 ** -7 * ref.abs() + 2e-3 * ref.abs().max()
+    bad = (y - ref).abs() > tol
+    assert not bad.any(), f"{int(bad.sum())} elements out of tolerance, max diff {(y - ref).abs().max()}"
+    assert (y - ref).norm() / ref.norm().clamp_min(1e-30) <= max(rel, 2.0 ** -8), float((y - ref).norm() / ref.norm())
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("G", [32, 64, 128])
+def test_w4_quantizer_bit_exact_vs_reference_golden(name, G):
+    n = native()
+    g = np.load(GOLD)
+    w = torch.from_numpy(g[f"{name}_w"]).view(torch.bfloat16).cuda()
+    N, K = w.shape
+    h = n.LinearHandle(K, N, "W4", G, 16)
+    h.load_bf16(w)
+    q, s = h.debug_get_w4()
+    assert np.array_equal(s, g[f"{name}_s{G}"])
+    live = np.repeat(g[f"{name}_s{G}"] != 0, G, axis=0)
+    assert np.array_equal(q[live], g[f"{name}_q{G}"][live])
+
+
+SHAPES = [(256, 64), (2048, 576), (2048, 3072), (1536, 200), (7168, 1536), (384, 48)]
+
+
+@pytest.mark.parametrize("K,N", SHAPES)
+@pytest.mark.parametrize("T", [1, 2, 3, 4, 7, 16, 33, 130])
+@pytest.mark.parametrize("G", [64, 128, 32])
+def test_w4_forward(K, N, T, G):
+    if G != 64 and (K, N) not in ((256, 64), (2048, 576)):
+        pytest.skip("group sweep on two shapes")
+    n = native()
+    torch.manual_seed(K + N + T)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16)
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16)
+    bias = (torch.randn(N) / 10).to(torch.bfloat16) if (T % 2 == 0) else None
+    q, s = quantize_weights_ref(w.T.contiguous(), G)
+    h = n.LinearHandle(K, N, "W4", G, 256)
+    h.load_bf16(w.cuda(), bias.cuda() if bias is not None else None)
+    y = h.forward(x.cuda())
+    close(y, linear_w4_ref(x, q, s, G, bias))
+    if T <= 4:   # the same rows through the general kernel
+        n.linear_force_gemm(True)
+        try:
+            y2 = h.forward(x.cuda())
+        finally:
+            n.linear_force_gemm(False)
+        close(y2, linear_w4_ref(x, q, s, G, bias))
+    # pre-quantised upload gives the same tiles
+    h2 = n.LinearHandle(K, N, "W4", G, 256)
+    h2.load_w4(q.to(torch.uint8).cuda(), s.cuda(), bias.cuda() if bias is not None else None)
+    assert torch.equal(h2.forward(x.cuda()), y)
+
+
+@pytest.mark.parametrize("K,N", SHAPES)
+@pytest.mark.parametrize("T", [1, 4, 5, 40])
+def test_bf16_forward(K, N, T):
+    n = native()
+    torch.manual_seed(K + N + T)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16)
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16)
+    h = n.LinearHandle(K, N, "BF16", 0, 64)
+    h.load_bf16(w.cuda())
+    close(h.forward(x.cuda()), linear_bf16_ref(x, w), rel=1e-3)
+
+
+@pytest.mark.parametrize("K,N", [(256, 64), (2048, 576), (7168, 1536), (1536, 200), (384, 48)])
+@pytest.mark.parametrize("T", [1, 3, 4, 9, 40])
+def test_fp8_forward(K, N, T):
+    n = native()
+    torch.manual_seed(K + N + T)
+    w = (torch.randn(N, K) / 4).to(torch.float8_e4m3fn)
+    sc = (torch.rand((N + 127) // 128, K // 128) + 0.5) / 32
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16)
+    bias = (torch.randn(N) / 10).to(torch.bfloat16) if T == 4 else None
+    h = n.LinearHandle(K, N, "FP8", 128, 64)
+    h.load_fp8(w.cuda(), sc.cuda(), bias.cuda() if bias is not None else None)
+    y = h.forward(x.cuda())
+    close(y, linear_fp8_ref(x, w, sc, bias), rel=2e-3)
+
+
+def test_bsz_tensor_and_graph_capture():
+    n = native()
+    torch.manual_seed(0)
+    K, N = 2048, 576
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16)
+    x = (torch.randn(4, K) / 10).to(torch.bfloat16).cuda()
+    q, s = quantize_weights_ref(w.T.contiguous(), 64)
+    h = n.LinearHandle(K, N, "W4", 64, 16)
+    h.load_bf16(w.cuda())
+    bsz = torch.tensor([2], dtype=torch.int32, device="cuda")
+    out = torch.full((4, N), 7.0, dtype=torch.bfloat16, device="cuda")
+    h.forward(x, bsz, out)
+    close(out[:2], linear_w4_ref(x[:2].cpu(), q, s, 64))
+    assert torch.all(out[2:] == 7.0)
+    g = torch.cuda.CUDAGraph()
+    y = torch.empty((4, N), dtype=torch.bfloat16, device="cuda")
+    s0 = torch.cuda.Stream()
+    with torch.cuda.stream(s0):
+        h.forward(x, None, y)
+        torch.cuda.synchronize()
+        with torch.cuda.graph(g, stream=s0):
+            h.forward(x, None, y)
+    y.zero_()
+    g.replay()
+    torch.cuda.synchronize()
+    close(y, linear_w4_ref(x.cpu(), q, s, 64))
+
+
+def test_errors_are_loud():
+    n = native()
+    with pytest.raises(n.KtxError):
+        n.LinearHandle(100, 64, "W4", 64, 16)          # in_features % 8
+    with pytest.raises(n.KtxError):
+        n.LinearHandle(256, 64, "W4", 48, 16)          # group size
+    h = n.LinearHandle(256, 64, "W4", 64, 4)
+    x = torch.zeros(2, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(n.KtxError):
+        h.forward(x)                                    # not loaded
+    h.load_bf16(torch.zeros(64, 256, dtype=torch.bfloat16, device="cuda"))
+    with pytest.raises(n.KtxError):
+        h.forward(torch.zeros(8, 256, dtype=torch.bfloat16, device="cuda"))   # T > max_len
+    assert torch.all(h.forward(x) == 0)
