@@ -14,7 +14,9 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libktx_hip.so")
 
-FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4}
+FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4, "GGUF": 5}
+GGML_TYPE_Q4_K, GGML_TYPE_Q6_K = 12, 14
+GGML_BLOCK_BYTES = {12: 144, 14: 210}
 MAT_GATE, MAT_UP, MAT_DOWN = 0, 1, 2
 
 
@@ -55,6 +57,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_load_quantized.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.ktx_moe_load_fp8.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_load_rawint4.argtypes = [C.c_void_p] * 7
+    lib.ktx_moe_load_gguf.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
     lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -198,6 +201,18 @@ class MoEHandle:
         torch.cuda.synchronize(self.device)
         check(lib.ktx_moe_load_rawint4(self._h, gate.data_ptr(), up.data_ptr(), down.data_ptr(), gate_scale.data_ptr(),
                                        up_scale.data_ptr(), down_scale.data_ptr()))
+
+    def load_gguf(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_type: int, up_type: int,
+                  down_type: int) -> None:
+        """Raw GGUF blocks (uint8 device tensors): gate/up [E, I, H/256*blk], down [E, H, I/256*blk]; ggml type ids."""
+        for t, n, kdim, ty in ((gate, self.I, self.H, gate_type), (up, self.I, self.H, up_type), (down, self.H, self.I, down_type)):
+            if ty not in GGML_BLOCK_BYTES:
+                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q4_K=12, Q6_K=14)")
+            shape = (self.E, n, kdim // 256 * GGML_BLOCK_BYTES[ty])
+            if t.dtype != torch.uint8 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
+                raise KtxError(f"load_gguf: expected contiguous uint8 {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_moe_load_gguf(self._h, gate.data_ptr(), up.data_ptr(), down.data_ptr(), gate_type, up_type, down_type))
 
     def load_quantized(self, expert: int, which: int, q, scale) -> None:
         """One expert matrix from host int8 [N,K] multiplicands + fp32 [N] scales (numpy arrays)."""

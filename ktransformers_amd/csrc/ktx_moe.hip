@@ -765,6 +765,7 @@ struct CombineParams {
   bf16_t* y;                   // [qlen][H]  (float* when partial_f32)
   int incremental;
   int partial_f32;
+  int dn_f32;                  // GGUF path: dn is fp32 and the sum is `out += dn * w` (llamafile/moe.hpp:447-449)
 };
 
 __global__ __launch_bounds__(256) void moe_combine_kernel(CombineParams p) {
@@ -779,6 +780,11 @@ __global__ __launch_bounds__(256) void moe_combine_kernel(CombineParams p) {
     const int r = p.row_of_pair[t * p.k + j];
     if (r < 0) continue;
     const float w = p.weights[t * p.k + j];
+    if (p.dn_f32) {
+      const float4 f = *reinterpret_cast<const float4*>(reinterpret_cast<const float*>(p.dn) + (size_t)r * p.H + h);
+      acc[0] = acc[0] + f.x * w; acc[1] = acc[1] + f.y * w; acc[2] = acc[2] + f.z * w; acc[3] = acc[3] + f.w * w;
+      continue;
+    }
     const uint2 v = *reinterpret_cast<const uint2*>(p.dn + (size_t)r * p.H + h);
     acc[0] = fmaf(bf16_to_f32((bf16_t)(v.x & 0xffffu)), w, acc[0]);
     acc[1] = fmaf(bf16_to_f32((bf16_t)(v.x >> 16)), w, acc[1]);
@@ -1334,6 +1340,8 @@ __global__ void pack_rawint4_scales_kernel(const bf16_t* __restrict__ src, int N
   out[idx] = src[(size_t)(rg * 4 + jrow) * G + 2 * (8 * st + kb8) + h];
 }
 
+#include "ktx_moe_gguf.inc"
+
 // =====================================================================================================
 // host side
 // =====================================================================================================
@@ -1346,7 +1354,8 @@ struct Workspace {
   bf16_t *a_buf = nullptr, *dn_buf = nullptr;
   int32_t *row_of_pair = nullptr, *src_of_row = nullptr, *counters = nullptr;
   Tile* tiles = nullptr;
-  size_t cap[10] = {0};
+  int16_t *x_bs = nullptr, *a_bs = nullptr;   // Q8_K 16-sums (GGUF path)
+  size_t cap[12] = {0};
 };
 static std::mutex g_ws_mu;
 static Workspace g_ws[64];
@@ -1369,6 +1378,9 @@ struct ktx_moe_s {
   uint8_t* mask = nullptr;
   Workspace* ws = nullptr;
   int max_pairs = 0, max_tiles = 0;
+  int gg_type[3] = {0, 0, 0};     // GGUF: ggml type of gate / up / down
+  size_t gg_stride[3] = {0, 0, 0};
+  bool loaded_gguf = false;
 };
 
 static int pick_mt(int qlen, int k, int E) {
@@ -1381,7 +1393,9 @@ static int pick_mt(int qlen, int k, int E) {
 
 extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_REQUIRE(cfg && out, "ktx_moe_create: null argument");
-  KTX_REQUIRE(cfg->format >= KTX_FMT_AMXINT4 && cfg->format <= KTX_FMT_BF16, "ktx_moe_create: unknown format");
+  KTX_REQUIRE(cfg->format >= KTX_FMT_AMXINT4 && cfg->format <= KTX_FMT_GGUF, "ktx_moe_create: unknown format");
+  KTX_REQUIRE(cfg->format != KTX_FMT_GGUF || (cfg->hidden_size % 256 == 0 && cfg->intermediate_size % 256 == 0),
+              "ktx_moe_create: GGUF k-quants need hidden_size and intermediate_size to be multiples of 256 (QK_K)");
   KTX_REQUIRE(cfg->format != KTX_FMT_RAWINT4 || cfg->group_size == 32,
               "ktx_moe_create: RAWINT4 supports group_size 32 (Kimi-K2 native int4) only");
   KTX_REQUIRE(cfg->format != KTX_FMT_RAWINT4 || (cfg->hidden_size % 512 == 0 && cfg->intermediate_size % 512 == 0),
@@ -1403,15 +1417,20 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   h->dn_stride = H * I * h->wbits / 8;
   h->max_pairs = cfg->max_len * cfg->num_experts_per_tok;
   h->max_tiles = std::min<int>(h->max_pairs, (int)E) + h->max_pairs / (cfg->format == KTX_FMT_RAWINT4 ? 4 : 16) + 1;
+  const bool gguf = cfg->format == KTX_FMT_GGUF;   // tiles are allocated by ktx_moe_load_gguf (size depends on the types)
+  if (!gguf) {
   KTX_HIP(hipMalloc(&h->gate_w, E * h->gu_stride));
   KTX_HIP(hipMalloc(&h->up_w, E * h->gu_stride));
   KTX_HIP(hipMalloc(&h->down_w, E * h->dn_stride));
+  }
   // scales: fp32 per row (int formats) | fp32 per 128x128 block (FP8) | bf16 per (row, 32-group) (RAWINT4)
   size_t gu_sbytes = E * I * sizeof(float), dn_sbytes = E * H * sizeof(float);
   if (cfg->format == KTX_FMT_RAWINT4) gu_sbytes = dn_sbytes = E * I * (H / 32) * sizeof(bf16_t);
+  if (!gguf) {
   KTX_HIP(hipMalloc(&h->gate_s, gu_sbytes));
   KTX_HIP(hipMalloc(&h->up_s, gu_sbytes));
   KTX_HIP(hipMalloc(&h->down_s, dn_sbytes));
+  }
   {
     // Growing the arena frees the old blocks: only legal while no forward using them is in flight.
     std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -1419,11 +1438,15 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
     Workspace* w = &g_ws[cfg->device];
     KTX_HIP(hipDeviceSynchronize());
     KTX_HIP(grow(w->x_q, w->cap[0], (size_t)cfg->max_len * H));
-    KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? H / 32 : 1)));
-    KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * sizeof(bf16_t)));
+    KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? H / 32 : gguf ? H / 256 : 1)));
+    KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * (gguf ? sizeof(float) : sizeof(bf16_t))));
     KTX_HIP(grow(w->a_q, w->cap[3], (size_t)h->max_pairs * I));
-    KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? I / 32 : 1)));
-    KTX_HIP(grow(w->dn_buf, w->cap[5], (size_t)h->max_pairs * H * sizeof(bf16_t)));
+    KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? I / 32 : gguf ? I / 256 : 1)));
+    KTX_HIP(grow(w->dn_buf, w->cap[5], (size_t)h->max_pairs * H * (gguf ? sizeof(float) : sizeof(bf16_t))));
+    if (gguf) {
+      KTX_HIP(grow(w->x_bs, w->cap[10], (size_t)cfg->max_len * (H / 16) * sizeof(int16_t)));
+      KTX_HIP(grow(w->a_bs, w->cap[11], (size_t)h->max_pairs * (I / 16) * sizeof(int16_t)));
+    }
     KTX_HIP(grow(w->row_of_pair, w->cap[6], (size_t)h->max_pairs * sizeof(int32_t)));
     KTX_HIP(grow(w->src_of_row, w->cap[7], (size_t)h->max_pairs * sizeof(int32_t)));
     KTX_HIP(grow(w->tiles, w->cap[8], (size_t)h->max_tiles * sizeof(Tile)));
@@ -1450,7 +1473,41 @@ extern "C" int ktx_moe_destroy(ktx_moe_t h) {
 extern "C" size_t ktx_moe_weight_bytes(ktx_moe_t h) {
   if (!h) return 0;
   const size_t E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  if (h->cfg.format == KTX_FMT_GGUF) return E * (h->gg_stride[0] + h->gg_stride[1] + h->gg_stride[2]);
   return E * (2 * h->gu_stride + h->dn_stride) + E * (2 * I + H) * sizeof(float);
+}
+
+// GGUF k-quant experts: raw ggml blocks [E][N][K/256] per matrix (DEVICE pointers) -> W tiles (ktx_moe_gguf.inc)
+extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, int gate_type,
+                                 int up_type, int down_type) {
+  KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_gguf: null argument");
+  KTX_REQUIRE(h->cfg.format == KTX_FMT_GGUF, "ktx_moe_load_gguf: handle was not created with KTX_FMT_GGUF");
+  const int types[3] = {gate_type, up_type, down_type};
+  for (int t : types)
+    KTX_REQUIRE(t == GG_Q4K || t == GG_Q6K, "ktx_moe_load_gguf: supported ggml types are Q4_K (12) and Q6_K (14)");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
+  const uint8_t* src[3] = {(const uint8_t*)d_gate, (const uint8_t*)d_up, (const uint8_t*)d_down};
+  uint8_t** dst[3] = {&h->gate_w, &h->up_w, &h->down_w};
+  for (int m = 0; m < 3; m++) {
+    if (*dst[m]) { KTX_HIP(hipFree(*dst[m])); *dst[m] = nullptr; }
+    h->gg_type[m] = types[m];
+    h->gg_stride[m] = gg_matrix_bytes(types[m], Ns[m], Ks[m]);
+    KTX_HIP(hipMalloc(dst[m], (size_t)E * h->gg_stride[m]));
+    const size_t src_stride = (size_t)Ns[m] * gg_src_row_bytes(types[m], Ks[m]);
+    const int ntiles = (Ns[m] / 16) * (Ks[m] / 256);
+    for (int e = 0; e < E; e++) {
+      if (types[m] == GG_Q4K)
+        hipLaunchKernelGGL(gg_pack_q4k_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
+      else
+        hipLaunchKernelGGL(gg_pack_q6k_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
+    }
+  }
+  KTX_HIP(hipGetLastError());
+  KTX_HIP(hipDeviceSynchronize());
+  h->loaded_gguf = true;
+  return 0;
 }
 
 static int pack_matrix(ktx_moe_s* h, const int8_t* d_q, int N, int K, uint8_t* d_dst, hipStream_t st) {
@@ -1654,6 +1711,8 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
                       const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st);
 static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                            const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st);
+static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                        const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st);
 
 // ---- optional per-kernel timing with HIP events on the launch stream (bench.py's roofline leg) -----------------
 // Slots: 0 prep, 1 gate/up GEMM, 2 act-quant, 3 down GEMM, 4 combine.  Not graph-capturable; off by default.
@@ -1798,6 +1857,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     return forward_fp(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   if (h->cfg.format == KTX_FMT_RAWINT4)
     return forward_rawint4(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
+  if (h->cfg.format == KTX_FMT_GGUF)
+    return forward_gguf(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   const int mt = pick_mt(qlen, k, E);
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
@@ -1840,7 +1901,7 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   }
   if (rc) return rc;
 
-  CombineParams cp;
+  CombineParams cp{};
   cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
   cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = incremental;
   cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
@@ -1893,7 +1954,7 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
     rc = fp8 ? launch_gemm_fp<true, false>(mt, g2, max_tiles, st) : launch_gemm_fp<false, false>(mt, g2, max_tiles, st);
   }
   if (rc) return rc;
-  CombineParams cp;
+  CombineParams cp{};
   cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
   cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
   cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
@@ -1963,10 +2024,86 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
     rc = qlen == 1 ? launch_rawint4<1, false>(g2, max_tiles, st) : launch_rawint4<4, false>(g2, max_tiles, st);
   }
   if (rc) return rc;
-  CombineParams cp;
+  CombineParams cp{};
   cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
   cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
   cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+  {
+    ProfScope ps(4, st);
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+  }
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+
+template <int WT, int MT, bool GATE_UP>
+static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
+  constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = WT == GG_Q4K ? 8 : 16;
+  const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4;
+  hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+template <int WT, bool GATE_UP>
+static int launch_gguf_mt(int mt, const GgGemmParams& p, int max_tiles, hipStream_t st) {
+  switch (mt) {
+    case 1: return launch_gguf<WT, 1, GATE_UP>(p, max_tiles, st);
+    case 2: return launch_gguf<WT, 2, GATE_UP>(p, max_tiles, st);
+    default: return launch_gguf<WT, 4, GATE_UP>(p, max_tiles, st);
+  }
+}
+
+// GGUF: bucket -> Q8_K(x) -> gate/up (+ act, fp32) -> Q8_K(a) -> down (fp32) -> combine (llamafile/moe.hpp:461-747)
+static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                        const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st) {
+  KTX_REQUIRE(h->loaded_gguf, "ktx_moe_forward: GGUF weights not loaded");
+  KTX_REQUIRE(h->gg_type[0] == h->gg_type[1], "ktx_moe_forward: gate and up must share one ggml type (one Q8_K input, moe.hpp:284-288)");
+  Workspace* ws = h->ws;
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const int mt = pick_mt(qlen, k, E);
+  const int npairs = qlen * k;
+  const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
+  PrepParams pp;
+  pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
+  pp.rows_per_tile = 16 * mt; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
+  pp.x_q = ws->x_q; pp.x_d = ws->x_d; pp.row_of_pair = ws->row_of_pair; pp.src_of_row = ws->src_of_row;
+  pp.tiles = ws->tiles; pp.counters = ws->counters;
+  {
+    ProfScope ps(0, st);
+    hipLaunchKernelGGL(moe_prep_kernel, dim3(1), dim3(1024), 0, st, pp);
+    hipLaunchKernelGGL(q8k_quant_kernel<false>, dim3(qlen), dim3(256), 0, st, d_input, H, ws->x_q, ws->x_d, ws->x_bs, d_bsz, 1, qlen);
+  }
+  KTX_HIP(hipGetLastError());
+  GgGemmParams g1{};
+  g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.stride0 = h->gg_stride[0]; g1.stride1 = h->gg_stride[1]; g1.N = I; g1.K = H;
+  g1.act_q = ws->x_q; g1.act_d = ws->x_d; g1.act_bs = ws->x_bs; g1.row_src = ws->src_of_row; g1.tiles = ws->tiles;
+  g1.counters = ws->counters; g1.out = reinterpret_cast<float*>(ws->a_buf);
+  int rc;
+  {
+    ProfScope ps(1, st);
+    rc = h->gg_type[0] == GG_Q4K ? launch_gguf_mt<GG_Q4K, true>(mt, g1, max_tiles, st) : launch_gguf_mt<GG_Q6K, true>(mt, g1, max_tiles, st);
+  }
+  if (rc) return rc;
+  {
+    ProfScope ps(2, st);
+    hipLaunchKernelGGL(q8k_quant_kernel<true>, dim3(npairs), dim3(256), 0, st, (const void*)ws->a_buf, I, ws->a_q, ws->a_d, ws->a_bs,
+                       ws->counters, 0, npairs);
+  }
+  KTX_HIP(hipGetLastError());
+  GgGemmParams g2{};
+  g2.w0 = h->down_w; g2.w1 = nullptr; g2.stride0 = h->gg_stride[2]; g2.stride1 = 0; g2.N = H; g2.K = I;
+  g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.act_bs = ws->a_bs; g2.row_src = nullptr; g2.tiles = ws->tiles;
+  g2.counters = ws->counters; g2.out = reinterpret_cast<float*>(ws->dn_buf);
+  {
+    ProfScope ps(3, st);
+    rc = h->gg_type[2] == GG_Q4K ? launch_gguf_mt<GG_Q4K, false>(mt, g2, max_tiles, st) : launch_gguf_mt<GG_Q6K, false>(mt, g2, max_tiles, st);
+  }
+  if (rc) return rc;
+  CombineParams cp{};
+  cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
+  cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
+  cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0; cp.dn_f32 = 1;
   {
     ProfScope ps(4, st);
     hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);

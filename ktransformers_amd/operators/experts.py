@@ -30,6 +30,7 @@ _BACKEND_TO_METHOD = {
     "AMXBF16": "BF16", "BF16": "BF16",
     "FP8": "FP8",                       # DeepSeek block-fp8 (weight + weight_scale_inv)
     "RAWINT4": "RAWINT4",               # Kimi-K2 native int4 (weight_packed + weight_scale, group 32)
+    "llamafile": "GGUF", "GGUF": "GGUF",  # GGUF k-quant blocks + ggml types (the reference's default backend, experts.py:199-224)
 }
 _GROUP_SIZE = {"FP8": 128, "RAWINT4": 32}
 
@@ -77,8 +78,6 @@ class KExpertsHIP(KExpertsBase):
         self.n_routed_experts = n_routed_experts
         self.out_device = out_device
         backend = kwargs.get("backend", "AMXInt4")
-        if backend == "llamafile":  # the reference default; GGUF k-quants are a §8(f) row, int4 is this build's default
-            backend = "AMXInt4"
         if backend not in _BACKEND_TO_METHOD:
             raise ValueError(f"KExpertsHIP: unsupported backend {backend!r} (have {sorted(_BACKEND_TO_METHOD)})")
         self.method = _BACKEND_TO_METHOD[backend]
@@ -106,6 +105,10 @@ class KExpertsHIP(KExpertsBase):
             w = self.load_weights(device=str(dev))[self.key]
         cfg = self.config
         inter = getattr(cfg, "moe_intermediate_size", None) or cfg.intermediate_size
+        if self.method == "GGUF" and "gate_type" not in w:
+            # a "llamafile" rule over a bf16 (safetensors) weight source: the reference would reject it; quantise online
+            # to the int4 format instead of failing, like its AMX backends do for bf16 sources.
+            self.method = "AMXINT4"
         h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=self.max_len,
                       method=self.method, device=dev, expert_begin=self.expert_begin,
                       global_expert_num=self.n_routed_experts, group_size=_GROUP_SIZE.get(self.method, 0))
@@ -119,6 +122,14 @@ class KExpertsHIP(KExpertsBase):
         if self.method in ("AMXINT4", "AMXINT8", "BF16"):
             # bf16 source weights; the integer formats are quantised online exactly like the reference's AMX backends
             h.load_bf16(prep(w["gate"], torch.bfloat16), prep(w["up"], torch.bfloat16), prep(w["down"], torch.bfloat16))
+        elif self.method == "GGUF":
+            # raw ggml blocks [E, N, K/256 * block_bytes] + type ids, as KExpertsBase.load_weights returns them
+            # (reference experts.py:89-135: gate/up/down mmap blobs and gate_type/up_type/down_type)
+            def blocks(t, n):
+                t = t if isinstance(t, torch.Tensor) else torch.as_tensor(t)
+                return t.view(torch.uint8).reshape(self.n_routed_experts, n, -1)[sl].to(device=dev).contiguous()
+            h.load_gguf(blocks(w["gate"], inter), blocks(w["up"], inter), blocks(w["down"], cfg.hidden_size),
+                        int(w["gate_type"]), int(w["up_type"]), int(w["down_type"]))
         elif self.method == "FP8":
             h.load_fp8(prep(w["gate"]).view(torch.uint8), prep(w["up"]).view(torch.uint8), prep(w["down"]).view(torch.uint8),
                        prep(w["gate_scale"], torch.float32), prep(w["up_scale"], torch.float32),

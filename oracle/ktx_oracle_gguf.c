@@ -1,0 +1,178 @@
+/* ktx_oracle_gguf.c — TEST INFRASTRUCTURE ONLY.  *** PARITY UNPINNED ***
+ *
+ * CPU restatement of the reference's llamafile/GGUF expert path:
+ *   LLAMA_MOE_TP::forward_one / forward_many   kt-kernel/operators/llamafile/moe.hpp:271-460, 461-747
+ *     bf16 input -> fp32 -> from_float(vec_dot_type = Q8_K) -> llamafile_sgemm(weights x Q8_K) -> fp32
+ *     act_fn(g) * u in fp32 with expf (moe.hpp:269, 374) -> from_float(Q8_K) -> down sgemm -> fp32
+ *     output[i] += down[i] * w in slot order (moe.hpp:447-449, 715-721) -> bf16 (moe-tp.hpp merge)
+ * The GEMM arithmetic itself lives in un-vendored dependencies that are NOT under /root/reference:
+ *   ggerganov/llama.cpp (submodule third_party/llama.cpp, pin not recorded in the tree; the reference's numpy
+ *   dequantisers cite ggml commit fca1caafea7de9fbd7efc733b9818f9cf2da3050, archive/ktransformers/util/custom_gguf.py:326)
+ *   — quantize_row_q8_K, block_q4_K / block_q6_K / block_q8_K, get_scale_min_k4, ggml_vec_dot_q{4,6}_K_q8_K —
+ *   and third_party/llamafile/iqk_mul_mat.inc (present) whose AVX2/AVX512 kernels the reference actually runs.
+ * What is restated here is ggml's PUBLISHED scalar algorithm for those functions.  The integer parts (Q8_K codes,
+ * sub-block dot products, 6-bit scale/min products) are exact in every implementation; the fp32 combine order across
+ * 256-blocks differs between ggml's scalar code, its SIMD paths and iqk — here it is one sequential FMA chain per
+ * output (acc = fma(d8*d, isum, acc); acc = fma(-(d8*dmin), msum, acc)), which is also what the HIP kernel does.
+ * Pins available in-tree: the block LAYOUTS (dequantised values) are checked against the reference's own numpy
+ * dequantize_q4_k / dequantize_q6_k (tests/golden/make_gguf_golden.py); the reference's only numeric test for this
+ * path is `diff < 0.5` against torch (kt-kernel/examples/test_moe.py:203-206), which needs the built extension.
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define QK_K 256
+#define GGML_TYPE_Q4_K 12
+#define GGML_TYPE_Q6_K 14
+
+float ktxo_bf16_to_f32(uint16_t h);
+uint16_t ktxo_f32_to_bf16(float f);
+
+static float fp16_to_f32(uint16_t h) {
+  const uint32_t s = (uint32_t)(h & 0x8000) << 16, e = (h >> 10) & 0x1f, m = h & 0x3ff;
+  uint32_t u;
+  if (e == 0) {
+    if (m == 0) u = s;
+    else {  /* subnormal */
+      int sh = 0; uint32_t mm = m;
+      while (!(mm & 0x400)) { mm <<= 1; sh++; }
+      u = s | ((uint32_t)(113 - sh) << 23) | ((mm & 0x3ff) << 13);
+    }
+  } else if (e == 31) u = s | 0x7f800000u | (m << 13);
+  else u = s | ((e + 112) << 23) | (m << 13);
+  float f; memcpy(&f, &u, 4); return f;
+}
+
+/* ggml-quants.c nearest_int(): round to nearest even via the 1.5*2^23 trick */
+static inline int nearest_int(float fval) {
+  float val = fval + 12582912.f;
+  int i; memcpy(&i, &val, sizeof(int));
+  return (i & 0x007fffff) - 0x00400000;
+}
+
+/* ggml-quants.c quantize_row_q8_K_ref: per 256: max = the element of largest magnitude (first on ties),
+ * iscale = -127/max, q = min(127, nearest_int(iscale*x)), d = 1/iscale, bsums = sums of 16. */
+void ktxo_quantize_row_q8_K(const float* x, int K, int8_t* q, float* d, int16_t* bsums) {
+  for (int b = 0; b < K / QK_K; b++, x += QK_K, q += QK_K, bsums += 16) {
+    float max = 0, amax = 0;
+    for (int j = 0; j < QK_K; j++) { const float ax = fabsf(x[j]); if (ax > amax) { amax = ax; max = x[j]; } }
+    if (!amax) { d[b] = 0; memset(q, 0, QK_K); memset(bsums, 0, 32); continue; }
+    const float iscale = -127.f / max;
+    for (int j = 0; j < QK_K; j++) { int v = nearest_int(iscale * x[j]); q[j] = (int8_t)(v < 127 ? v : 127); }
+    for (int j = 0; j < 16; j++) { int s = 0; for (int i = 0; i < 16; i++) s += q[j * 16 + i]; bsums[j] = (int16_t)s; }
+    d[b] = 1 / iscale;
+  }
+}
+
+/* ggml-quants.c get_scale_min_k4 */
+static inline void get_scale_min_k4(int j, const uint8_t* q, uint8_t* d, uint8_t* m) {
+  if (j < 4) { *d = q[j] & 63; *m = q[j + 4] & 63; }
+  else { *d = (q[j + 4] & 0xF) | ((q[j - 4] >> 6) << 4); *m = (q[j + 4] >> 4) | ((q[j - 0] >> 6) << 4); }
+}
+
+/* block_q4_K: { fp16 d, fp16 dmin, uint8 scales[12], uint8 qs[128] } = 144 B (custom_gguf.py:326-343) */
+float ktxo_vec_dot_q4_K(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 144, q8 += QK_K, bs += 16) {
+    uint16_t dh, mh; memcpy(&dh, wrow, 2); memcpy(&mh, wrow + 2, 2);
+    const float d = fp16_to_f32(dh), dmin = fp16_to_f32(mh);
+    const uint8_t *sc = wrow + 4, *qs = wrow + 16;
+    int32_t isum = 0, msum = 0;
+    for (int j = 0; j < 8; j++) {
+      uint8_t s, m; get_scale_min_k4(j, sc, &s, &m);
+      const uint8_t* q = qs + (j / 2) * 32;
+      int32_t dot = 0;
+      for (int l = 0; l < 32; l++) dot += (int32_t)((j & 1) ? (q[l] >> 4) : (q[l] & 0xF)) * q8[j * 32 + l];
+      isum += (int32_t)s * dot;
+      msum += (int32_t)m * ((int32_t)bs[2 * j] + bs[2 * j + 1]);
+    }
+    acc = fmaf(d8[b] * d, (float)isum, acc);
+    acc = fmaf(-(d8[b] * dmin), (float)msum, acc);
+  }
+  return acc;
+}
+
+/* block_q6_K: { uint8 ql[128], uint8 qh[64], int8 scales[16], fp16 d } = 210 B (custom_gguf.py dequantize_q6_k) */
+float ktxo_vec_dot_q6_K(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  (void)bs;
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 210, q8 += QK_K) {
+    const uint8_t *ql = wrow, *qh = wrow + 128;
+    const int8_t* sc = (const int8_t*)(wrow + 192);
+    uint16_t dh; memcpy(&dh, wrow + 208, 2);
+    const float d = fp16_to_f32(dh);
+    int32_t isum = 0;
+    for (int h = 0; h < 2; h++) {            /* two halves of 128 */
+      int32_t dots[8] = {0};
+      for (int l = 0; l < 32; l++) {
+        const int is = l / 16;
+        const int q1 = (int)((ql[h * 64 + l] & 0xF) | (((qh[h * 32 + l] >> 0) & 3) << 4)) - 32;
+        const int q2 = (int)((ql[h * 64 + l + 32] & 0xF) | (((qh[h * 32 + l] >> 2) & 3) << 4)) - 32;
+        const int q3 = (int)((ql[h * 64 + l] >> 4) | (((qh[h * 32 + l] >> 4) & 3) << 4)) - 32;
+        const int q4 = (int)((ql[h * 64 + l + 32] >> 4) | (((qh[h * 32 + l] >> 6) & 3) << 4)) - 32;
+        dots[is + 0] += q1 * q8[h * 128 + l];
+        dots[is + 2] += q2 * q8[h * 128 + l + 32];
+        dots[is + 4] += q3 * q8[h * 128 + l + 64];
+        dots[is + 6] += q4 * q8[h * 128 + l + 96];
+      }
+      for (int j = 0; j < 8; j++) isum += (int32_t)sc[h * 8 + j] * dots[j];
+    }
+    acc = fmaf(d8[b] * d, (float)isum, acc);
+  }
+  return acc;
+}
+
+static size_t row_bytes(int type, int K) { return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : 210); }
+
+static float vec_dot(int type, const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  return type == GGML_TYPE_Q4_K ? ktxo_vec_dot_q4_K(wrow, K, q8, d8, bs) : ktxo_vec_dot_q6_K(wrow, K, q8, d8, bs);
+}
+
+typedef struct {
+  int32_t E, H, I, gate_type, up_type, down_type;
+  const uint8_t *gate, *up, *down;      /* raw GGUF blocks [E][N][K/256 blocks] */
+  const uint8_t* gpu_experts_mask;      /* nullable */
+} ktxo_gguf_moe;
+
+/* x bf16 [T][H], ids [T][k], w [T][k] -> y bf16 [T][H]; inter_out (nullable) receives the fp32 intermediate of token 0's
+ * slots [k][I] for white-box tests.  Returns 0, or -1 for an unsupported type. */
+int ktxo_moe_forward_gguf(const ktxo_gguf_moe* m, int T, int k, const int64_t* ids, const float* w, const uint16_t* x,
+                          uint16_t* y, float* inter_out) {
+  const int H = m->H, I = m->I;
+  const int types[3] = {m->gate_type, m->up_type, m->down_type};
+  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q6_K) return -1;
+  float* xf = malloc(sizeof(float) * H);
+  int8_t* xq = malloc(H); float* xd = malloc(sizeof(float) * (H / QK_K)); int16_t* xbs = malloc(2 * (H / 16));
+  float* inter = malloc(sizeof(float) * I);
+  int8_t* aq = malloc(I); float* ad = malloc(sizeof(float) * (I / QK_K)); int16_t* abs_ = malloc(2 * (I / 16));
+  float* out = malloc(sizeof(float) * H);
+  for (int t = 0; t < T; t++) {
+    for (int i = 0; i < H; i++) xf[i] = ktxo_bf16_to_f32(x[(size_t)t * H + i]);          /* to_float (moe.hpp:283) */
+    ktxo_quantize_row_q8_K(xf, H, xq, xd, xbs);                                           /* from_float(Q8_K) (:286) */
+    for (int i = 0; i < H; i++) out[i] = 0;                                               /* moe.hpp:419-421 */
+    for (int j = 0; j < k; j++) {
+      const int64_t e = ids[(size_t)t * k + j];
+      if (e < 0 || e >= m->E || (m->gpu_experts_mask && m->gpu_experts_mask[e])) continue; /* should_skip_expert */
+      const uint8_t* g = m->gate + (size_t)e * I * row_bytes(m->gate_type, H);
+      const uint8_t* u = m->up + (size_t)e * I * row_bytes(m->up_type, H);
+      const uint8_t* dn = m->down + (size_t)e * H * row_bytes(m->down_type, I);
+      for (int i = 0; i < I; i++) {
+        const float gv = vec_dot(m->gate_type, g + (size_t)i * row_bytes(m->gate_type, H), H, xq, xd, xbs);
+        const float uv = vec_dot(m->up_type, u + (size_t)i * row_bytes(m->up_type, H), H, xq, xd, xbs);
+        inter[i] = (gv / (1.0f + expf(-gv))) * uv;                                        /* act_fn(g) * u (:269,374) */
+      }
+      if (inter_out && t == 0) memcpy(inter_out + (size_t)j * I, inter, sizeof(float) * I);
+      ktxo_quantize_row_q8_K(inter, I, aq, ad, abs_);                                     /* from_float (:388) */
+      const float ew = w[(size_t)t * k + j];
+      for (int i = 0; i < H; i++) {
+        const float dv = vec_dot(m->down_type, dn + (size_t)i * row_bytes(m->down_type, I), I, aq, ad, abs_);
+        out[i] += dv * ew;                                                                /* moe.hpp:447-449 */
+      }
+    }
+    for (int i = 0; i < H; i++) y[(size_t)t * H + i] = ktxo_f32_to_bf16(out[i]);
+  }
+  free(xf); free(xq); free(xd); free(xbs); free(inter); free(aq); free(ad); free(abs_); free(out);
+  return 0;
+}

@@ -76,3 +76,34 @@ def rawint4_quantize(w_f32, group=32):
     q = q.reshape(E, N, K)
     packed = (q[..., 1::2] << 4) | q[..., 0::2]
     return np.ascontiguousarray(packed), np.ascontiguousarray(sb.reshape(E, N, K // group))
+
+
+def write_gguf(path, tensors, meta=None, alignment=32):
+    """Minimal GGUF v3 writer for the loader tests.  tensors: {name: (ggml_type, shape_ggml_order, raw_bytes)};
+    shape is in ggml order (fastest dim first), raw_bytes the tensor's blocks."""
+    import struct
+
+    def s(x):
+        b = x.encode()
+        return struct.pack("<Q", len(b)) + b
+
+    meta = dict(meta or {})
+    meta.setdefault("general.architecture", "deepseek2")
+    meta.setdefault("general.alignment", alignment)
+    kv = b""
+    for k, v in meta.items():
+        if isinstance(v, str):
+            kv += s(k) + struct.pack("<I", 8) + s(v)
+        else:
+            kv += s(k) + struct.pack("<I", 4) + struct.pack("<I", int(v))
+    infos, blob, off = b"", b"", 0
+    for name, (ty, shape, raw) in tensors.items():
+        raw = bytes(raw)
+        off += (alignment - off % alignment) % alignment
+        blob += b"\0" * (off - len(blob)) + raw
+        infos += s(name) + struct.pack("<I", len(shape)) + b"".join(struct.pack("<Q", d) for d in shape) + struct.pack("<IQ", ty, off)
+        off += len(raw)
+    head = b"GGUF" + struct.pack("<IQQ", 3, len(tensors), len(meta)) + kv + infos
+    pad = (alignment - len(head) % alignment) % alignment
+    with open(path, "wb") as f:
+        f.write(head + b"\0" * pad + blob)

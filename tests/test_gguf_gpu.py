@@ -1,0 +1,107 @@
+"""GPU: GGUF k-quant experts (KTX_FMT_GGUF, csrc/ktx_moe_gguf.inc) against oracle/ktx_oracle_gguf.c through the C ABI.
+
+Every integer stage (Q8_K codes, sub-block dot products, scale/min products) is exact on both sides and the fp32 combine is
+the same FMA chain, so gate/up/down outputs agree to the last bit EXCEPT where the device expf and glibc expf differ in
+the final ulp of SiLU: that perturbs single intermediates by 1 ulp, which can flip a Q8_K code by one step.  Bound used:
+|y - oracle| <= 2^-7 |oracle| + 2e-3 max|oracle|, and >= 99 % of the output elements bit-identical."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from helpers import bf16_to_f32  # noqa: E402
+from oracle.gguf_ref import GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle  # noqa: E402
+from oracle.oracle import f32_to_bf16  # noqa: E402
+
+Q4, Q6 = GGML_TYPE_Q4_K, GGML_TYPE_Q6_K
+
+
+def make(E, H, I, types, seed):
+    rng = np.random.default_rng(seed)
+    gate = QUANT[types[0]]((rng.standard_normal((E, I, H)) / 10).astype(np.float32))
+    up = QUANT[types[1]]((rng.standard_normal((E, I, H)) / 10).astype(np.float32))
+    down = QUANT[types[2]]((rng.standard_normal((E, H, I)) / 10).astype(np.float32))
+    return gate, up, down
+
+
+def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None):
+    from ktransformers_amd import _native as n
+    o = GgufOracle()
+    gate, up, down = make(E, H, I, types, seed)
+    rng = np.random.default_rng(seed + 1)
+    x = f32_to_bf16(rng.standard_normal((T, H)).astype(np.float32))
+    ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
+    if invalid:
+        ids[0, 0] = -1
+        ids[T - 1, k - 1] = E + 3
+    w = rng.random((T, k)).astype(np.float32)
+    ref = bf16_to_f32(o.moe_forward(gate, up, down, types, E, H, I, ids, w, x))
+    h = n.MoEHandle(E, k, H, I, max_len or max(T, 16), "GGUF", 0)
+    h.load_gguf(torch.from_numpy(gate).cuda(), torch.from_numpy(up).cuda(), torch.from_numpy(down).cuda(), *types)
+    y = h.forward(torch.from_numpy(x.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(ids).cuda(),
+                  torch.from_numpy(w).cuda())
+    y = y.float().cpu().numpy()
+    tol = 2.0 ** -7 * np.abs(ref) + 2e-3 * np.abs(ref).max()
+    assert (np.abs(y - ref) <= tol).all(), f"max diff {np.abs(y - ref).max()} (ref max {np.abs(ref).max()})"
+    same = float((y == ref).mean())
+    assert same >= 0.99, same
+    return h
+
+
+@pytest.mark.parametrize("types", [(Q4, Q4, Q6), (Q4, Q4, Q4), (Q6, Q6, Q6), (Q6, Q6, Q4)])
+@pytest.mark.parametrize("T", [1, 3, 19])
+def test_small(types, T):
+    run_case(4, 2, 256, 512, T, types, seed=T)
+
+
+def test_invalid_ids_and_ragged_tiles():
+    run_case(8, 3, 512, 256, 37, (Q4, Q4, Q6), seed=5, invalid=True)
+
+
+@pytest.mark.parametrize("T", [1, 130])
+def test_mixtral_like_shape(T):
+    """q4_k_m mix at a Mixtral-like aspect (H % 256 == 0, I % 256 == 0), prefill tile sizes MT = 1 / 4."""
+    run_case(8, 2, 1024, 3584, T, (Q4, Q4, Q6), seed=9)
+
+
+def test_errors():
+    from ktransformers_amd import _native as n
+    with pytest.raises(n.KtxError):
+        n.MoEHandle(4, 2, 384, 512, 16, "GGUF", 0)                       # H % 256
+    h = n.MoEHandle(4, 2, 256, 512, 16, "GGUF", 0)
+    x = torch.zeros(1, 256, dtype=torch.bfloat16, device="cuda")
+    with pytest.raises(n.KtxError):
+        h.forward(x, torch.zeros(1, 2, dtype=torch.long, device="cuda"), torch.zeros(1, 2, device="cuda"))   # not loaded
+    g = torch.zeros(4, 512, 144, dtype=torch.uint8, device="cuda")
+    d = torch.zeros(4, 256, 2 * 210, dtype=torch.uint8, device="cuda")
+    with pytest.raises(n.KtxError):
+        h.load_gguf(g, g, d, 12, 12, 8)                                   # Q8_0 not supported
+
+
+def test_llamafile_backend_through_the_operator_and_gguf_file(tmp_path):
+    """GGUF file -> GGUFLoader -> KTransformersExperts(backend="llamafile") -> HIP, against the oracle on the same blocks."""
+    from test_gguf_loader_cpu import build_file
+    from toy_model import ToyConfig
+    from ktransformers_amd.operators.experts import KTransformersExperts
+    from ktransformers_amd.util.gguf_loader import GGUFLoader
+    from ktransformers_amd.util.utils import InferenceState
+
+    src = build_file(str(tmp_path / "toy.gguf"))
+    E, H, I, k, T = src["E"], src["H"], src["I"], 2, 5
+    cfg = ToyConfig(hidden_size=H, moe_intermediate_size=I, intermediate_size=I, n_routed_experts=E, num_experts_per_tok=k)
+    ld = GGUFLoader(str(tmp_path))
+    orig = torch.nn.ModuleList([torch.nn.Identity() for _ in range(E)])
+    ex = KTransformersExperts("model.layers.1.mlp.experts", ld, cfg, orig, prefill_device="cuda", prefill_op="KExpertsTorch",
+                              generate_device="cpu", generate_op="KExpertsCPU", out_device="cuda", backend="llamafile",
+                              max_len=16)
+    ex.load(mode=InferenceState.GENERATE)
+    assert ex.generate_experts.method == "GGUF"
+    rng = np.random.default_rng(3)
+    x = f32_to_bf16(rng.standard_normal((T, H)).astype(np.float32))
+    ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
+    w = rng.random((T, k)).astype(np.float32)
+    y = ex.forward(torch.from_numpy(x.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(ids).cuda(),
+                   torch.from_numpy(w).cuda()).float().cpu().numpy()
+    ref = bf16_to_f32(GgufOracle().moe_forward(src["gate"], src["up"], src["down"], (Q4, Q4, Q6), E, H, I, ids, w, x))
+    assert (np.abs(y - ref) <= 2.0 ** -7 * np.abs(ref) + 2e-3 * np.abs(ref).max()).all()

@@ -1,0 +1,63 @@
+"""CPU: the GGUF reader (util/gguf_loader.py) on a file written by tests/helpers.write_gguf — header parsing, offsets,
+name translation, de-quantisation and raw expert blocks.  tests/golden/gguf_loader_golden.json records what the
+REFERENCE's own GGUFLoader (archive/ktransformers/util/custom_loader.py) reports for the same file."""
+import hashlib
+import json
+import os
+
+import numpy as np
+import torch
+
+from helpers import write_gguf
+from oracle.gguf_ref import dequantize_q4_k, dequantize_q6_k, quantize_q4_k, quantize_q6_k
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gguf_loader_golden.json")
+
+
+def build_file(path):
+    rng = np.random.default_rng(7)
+    E, H, I = 4, 256, 512
+    gate = quantize_q4_k((rng.standard_normal((E, I, H)) / 10).astype(np.float32))
+    up = quantize_q4_k((rng.standard_normal((E, I, H)) / 10).astype(np.float32))
+    down = quantize_q6_k((rng.standard_normal((E, H, I)) / 10).astype(np.float32))
+    norm = rng.standard_normal(H).astype(np.float32)
+    attn = (rng.standard_normal((64, H)) / 10).astype(np.float16)
+    tensors = {
+        "blk.1.ffn_gate_exps.weight": (12, [H, I, E], gate.tobytes()),
+        "blk.1.ffn_up_exps.weight": (12, [H, I, E], up.tobytes()),
+        "blk.1.ffn_down_exps.weight": (14, [I, H, E], down.tobytes()),
+        "blk.1.attn_norm.weight": (0, [H], norm.tobytes()),
+        "blk.1.attn_kv_a_mqa.weight": (1, [H, 64], attn.tobytes()),
+    }
+    write_gguf(path, tensors, {"deepseek2.expert_count": E})
+    return dict(gate=gate, up=up, down=down, norm=norm, attn=attn, E=E, H=H, I=I)
+
+
+def test_reader_matches_reference_loader_and_roundtrips(tmp_path):
+    from ktransformers_amd.util.gguf_loader import GGUFLoader, translate_name_to_gguf
+    path = str(tmp_path / "toy.gguf")
+    src = build_file(path)
+    gold = json.load(open(GOLD))
+    assert hashlib.sha256(open(path, "rb").read()).hexdigest() == gold["sha256"], "writer output changed; regenerate the golden"
+    ld = GGUFLoader(str(tmp_path))
+    for name, g in gold["tensors"].items():
+        t = ld.tensor_info[name]
+        assert (t["ggml_type"], t["shape"], t["offset"]) == (g["ggml_type"], g["shape"], g["offset"]), name
+    assert ld.gguf_file_meta["deepseek2.expert_count"] == gold["meta"]["deepseek2.expert_count"]
+    # HF names resolve like the reference's translate_name_to_gguf
+    for hf, gg in gold["names"].items():
+        assert translate_name_to_gguf(hf) == gg
+    assert ld.has_tensor("model.layers.1.input_layernorm.weight") and not ld.has_tensor("model.layers.2.input_layernorm.weight")
+    assert torch.equal(ld.load_gguf_tensor("model.layers.1.input_layernorm.weight", target_dtype=torch.float32),
+                       torch.from_numpy(src["norm"]))
+    a = ld.load_gguf_tensor("model.layers.1.self_attn.kv_a_proj_with_mqa.weight", target_dtype=torch.float32)
+    assert a.shape == (64, src["H"]) and torch.equal(a, torch.from_numpy(src["attn"].astype(np.float32)))
+    ex = ld.load_experts("model.layers.1.mlp.experts")
+    assert (ex["gate_type"], ex["up_type"], ex["down_type"]) == (12, 12, 14)
+    assert np.array_equal(ex["gate"].numpy(), src["gate"].reshape(-1)) and np.array_equal(ex["down"].numpy(), src["down"].reshape(-1))
+    assert ld.get_expert_count("model.layers.1.mlp.experts") == src["E"]
+    deq = ld.load_gguf_tensor("blk.1.ffn_down_exps.weight", target_dtype=torch.float32)
+    assert deq.shape == (src["E"], src["H"], src["I"])
+    assert np.array_equal(deq.numpy(), dequantize_q6_k(src["down"]).reshape(src["E"], src["H"], src["I"]))
+    deq4 = ld.load_gguf_tensor("blk.1.ffn_gate_exps.weight", target_dtype=torch.float32)
+    assert np.array_equal(deq4.numpy(), dequantize_q4_k(src["gate"]).reshape(src["E"], src["I"], src["H"]))
