@@ -96,6 +96,13 @@ int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void* d_up, cons
 int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, int gate_type, int up_type,
                       int down_type);
 
+/* The weighted combine of ktx_moe_forward alone (operators/amx/moe_base.hpp:413-436): y[t] = (incremental ? y[t] : 0) +
+ * sum_j fma(rows[row_of_pair[t*k+j]], w[t][j], .) in slot order, fp32, one bf16 rounding; row_of_pair < 0 skips the slot.
+ * d_rows: bf16 [*][hidden] per-pair expert outputs.  Used by expert-parallel prefill, where the rows arrive over the
+ * all-to-all (ktransformers_amd/parallel.py). */
+int ktx_moe_combine(int qlen, int k, int hidden, const void* d_rows, const int32_t* d_row_of_pair, const float* d_weights,
+                    void* d_output, int incremental, ktx_stream_t stream);
+
 /* should_skip_expert mask (operators/common.hpp:241-258): mask[e] != 0 => expert e contributes nothing. HOST ptr, may be NULL. */
 int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask);
 

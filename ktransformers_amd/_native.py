@@ -58,6 +58,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_load_fp8.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_load_rawint4.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_load_gguf.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
+    lib.ktx_moe_combine.argtypes = [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
     lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
@@ -285,6 +286,21 @@ class MoEHandle:
 
 GATE_SCORING = {"sigmoid": 0, "softmax": 1}
 GATE_TOPK = {"greedy": 0, "group_limited_greedy": 1, "noaux_tc": 2}
+
+
+def moe_combine(rows: torch.Tensor, row_of_pair: torch.Tensor, weights: torch.Tensor, out: torch.Tensor | None = None,
+                incremental: bool = False) -> torch.Tensor:
+    """rows bf16 [R, H]; row_of_pair int32 [T, k] (-1 = skipped slot); weights fp32 [T, k] -> bf16 [T, H] (ktx_moe_combine)."""
+    T, k = row_of_pair.shape
+    H = rows.shape[1]
+    if rows.dtype != torch.bfloat16 or row_of_pair.dtype != torch.int32 or weights.dtype != torch.float32:
+        raise KtxError("moe_combine: rows bf16, row_of_pair int32, weights fp32")
+    rows, rp, w = rows.contiguous(), row_of_pair.contiguous(), weights.contiguous()
+    if out is None:
+        out = torch.empty((T, H), dtype=torch.bfloat16, device=rows.device)
+    check(lib.ktx_moe_combine(T, k, H, rows.data_ptr(), rp.data_ptr(), w.data_ptr(), out.data_ptr(), 1 if incremental else 0,
+                              _stream_ptr(rows.device)))
+    return out
 
 
 LIN_FMT = {"BF16": 0, "W4": 1, "FP8": 2}

@@ -2037,6 +2037,20 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
 }
 
 
+// Slot-ordered weighted combine on its own (expert-parallel prefill: the per-pair expert outputs come back over the
+// all-to-all and are summed at the token's home rank exactly like the single-GPU path sums them).
+extern "C" int ktx_moe_combine(int qlen, int k, int hidden, const void* d_rows, const int32_t* d_row_of_pair,
+                               const float* d_weights, void* d_output, int incremental, ktx_stream_t stream) {
+  KTX_REQUIRE(d_rows && d_row_of_pair && d_weights && d_output, "ktx_moe_combine: null pointer");
+  KTX_REQUIRE(qlen > 0 && k > 0 && hidden > 0 && hidden % 4 == 0, "ktx_moe_combine: bad shape");
+  CombineParams cp{};
+  cp.d_bsz = nullptr; cp.qlen = qlen; cp.k = k; cp.H = hidden; cp.dn = (const bf16_t*)d_rows; cp.row_of_pair = d_row_of_pair;
+  cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = incremental ? 1 : 0;
+  hipLaunchKernelGGL(moe_combine_kernel, dim3((hidden / 4 + 255) / 256, qlen), dim3(256), 0, (hipStream_t)stream, cp);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int WT, int MT, bool GATE_UP>
 static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = WT == GG_Q4K ? 8 : 16;

@@ -6,6 +6,7 @@ of TP_MOE_Common::forward + merge_results (kt-kernel/operators/moe-tp.hpp:201-24
 where every part sees all tokens, computes an fp32 partial [T,H], and the partials are summed in fp32 before the single
 bf16 rounding.  Sharding by EXPERT instead of by intermediate column keeps exactly that reduce shape:
 
+  prefill / large T: all-to-all-v dispatch + combine (ep_prefill_forward) — bit-identical to the single-GPU forward.
   decode / small T ("replicate + reduce"): all-gather the ranks' token rows (x, ids, w — a few KiB),
   every rank runs the experts it owns on all gathered tokens (ids outside its range are skipped inside the kernel),
   reduce-scatter the fp32 partials so each rank receives the sum for its own tokens, round to bf16 once.
@@ -42,6 +43,51 @@ def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch
     return out.to(torch.bfloat16)
 
 
+def ep_prefill_forward(local_rows: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
+                       combine: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
+                       x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, E: int, group=None) -> torch.Tensor:
+    """Prefill / large-T expert parallelism: all-to-all-v dispatch of (token, slot) rows to the rank that
+    owns the slot's expert, local experts, all-to-all-v back, slot-ordered combine at the token's home rank.
+
+    x bf16 [T,H], ids int64 [T,k] (global expert ids), w fp32 [T,k] — this rank's tokens; returns bf16 [T,H].
+    `local_rows(rows bf16 [n,H], expert_ids int64 [n]) -> bf16 [n,H]` = Expert_id(row) (MoEHandle.forward with k=1 and
+    weight 1.0, which returns the expert's bf16 output unchanged); `combine(rows, row_of_pair int32 [T,k], w) -> bf16 [T,H]`
+    is the single-GPU combine (ktransformers_amd._native.moe_combine).  Because the per-pair expert outputs and the
+    combine are the single-GPU ones, the result is bit-identical to the single-GPU forward (unlike the decode path,
+    whose cross-rank fp32 reduction reorders the sum).  Volume per rank and direction: (#pairs leaving the rank)*H*2 B.
+    The split sizes are read on the host (one small sync): prefill is not graph-captured in the reference either."""
+    world = dist.get_world_size(group)
+    T, H = x.shape
+    k = ids.shape[1]
+    if E % world != 0:
+        raise ValueError(f"expert count {E} not divisible by world size {world}")
+    per = E // world
+    flat = ids.reshape(-1)
+    valid = (flat >= 0) & (flat < E)
+    dest = torch.where(valid, torch.div(flat, per, rounding_mode="floor"), torch.full_like(flat, world))
+    order = torch.argsort(dest, stable=True)
+    send_counts_t = torch.bincount(dest, minlength=world + 1)[:world]
+    recv_counts_t = torch.empty_like(send_counts_t)
+    dist.all_to_all_single(recv_counts_t, send_counts_t, group=group)
+    send_counts, recv_counts = send_counts_t.tolist(), recv_counts_t.tolist()
+    n_send, n_recv = sum(send_counts), sum(recv_counts)
+    sel = order[:n_send]
+    send_x = x[torch.div(sel, k, rounding_mode="floor")].contiguous()
+    send_ids = flat[sel].contiguous()
+    recv_x = torch.empty((n_recv, H), dtype=x.dtype, device=x.device)
+    recv_ids = torch.empty((n_recv,), dtype=flat.dtype, device=x.device)
+    dist.all_to_all_single(recv_x, send_x, recv_counts, send_counts, group=group)
+    dist.all_to_all_single(recv_ids, send_ids, recv_counts, send_counts, group=group)
+    out_rows = local_rows(recv_x, recv_ids) if n_recv else recv_x
+    back = torch.empty((n_send, H), dtype=x.dtype, device=x.device)
+    dist.all_to_all_single(back, out_rows.contiguous(), send_counts, recv_counts, group=group)
+    row_of_pair = torch.full((T * k,), -1, dtype=torch.int32, device=x.device)
+    row_of_pair[sel] = torch.arange(n_send, dtype=torch.int32, device=x.device)
+    if n_send == 0:
+        back = torch.zeros((1, H), dtype=x.dtype, device=x.device)
+    return combine(back, row_of_pair.view(T, k), w)
+
+
 def expert_range(E: int, world: int, rank: int) -> tuple[int, int]:
     """Contiguous expert shard [begin, begin+count) of rank `rank`."""
     if E % world != 0:
@@ -60,6 +106,19 @@ class ExpertParallelMoE:
 
     def forward(self, x, ids, w):
         return ep_decode_forward(self.handle.forward_partial, x, ids, w, self.group)
+
+    def forward_prefill(self, x, ids, w):
+        """All-to-all-v dispatch / combine; bit-identical to the single-GPU forward.  The local handle must have been
+        created with max_len >= the rows this rank can receive (world * T * k in the worst case)."""
+        from ktransformers_amd._native import moe_combine
+
+        E = self.handle.E * dist.get_world_size(self.group)
+
+        def local_rows(rows, eids):
+            ones = torch.ones((rows.shape[0], 1), dtype=torch.float32, device=rows.device)
+            return self.handle.forward(rows, eids.view(-1, 1), ones)
+
+        return ep_prefill_forward(local_rows, moe_combine, x, ids, w, E, self.group)
 
     # ---- bench support ------------------------------------------------------------------------------------------
     @staticmethod

@@ -74,3 +74,65 @@ def test_expert_range():
     assert expert_range(256, 8, 3) == (96, 32)
     with pytest.raises(ValueError):
         expert_range(10, 4, 0)
+
+
+def _prefill_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ktransformers_amd.parallel import ep_prefill_forward, expert_range
+    from oracle.oracle import FMT_AMXINT4, Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    Tl = 5 + rank                                   # ragged: ranks hold different token counts
+    total = sum(5 + r for r in range(world))
+    c = make_case(23, E, K, H, I, total, invalid_ids=True)
+    moe = o.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"])
+    begin, cnt = expert_range(E, world, rank)
+    seen = []
+
+    def local_rows(rows, eids):
+        e = eids.numpy()
+        assert ((e >= begin) & (e < begin + cnt)).all(), "a row reached a rank that does not own its expert"
+        seen.append(len(e))
+        xs = rows.view(torch.int16).numpy().view(np.uint16)
+        y = o.moe_forward(moe, e.reshape(-1, 1), np.ones((len(e), 1), np.float32), xs)
+        return torch.from_numpy(y.view(np.int16).copy()).view(torch.bfloat16)
+
+    def combine(rows, row_of_pair, w):
+        r = bf16_to_f32(rows.view(torch.int16).numpy().view(np.uint16)).astype(np.float64)
+        rp, wn = row_of_pair.numpy(), w.numpy().astype(np.float64)
+        acc = np.zeros((rp.shape[0], H), np.float32)
+        for j in range(rp.shape[1]):                # slot order, fp32 FMA (product exact in fp64, one fp32 rounding)
+            ok = rp[:, j] >= 0
+            acc[ok] = (r[rp[ok, j]] * wn[ok, j:j + 1] + acc[ok].astype(np.float64)).astype(np.float32)
+        from oracle.oracle import f32_to_bf16
+        return torch.from_numpy(f32_to_bf16(acc).view(np.int16).copy()).view(torch.bfloat16)
+
+    off = sum(5 + r for r in range(rank))
+    sl = slice(off, off + Tl)
+    x = torch.from_numpy(c["x"][sl].view(np.int16).copy()).view(torch.bfloat16)
+    y = ep_prefill_forward(local_rows, combine, x, torch.from_numpy(c["ids"][sl]), torch.from_numpy(c["w"][sl]), E)
+    full = o.moe_forward(moe, c["ids"], c["w"], c["x"])
+    q.put((rank, y.view(torch.int16).numpy().view(np.uint16).copy(), full[sl].copy(), sum(seen)))
+    dist.destroy_process_group()
+
+
+def test_expert_parallel_prefill_all_to_all_is_bit_identical():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 31500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_prefill_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=300) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    rows = 0
+    for rank, got, want, n in res:
+        assert np.array_equal(got, want), f"rank {rank}: {(got != want).sum()} elements differ"
+        rows += n
+    assert rows > 0
