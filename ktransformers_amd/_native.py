@@ -141,6 +141,8 @@ class MoEHandle:
         dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
         if dev.type != "cuda":
             raise KtxError("MoEHandle needs a HIP device; there is no CPU path")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         if method not in FMT:
             raise KtxError(f"unknown method {method!r}")
         self.device = dev
@@ -314,6 +316,8 @@ class LinearHandle:
         dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
         if dev.type != "cuda":
             raise KtxError("LinearHandle needs a HIP device; there is no CPU path")
+        if dev.index is None:
+            dev = torch.device("cuda", torch.cuda.current_device())
         if fmt not in LIN_FMT:
             raise KtxError(f"unknown linear format {fmt!r}")
         self.device, self.fmt, self.K, self.N, self.max_len = dev, fmt, in_features, out_features, max_len

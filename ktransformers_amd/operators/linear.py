@@ -58,8 +58,13 @@ class KLinearBase(nn.Module):
             return nn.Parameter(w, requires_grad=False), nn.Parameter(bias, requires_grad=False)
         return nn.Parameter(w, requires_grad=False)
 
+    def _dev(self) -> torch.device:
+        d = torch.device(self.device)
+        return torch.device("cuda", torch.cuda.current_device()) if d.type == "cuda" and d.index is None else d
+
     def _make_handle(self, group_size: int = 0):
         from ktransformers_amd._native import LinearHandle
+        self.device = str(self._dev())
         return LinearHandle(self.in_features, self.out_features, self.FMT, group_size, self.max_len, torch.device(self.device))
 
     def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor = None, **kwargs) -> torch.Tensor:

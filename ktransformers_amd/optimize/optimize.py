@@ -24,7 +24,11 @@ from ktransformers_amd.util.utils import load_weights, set_module
 
 _ALIAS_PREFIXES = (("ktransformers.operators.", "ktransformers_amd.operators."),
                    ("ktransformers.optimize.", "ktransformers_amd.optimize."),
-                   ("ktransformers.util.", "ktransformers_amd.util."))
+                   ("ktransformers.util.", "ktransformers_amd.util."),
+                   # the host model tree: both reference modeling files map onto the one skeleton
+                   ("ktransformers.models.modeling_deepseek_v3.", "ktransformers_amd.models.modeling_deepseek."),
+                   ("ktransformers.models.modeling_deepseek.", "ktransformers_amd.models.modeling_deepseek."),
+                   ("ktransformers.models.", "ktransformers_amd.models."))
 
 
 def resolve_class(path: str):

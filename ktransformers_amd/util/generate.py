@@ -1,0 +1,97 @@
+"""Decode-loop glue — mirror of archive/ktransformers/util/utils.py:356-540 (prefill_and_generate:
+chunked prefill, then one token per step through a captured graph, greedy sampling) and util/cuda_graph_runner.py:19-100
+(CUDAGraphRunner: static input buffers `cur_token`, `position_ids`, `cache_position`, one captured decode step, logits out).
+
+Everything between the embedding and the logits is HIP kernels from this package enqueued by the injected operators; the
+graph is a HIP graph (torch.cuda.CUDAGraph on ROCm).  The kv length the MLA kernel uses is derived ON THE DEVICE from
+position_ids, so the captured graph stays valid as the sequence grows."""
+from __future__ import annotations
+
+import torch
+
+from ktransformers_amd.util.utils import InferenceState
+
+
+def set_inference_mode(model: torch.nn.Module, mode: InferenceState) -> None:
+    for m in model.modules():
+        if hasattr(m, "set_inference_mode") and not isinstance(getattr(type(m), "set_inference_mode", None), property):
+            try:
+                m.set_inference_mode(mode)
+            except NotImplementedError:
+                pass
+
+
+class CUDAGraphRunner:
+    """util/cuda_graph_runner.py:19-100."""
+
+    def __init__(self):
+        self.graph = None
+        self.input_buffers = {}
+        self.output_buffers = {}
+
+    def capture(self, model, cur_token, position_ids, cache_position, past_key_values, main_device="cuda:0", **kwargs):
+        assert self.graph is None
+        self.model = model
+        dev = torch.device(main_device)
+        self.input_buffers = {"cur_token": cur_token.clone(), "position_ids": position_ids.clone(),
+                              "cache_position": cache_position.clone()}
+        ib = self.input_buffers
+        stream = torch.cuda.Stream(device=dev)
+        stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(stream):
+            for _ in range(2):   # warm-up outside the capture: lazy handle creation, workspace growth, attribute setting
+                logits = model(ib["cur_token"], ib["position_ids"], past_key_values, ib["cache_position"])
+        torch.cuda.current_stream(dev).wait_stream(stream)
+        torch.cuda.synchronize(dev)
+        self.graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.graph, stream=stream):
+            logits = model(ib["cur_token"], ib["position_ids"], past_key_values, ib["cache_position"])
+        torch.cuda.synchronize(dev)
+        self.output_buffers = {"logits": logits}
+
+    def forward(self, cur_token, position_ids, cache_position):
+        ib = self.input_buffers
+        ib["cur_token"].copy_(cur_token)
+        ib["position_ids"].copy_(position_ids)
+        ib["cache_position"].copy_(cache_position)
+        self.graph.replay()
+        return self.output_buffers["logits"]
+
+    __call__ = forward
+
+
+@torch.no_grad()
+def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_new_tokens: int = 16, use_cuda_graph: bool = True,
+                         chunk_size: int = 8192, return_logits: bool = False):
+    """Greedy generation (utils.py:356-540 with do_sample=False): returns the generated token ids [max_new_tokens]
+    (and the fp32 logits of every generated position when return_logits)."""
+    dev = input_ids.device
+    T = input_ids.shape[1]
+    set_inference_mode(model, InferenceState.PREFILL)
+    logits = None
+    for s in range(0, T, chunk_size):                                    # chunk_prefill (utils.py:496-511)
+        e = min(T, s + chunk_size)
+        pos = torch.arange(s, e, device=dev).unsqueeze(0)
+        logits = model(input_ids[:, s:e], pos, past_key_values, pos[0], last_token_only=True)
+    set_inference_mode(model, InferenceState.GENERATE)
+    tokens, all_logits = [], []
+    nxt = logits[0, -1].argmax(dim=-1)
+    runner = None
+    for i in range(max_new_tokens):
+        tokens.append(nxt.clone())
+        if return_logits:
+            all_logits.append(logits[0, -1].clone())
+        if i == max_new_tokens - 1:
+            break
+        cur = nxt.view(1, 1)
+        pos = torch.tensor([[T + i]], device=dev, dtype=torch.long)
+        if use_cuda_graph:
+            if runner is None:
+                runner = CUDAGraphRunner()
+                runner.capture(model, cur, pos, pos[0], past_key_values, main_device=str(dev))
+            logits = runner(cur, pos, pos[0])
+        else:
+            logits = model(cur, pos, past_key_values, pos[0])
+        nxt = logits[0, -1].argmax(dim=-1)
+    out = torch.stack(tokens)
+    return (out, torch.stack(all_logits)) if return_logits else out
