@@ -129,10 +129,14 @@ class FullDecodeRunner:
          MoE: router (logits + group-limited top-k) -> routed experts                        (a1, a5-a12, every MoE layer)
     The hidden state fed to router and experts changes every step (nsets pre-generated rows), so routing changes too."""
 
-    def __init__(self, wl, layers, dev, ctx=4096, nsets=16, seed=3):
+    def __init__(self, wl, layers, dev, ctx=4096, nsets=16, seed=3, ep=False):
         from ktransformers_amd._native import GateHandle, MLAWrapper
+        from ktransformers_amd.parallel import ExpertParallelMoE
 
         self.wl, self.layers, self.dev, self.nsets = wl, layers, dev, nsets
+        # N > 1: every rank decodes its own token (attention + router replicated), the routed experts are sharded
+        # expert-parallel: all-gather (x, ids, w) -> local experts -> reduce-scatter (ktransformers_amd/parallel.py)
+        self.ep = [ExpertParallelMoE(h) for h in layers] if ep else None
         H, E, k, L = wl["H"], wl["E"], wl["k"], wl["L"]
         gc = wl["gate"]
         g = torch.Generator(device=dev)
@@ -167,15 +171,25 @@ class FullDecodeRunner:
             li = a - (self.nattn - len(self.layers))
             if li >= 0:
                 ids, w = self.gate.forward(self.x, self.gate_w[li], self.gate_b[li])
-                self.layers[li].forward(self.x, ids, w, out=self.y[li & 1])
+                if self.ep is not None:
+                    self.y[li & 1] = self.ep[li].forward(self.x, ids, w)
+                else:
+                    self.layers[li].forward(self.x, ids, w, out=self.y[li & 1])
 
     def capture(self):
         self.step_eager()
         torch.cuda.synchronize(self.dev)
-        self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.step_eager()
-        torch.cuda.synchronize(self.dev)
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self.step_eager()
+            torch.cuda.synchronize(self.dev)
+            self.graph = g
+        except Exception as e:   # collectives not capturable on this stack: stay eager, say so
+            if self.ep is None:
+                raise
+            log(f"[bench] EP graph capture failed ({type(e).__name__}: {e}); running eagerly")
+            self.graph = None
 
     def step(self, i):
         self.x.copy_(self.x_all[i % self.nsets])
@@ -183,6 +197,117 @@ class FullDecodeRunner:
             self.graph.replay()
         else:
             self.step_eager()
+
+
+class RandomLoader:
+    """Weight source for the whole-model run: tensors are generated on the device on demand (seeded by their name) with
+    the shapes of the meta-device skeleton — there is no network for checkpoints.  Same protocol as util/loader.py."""
+
+    def __init__(self, shapes, dev):
+        self.shapes, self.dev, self.tensor_device_map = shapes, dev, {}
+
+    def has_tensor(self, name):
+        return name in self.shapes
+
+    def _gen(self, name, shape, scale, mean=0.0):
+        import zlib
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(zlib.crc32(name.encode()))
+        return (torch.randn(tuple(shape), generator=g, device=self.dev) * scale + mean).to(torch.bfloat16)
+
+    def load_tensor(self, name, device="cpu"):
+        shape = self.shapes[name]
+        if "layernorm" in name or name.endswith("norm.weight"):
+            return self._gen(name, shape, 0.1, 1.0)
+        if "embed_tokens" in name:
+            return self._gen(name, shape, 1.0)
+        if name.endswith("e_score_correction_bias"):
+            return self._gen(name, shape, 0.1).float()
+        return self._gen(name, shape, shape[-1] ** -0.5)
+
+    def get_expert_count(self, key):
+        n = 0
+        while f"{key}.{n}.gate_proj.weight" in self.shapes:
+            n += 1
+        return n
+
+    def load_experts(self, key, device="cpu"):
+        n = self.get_expert_count(key)
+        out = {}
+        for proj in ("gate", "up", "down"):
+            shape = (n,) + tuple(self.shapes[f"{key}.0.{proj}_proj.weight"])
+            out[proj] = self._gen(f"{key}.{proj}", shape, 0.1)          # randn/10 like the reference's MoE tests
+        return out
+
+
+class GreedyStep(torch.nn.Module):
+    def __init__(self, model):
+        super().__init__()
+        self.model = model
+
+    def forward(self, cur_token, position_ids, past_key_values, cache_position):
+        logits = self.model(cur_token, position_ids, past_key_values, cache_position)
+        return logits[0, -1].argmax(dim=-1).view(1, 1)                   # greedy sampling (utils.py:485-494, do_sample=False)
+
+
+class ModelDecodeRunner:
+    """Whole-model greedy decode of DeepSeek-V2-Lite through the YAML-injected operators, one HIP graph per token:
+    embedding -> 27 x [RMSNorm, MLA attention operator (W4 q/kv_a/o projections, RoPE, absorb, paged MQA over `ctx` cached
+    tokens, cache append), RMSNorm, dense MLP (layer 0) | router + 6-of-64 int4 routed experts + shared experts] -> RMSNorm ->
+    lm_head (W4) -> argmax.  The sampled token is fed back, so routing follows the model."""
+
+    def __init__(self, dev, ctx, max_new):
+        from ktransformers_amd.models.custom_cache import StaticCache
+        from ktransformers_amd.models.modeling_deepseek import DeepseekForCausalLM, make_config
+        from ktransformers_amd.optimize.optimize import optimize_and_load
+        from ktransformers_amd.util.generate import CUDAGraphRunner, set_inference_mode
+        from ktransformers_amd.util.utils import InferenceState
+
+        cfg = make_config(max_position_embeddings=max(4096, ctx + max_new + 64),
+                          rope_scaling={"type": "yarn", "factor": 40, "mscale": 0.707, "mscale_all_dim": 0.707,
+                                        "original_max_position_embeddings": 4096, "beta_fast": 32, "beta_slow": 1})
+        self.cfg, self.dev = cfg, dev
+        torch.set_default_dtype(torch.bfloat16)
+        try:
+            with torch.device("meta"):
+                model = DeepseekForCausalLM(cfg)
+            shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
+            rules = os.path.join(os.path.dirname(os.path.abspath(__file__)), "ktransformers_amd", "optimize", "optimize_rules",
+                                 "DeepSeek-V2-Lite-Chat.yaml")
+            import contextlib
+            import io
+            with contextlib.redirect_stdout(io.StringIO()):                   # "Injecting ..." lines
+                optimize_and_load(model, rules, RandomLoader(shapes, dev), cfg, default_device=str(dev))
+        finally:
+            torch.set_default_dtype(torch.float32)
+        set_inference_mode(model, InferenceState.GENERATE)
+        self.model = model
+        self.cache = StaticCache(cfg, 1, ctx + max_new + 64, str(dev), torch.bfloat16)
+        for kc in self.cache.key_cache:
+            kc.normal_()
+        self.step_mod = GreedyStep(model)
+        self.pos = torch.tensor([[ctx]], device=dev, dtype=torch.long)
+        self.cur = torch.tensor([[1]], device=dev, dtype=torch.long)
+        self.runner = CUDAGraphRunner()
+        with torch.no_grad():
+            self.runner.capture(self.step_mod, self.cur, self.pos, self.pos[0], self.cache, main_device=str(dev))
+        self.tokens = []
+
+    def moe_handles(self):
+        return [l.mlp.experts.generate_experts.handle for l in self.model.model.layers if hasattr(l.mlp, "experts")]
+
+    def linear_bytes(self):
+        tot = 0
+        for m in self.model.modules():
+            h = getattr(m, "_h", None)
+            if h is not None and hasattr(h, "weight_bytes"):
+                tot += h.weight_bytes()
+        return tot
+
+    def step(self, i):
+        nxt = self.runner(self.cur, self.pos, self.pos[0])
+        self.cur.copy_(nxt)
+        self.pos += 1
 
 
 def timed(fn, steps, warmup, dev, dist_on):
@@ -287,6 +412,7 @@ def main():
     ap.add_argument("--hot-path", default="full", choices=["full", "moe"],
                     help="full: MLA attention + router + routed experts per layer; moe: routed experts only")
     ap.add_argument("--ctx", type=int, default=4096, help="cached tokens the MLA decode attends over")
+    ap.add_argument("--no-model", action="store_true", help="skip the whole-model greedy-decode measurement (N=1 only)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(WORKLOADS[args.workload])), flush=True)
@@ -321,16 +447,16 @@ def main():
             f"built in {time.perf_counter() - t0:.1f}s")
 
     # ---------------- decode ----------------
-    if dist_on:
+    if dist_on and args.hot_path == "moe":
         runner = ExpertParallelMoE.bench_runner(wl, layers, dev, world, rank, use_graph=not args.no_graph)
         step = runner.step
-        tokens_per_step = world  # one token per rank per step
     else:
-        r = FullDecodeRunner(wl, layers, dev, ctx=args.ctx) if args.hot_path == "full" else DecodeRunner(wl, layers, T=1, dev=dev)
+        r = FullDecodeRunner(wl, layers, dev, ctx=args.ctx, seed=3 + rank, ep=dist_on) if args.hot_path == "full" \
+            else DecodeRunner(wl, layers, T=1, dev=dev)
         if not args.no_graph:
             r.capture()
         step = r.step
-        tokens_per_step = 1
+    tokens_per_step = world  # one token per rank per step (weak scaling)
     dt = timed(step, args.steps, args.warmup, dev, dist_on)
     ms_per_step = dt / args.steps * 1e3
     decode_tps = tokens_per_step * args.steps / dt
@@ -345,7 +471,9 @@ def main():
                    "hip_graph": not args.no_graph,
                    "step": ("MLA cache-append + absorbed paged attention (ctx %d, %d heads, %d layers) + router + routed "
                             "experts (%d layers)" % (args.ctx, wl["heads"], wl["attn_layers"], L))
-                   if (args.hot_path == "full" and not dist_on) else "router-less routed experts only"},
+                   + ("; routed experts sharded expert-parallel over %d ranks (all-gather + reduce-scatter per layer), "
+                      "attention and router replicated, one token per rank" % world if dist_on else "")
+                   if args.hot_path == "full" else "router-less routed experts only"},
     }
 
     if not dist_on:
@@ -384,10 +512,21 @@ def main():
         gu_bytes = k * 2 * I * H * 0.5 + k * 2 * I * 4 + H * 2  # packed gate+up of k experts + fp32 row scales + bf16 x row
         dn_bytes = k * H * I * 0.5 + k * H * 4 + k * I * 2 + H * 2
         ach = gu_bytes / (gu_us * 1e-6) / 1e9
+        # HBM bytes per launch from the PMC passes (collected offline with rocprofv3 --pmc, see scripts/pmc_summary.py;
+        # counters cannot be read from inside this process)
+        traffic = None
+        try:
+            pmc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_decode.json")))
+            for name, e in pmc["kernels"].items():
+                if name.startswith("moe_dec_gateup_kernel") and args.workload == "v2lite-int4":
+                    traffic = e["hbm_bytes"]
+        except Exception:
+            traffic = None
         out["roofline"] = {"bound": "hbm",
                            "kernel": "moe_dec_gateup_kernel (x-quant + gate/up W4A8 MFMA GEMV + SiLU*up, decode path)",
                            "achieved": round(ach, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": None,
+                           "frac": round(ach / HBM_PEAK_GBS, 4), "traffic": traffic,
+                           "traffic_source": "profiles/r01_pmc_decode.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, bytes per launch)" if traffic else None,
                            "algorithmic_bytes_per_launch": int(gu_bytes), "avg_launch_us": round(gu_us, 3)}
         out["kernels_us"] = {"gate_up": round(gu_us, 3), "down_combine": round(dn_us, 3)}
         out["down_kernel_GBs"] = round(dn_bytes / (dn_us * 1e-6) / 1e9, 1)
@@ -403,6 +542,25 @@ def main():
             out["prefill"] = {"value": round(Tp * psteps / dtp, 1), "unit": "tok/s", "tokens": Tp,
                               "ms_per_chunk": round(dtp / psteps * 1e3, 3),
                               "tflops": round(2 * 3 * H * I * k * Tp * L / (dtp / psteps) / 1e12, 1)}
+        # ---------------- whole model: every operator of the decoder stack, greedy decode -------------------------------
+        if not args.no_model and args.workload == "v2lite-int4":
+            try:
+                t0 = time.perf_counter()
+                msteps = max(50, args.steps // 2)
+                mr = ModelDecodeRunner(dev, args.ctx, msteps + 32)
+                log(f"[bench] whole-model skeleton injected and loaded in {time.perf_counter() - t0:.1f}s")
+                dtw = timed(mr.step, msteps, 10, dev, False)
+                out["whole_model"] = {
+                    "value": round(msteps / dtw, 2), "unit": "tok/s", "ms_per_token": round(dtw / msteps * 1e3, 4),
+                    "what": "DeepSeek-V2-Lite 27 layers end to end (embedding, RMSNorm, W4-g64 linears, MLA operator at ctx %d, "
+                            "router, int4 routed + shared experts, lm_head, greedy argmax), one HIP graph per token, random "
+                            "weights" % args.ctx,
+                    "weight_bytes_streamed_per_token": int(mr.linear_bytes() + L * (gu_bytes + dn_bytes)),
+                }
+                del mr
+                torch.cuda.empty_cache()
+            except Exception as e:   # the whole-model run is an extra; never lose the primary line over it
+                out["whole_model"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
 
