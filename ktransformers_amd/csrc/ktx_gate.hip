@@ -42,14 +42,62 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const int32_t* d_bsz, 
 }
 
 // ---- selection ---------------------------------------------------------------------------------------------------------
+// Wave-wide reductions of the selection run on DPP + v_readlane, not on ds_bpermute shuffles: the selection is one
+// wavefront walking a chain of ~60 dependent reductions, and a bpermute costs an LDS round trip (~60 cycles) each.
+template <int CTRL>
+__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
+#define KTX_DPP_QUAD_1032 0xB1
+#define KTX_DPP_QUAD_2301 0x4E
+#define KTX_DPP_ROW_HALF_MIRROR 0x141
+#define KTX_DPP_ROW_MIRROR 0x140
+
+__device__ __forceinline__ float gate_wave_max(float v) {
+  v = fmaxf(v, dpp_f<KTX_DPP_QUAD_1032>(v));
+  v = fmaxf(v, dpp_f<KTX_DPP_QUAD_2301>(v));
+  v = fmaxf(v, dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v));
+  v = fmaxf(v, dpp_f<KTX_DPP_ROW_MIRROR>(v));          // every lane of a 16-lane row holds the row's max
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// fp32 sum over the wave: a fixed tree (pairs, quads, eights, rows, then rows 0..3 left to right)
+__device__ __forceinline__ float gate_wave_sum(float v) {
+  v += dpp_f<KTX_DPP_QUAD_1032>(v);
+  v += dpp_f<KTX_DPP_QUAD_2301>(v);
+  v += dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v);
+  v += dpp_f<KTX_DPP_ROW_MIRROR>(v);
+  const int b = __float_as_int(v);
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return ((r0 + r1) + r2) + r3;
+}
 // (value, index) argmax over the wave; ties -> lower index.  Every lane returns the winner.
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) {
-    const float ov = __shfl_xor(v, o, 64);
-    const int oi = __shfl_xor(i, o, 64);
-    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }
+#define KTX_ARGMAX_STEP(CTRL)                                               \
+  {                                                                         \
+    const float ov = dpp_f<CTRL>(v);                                        \
+    const int oi = dpp_i<CTRL>(i);                                          \
+    if (ov > v || (ov == v && oi < i)) { v = ov; i = oi; }                  \
   }
+  KTX_ARGMAX_STEP(KTX_DPP_QUAD_1032)
+  KTX_ARGMAX_STEP(KTX_DPP_QUAD_2301)
+  KTX_ARGMAX_STEP(KTX_DPP_ROW_HALF_MIRROR)
+  KTX_ARGMAX_STEP(KTX_DPP_ROW_MIRROR)
+#undef KTX_ARGMAX_STEP
+  const int vb = __float_as_int(v);
+  float bv = __int_as_float(__builtin_amdgcn_readlane(vb, 0));
+  int bi = __builtin_amdgcn_readlane(i, 0);
+#pragma unroll
+  for (int r = 1; r < 4; r++) {
+    const float ov = __int_as_float(__builtin_amdgcn_readlane(vb, 16 * r));
+    const int oi = __builtin_amdgcn_readlane(i, 16 * r);
+    if (ov > bv || (ov == bv && oi < bi)) { bv = ov; bi = oi; }
+  }
+  v = bv;
+  i = bi;
 }
 
 template <int EPL>  // scores per lane: expert e lives on lane e % 64, slot e / 64 (E <= 64*EPL)
@@ -64,19 +112,18 @@ __device__ __forceinline__ void gate_select_token(const ktx_gate_config& c, int 
 #pragma unroll
   for (int s = 0; s < EPL; s++) {
     const int e = s * 64 + lane;
-    score[s] = e < E ? logits[(size_t)t * E + e] : NEG;
+    score[s] = e < E ? logits[e] : NEG;   // `logits` = this token's row
     mx = fmaxf(mx, score[s]);
   }
   if (c.scoring == KTX_GATE_SOFTMAX) {
-    mx = wave_max(mx);
+    mx = gate_wave_max(mx);
     float sum = 0.0f;
 #pragma unroll
     for (int s = 0; s < EPL; s++) {
       score[s] = (s * 64 + lane < E) ? expf(score[s] - mx) : 0.0f;
       sum += score[s];
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o, 64);
+    sum = gate_wave_sum(sum);
 #pragma unroll
     for (int s = 0; s < EPL; s++) score[s] = score[s] / sum;
   } else {
@@ -147,7 +194,7 @@ __device__ __forceinline__ void gate_select_token(const ktx_gate_config& c, int 
 #pragma unroll
     for (int s = 0; s < EPL; s++)
       if (s * 64 + lane == bi) { sc = score[s]; choice[s] = NEG; }
-    sc = __shfl(sc, bi & 63, 64);
+    sc = __int_as_float(__builtin_amdgcn_readlane(__float_as_int(sc), bi & 63));
     // V2 (modeling_deepseek.py:426-448) takes the weight straight from the (masked) score it ranked on; V3 gathers
     // the unbiased score of the winner (modeling_deepseek_v3.py:472)
     if (c.topk_method != KTX_GATE_NOAUX_TC) sc = bv;
@@ -175,15 +222,19 @@ __global__ __launch_bounds__(64) void gate_select_kernel(ktx_gate_config c, cons
   if (d_bsz) T = min(max(*d_bsz, 0), qlen);
   const int t = blockIdx.x;
   if (t >= T) return;
-  gate_select_token<EPL>(c, t, threadIdx.x, logits, bias, topk_idx, topk_w);
+  gate_select_token<EPL>(c, t, threadIdx.x, logits + (size_t)t * c.n_routed_experts, bias, topk_idx, topk_w);
 }
 
 // ---- fused router for decode-sized batches: logits GEMV + selection in ONE launch -----------------------------------------
 // Every workgroup computes 4 experts' logits for one token; the last workgroup of a token to finish (arrival ticket on a
-// per-token counter) performs the selection.  Hand-off = the placement-independent recipe of cdna_hip_programming.md §6
-// G16: plain stores -> __syncthreads -> one-lane agent-scope release -> counter; last arriver: one-lane agent-scope
-// acquire -> __syncthreads -> plain loads.  No workgroup ever waits, so residency does not matter.  The counter is reset by
-// the last arriver (zeroed at allocation), keeping the launch graph-replayable without a memset node.
+// per-token counter) performs the selection.  Hand-off WITHOUT fences (MI355X_MICROARCH.md, "handoff-flag": sc1 payload ->
+// s_waitcnt vmcnt(0) -> flag): the logits are written with write-through `sc1` stores (relaxed agent-scope atomic stores),
+// drained, then the ticket is taken; the last arriver reads them back with `sc1` loads, which bypass its L1 — no
+// buffer_wbl2 / buffer_inv (~3.5 us the pair) is needed because neither side keeps the payload in a non-coherent cache.
+// No workgroup ever waits, so residency does not matter.  The counter is reset by the last arriver (zeroed at allocation),
+// keeping the launch graph-replayable without a memset node.  (A single-workgroup router was tried for the 64 x 2048
+// DeepSeek-V2-Lite gate: one CU pulls only ~75 GB/s, 4.6-6.7 us for the 256 KiB, vs 2.4-2.9 us on 16 CUs —
+// scripts/gate_probe.hip.)
 template <int EPL>
 __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, const int32_t* d_bsz, int qlen,
                                                          const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
@@ -191,6 +242,7 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
                                                          int32_t* __restrict__ counters, int64_t* __restrict__ topk_idx,
                                                          float* __restrict__ topk_w) {
   __shared__ int s_last;
+  __shared__ float s_logits[KTX_GATE_MAX_E];
   int T = qlen;
   if (d_bsz) T = min(max(*d_bsz, 0), qlen);
   const int t = blockIdx.y;
@@ -202,35 +254,44 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
     const bf16_t* xr = x + (size_t)t * H;
     const bf16_t* wr = w + (size_t)e * H;
     float acc = 0.0f;
-    for (int j = lane * 8; j < H; j += 512) {
-      const uint4 a = *reinterpret_cast<const uint4*>(xr + j);
-      const uint4 b = *reinterpret_cast<const uint4*>(wr + j);
-      const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
+    for (int j0 = lane * 8; j0 < H; j0 += 512 * 8) {   // 8 column blocks' loads in flight before the first FMA
+      uint4 a[8], b[8];
 #pragma unroll
-      for (int q = 0; q < 4; q++) {
-        acc = fmaf(bf16_to_f32((bf16_t)(av[q] & 0xffffu)), bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
-        acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
+      for (int u = 0; u < 8; u++) {
+        const int j = j0 + u * 512;
+        a[u] = j < H ? *reinterpret_cast<const uint4*>(xr + j) : make_uint4(0, 0, 0, 0);
+        b[u] = j < H ? *reinterpret_cast<const uint4*>(wr + j) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const uint32_t av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          acc = fmaf(bf16_to_f32((bf16_t)(av[q] & 0xffffu)), bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
+          acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
+        }
       }
     }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
-    if (lane == 0) logits[(size_t)t * E + e] = acc;
+    if (lane == 0) __hip_atomic_store(&logits[(size_t)t * E + e], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 store
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (threadIdx.x == 0) {
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     const int ticket = __hip_atomic_fetch_add(&counters[t], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const int last = ticket == (int)gridDim.x - 1;
     if (last) {
       __hip_atomic_store(&counters[t], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     }
     s_last = last;
   }
   __syncthreads();
-  if (s_last && threadIdx.x < 64) gate_select_token<EPL>(c, t, threadIdx.x, logits, bias, topk_idx, topk_w);
+  if (!s_last) return;
+  for (int i = threadIdx.x; i < E; i += 256)   // sc1 loads: served past this CU's L1
+    s_logits[i] = __hip_atomic_load(&logits[(size_t)t * E + i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  __syncthreads();
+  if (threadIdx.x < 64) gate_select_token<EPL>(c, t, threadIdx.x, s_logits, bias, topk_idx, topk_w);
 }
 
 extern "C" int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x,

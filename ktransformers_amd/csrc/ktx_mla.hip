@@ -72,35 +72,51 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584] row-major [ckv | k_pe | pad]
   bf16_t* Pt = Kt + 2 * MLA_TILE * MLA_KROW;                           // [NWV][16][32]
-  int* s_req = reinterpret_cast<int*>(Pt + NWV * 16 * MLA_TILE);       // [4]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, hb = blockIdx.y, qt = blockIdx.z;
   int B = p.batch;
   if (p.d_bsz) B = min(max(*p.d_bsz, 0), p.batch);
 
-  // which request owns query token qt?  (qo_indptr is tiny: linear scan by one lane)
-  if (tid == 0) {
-    int b = -1;
-    for (int i = 0; i < B; i++)
-      if (qt >= p.qo_indptr[i] && qt < p.qo_indptr[i + 1]) { b = i; break; }
-    int kv_end = 0, app = -1;
-    if (b >= 0) {
-      const int qo_len = p.qo_indptr[b + 1] - p.qo_indptr[b];
-      kv_end = p.kv_len[b] - qo_len + (qt - p.qo_indptr[b]) + 1;   // causal: positions < kv_end are visible
-      kv_end = max(kv_end, 0);
-      // fused cache append (decode: one new token per request): the newest position is taken from the append buffers
-      if (p.app_ckv && qo_len == 1) app = p.kv_len[b] - 1;
-    }
-    s_req[0] = b;
-    s_req[1] = kv_end;
-    s_req[2] = b >= 0 ? p.kv_indptr[b] : 0;
-    s_req[3] = app;
-  }
-  __syncthreads();
-  const int req = s_req[0], kv_end = s_req[1], page_base = s_req[2], app_pos = s_req[3];
+  // ---- Q fragments first: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope).  Their
+  // addresses depend on nothing but the block indices, so they are in flight while the request lookup below resolves.
   const int hbw = wave / DSPLIT, ds = wave % DSPLIT;
   const int head0 = (hb * HBW + hbw) * 16;
+  v8bf qf[18];
+  {
+    const int h = head0 + (lane & 15);
+    const bf16_t* qn = p.q_nope + ((size_t)qt * p.Hq + h) * MLA_DC + (lane >> 4) * 8;
+    const bf16_t* qr = p.q_pe + ((size_t)qt * p.Hq + h) * MLA_DR + (lane >> 4) * 8;
+#pragma unroll
+    for (int s = 0; s < 16; s++) qf[s] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
+#pragma unroll
+    for (int s = 0; s < 2; s++) qf[16 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
+  }
+
+  // which request owns query token qt?  Every wavefront resolves it on its own with ONE round of independent loads
+  // (lane i looks at request i), instead of a serial scan by one lane followed by dependent loads and a barrier: after a
+  // kernel boundary every one of those loads is an L2 miss (~1-2 us each).
+  int req = -1, kv_end = 0, page_base = 0, app_pos = -1;
+  for (int b0 = 0; b0 < B && req < 0; b0 += 64) {
+    const int i = b0 + lane;
+    int q0 = 0x7fffffff, q1 = 0, kl = 0, kp = 0;
+    if (i < B) { q0 = p.qo_indptr[i]; q1 = p.qo_indptr[i + 1]; kl = p.kv_len[i]; kp = p.kv_indptr[i]; }
+    const unsigned long long hit = __ballot(qt >= q0 && qt < q1);
+    if (hit) {
+      const int src = __ffsll((long long)hit) - 1;
+      q0 = __shfl(q0, src, 64); q1 = __shfl(q1, src, 64); kl = __shfl(kl, src, 64); kp = __shfl(kp, src, 64);
+      req = b0 + src;
+      const int qo_len = q1 - q0;
+      kv_end = max(kl - qo_len + (qt - q0) + 1, 0);   // causal: positions < kv_end are visible
+      page_base = kp;
+      // fused cache append (decode: one new token per request): the newest position is taken from the append buffers
+      if (p.app_ckv && qo_len == 1) app_pos = kl - 1;
+    }
+  }
+  req = __builtin_amdgcn_readfirstlane(req);
+  kv_end = __builtin_amdgcn_readfirstlane(kv_end);
+  page_base = __builtin_amdgcn_readfirstlane(page_base);
+  app_pos = __builtin_amdgcn_readfirstlane(app_pos);
   const size_t pidx = ((size_t)qt * p.Hq + head0) * p.nsplit + split;  // + head*nsplit per head
   if (req < 0) return;
 
@@ -177,17 +193,6 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     // first tile in flight while the Q fragments arrive
     stage_ckv(t_begin, Kt);
     load_kpe(t_begin);
-    // ---- Q fragments: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope) ----------
-    v8bf qf[18];
-    {
-      const int h = head0 + (lane & 15);
-      const bf16_t* qn = p.q_nope + ((size_t)qt * p.Hq + h) * MLA_DC + (lane >> 4) * 8;
-      const bf16_t* qr = p.q_pe + ((size_t)qt * p.Hq + h) * MLA_DR + (lane >> 4) * 8;
-#pragma unroll
-      for (int s = 0; s < 16; s++) qf[s] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
-#pragma unroll
-      for (int s = 0; s < 2; s++) qf[16 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
-    }
     store_kpe(Kt);
     bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
 
@@ -273,71 +278,75 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
 
 // merge the KV splits: one 256-thread workgroup per (query token, head, quarter of the 512 output dims) — a workgroup
 // pulls cross-XCD data at only ~65 GB/s (MI355X_MICROARCH.md handoff-payload), so the partials of one head are spread
-// over four workgroups.  Every workgroup recomputes the (tiny) softmax statistics split-parallel and parks the weights in
-// LDS; thread (sl, dg) then accumulates splits sl, sl+16, ... for 8 dims with unconditional, independent loads (a dead
-// split's load is redirected to a live one and weighted by 0); the 16 split-lanes meet in LDS.
+// over four workgroups.  Thread (sl, dg) owns splits sl, sl+16, ... for 8 dims.  EVERY global load of the kernel — the
+// (m, l) pairs, the partial outputs, the bounds — is issued before the first use: right after the kernel boundary each of
+// them is an L2 miss, and a stats -> weights -> addresses -> loads chain would pay that latency three times over.  A dead
+// split's partial may be stale memory, so it is selected away (not multiplied by 0).
+template <int NS>   // splits per thread: nsplit <= 16 * NS
 __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p, bf16_t* out, float* lse) {
   __shared__ float s_w[1024];
   __shared__ float s_red[8];
-  __shared__ int s_live;
   __shared__ float s_acc[16][128 + 4];
   const int qt = blockIdx.y, h = blockIdx.x, quarter = blockIdx.z, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int B = p.batch;
-  if (p.d_bsz) B = min(max(*p.d_bsz, 0), p.batch);
-  if (qt >= p.qo_indptr[B]) return;
+  const int dg = tid & 15, sl = tid >> 4;   // 16 dim groups of 8 dims x 16 split lanes
   const size_t base = ((size_t)qt * p.Hq + h) * p.nsplit;
-  if (tid == 0) s_live = 0x7fffffff;
-  __syncthreads();
-  float mstar = -__builtin_inff();
-  int live = 0x7fffffff;
-  for (int s = tid; s < p.nsplit; s += 256) {
-    const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + (base + s) * 2);
-    if (ml.y > 0.f) { mstar = fmaxf(mstar, ml.x); live = min(live, s); }
+  // ---- all loads
+  int B = p.batch;
+  const int bsz_raw = p.d_bsz ? *p.d_bsz : p.batch;
+  float2 ml[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int s = tid + i * 256;
+    ml[i] = s < p.nsplit ? *reinterpret_cast<const float2*>(p.part_ml + (base + s) * 2) : make_float2(0.f, 0.f);
   }
+  float4 va[NS], vb[NS];
+  const float* po = p.part_o + base * MLA_DC + quarter * 128 + dg * 8;
+#pragma unroll
+  for (int u = 0; u < NS; u++) {
+    const int s = min(sl + 16 * u, p.nsplit - 1);
+    va[u] = *reinterpret_cast<const float4*>(po + (size_t)s * MLA_DC);
+    vb[u] = *reinterpret_cast<const float4*>(po + (size_t)s * MLA_DC + 4);
+  }
+  if (p.d_bsz) B = min(max(bsz_raw, 0), p.batch);
+  const int q_total = p.qo_indptr[B];
+
+  // ---- softmax statistics, split-parallel; weights parked in LDS
+  float mstar = -__builtin_inff();
+#pragma unroll
+  for (int i = 0; i < 4; i++)
+    if (ml[i].y > 0.f) mstar = fmaxf(mstar, ml[i].x);
   mstar = wave_max(mstar);
   if (lane == 0) s_red[wave] = mstar;
-  if (live != 0x7fffffff) atomicMin(&s_live, live);
   __syncthreads();
   mstar = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
   float lsum = 0.f;
-  for (int s = tid; s < p.nsplit; s += 256) {
-    const float2 ml = *reinterpret_cast<const float2*>(p.part_ml + (base + s) * 2);
-    const float w = ml.y > 0.f ? __expf(ml.x - mstar) : 0.f;
-    s_w[s] = w;
-    lsum += ml.y * w;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int s = tid + i * 256;
+    const float w = ml[i].y > 0.f ? __expf(ml[i].x - mstar) : 0.f;
+    if (s < p.nsplit) s_w[s] = w;
+    lsum += ml[i].y * w;
   }
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
   if (lane == 0) s_red[4 + wave] = lsum;
   __syncthreads();
   lsum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
-  const int live0 = s_live;
-  const int dg = tid & 15, sl = tid >> 4;   // 16 dim groups of 8 dims x 16 split lanes
+
   float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-  if (live0 != 0x7fffffff) {
-    const float* po = p.part_o + base * MLA_DC + quarter * 128 + dg * 8;
-    for (int s0 = sl; s0 < p.nsplit; s0 += 64) {
-      float wv[4];
-      float4 va[4], vb[4];
 #pragma unroll
-      for (int u = 0; u < 4; u++) {
-        const int s = s0 + 16 * u;
-        wv[u] = s < p.nsplit ? s_w[s] : 0.f;
-        const int ss = wv[u] > 0.f ? s : live0;
-        va[u] = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC);
-        vb[u] = *reinterpret_cast<const float4*>(po + (size_t)ss * MLA_DC + 4);
-      }
-#pragma unroll
-      for (int u = 0; u < 4; u++) {
-        acc[0] += va[u].x * wv[u]; acc[1] += va[u].y * wv[u]; acc[2] += va[u].z * wv[u]; acc[3] += va[u].w * wv[u];
-        acc[4] += vb[u].x * wv[u]; acc[5] += vb[u].y * wv[u]; acc[6] += vb[u].z * wv[u]; acc[7] += vb[u].w * wv[u];
-      }
+  for (int u = 0; u < NS; u++) {
+    const int s = sl + 16 * u;
+    const float w = s < p.nsplit ? s_w[s] : 0.f;
+    if (w > 0.f) {
+      acc[0] += va[u].x * w; acc[1] += va[u].y * w; acc[2] += va[u].z * w; acc[3] += va[u].w * w;
+      acc[4] += vb[u].x * w; acc[5] += vb[u].y * w; acc[6] += vb[u].z * w; acc[7] += vb[u].w * w;
     }
   }
 #pragma unroll
   for (int q = 0; q < 8; q++) s_acc[sl][dg * 8 + q] = acc[q];
   __syncthreads();
-  if (tid < 64) {   // 128 dims: two per thread
+  if (tid < 64 && qt < q_total) {   // 128 dims: two per thread
     const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
     float v0 = 0.f, v1 = 0.f;
 #pragma unroll
@@ -433,7 +442,15 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
     hipLaunchKernelGGL((mla_decode_kernel<1, 4>), grid, dim3(256), lds, st, p);
   }
   KTX_HIP(hipGetLastError());
-  hipLaunchKernelGGL(mla_merge_kernel, dim3(Hq, total_q_tokens, 4), dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+  {
+    const dim3 mg(Hq, total_q_tokens, 4);
+    if (p.nsplit <= 32) hipLaunchKernelGGL(mla_merge_kernel<2>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+    else if (p.nsplit <= 64) hipLaunchKernelGGL(mla_merge_kernel<4>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+    else if (p.nsplit <= 144) hipLaunchKernelGGL(mla_merge_kernel<9>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+    else if (p.nsplit <= 256) hipLaunchKernelGGL(mla_merge_kernel<16>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+    else if (p.nsplit <= 512) hipLaunchKernelGGL(mla_merge_kernel<32>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+    else hipLaunchKernelGGL(mla_merge_kernel<64>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+  }
   KTX_HIP(hipGetLastError());
   return 0;
 }

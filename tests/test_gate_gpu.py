@@ -44,3 +44,35 @@ def test_router_matches_reference_math(name, T):
         ref = dict(zip(ridx[t].tolist(), rw[t].tolist()))
         for e, v in zip(idx[t].tolist(), wt[t].tolist()):
             assert abs(v - ref[e]) <= 2e-6 * max(abs(ref[e]), 1e-6) + 1e-9, (t, e, v, ref[e])
+
+
+def test_fused_router_handoff_is_never_stale_under_load():
+    """The fused router hands the logits from 16+ workgroups to the last arriver with sc1 stores/loads and no fences:
+    hammer it (changing inputs every launch, a bandwidth hog on another stream) and require every launch to equal the
+    two-kernel logits + select path exactly."""
+    import ctypes as C
+    from ktransformers_amd import _native as n
+    torch.manual_seed(0)
+    for (E, H, k, ng, tg, sc, tm) in ((64, 2048, 6, 1, 1, "softmax", "greedy"), (256, 7168, 8, 8, 4, "sigmoid", "noaux_tc")):
+        g = n.GateHandle(E, H, k, ng, tg, sc, tm, True, 2.5)
+        w = (torch.randn(E, H, device="cuda") * H ** -0.5).to(torch.bfloat16)
+        bias = (torch.randn(E, device="cuda") * 0.1) if tm == "noaux_tc" else None
+        hog = torch.empty(64 << 20, dtype=torch.float32, device="cuda")
+        side = torch.cuda.Stream()
+        xs = (torch.randn(300, 3, H, device="cuda") / 10).to(torch.bfloat16)
+        outs = []
+        for i in range(300):
+            if i % 10 == 0:
+                with torch.cuda.stream(side):
+                    hog.add_(1.0)
+            outs.append(g.forward(xs[i], w, bias))
+        torch.cuda.synchronize()
+        for i in range(300):
+            logits = torch.empty((3, E), dtype=torch.float32, device="cuda")
+            n.check(n.lib.ktx_gate_logits(C.byref(g.cfg), None, 3, xs[i].data_ptr(), w.data_ptr(), logits.data_ptr(),
+                                          torch.cuda.current_stream().cuda_stream))
+            idx = torch.empty((3, k), dtype=torch.int64, device="cuda")
+            wt = torch.empty((3, k), dtype=torch.float32, device="cuda")
+            n.check(n.lib.ktx_gate_select(C.byref(g.cfg), None, 3, logits.data_ptr(), bias.data_ptr() if bias is not None else None,
+                                          idx.data_ptr(), wt.data_ptr(), torch.cuda.current_stream().cuda_stream))
+            assert torch.equal(outs[i][0], idx) and torch.equal(outs[i][1], wt), f"launch {i} differs"
