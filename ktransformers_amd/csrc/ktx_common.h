@@ -52,10 +52,44 @@ __device__ __forceinline__ int quant_rne_sat8(float v) {
   return (int)r;
 }
 
+// ---- wave-wide reductions on DPP + v_readlane ------------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute (an LDS crossbar round trip, ~60 cycles); in the latency-bound decode kernels a single
+// wavefront walks chains of such reductions, so they are done with DPP row operations (quad_perm, row_half_mirror,
+// row_mirror: all-reduce inside each 16-lane row) and four v_readlane for the rows.
+template <int CTRL>
+__device__ __forceinline__ int ktx_dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
+template <int CTRL>
+__device__ __forceinline__ float ktx_dpp_f(float v) { return __int_as_float(ktx_dpp_i<CTRL>(__float_as_int(v))); }
+#define KTX_DPP_QUAD_1032 0xB1
+#define KTX_DPP_QUAD_2301 0x4E
+#define KTX_DPP_ROW_HALF_MIRROR 0x141
+#define KTX_DPP_ROW_MIRROR 0x140
+
+// all-reduce inside each row of 16 lanes (the MFMA column group): every lane gets its row's result
+__device__ __forceinline__ float row16_max(float v) {
+  v = fmaxf(v, ktx_dpp_f<KTX_DPP_QUAD_1032>(v));
+  v = fmaxf(v, ktx_dpp_f<KTX_DPP_QUAD_2301>(v));
+  v = fmaxf(v, ktx_dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v));
+  return fmaxf(v, ktx_dpp_f<KTX_DPP_ROW_MIRROR>(v));
+}
+__device__ __forceinline__ float row16_sum(float v) {
+  v += ktx_dpp_f<KTX_DPP_QUAD_1032>(v);
+  v += ktx_dpp_f<KTX_DPP_QUAD_2301>(v);
+  v += ktx_dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v);
+  return v + ktx_dpp_f<KTX_DPP_ROW_MIRROR>(v);
+}
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
-  return v;
+  const int b = __float_as_int(row16_max(v));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
+}
+// fixed summation tree: pairs, quads, eights, rows, then rows 0..3 left to right
+__device__ __forceinline__ float wave_sum(float v) {
+  const int b = __float_as_int(row16_sum(v));
+  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
+  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
+  return ((r0 + r1) + r2) + r3;
 }
 
 #endif

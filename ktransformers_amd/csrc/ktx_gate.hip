@@ -42,38 +42,11 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const int32_t* d_bsz, 
 }
 
 // ---- selection ---------------------------------------------------------------------------------------------------------
-// Wave-wide reductions of the selection run on DPP + v_readlane, not on ds_bpermute shuffles: the selection is one
-// wavefront walking a chain of ~60 dependent reductions, and a bpermute costs an LDS round trip (~60 cycles) each.
-template <int CTRL>
-__device__ __forceinline__ int dpp_i(int v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, false); }
-template <int CTRL>
-__device__ __forceinline__ float dpp_f(float v) { return __int_as_float(dpp_i<CTRL>(__float_as_int(v))); }
-#define KTX_DPP_QUAD_1032 0xB1
-#define KTX_DPP_QUAD_2301 0x4E
-#define KTX_DPP_ROW_HALF_MIRROR 0x141
-#define KTX_DPP_ROW_MIRROR 0x140
-
-__device__ __forceinline__ float gate_wave_max(float v) {
-  v = fmaxf(v, dpp_f<KTX_DPP_QUAD_1032>(v));
-  v = fmaxf(v, dpp_f<KTX_DPP_QUAD_2301>(v));
-  v = fmaxf(v, dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v));
-  v = fmaxf(v, dpp_f<KTX_DPP_ROW_MIRROR>(v));          // every lane of a 16-lane row holds the row's max
-  const int b = __float_as_int(v);
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
-  return fmaxf(fmaxf(r0, r1), fmaxf(r2, r3));
-}
-// fp32 sum over the wave: a fixed tree (pairs, quads, eights, rows, then rows 0..3 left to right)
-__device__ __forceinline__ float gate_wave_sum(float v) {
-  v += dpp_f<KTX_DPP_QUAD_1032>(v);
-  v += dpp_f<KTX_DPP_QUAD_2301>(v);
-  v += dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v);
-  v += dpp_f<KTX_DPP_ROW_MIRROR>(v);
-  const int b = __float_as_int(v);
-  const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));
-  const float r2 = __int_as_float(__builtin_amdgcn_readlane(b, 32)), r3 = __int_as_float(__builtin_amdgcn_readlane(b, 48));
-  return ((r0 + r1) + r2) + r3;
-}
+// Wave-wide reductions of the selection run on DPP + v_readlane (ktx_common.h), not on ds_bpermute shuffles.
+#define dpp_i ktx_dpp_i
+#define dpp_f ktx_dpp_f
+#define gate_wave_max wave_max
+#define gate_wave_sum wave_sum
 // (value, index) argmax over the wave; ties -> lower index.  Every lane returns the winner.
 __device__ __forceinline__ void wave_argmax(float& v, int& i) {
 #define KTX_ARGMAX_STEP(CTRL)                                               \

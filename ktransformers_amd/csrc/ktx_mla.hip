@@ -104,7 +104,8 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     const unsigned long long hit = __ballot(qt >= q0 && qt < q1);
     if (hit) {
       const int src = __ffsll((long long)hit) - 1;
-      q0 = __shfl(q0, src, 64); q1 = __shfl(q1, src, 64); kl = __shfl(kl, src, 64); kp = __shfl(kp, src, 64);
+      q0 = __builtin_amdgcn_readlane(q0, src); q1 = __builtin_amdgcn_readlane(q1, src);
+      kl = __builtin_amdgcn_readlane(kl, src); kp = __builtin_amdgcn_readlane(kp, src);
       req = b0 + src;
       const int qo_len = q1 - q0;
       kv_end = max(kl - qo_len + (qt - q0) + 1, 0);   // causal: positions < kv_end are visible
@@ -226,14 +227,10 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       for (int r = 0; r < 4; r++) {
         const float a = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
         const float b = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
-        float mx = fmaxf(a, b);
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+        const float mx = row16_max(fmaxf(a, b));
         const float m_new = fmaxf(m_run[r], mx);        // finite: every processed tile has >= 1 visible token
         const float pa = __expf(a - m_new), pb = __expf(b - m_new);
-        float sum = pa + pb;
-#pragma unroll
-        for (int off = 8; off > 0; off >>= 1) sum += __shfl_xor(sum, off, 64);
+        const float sum = row16_sum(pa + pb);
         alpha[r] = __expf(m_run[r] - m_new);
         l_run[r] = l_run[r] * alpha[r] + sum;
         m_run[r] = m_new;
@@ -327,8 +324,7 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p, bf16_t* out
     if (s < p.nsplit) s_w[s] = w;
     lsum += ml[i].y * w;
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) lsum += __shfl_xor(lsum, o, 64);
+  lsum = wave_sum(lsum);
   if (lane == 0) s_red[4 + wave] = lsum;
   __syncthreads();
   lsum = (s_red[4] + s_red[5]) + (s_red[6] + s_red[7]);
