@@ -73,6 +73,26 @@ int ktx_linear_load_fp8(ktx_linear_t h, const void* d_w, const float* d_scale_in
  * Mirrors KLinear*.forward(x, bsz_tensor) (linear.py:174,409,679). */
 int ktx_linear_forward(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y, ktx_stream_t stream);
 
+/* Fusions around one linear of the decoder layer (all optional, NULL = off):
+ *   norm_weight/norm_eps : RMSNorm of the input row inside the kernel (input_layernorm / post_attention_layernorm in front
+ *                          of the projections, modeling_deepseek_v3.py:1207,1222) — only where the decode kernel runs
+ *                          (ktx_linear_decode_eligible(h, T) != 0, i.e. T <= 4); otherwise call ktx_rmsnorm first.
+ *   add1, add2           : bf16 [T][out_features] tensors (row strides add*_ld, 0 = out_features) added to the result in
+ *                          this order with torch's bf16 rounding: y = bf16(add2 + bf16(add1 + linear(x))) — the residual
+ *                          adds and the routed + shared sum (modeling_deepseek_v3.py:1219,1225,529). */
+typedef struct ktx_linear_fusion {
+  const void* norm_weight;
+  float norm_eps;
+  const void* add1;
+  int64_t add1_ld;
+  const void* add2;
+  int64_t add2_ld;
+  int64_t x_ld, y_ld; /* row strides of x / y in elements (multiples of 8); 0 = in_features / out_features */
+} ktx_linear_fusion;
+int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
+                             const ktx_linear_fusion* fusion, ktx_stream_t stream);
+int ktx_linear_decode_eligible(ktx_linear_t h, int T);
+
 /* Batched form for the per-head absorb products of MLA (torch.matmul(q_nope, q_absorb) / matmul(attn, out_absorb.mT),
  * archive/ktransformers/operators/attention.py:414-418,465-468): batch b uses weight matrix b ([batch][N][K] at load)
  * and reads x[t*ldx + b*x_batch_stride + k], writes y[t*ldy + b*y_batch_stride + n] (strides in elements). */

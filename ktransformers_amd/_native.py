@@ -38,6 +38,11 @@ class _LinearConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in ("in_features", "out_features", "format", "group_size", "max_len", "device", "batch")]
 
 
+class _LinearFusion(C.Structure):
+    _fields_ = [("norm_weight", C.c_void_p), ("norm_eps", C.c_float), ("add1", C.c_void_p), ("add1_ld", C.c_int64),
+                ("add2", C.c_void_p), ("add2_ld", C.c_int64), ("x_ld", C.c_int64), ("y_ld", C.c_int64)]
+
+
 class _MoeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
@@ -86,6 +91,9 @@ def _load() -> C.CDLL:
     lib.ktx_linear_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_linear_forward_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                C.c_int64, C.c_int64, C.c_void_p]
+    lib.ktx_linear_forward_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
+                                             C.c_void_p]
+    lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
     lib.ktx_linear_weight_bytes.argtypes = [C.c_void_p]
     lib.ktx_linear_weight_bytes.restype = C.c_size_t
     lib.ktx_linear_debug_get_w4.argtypes = [C.c_void_p] * 3
@@ -383,13 +391,21 @@ class LinearHandle:
         check(lib.ktx_linear_debug_get_w4(self._h, q.ctypes.data, s.ctypes.data))
         return q, s
 
-    def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor | None = None, out: torch.Tensor | None = None) -> torch.Tensor:
-        """x: bf16 [..., in] -> bf16 [..., out] on the current stream."""
+    def decode_eligible(self, T: int) -> bool:
+        return bool(lib.ktx_linear_decode_eligible(self._h, int(T)))
+
+    def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor | None = None, out: torch.Tensor | None = None,
+                norm: tuple | None = None, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None) -> torch.Tensor:
+        """x: bf16 [..., in] -> bf16 [..., out] on the current stream.  Optional fusions (include/ktx_linear.h,
+        ktx_linear_fusion): norm = (weight bf16 [in], eps) applies RMSNorm to x inside the kernel (falls back to a separate
+        ktx_rmsnorm launch where the decode kernel does not run); add1 / add2 = bf16 [..., out] tensors added in that order."""
         if x.dtype != torch.bfloat16 or x.shape[-1] != self.K or x.device != self.device:
             raise KtxError(f"forward: expected bf16 [..., {self.K}] on {self.device}, got {x.dtype} {tuple(x.shape)} on {x.device}")
-        x2 = x.reshape(-1, self.K)
-        if not x2.is_contiguous():
+        x2 = x if x.dim() == 2 else x.reshape(-1, self.K)
+        strided = x2.dim() == 2 and x2.stride(1) == 1 and x2.stride(0) % 8 == 0 and x2.stride(0) != self.K
+        if not x2.is_contiguous() and not strided:
             x2 = x2.contiguous()
+            strided = False
         T = x2.shape[0]
         if out is None:
             out = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
@@ -399,9 +415,29 @@ class LinearHandle:
             if bsz_tensor.dtype != torch.int32 or bsz_tensor.device != self.device:
                 raise KtxError("forward: bsz_tensor must be int32 on the handle's device")
             bsz = bsz_tensor.data_ptr()
-        check(lib.ktx_linear_forward(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+        if norm is None and add1 is None and add2 is None and not strided:
+            check(lib.ktx_linear_forward(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+            return out.reshape(*x.shape[:-1], self.N)
+        fu = _LinearFusion(None, 0.0, None, 0, None, 0, x2.stride(0) if strided else 0, 0)
+        keep = []
+        if norm is not None:
+            nw, eps = norm
+            if self.decode_eligible(T):
+                fu.norm_weight, fu.norm_eps = nw.data_ptr(), float(eps)
+            else:
+                x2 = rmsnorm(x2, nw, eps, native_rounding=True)
+                fu.x_ld = 0
+            keep.append(nw)
+        for name, a in (("add1", add1), ("add2", add2)):
+            if a is not None:
+                a2 = a.reshape(-1, self.N)
+                if a2.dtype != torch.bfloat16 or a2.shape[0] != T or a2.stride(1) != 1 or a2.device != self.device:
+                    raise KtxError(f"forward: {name} must be bf16 [{T}, {self.N}] on {self.device}")
+                setattr(fu, name, a2.data_ptr())
+                setattr(fu, name + "_ld", a2.stride(0))
+                keep.append(a2)
+        check(lib.ktx_linear_forward_fused(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), C.byref(fu), _stream_ptr(self.device)))
         return out.reshape(*x.shape[:-1], self.N)
-
 
     def forward_batched(self, x: torch.Tensor, out: torch.Tensor | None = None, bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
         """x: bf16 [T, batch, in] (any row / batch strides that are multiples of 8, unit stride along `in`) ->

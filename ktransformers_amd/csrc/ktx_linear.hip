@@ -97,6 +97,12 @@ struct LinParams {
   long ldx, ldy;        // row strides of x / y in elements
   long xbs, ybs;        // batched (per-head) linears: element offsets of batch b inside a row of x / y
   size_t wbs, scbs;     // bytes of one batch's tiles / scales
+  // fusions (ktx_linear_forward_fused): RMSNorm of the input row in the prologue (decode kernel only), up to two
+  // residual-style addends in the epilogue
+  const bf16_t* norm_w;
+  float norm_eps;
+  const bf16_t *add1, *add2;
+  long ld1, ld2;
 };
 
 // batch b of a batched linear: shift the base pointers once
@@ -179,6 +185,26 @@ __device__ __forceinline__ bf16_t lin_out(float v, const bf16_t* bias, int n) {
   if (bias) o = f32_to_bf16(bf16_to_f32(o) + bf16_to_f32(bias[n]));   // x = gemm(...); x = x + bias (linear.py:709)
   return o;
 }
+// bf16 tensor adds that follow the linear in the decoder layer (residual + attn_out; routed + shared; residual + mlp_out:
+// modeling_deepseek_v3.py:1219,1225, :529), each with torch's bf16 rounding, folded into the epilogue
+__device__ __forceinline__ bf16_t lin_addends(bf16_t o, const LinParams& p, int row, int n) {
+  if (p.add1) o = f32_to_bf16(bf16_to_f32(p.add1[(size_t)row * p.ld1 + n]) + bf16_to_f32(o));
+  if (p.add2) o = f32_to_bf16(bf16_to_f32(p.add2[(size_t)row * p.ld2 + n]) + bf16_to_f32(o));
+  return o;
+}
+// 8 bf16 of an input row -> RMSNorm'ed (DeepseekV3RMSNorm.forward: w * bf16(x * r), both roundings)
+__device__ __forceinline__ uint4 lin_norm8(const uint4& v, float r, const bf16_t* __restrict__ w8) {
+  const uint4 wv = *reinterpret_cast<const uint4*>(w8);
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w}, wd[4] = {wv.x, wv.y, wv.z, wv.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = bf16_to_f32(f32_to_bf16(__uint_as_float(d[i] << 16) * r)) * __uint_as_float(wd[i] << 16);
+    const float b = bf16_to_f32(f32_to_bf16(__uint_as_float(d[i] & 0xffff0000u) * r)) * __uint_as_float(wd[i] & 0xffff0000u);
+    o[i] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
+  }
+  return make_uint4(o[0], o[1], o[2], o[3]);
+}
 
 // =====================================================================================================
 // Decode kernel: T <= 4 token slots, the whole activation row block lives in LDS, a wavefront streams one strip over
@@ -226,10 +252,46 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
 
   // ---- stage the activations (every workgroup its own copy), group sums / fp8 quantisation on the way
   const int npiece = NKS * 16;   // 8-element pieces per token
+  float rnorm[4] = {1.f, 1.f, 1.f, 1.f};
+  if (p.norm_w) {   // fused input RMSNorm: first the inverse RMS of every token row (rows are re-read below from L1/L2)
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int idx = tid; idx < TP * npiece; idx += 512) {
+      const int tok = idx / npiece, col = idx - tok * npiece;
+      if (tok < bsz && col * 8 < p.Kx) {
+        const uint4 v = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
+        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+        float q = 0.f;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float a = __uint_as_float(d[i] << 16), b = __uint_as_float(d[i] & 0xffff0000u);
+          q += a * a + b * b;
+        }
+#pragma unroll
+        for (int t4 = 0; t4 < 4; t4++) ss[t4] += tok == t4 ? q : 0.f;
+      }
+    }
+    float* nred = red;   // [8 waves][4], free until the epilogue
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) {
+      const float w = wave_sum(ss[t4]);
+      if (lane == 0) nred[wave * 4 + t4] = w;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) {
+      float tot = 0.f;
+      for (int w = 0; w < 8; w++) tot += nred[w * 4 + t4];
+      rnorm[t4] = 1.0f / sqrtf(tot / (float)p.Kx + p.norm_eps);
+    }
+    __syncthreads();
+  }
   for (int idx = tid; idx < TP * npiece; idx += 512) {
     const int tok = idx / npiece, col = idx - tok * npiece;
     uint4 v = make_uint4(0, 0, 0, 0);
-    if (tok < bsz && col * 8 < p.Kx) v = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
+    if (tok < bsz && col * 8 < p.Kx) {
+      v = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
+      if (p.norm_w) v = lin_norm8(v, tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3], p.norm_w + col * 8);
+    }
     if constexpr (FMT == F_FP8) {
       float am = amax8_bf16(v);
 #pragma unroll
@@ -280,7 +342,7 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
       const int nsl = 8 / p.SW;
       float v = 0.f;
       for (int s = 0; s < nsl; s++) v += red[((s * p.SW + swo) * 4 + r) * 16 + f];
-      p.y[(size_t)r * p.ldy + n] = lin_out(v, p.bias, n);
+      p.y[(size_t)r * p.ldy + n] = lin_addends(lin_out(v, p.bias, n), p, r, n);
     }
   }
 }
@@ -419,7 +481,7 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(LinParams p) {
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = row0 + t * 16 + (lane >> 4) * 4 + r;
-      if (row < bsz) p.y[(size_t)row * p.ldy + n] = lin_out(acc[t][r], p.bias, n);
+      if (row < bsz) p.y[(size_t)row * p.ldy + n] = lin_addends(lin_out(acc[t][r], p.bias, n), p, row, n);
     }
 }
 
@@ -612,12 +674,11 @@ int launch_gemm(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
 
 bool g_lin_force_gemm = false;
 
+bool dec_fits(const ktx_linear_s* h, int T);
+
 template <int FMT, int G>
 int forward_fmt(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
-  const int ncol16 = FMT == F_FP8 ? h->NKS * 8 : h->NKS * 16;
-  const int TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
-  const size_t dec_smem = (size_t)ncol16 * TP * 16 + (size_t)h->NKS * Fmt<FMT, G>::GPK * 16 + 2048;
-  if (p.T <= 4 && dec_smem <= 160 * 1024 && !g_lin_force_gemm) return launch_dec<FMT, G>(h, p, st);
+  if (dec_fits(h, p.T)) return launch_dec<FMT, G>(h, p, st);
   if (p.T <= 16) return launch_gemm<FMT, G, 1>(h, p, st);
   if (p.T <= 32) return launch_gemm<FMT, G, 2>(h, p, st);
   return launch_gemm<FMT, G, 4>(h, p, st);
@@ -738,8 +799,20 @@ extern "C" int ktx_linear_load_fp8(ktx_linear_t h, const void* d_w, const float*
   return 0;
 }
 
+namespace { bool dec_fits(const ktx_linear_s* h, int T); }
+static bool dec_eligible(const ktx_linear_s* h, int T) { return dec_fits(h, T); }
+namespace {
+bool dec_fits(const ktx_linear_s* h, int T) {
+  const int ncol16 = h->cfg.format == KTX_LIN_FP8 ? h->NKS * 8 : h->NKS * 16;
+  const int TP = T <= 1 ? 1 : T <= 2 ? 2 : 4;
+  const int gpk = h->cfg.format == KTX_LIN_W4 ? 128 / h->cfg.group_size : 1;
+  const size_t dec_smem = (size_t)ncol16 * TP * 16 + (size_t)h->NKS * gpk * 16 + 2048;
+  return T <= 4 && dec_smem <= 160 * 1024 && !g_lin_force_gemm;
+}
+}  // namespace
+
 static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, long ldx, long xbs, void* d_y,
-                               long ldy, long ybs, ktx_stream_t stream) {
+                               long ldy, long ybs, ktx_stream_t stream, const ktx_linear_fusion* fu = nullptr) {
   KTX_REQUIRE(h && d_x && d_y, "ktx_linear_forward: null argument");
   KTX_REQUIRE(h->loaded, "ktx_linear_forward: weights not loaded");
   KTX_REQUIRE(T >= 0 && T <= h->cfg.max_len, "ktx_linear_forward: T exceeds max_len");
@@ -751,6 +824,14 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   p.T = T; p.N = h->cfg.out_features; p.Kx = h->cfg.in_features; p.NKS = h->NKS; p.nstrips = h->nstrips;
   p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
   p.wbs = h->w_bytes / h->batch; p.scbs = h->sc_bytes / h->batch;
+  if (fu) {
+    KTX_REQUIRE(h->batch == 1, "ktx_linear_forward_fused: not for batched handles");
+    KTX_REQUIRE(!fu->norm_weight || dec_eligible(h, T),
+                "ktx_linear_forward_fused: the RMSNorm prologue exists in the decode kernel only (T <= 4); run ktx_rmsnorm first");
+    p.norm_w = (const bf16_t*)fu->norm_weight; p.norm_eps = fu->norm_eps;
+    p.add1 = (const bf16_t*)fu->add1; p.ld1 = fu->add1_ld ? fu->add1_ld : h->cfg.out_features;
+    p.add2 = (const bf16_t*)fu->add2; p.ld2 = fu->add2_ld ? fu->add2_ld : h->cfg.out_features;
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (h->cfg.format) {
     case KTX_LIN_BF16: return forward_fmt<F_BF16, 128>(h, p, st);
@@ -769,6 +850,16 @@ extern "C" int ktx_linear_forward(ktx_linear_t h, const int32_t* d_bsz, int T, c
   KTX_REQUIRE(h->batch == 1, "ktx_linear_forward: batched handle (use ktx_linear_forward_batched)");
   return linear_forward_impl(h, d_bsz, T, d_x, h->cfg.in_features, 0, d_y, h->cfg.out_features, 0, stream);
 }
+
+extern "C" int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
+                                        const ktx_linear_fusion* fusion, ktx_stream_t stream) {
+  KTX_REQUIRE(h, "ktx_linear_forward_fused: null handle");
+  const long ldx = fusion && fusion->x_ld ? (long)fusion->x_ld : (long)h->cfg.in_features;
+  const long ldy = fusion && fusion->y_ld ? (long)fusion->y_ld : (long)h->cfg.out_features;
+  return linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion);
+}
+
+extern "C" int ktx_linear_decode_eligible(ktx_linear_t h, int T) { return h && dec_eligible(h, T) ? 1 : 0; }
 
 extern "C" int ktx_linear_forward_batched(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, int64_t ldx,
                                           int64_t x_batch_stride, void* d_y, int64_t ldy, int64_t y_batch_stride,

@@ -122,15 +122,25 @@ class DeepseekDecoderLayer(nn.Module):
         self.post_attention_layernorm = DeepseekRMSNorm(config.hidden_size, config.rms_norm_eps)
 
     def forward(self, hidden_states, position_ids=None, past_key_value=None, cache_position=None, **kwargs):
-        residual = hidden_states
-        hidden_states = self.input_layernorm(hidden_states)
-        hidden_states, _, past_key_value = self.self_attn(hidden_states, position_ids=position_ids,
-                                                          past_key_value=past_key_value, cache_position=cache_position)
-        hidden_states = residual + hidden_states
+        """DeepseekV3DecoderLayer.forward (modeling_deepseek_v3.py:1188-1262).  When the injected operators expose the
+        fusion hooks, input_layernorm runs inside the attention's first GEMV and both residual adds inside the epilogues
+        of o_proj / the MLP's down_proj (same roundings, fewer launches); otherwise the plain sequence."""
+        attn, mlp = self.self_attn, self.mlp
+        if getattr(type(attn), "SUPPORTS_FUSION", False):
+            hidden_states, _, past_key_value = attn(hidden_states, position_ids=position_ids, past_key_value=past_key_value,
+                                                    cache_position=cache_position, pre_norm=self.input_layernorm,
+                                                    residual=hidden_states)
+        else:
+            residual = hidden_states
+            hidden_states = self.input_layernorm(hidden_states)
+            hidden_states, _, past_key_value = attn(hidden_states, position_ids=position_ids,
+                                                    past_key_value=past_key_value, cache_position=cache_position)
+            hidden_states = residual + hidden_states
         residual = hidden_states
         hidden_states = self.post_attention_layernorm(hidden_states)
-        hidden_states = self.mlp(hidden_states)
-        return residual + hidden_states
+        if getattr(type(mlp), "SUPPORTS_FUSION", False):
+            return mlp(hidden_states, **{type(mlp).RESIDUAL_KW: residual})
+        return residual + mlp(hidden_states)
 
 
 class DeepseekModel(nn.Module):

@@ -27,12 +27,14 @@ from ktransformers_amd.operators.RoPE import yarn_get_mscale
 
 
 class KDeepseekV2Attention(BaseInjectedModule):
+    SUPPORTS_FUSION = True     # forward(..., pre_norm=, residual=)
+
     def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, prefill_device: str = "cuda",
                  generate_device: str = "cuda", chunck_size: int = 1000, absorb_for_prefill: bool = False, **kwargs):
         BaseInjectedModule.__init__(self, key, gguf_loader, config, orig_module, prefill_device, generate_device, **kwargs)
         c = config
         for name, val in (("chunck_size", chunck_size), ("absorb_for_prefill", absorb_for_prefill), ("mla_wrapper", None),
-                          ("_absorb", None), ("_decode_plan", None)):
+                          ("_absorb", None), ("_decode_plan", None), ("_qkv", None)):
             object.__setattr__(self, name, val)
         for name in ("num_heads", "q_lora_rank", "qk_rope_head_dim", "kv_lora_rank", "v_head_dim", "qk_nope_head_dim",
                      "q_head_dim", "layer_idx"):
@@ -48,6 +50,26 @@ class KDeepseekV2Attention(BaseInjectedModule):
                 m = yarn_get_mscale(rs["factor"], rs["mscale_all_dim"])
                 scale = scale * m * m
             orig_module.softmax_scale = scale
+
+    def load(self):
+        """Children load themselves; then the two projections that read the layer input (q_proj | q_a_proj and
+        kv_a_proj_with_mqa) are re-loaded as ONE row-concatenated quantised linear: same rows, one GEMV launch."""
+        BaseInjectedModule.load(self)
+        from ktransformers_amd.operators.linear import KTransformersLinear, build_merged_linear
+
+        first = "q_proj" if self.q_lora_rank is None else "q_a_proj"
+        a, b = getattr(self.orig_module, first), self.orig_module.kv_a_proj_with_mqa
+        if (isinstance(a, KTransformersLinear) and isinstance(b, KTransformersLinear) and a.generate_linear is not None
+                and type(a.generate_linear) is type(b.generate_linear)):
+            merged = build_merged_linear(a.generate_linear, [f"{self.key}.{first}", f"{self.key}.kv_a_proj_with_mqa"],
+                                         self.gguf_loader, a.generate_linear.device)
+            if merged is not None:
+                object.__setattr__(self, "_qkv", merged)
+                for m in (a, b):
+                    for op in {id(m.generate_linear): m.generate_linear, id(m.prefill_linear): m.prefill_linear}.values():
+                        if op is not None:
+                            op.unload()
+                            op.loaded = True
 
     # ---- absorbed kv_b_proj (attention.py:67-74): W_UK [H, nope, lora] used as q_nope @ W_UK, W_UV [H, v, lora] --------
     def get_absorbed(self):
@@ -85,8 +107,11 @@ class KDeepseekV2Attention(BaseInjectedModule):
 
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.Tensor] = None, past_key_value=None, output_attentions: bool = False,
-                use_cache: bool = False, cache_position: Optional[torch.Tensor] = None, **kwargs
-                ) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
+                use_cache: bool = False, cache_position: Optional[torch.Tensor] = None, pre_norm=None, residual=None,
+                **kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
+        """`pre_norm` (an RMSNorm module: the layer's input_layernorm, applied to hidden_states here instead of by the
+        caller) and `residual` (added to the output) are fusion hooks used by the decoder-layer glue; without them the
+        signature and behaviour are the reference's."""
         from ktransformers_amd._native import MLAWrapper, mla_prep, rmsnorm
 
         bsz, q_len, _ = hidden_states.size()
@@ -98,14 +123,23 @@ class KDeepseekV2Attention(BaseInjectedModule):
         H, nope, rope, lora = self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim, self.kv_lora_rank
         x = hidden_states.reshape(q_len, -1)
 
-        if self.q_lora_rank is None:
-            q = self.q_proj(x)
+        norm = None if pre_norm is None else (pre_norm.weight, pre_norm.variance_epsilon)
+        if self._qkv is not None:
+            op, (n0, _) = self._qkv
+            qkv = op.forward(x, norm=norm) if norm is not None else op.forward(x)   # [T, n0 + lora + rope]
+            first, kv = qkv[:, :n0], qkv[:, n0:]
         else:
-            qa = self.q_a_proj(x)
+            if norm is not None:
+                x = rmsnorm(x.contiguous(), norm[0], norm[1], native_rounding=True)
+            first = (self.q_proj if self.q_lora_rank is None else self.q_a_proj)(x)
+            kv = self.kv_a_proj_with_mqa(x)
+        if self.q_lora_rank is None:
+            q = first
+        else:
             ln = self.q_a_layernorm                                        # DeepseekV3RMSNorm.forward (native rounding)
-            q = self.q_b_proj(rmsnorm(qa, ln.weight.to(torch.bfloat16), ln.variance_epsilon, native_rounding=True))
-        kv = self.kv_a_proj_with_mqa(x)
-        q = q.reshape(q_len, H * (nope + rope))
+            q = self.q_b_proj(first, norm=(ln.weight, ln.variance_epsilon)) if hasattr(self.q_b_proj, "generate_linear") \
+                else self.q_b_proj(rmsnorm(first, ln.weight.to(torch.bfloat16), ln.variance_epsilon, native_rounding=True))
+            q = q.reshape(q_len, H * (nope + rope))
 
         inv_freq, mscale = self._rope_params(dev)
         pos = position_ids.reshape(-1).to(torch.int64)
@@ -114,7 +148,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
                                           H, nope, rope, lora)
 
         qabs, oabs = self.get_absorbed()
-        q3 = q.view(q_len, H, nope + rope)
+        q3 = q.unflatten(1, (H, nope + rope))                              # strided view when q is a slice of the merged GEMV
         q_nope = qabs.forward_batched(q3[:, :, :nope])                     # [T, H, lora]
 
         Hp = (H + 15) // 16 * 16          # the MLA kernel tiles heads by 16 (every shipped model: 16 / 64 / 128 heads)
@@ -144,7 +178,13 @@ class KDeepseekV2Attention(BaseInjectedModule):
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16)
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
-        out = self.o_proj(out.reshape(q_len, H * self.v_head_dim))
+        out = out.reshape(q_len, H * self.v_head_dim)
+        if residual is not None and hasattr(self.o_proj, "generate_linear"):
+            out = self.o_proj(out, add1=residual.reshape(q_len, -1))        # hidden = residual + attn (o_proj epilogue)
+        else:
+            out = self.o_proj(out)
+            if residual is not None:
+                out = residual.reshape(q_len, -1) + out
         return out.reshape(bsz, q_len, -1), None, past_key_value
 
 

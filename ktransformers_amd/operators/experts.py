@@ -250,11 +250,28 @@ class KTransformersExperts(BaseInjectedModule, KExpertsBase):
 
 class _KMoEBlock(BaseInjectedModule):
     """Shared orchestration of the model-specific MoE blocks: gate -> routed experts (+ shared experts)."""
+    SUPPORTS_FUSION, RESIDUAL_KW = True, "residual"
 
     def moe_kexperts(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weight: torch.Tensor) -> torch.Tensor:
         return self.experts(x, topk_ids, topk_weight)
 
-    def forward(self, hidden_states):
+    def forward(self, hidden_states, residual=None):
+        """`residual` (fusion hook of the decoder-layer glue): returns residual + mlp(hidden_states), the two adds riding in
+        the shared experts' down_proj epilogue when that operator supports it."""
+        out = self._forward(hidden_states, residual)
+        return out
+
+    def _finish(self, y, identity, residual, orig_shape):
+        shared = getattr(self.config, "n_shared_experts", None) is not None
+        se = self.shared_experts if shared else None
+        if se is not None and hasattr(se, "_gate_up"):                     # KDeepseekV3MLP: adds fused into down_proj
+            return se(identity, add1=y.view(*orig_shape), add2=residual).view(*orig_shape)
+        if se is not None:
+            y = y.view(*orig_shape) + se(identity).view(*orig_shape)
+        y = y.view(*orig_shape)
+        return y if residual is None else residual + y
+
+    def _forward(self, hidden_states, residual=None):
         identity = hidden_states
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
@@ -266,19 +283,11 @@ class _KMoEBlock(BaseInjectedModule):
         if (sequence_length == 1 and gen is not None and hasattr(gen, "submit_for_one_decode")
                 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             gen.submit_for_one_decode(hidden_states[0], topk_idx[0], topk_weight[0])
-            if shared:
-                y_ = self.shared_experts(identity).squeeze(0)
             y = gen.sync_for_one_decode().unsqueeze(0)
-            if shared:
-                y = y + y_
-            return y.reshape(*orig_shape)
+            return self._finish(y, identity, residual, orig_shape)
 
-        if shared:
-            y_ = self.shared_experts(identity).squeeze(0)
         y = self.moe_kexperts(hidden_states, topk_idx, topk_weight).view(*orig_shape).to(device=hidden_states.device)
-        if shared:
-            y = y + y_.view(*orig_shape)
-        return y
+        return self._finish(y, identity, residual, orig_shape)
 
 
 class KDeepseekV2MoE(_KMoEBlock):

@@ -67,11 +67,13 @@ class KLinearBase(nn.Module):
         self.device = str(self._dev())
         return LinearHandle(self.in_features, self.out_features, self.FMT, group_size, self.max_len, torch.device(self.device))
 
-    def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor = None, **kwargs) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor = None, **fusion) -> torch.Tensor:
+        """`fusion`: norm=(weight, eps), add1=, add2= — see LinearHandle.forward (an extension of the reference signature;
+        plain calls behave exactly like KLinear*.forward(x, bsz_tensor))."""
         if self._h is None:
             raise RuntimeError(f"{type(self).__name__}({self.key}): forward before load()")
         dtype, dev = x.dtype, x.device
-        y = self._h.forward(x.to(device=self.device, dtype=torch.bfloat16), bsz_tensor)
+        y = self._h.forward(x.to(device=self.device, dtype=torch.bfloat16), bsz_tensor, **fusion)
         return y.to(dtype=dtype, device=dev)
 
     def unload(self):
@@ -168,6 +170,23 @@ class KLinearFP8(KLinearBase):
         self.loaded = True
 
 
+def build_merged_linear(template: "KLinearBase", keys: list, loader, device: str):
+    """One operator over the row-concatenation of several linears that share their input (q_proj | kv_a_proj_with_mqa;
+    gate_proj | up_proj): per-(group, output-row) quantisation is independent of the other rows, so the merged GEMV gives
+    exactly the rows the separate operators would, in one launch.  `template` supplies the operator class and its options."""
+    ws = [loader.load_tensor(k + ".weight", device=device) for k in keys]
+    if any(loader.has_tensor(k + ".weight_scale_inv") or loader.has_tensor(k + ".bias") for k in keys):
+        return None                                   # fp8 block scales / biases: keep the separate operators
+    w = torch.cat([t.to(torch.bfloat16) for t in ws], dim=0).contiguous()
+    holder = nn.Linear(w.shape[1], w.shape[0], bias=False, device="meta")
+    kw = {}
+    if isinstance(template, KLinearMarlin):
+        kw = dict(num_bits=template.num_bits, group_size=template.group_size, act_order=template.act_order)
+    op = type(template)("+".join(keys), loader, template.config, holder, device, max_len=template.max_len, **kw)
+    op.load(nn.Parameter(w, requires_grad=False))
+    return op, [t.shape[0] for t in ws]
+
+
 LINEAR_MAP = {
     "KLinearMarlin": KLinearMarlin,
     "KLinearTorch": KLinearTorch,
@@ -204,12 +223,12 @@ class KTransformersLinear(BaseInjectedModule):
         object.__setattr__(self, "mode", InferenceState.UNLOAD)
         object.__setattr__(self, "weight", None)
 
-    def forward(self, x, bsz_tensor=None):
+    def forward(self, x, bsz_tensor=None, **fusion):
         if self.mode == InferenceState.PREFILL:
             assert self.prefill_linear is not None, "cpu linear is not initialized"
-            return self.prefill_linear.forward(x, bsz_tensor)
+            return self.prefill_linear.forward(x, bsz_tensor, **fusion)
         assert self.generate_linear is not None, "gpu linear is not initialized"
-        return self.generate_linear.forward(x, bsz_tensor)
+        return self.generate_linear.forward(x, bsz_tensor, **fusion)
 
     def load(self, w=None, mode: InferenceState = InferenceState.GENERATE):
         if not mode:

@@ -1,0 +1,67 @@
+"""Dense / shared-expert MLP operator — counterpart of archive/ktransformers/operators/mlp.py (kDeepseekV3MLP):
+down_proj(act_fn(gate_proj(x)) * up_proj(x)) (models/modeling_deepseek_v3.py:396-398).
+
+gate_proj and up_proj share their input, so they are loaded as ONE row-concatenated quantised linear (one GEMV launch,
+exactly the rows the two separate operators give), followed by ktx_silu_mul and down_proj; the residual-style adds that
+follow an MLP in the decoder layer can ride in down_proj's epilogue (`add1`, `add2`)."""
+from __future__ import annotations
+
+import torch
+from torch import nn
+
+from ktransformers_amd.operators.base_operator import BaseInjectedModule
+from ktransformers_amd.operators.linear import KTransformersLinear, build_merged_linear
+
+
+class KDeepseekV3MLP(BaseInjectedModule):
+    SUPPORTS_FUSION, RESIDUAL_KW = True, "add1"
+
+    def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, prefill_device: str = "cuda",
+                 generate_device: str = "cuda", **kwargs):
+        BaseInjectedModule.__init__(self, key, gguf_loader, config, orig_module, prefill_device, generate_device, **kwargs)
+        object.__setattr__(self, "_gate_up", None)
+
+    def load(self):
+        down, gate, up = self.orig_module.down_proj, self.orig_module.gate_proj, self.orig_module.up_proj
+        from ktransformers_amd.util.utils import load_weights
+        load_weights(down, self.gguf_loader, self.key + ".down_proj.")
+        merged = None
+        if all(isinstance(m, KTransformersLinear) for m in (down, gate, up)) and down.generate_linear is not None:
+            merged = build_merged_linear(down.generate_linear, [self.key + ".gate_proj", self.key + ".up_proj"],
+                                         self.gguf_loader, down.generate_linear.device)
+        if merged is not None:
+            object.__setattr__(self, "_gate_up", merged[0])
+            for m in (gate, up):                       # their rows live in the merged operator
+                for op in {id(m.generate_linear): m.generate_linear, id(m.prefill_linear): m.prefill_linear}.values():
+                    if op is not None:
+                        op.unload()
+                        op.loaded = True
+        else:
+            load_weights(gate, self.gguf_loader, self.key + ".gate_proj.")
+            load_weights(up, self.gguf_loader, self.key + ".up_proj.")
+
+    def forward(self, x: torch.Tensor, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
+                norm: tuple | None = None) -> torch.Tensor:
+        from ktransformers_amd._native import rmsnorm, silu_mul
+
+        shape = x.shape
+        x2 = x.reshape(-1, shape[-1])
+        if self._gate_up is not None:
+            gu = self._gate_up.forward(x2, norm=norm) if norm is not None else self._gate_up.forward(x2)
+        else:
+            if norm is not None:
+                x2 = rmsnorm(x2, norm[0], norm[1], native_rounding=True)
+            gu = torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1)
+        a = silu_mul(gu)
+        down = self.orig_module.down_proj
+        fusion = {k: v.reshape(-1, shape[-1]) for k, v in (("add1", add1), ("add2", add2)) if v is not None}
+        if isinstance(down, KTransformersLinear):
+            y = down(a, **fusion)
+        else:
+            y = down(a)
+            for v in fusion.values():
+                y = v + y
+        return y.reshape(*shape[:-1], y.shape[-1])
+
+
+kDeepseekV3MLP = KDeepseekV3MLP
