@@ -88,6 +88,8 @@ typedef struct ktx_linear_fusion {
   const void* add2;
   int64_t add2_ld;
   int64_t x_ld, y_ld; /* row strides of x / y in elements (multiples of 8); 0 = in_features / out_features */
+  int32_t glu;        /* the matrix is [gate | up] interleaved 8 rows / 8 rows per 16-row strip: y = act_fn(gate(x)) * up(x),
+                         out_features / 2 columns (DeepseekV3MLP, modeling_deepseek_v3.py:396-398) */
 } ktx_linear_fusion;
 int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
                              const ktx_linear_fusion* fusion, ktx_stream_t stream);

@@ -40,7 +40,7 @@ class _LinearConfig(C.Structure):
 
 class _LinearFusion(C.Structure):
     _fields_ = [("norm_weight", C.c_void_p), ("norm_eps", C.c_float), ("add1", C.c_void_p), ("add1_ld", C.c_int64),
-                ("add2", C.c_void_p), ("add2_ld", C.c_int64), ("x_ld", C.c_int64), ("y_ld", C.c_int64)]
+                ("add2", C.c_void_p), ("add2_ld", C.c_int64), ("x_ld", C.c_int64), ("y_ld", C.c_int64), ("glu", C.c_int32)]
 
 
 class _MoeConfig(C.Structure):
@@ -395,7 +395,8 @@ class LinearHandle:
         return bool(lib.ktx_linear_decode_eligible(self._h, int(T)))
 
     def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor | None = None, out: torch.Tensor | None = None,
-                norm: tuple | None = None, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None) -> torch.Tensor:
+                norm: tuple | None = None, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
+                glu: bool = False) -> torch.Tensor:
         """x: bf16 [..., in] -> bf16 [..., out] on the current stream.  Optional fusions (include/ktx_linear.h,
         ktx_linear_fusion): norm = (weight bf16 [in], eps) applies RMSNorm to x inside the kernel (falls back to a separate
         ktx_rmsnorm launch where the decode kernel does not run); add1 / add2 = bf16 [..., out] tensors added in that order."""
@@ -407,18 +408,19 @@ class LinearHandle:
             x2 = x2.contiguous()
             strided = False
         T = x2.shape[0]
+        n_out = self.N // 2 if glu else self.N
         if out is None:
-            out = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
-                torch.zeros((T, self.N), dtype=torch.bfloat16, device=self.device)
+            out = torch.empty((T, n_out), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
+                torch.zeros((T, n_out), dtype=torch.bfloat16, device=self.device)
         bsz = None
         if bsz_tensor is not None:
             if bsz_tensor.dtype != torch.int32 or bsz_tensor.device != self.device:
                 raise KtxError("forward: bsz_tensor must be int32 on the handle's device")
             bsz = bsz_tensor.data_ptr()
-        if norm is None and add1 is None and add2 is None and not strided:
+        if norm is None and add1 is None and add2 is None and not strided and not glu:
             check(lib.ktx_linear_forward(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
             return out.reshape(*x.shape[:-1], self.N)
-        fu = _LinearFusion(None, 0.0, None, 0, None, 0, x2.stride(0) if strided else 0, 0)
+        fu = _LinearFusion(None, 0.0, None, 0, None, 0, x2.stride(0) if strided else 0, 0, 1 if glu else 0)
         keep = []
         if norm is not None:
             nw, eps = norm
@@ -437,7 +439,7 @@ class LinearHandle:
                 setattr(fu, name + "_ld", a2.stride(0))
                 keep.append(a2)
         check(lib.ktx_linear_forward_fused(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), C.byref(fu), _stream_ptr(self.device)))
-        return out.reshape(*x.shape[:-1], self.N)
+        return out.reshape(*x.shape[:-1], n_out)
 
     def forward_batched(self, x: torch.Tensor, out: torch.Tensor | None = None, bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
         """x: bf16 [T, batch, in] (any row / batch strides that are multiples of 8, unit stride along `in`) ->

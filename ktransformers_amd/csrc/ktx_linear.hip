@@ -103,6 +103,7 @@ struct LinParams {
   float norm_eps;
   const bf16_t *add1, *add2;
   long ld1, ld2;
+  int glu;   // rows interleaved per strip as [8 gate | 8 up]: the epilogue writes act_fn(gate) * up, N/2 columns
 };
 
 // batch b of a batched linear: shift the base pointers once
@@ -191,6 +192,13 @@ __device__ __forceinline__ bf16_t lin_addends(bf16_t o, const LinParams& p, int 
   if (p.add1) o = f32_to_bf16(bf16_to_f32(p.add1[(size_t)row * p.ld1 + n]) + bf16_to_f32(o));
   if (p.add2) o = f32_to_bf16(bf16_to_f32(p.add2[(size_t)row * p.ld2 + n]) + bf16_to_f32(o));
   return o;
+}
+// DeepseekV3MLP (modeling_deepseek_v3.py:396-398) between the merged gate|up GEMV and down_proj, in bf16 tensor arithmetic:
+// bf16(silu(bf16 g)) * bf16 u -> bf16
+__device__ __forceinline__ bf16_t lin_glu(float g, float u) {
+  const float gb = bf16_to_f32(f32_to_bf16(g)), ub = bf16_to_f32(f32_to_bf16(u));
+  const float sb = bf16_to_f32(f32_to_bf16(gb / (1.0f + expf(-gb))));
+  return f32_to_bf16(sb * ub);
 }
 // 8 bf16 of an input row -> RMSNorm'ed (DeepseekV3RMSNorm.forward: w * bf16(x * r), both roundings)
 __device__ __forceinline__ uint4 lin_norm8(const uint4& v, float r, const bf16_t* __restrict__ w8) {
@@ -342,7 +350,15 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
       const int nsl = 8 / p.SW;
       float v = 0.f;
       for (int s = 0; s < nsl; s++) v += red[((s * p.SW + swo) * 4 + r) * 16 + f];
-      p.y[(size_t)r * p.ldy + n] = lin_addends(lin_out(v, p.bias, n), p, r, n);
+      if (p.glu) {
+        if (f < 8) {
+          float u = 0.f;
+          for (int s = 0; s < nsl; s++) u += red[((s * p.SW + swo) * 4 + r) * 16 + f + 8];
+          p.y[(size_t)r * p.ldy + (blockIdx.x * p.SW + swo) * 8 + f] = lin_glu(v, u);
+        }
+      } else {
+        p.y[(size_t)r * p.ldy + n] = lin_addends(lin_out(v, p.bias, n), p, r, n);
+      }
     }
   }
 }
@@ -475,13 +491,18 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(LinParams p) {
 
   if (!strip_ok) return;
   const int n = strip * 16 + (lane & 15);
-  if (n >= p.N) return;
+  if (n >= p.N && !p.glu) return;
 #pragma unroll
   for (int t = 0; t < MT; t++)
 #pragma unroll
     for (int r = 0; r < 4; r++) {
       const int row = row0 + t * 16 + (lane >> 4) * 4 + r;
-      if (row < bsz) p.y[(size_t)row * p.ldy + n] = lin_addends(lin_out(acc[t][r], p.bias, n), p, row, n);
+      if (p.glu) {
+        const float u = __shfl(acc[t][r], (lane & 48) | ((lane + 8) & 15), 64);   // the up row sits 8 lanes to the right
+        if (row < bsz && (lane & 15) < 8) p.y[(size_t)row * p.ldy + strip * 8 + (lane & 15)] = lin_glu(acc[t][r], u);
+      } else if (row < bsz) {
+        p.y[(size_t)row * p.ldy + n] = lin_addends(lin_out(acc[t][r], p.bias, n), p, row, n);
+      }
     }
 }
 
@@ -831,6 +852,9 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
     p.norm_w = (const bf16_t*)fu->norm_weight; p.norm_eps = fu->norm_eps;
     p.add1 = (const bf16_t*)fu->add1; p.ld1 = fu->add1_ld ? fu->add1_ld : h->cfg.out_features;
     p.add2 = (const bf16_t*)fu->add2; p.ld2 = fu->add2_ld ? fu->add2_ld : h->cfg.out_features;
+    p.glu = fu->glu ? 1 : 0;
+    KTX_REQUIRE(!p.glu || (h->cfg.out_features % 16 == 0 && !h->d_bias && !p.add1 && !p.add2),
+                "ktx_linear_forward_fused: glu needs out_features % 16 == 0 and no bias / addends");
   }
   hipStream_t st = (hipStream_t)stream;
   switch (h->cfg.format) {
@@ -855,7 +879,7 @@ extern "C" int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, in
                                         const ktx_linear_fusion* fusion, ktx_stream_t stream) {
   KTX_REQUIRE(h, "ktx_linear_forward_fused: null handle");
   const long ldx = fusion && fusion->x_ld ? (long)fusion->x_ld : (long)h->cfg.in_features;
-  const long ldy = fusion && fusion->y_ld ? (long)fusion->y_ld : (long)h->cfg.out_features;
+  const long ldy = fusion && fusion->y_ld ? (long)fusion->y_ld : (long)(fusion && fusion->glu ? h->cfg.out_features / 2 : h->cfg.out_features);
   return linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion);
 }
 

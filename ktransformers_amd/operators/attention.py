@@ -162,8 +162,16 @@ class KDeepseekV2Attention(BaseInjectedModule):
             object.__setattr__(self, "mla_wrapper", MLAWrapper(1, past_key_value.max_pages, use_cuda_graph=True, device=dev,
                                                                max_q_tokens=self._max_len()))
         if q_len == 1:
-            # kv_len is read on the device: positions + 1 (attention.py:430-433); the kernel appends the new row itself
-            kv_len = (pos + 1).to(torch.int32)
+            # kv_len is read on the device: positions + 1 (attention.py:430-433); the kernel appends the new row itself.
+            # Every layer of a step sees the same position tensor: derive kv_len once per step, not once per layer.
+            # (keyed on the capture state too: a value computed in an eager warm-up must not leak into a captured graph)
+            key = (id(position_ids), position_ids._version, torch.cuda.is_current_stream_capturing())
+            memo = getattr(past_key_value, "_kv_len_memo", None)
+            if memo is not None and memo[0] == key and memo[1] is position_ids:
+                kv_len = memo[2]
+            else:
+                kv_len = (pos + 1).to(torch.int32)
+                past_key_value._kv_len_memo = (key, position_ids, kv_len)
             self.mla_wrapper.plan(None, None, None, kv_len, None, Hp, lora, rope, past_key_value.page_size,
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16)
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)

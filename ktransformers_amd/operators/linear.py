@@ -170,14 +170,20 @@ class KLinearFP8(KLinearBase):
         self.loaded = True
 
 
-def build_merged_linear(template: "KLinearBase", keys: list, loader, device: str):
+def build_merged_linear(template: "KLinearBase", keys: list, loader, device: str, interleave8: bool = False):
     """One operator over the row-concatenation of several linears that share their input (q_proj | kv_a_proj_with_mqa;
     gate_proj | up_proj): per-(group, output-row) quantisation is independent of the other rows, so the merged GEMV gives
     exactly the rows the separate operators would, in one launch.  `template` supplies the operator class and its options."""
     ws = [loader.load_tensor(k + ".weight", device=device) for k in keys]
     if any(loader.has_tensor(k + ".weight_scale_inv") or loader.has_tensor(k + ".bias") for k in keys):
         return None                                   # fp8 block scales / biases: keep the separate operators
-    w = torch.cat([t.to(torch.bfloat16) for t in ws], dim=0).contiguous()
+    if interleave8:   # [gate | up] -> per 16-row strip 8 gate rows then 8 up rows (the `glu` epilogue of ktx_linear_forward_fused)
+        g, u = (t.to(torch.bfloat16) for t in ws)
+        if g.shape != u.shape or g.shape[0] % 8 != 0:
+            return None
+        w = torch.stack([g.view(-1, 8, g.shape[1]), u.view(-1, 8, u.shape[1])], dim=1).reshape(-1, g.shape[1]).contiguous()
+    else:
+        w = torch.cat([t.to(torch.bfloat16) for t in ws], dim=0).contiguous()
     holder = nn.Linear(w.shape[1], w.shape[0], bias=False, device="meta")
     kw = {}
     if isinstance(template, KLinearMarlin):

@@ -28,7 +28,7 @@ class KDeepseekV3MLP(BaseInjectedModule):
         merged = None
         if all(isinstance(m, KTransformersLinear) for m in (down, gate, up)) and down.generate_linear is not None:
             merged = build_merged_linear(down.generate_linear, [self.key + ".gate_proj", self.key + ".up_proj"],
-                                         self.gguf_loader, down.generate_linear.device)
+                                         self.gguf_loader, down.generate_linear.device, interleave8=True)
         if merged is not None:
             object.__setattr__(self, "_gate_up", merged[0])
             for m in (gate, up):                       # their rows live in the merged operator
@@ -46,13 +46,12 @@ class KDeepseekV3MLP(BaseInjectedModule):
 
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
-        if self._gate_up is not None:
-            gu = self._gate_up.forward(x2, norm=norm) if norm is not None else self._gate_up.forward(x2)
+        if self._gate_up is not None:       # one launch: merged GEMV with the SiLU * up epilogue
+            a = self._gate_up.forward(x2, norm=norm, glu=True)
         else:
             if norm is not None:
                 x2 = rmsnorm(x2, norm[0], norm[1], native_rounding=True)
-            gu = torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1)
-        a = silu_mul(gu)
+            a = silu_mul(torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1))
         down = self.orig_module.down_proj
         fusion = {k: v.reshape(-1, shape[-1]) for k, v in (("add1", add1), ("add2", add2)) if v is not None}
         if isinstance(down, KTransformersLinear):

@@ -148,3 +148,42 @@ def test_errors_are_loud():
     with pytest.raises(n.KtxError):
         h.forward(torch.zeros(8, 256, dtype=torch.bfloat16, device="cuda"))   # T > max_len
     assert torch.all(h.forward(x) == 0)
+
+
+@pytest.mark.parametrize("T", [1, 3, 4, 9, 40])
+@pytest.mark.parametrize("fmt", ["W4", "BF16"])
+def test_fused_norm_glu_and_addends(T, fmt):
+    """ktx_linear_forward_fused: RMSNorm prologue, [gate|up] GLU epilogue and two addends equal the unfused sequence
+    (same kernels, same roundings) bit for bit."""
+    n = native()
+    torch.manual_seed(T)
+    K, I, N = 512, 256, 384
+    x = (torch.randn(T, K)).to(torch.bfloat16).cuda()
+    nw = (1 + 0.1 * torch.randn(K)).to(torch.bfloat16).cuda()
+    g = (torch.randn(I, K) / 10).to(torch.bfloat16).cuda()
+    u = (torch.randn(I, K) / 10).to(torch.bfloat16).cuda()
+    hg, hu = n.LinearHandle(K, I, fmt, 64, 64), n.LinearHandle(K, I, fmt, 64, 64)
+    hg.load_bf16(g); hu.load_bf16(u)
+    inter = torch.stack([g.view(-1, 8, K), u.view(-1, 8, K)], dim=1).reshape(-1, K).contiguous()
+    hm = n.LinearHandle(K, 2 * I, fmt, 64, 64)
+    hm.load_bf16(inter)
+    xn = n.rmsnorm(x, nw, 1e-6, native_rounding=True)
+    ref = n.silu_mul(torch.cat([hg.forward(xn), hu.forward(xn)], dim=-1))
+    got = hm.forward(x, norm=(nw, 1e-6), glu=True)
+    assert got.shape == (T, I)
+    # the fused prologue sums the squares in a different order: allow the rare 1-ulp flip of a normalised activation
+    assert (got != ref).float().mean() < 0.02 and torch.allclose(got.float(), ref.float(), rtol=2 ** -6, atol=1e-3)
+    assert torch.equal(hm.forward(xn, glu=True), ref)
+    # addends
+    w = (torch.randn(N, I) / 10).to(torch.bfloat16).cuda()
+    hd = n.LinearHandle(I, N, fmt, 64, 64)
+    hd.load_bf16(w)
+    a1 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    a2 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    y = hd.forward(ref)
+    want = a2 + (a1 + y)
+    assert torch.equal(hd.forward(ref, add1=a1, add2=a2), want)
+    # strided input rows (a slice of a wider buffer)
+    wide = torch.zeros(T, I + 64, dtype=torch.bfloat16, device="cuda")
+    wide[:, :I] = ref
+    assert torch.equal(hd.forward(wide[:, :I]), y)
