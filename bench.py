@@ -285,6 +285,7 @@ class ModelDecodeRunner:
         self.cache = StaticCache(cfg, 1, ctx + max_new + 64, str(dev), torch.bfloat16)
         for kc in self.cache.key_cache:
             kc.normal_()
+        self.cache.past_tokens = [ctx] * cfg.num_hidden_layers           # the prompt the cache pretends to hold
         self.step_mod = GreedyStep(model)
         self.pos = torch.tensor([[ctx]], device=dev, dtype=torch.long)
         self.cur = torch.tensor([[1]], device=dev, dtype=torch.long)

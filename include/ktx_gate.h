@@ -51,6 +51,14 @@ int ktx_gate_forward(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen,
                      const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
                      float* d_topk_weight, void* stream);
 
+/* ktx_gate_forward with the MoE block's input RMSNorm folded in (post_attention_layernorm in front of the router,
+ * modeling_deepseek_v3.py:1222-1224): d_x is the UN-normalised hidden state, the logits are taken on
+ * xn = norm_weight * bf16(x * rsqrt(mean(x^2) + eps)), and xn (bf16 [qlen][hidden]) is written to d_xn_out for the experts
+ * that consume it next.  hidden_size <= 8192. */
+int ktx_gate_forward_norm(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x,
+                          const void* d_norm_weight, float norm_eps, void* d_xn_out, const void* d_w, const float* d_bias,
+                          float* d_logits, int32_t* d_counters, int64_t* d_topk_idx, float* d_topk_weight, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

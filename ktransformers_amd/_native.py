@@ -75,6 +75,7 @@ def _load() -> C.CDLL:
     lib.ktx_gate_select.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_void_p]
     lib.ktx_gate_forward.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int] + [C.c_void_p] * 8
+    lib.ktx_gate_forward_norm.argtypes = [C.POINTER(_GateConfig), C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_float] + [C.c_void_p] * 8
     lib.ktx_mla_workspace_bytes.argtypes = [C.POINTER(_MlaConfig), C.c_int]
     lib.ktx_mla_workspace_bytes.restype = C.c_size_t
     lib.ktx_mla_decode.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
@@ -478,13 +479,33 @@ class GateHandle:
         self._counters: dict = {}
 
     def forward(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
-                bsz_tensor: torch.Tensor | None = None):
+                bsz_tensor: torch.Tensor | None = None, norm: tuple | None = None):
         """x bf16 [T,H]; weight [E,H] (bf16 for the HIP GEMV; any float dtype for the library GEMM); bias fp32 [E]|None
-        -> (topk_idx int64 [T,k], topk_weight fp32 [T,k])."""
+        -> (topk_idx int64 [T,k], topk_weight fp32 [T,k]).  norm = (weight bf16 [H], eps): x is the un-normalised hidden
+        state, RMSNorm runs inside the router launch and the normalised rows are returned as a third value."""
         T = x.shape[0]
         dev = x.device
         st = _stream_ptr(dev)
         bsz_ptr = bsz_tensor.data_ptr() if bsz_tensor is not None else None
+        if norm is not None:
+            fusable = (T <= self.LOGITS_HIP_MAX_T and weight.dtype == torch.bfloat16 and x.dtype == torch.bfloat16
+                       and self.H <= 8192)
+            if not fusable:
+                xn = rmsnorm(x, norm[0], norm[1], native_rounding=True)
+                return (*self.forward(xn, weight, bias, bsz_tensor), xn)
+            logits = torch.empty((T, self.E), dtype=torch.float32, device=dev)
+            idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
+            wt = torch.empty((T, self.k), dtype=torch.float32, device=dev)
+            xn = torch.empty((T, self.H), dtype=torch.bfloat16, device=dev)
+            cnt = self._counters.get(dev)
+            if cnt is None:
+                cnt = self._counters[dev] = torch.zeros(self.LOGITS_HIP_MAX_T, dtype=torch.int32, device=dev)
+            xc, wc = x.contiguous(), weight.contiguous()
+            b = bias.to(device=dev, dtype=torch.float32).contiguous() if bias is not None else None
+            check(lib.ktx_gate_forward_norm(C.byref(self.cfg), bsz_ptr, T, xc.data_ptr(), norm[0].data_ptr(), float(norm[1]),
+                                            xn.data_ptr(), wc.data_ptr(), b.data_ptr() if b is not None else None,
+                                            logits.data_ptr(), cnt.data_ptr(), idx.data_ptr(), wt.data_ptr(), st))
+            return idx, wt, xn
         if T <= self.LOGITS_HIP_MAX_T and weight.dtype == torch.bfloat16 and x.dtype == torch.bfloat16:
             # one launch: logits GEMV, then the last workgroup of each token selects (include/ktx_gate.h)
             logits = torch.empty((T, self.E), dtype=torch.float32, device=dev)

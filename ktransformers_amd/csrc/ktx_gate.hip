@@ -36,8 +36,7 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const int32_t* d_bsz, 
       acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
     }
   }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+  acc = wave_sum(acc);   // same tree as gate_fused_kernel: the two paths give identical logits
   if (lane == 0) logits[(size_t)t * E + e] = acc;
 }
 
@@ -208,12 +207,13 @@ __global__ __launch_bounds__(64) void gate_select_kernel(ktx_gate_config c, cons
 // keeping the launch graph-replayable without a memset node.  (A single-workgroup router was tried for the 64 x 2048
 // DeepSeek-V2-Lite gate: one CU pulls only ~75 GB/s, 4.6-6.7 us for the 256 KiB, vs 2.4-2.9 us on 16 CUs —
 // scripts/gate_probe.hip.)
-template <int EPL>
+template <int EPL, int NJ>   // NJ = 512-column blocks held in registers by the fused-RMSNorm variant (0: no norm)
 __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, const int32_t* d_bsz, int qlen,
                                                          const bf16_t* __restrict__ x, const bf16_t* __restrict__ w,
                                                          const float* __restrict__ bias, float* __restrict__ logits,
                                                          int32_t* __restrict__ counters, int64_t* __restrict__ topk_idx,
-                                                         float* __restrict__ topk_w) {
+                                                         float* __restrict__ topk_w, const bf16_t* __restrict__ norm_w,
+                                                         float norm_eps, bf16_t* __restrict__ xn_out) {
   __shared__ int s_last;
   __shared__ float s_logits[KTX_GATE_MAX_E];
   int T = qlen;
@@ -227,6 +227,54 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
     const bf16_t* xr = x + (size_t)t * H;
     const bf16_t* wr = w + (size_t)e * H;
     float acc = 0.0f;
+    if constexpr (NJ > 0) {
+      // fused post_attention_layernorm (H <= 512*NJ): the wavefront holds the whole row (112 elements per lane at H = 7168),
+      // so the inverse RMS is one wave reduction; the normalised row (DeepseekV3RMSNorm: w * bf16(x * r)) feeds the dot
+      // products and is written once (workgroup 0, wavefront 0) for the experts that run after the router.
+      uint4 xa[NJ], wn[NJ], b[NJ];
+      float ss = 0.f;
+      // every load of the kernel (x, norm weight, router weights) is issued before the first use
+#pragma unroll
+      for (int u = 0; u < NJ; u++) {
+        const int j = lane * 8 + u * 512;
+        const bool ok = j < H;
+        xa[u] = ok ? *reinterpret_cast<const uint4*>(xr + j) : make_uint4(0, 0, 0, 0);
+        wn[u] = ok ? *reinterpret_cast<const uint4*>(norm_w + j) : make_uint4(0, 0, 0, 0);
+        b[u] = ok ? *reinterpret_cast<const uint4*>(wr + j) : make_uint4(0, 0, 0, 0);
+      }
+#pragma unroll
+      for (int u = 0; u < NJ; u++) {
+        const uint32_t av[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
+#pragma unroll
+        for (int q = 0; q < 4; q++) {
+          const float lo = bf16_to_f32((bf16_t)(av[q] & 0xffffu)), hi = bf16_to_f32((bf16_t)(av[q] >> 16));
+          ss += lo * lo + hi * hi;
+        }
+      }
+      ss = wave_sum(ss);
+      const float r = 1.0f / sqrtf(ss / (float)H + norm_eps);
+#pragma unroll
+      for (int u = 0; u < NJ; u++) {
+        const int j = lane * 8 + u * 512;
+        if (j < H) {
+          const uint32_t av[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w}, wv[4] = {wn[u].x, wn[u].y, wn[u].z, wn[u].w};
+          const uint32_t bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
+          uint32_t o[4];
+#pragma unroll
+          for (int q = 0; q < 4; q++) {
+            const float lo = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(bf16_to_f32((bf16_t)(av[q] & 0xffffu)) * r)) *
+                                                     bf16_to_f32((bf16_t)(wv[q] & 0xffffu))));
+            const float hi = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(bf16_to_f32((bf16_t)(av[q] >> 16)) * r)) *
+                                                     bf16_to_f32((bf16_t)(wv[q] >> 16))));
+            o[q] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
+            acc = fmaf(lo, bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
+            acc = fmaf(hi, bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
+          }
+          if (xn_out && blockIdx.x == 0 && threadIdx.x < 64)
+            *reinterpret_cast<uint4*>(xn_out + (size_t)t * H + j) = make_uint4(o[0], o[1], o[2], o[3]);
+        }
+      }
+    } else
     for (int j0 = lane * 8; j0 < H; j0 += 512 * 8) {   // 8 column blocks' loads in flight before the first FMA
       uint4 a[8], b[8];
 #pragma unroll
@@ -245,8 +293,7 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
         }
       }
     }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_xor(acc, o, 64);
+    acc = wave_sum(acc);
     if (lane == 0) __hip_atomic_store(&logits[(size_t)t * E + e], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 store
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -278,9 +325,9 @@ extern "C" int ktx_gate_logits(const ktx_gate_config* cfg, const int32_t* d_bsz,
   return 0;
 }
 
-extern "C" int ktx_gate_forward(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x, const void* d_w,
-                                const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
-                                float* d_topk_weight, void* stream) {
+static int gate_forward_impl(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x, const void* d_w,
+                             const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
+                             float* d_topk_weight, const void* d_norm_w, float norm_eps, void* d_xn_out, void* stream) {
   KTX_REQUIRE(cfg && d_x && d_w && d_logits && d_counters && d_topk_idx && d_topk_weight && qlen > 0, "ktx_gate_forward: bad argument");
   const int E = cfg->n_routed_experts;
   KTX_REQUIRE(cfg->hidden_size % 8 == 0, "ktx_gate_forward: hidden_size must be a multiple of 8");
@@ -291,16 +338,41 @@ extern "C" int ktx_gate_forward(const ktx_gate_config* cfg, const int32_t* d_bsz
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((E + 3) / 4, qlen);
   const int epl = (E + 63) / 64;
-#define KTX_FUSED(N) hipLaunchKernelGGL(gate_fused_kernel<N>, grid, dim3(256), 0, st, *cfg, d_bsz, qlen, (const bf16_t*)d_x, (const bf16_t*)d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight)
+#define KTX_FUSED2(N, J) hipLaunchKernelGGL((gate_fused_kernel<N, J>), grid, dim3(256), 0, st, *cfg, d_bsz, qlen, (const bf16_t*)d_x, (const bf16_t*)d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight, (const bf16_t*)d_norm_w, norm_eps, (bf16_t*)d_xn_out)
+#define KTX_FUSED(N)                                                          \
+  do {                                                                        \
+    if (!d_norm_w) KTX_FUSED2(N, 0);                                          \
+    else if (cfg->hidden_size <= 2048) KTX_FUSED2(N, 4);                      \
+    else if (cfg->hidden_size <= 4096) KTX_FUSED2(N, 8);                      \
+    else KTX_FUSED2(N, 16);                                                   \
+  } while (0)
+  KTX_REQUIRE(!d_norm_w || cfg->hidden_size <= 8192, "ktx_gate_forward_norm: the fused RMSNorm needs hidden_size <= 8192");
   if (epl <= 1) KTX_FUSED(1);
   else if (epl <= 2) KTX_FUSED(2);
   else if (epl <= 4) KTX_FUSED(4);
   else if (epl <= 6) KTX_FUSED(6);
   else if (epl <= 8) KTX_FUSED(8);
   else KTX_FUSED(16);
+#undef KTX_FUSED2
 #undef KTX_FUSED
   KTX_HIP(hipGetLastError());
   return 0;
+}
+
+extern "C" int ktx_gate_forward(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x, const void* d_w,
+                                const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
+                                float* d_topk_weight, void* stream) {
+  return gate_forward_impl(cfg, d_bsz, qlen, d_x, d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight, nullptr, 0.f,
+                           nullptr, stream);
+}
+
+extern "C" int ktx_gate_forward_norm(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const void* d_x,
+                                     const void* d_norm_weight, float norm_eps, void* d_xn_out, const void* d_w,
+                                     const float* d_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
+                                     float* d_topk_weight, void* stream) {
+  KTX_REQUIRE(d_norm_weight && d_xn_out, "ktx_gate_forward_norm: null norm weight / output");
+  return gate_forward_impl(cfg, d_bsz, qlen, d_x, d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight, d_norm_weight,
+                           norm_eps, d_xn_out, stream);
 }
 
 extern "C" int ktx_gate_select(const ktx_gate_config* cfg, const int32_t* d_bsz, int qlen, const float* d_logits,

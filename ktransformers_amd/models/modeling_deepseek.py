@@ -137,9 +137,9 @@ class DeepseekDecoderLayer(nn.Module):
                                                     past_key_value=past_key_value, cache_position=cache_position)
             hidden_states = residual + hidden_states
         residual = hidden_states
+        if getattr(type(mlp), "SUPPORTS_FUSION", False):   # post_attention_layernorm runs inside the MLP's first launch
+            return mlp(hidden_states, **{type(mlp).RESIDUAL_KW: residual, type(mlp).PRE_NORM_KW: self.post_attention_layernorm})
         hidden_states = self.post_attention_layernorm(hidden_states)
-        if getattr(type(mlp), "SUPPORTS_FUSION", False):
-            return mlp(hidden_states, **{type(mlp).RESIDUAL_KW: residual})
         return residual + mlp(hidden_states)
 
 

@@ -172,8 +172,11 @@ class KDeepseekV2Attention(BaseInjectedModule):
             else:
                 kv_len = (pos + 1).to(torch.int32)
                 past_key_value._kv_len_memo = (key, position_ids, kv_len)
+            # split count: a launch-grid constant of the captured graph — size it for the context seen now plus headroom
+            # (longer contexts later just put several tiles in a split)
+            hint = int(past_key_value.get_seq_length(self.layer_idx)) + 512
             self.mla_wrapper.plan(None, None, None, kv_len, None, Hp, lora, rope, past_key_value.page_size,
-                                  self.softmax_scale, torch.bfloat16, torch.bfloat16)
+                                  self.softmax_scale, torch.bfloat16, torch.bfloat16, max_kv_len=hint)
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
             past_key_value.note_appended(self.layer_idx, 1)
             object.__setattr__(self, "_decode_plan", kv_len)

@@ -250,16 +250,16 @@ class KTransformersExperts(BaseInjectedModule, KExpertsBase):
 
 class _KMoEBlock(BaseInjectedModule):
     """Shared orchestration of the model-specific MoE blocks: gate -> routed experts (+ shared experts)."""
-    SUPPORTS_FUSION, RESIDUAL_KW = True, "residual"
+    SUPPORTS_FUSION, RESIDUAL_KW, PRE_NORM_KW = True, "residual", "pre_norm"
 
     def moe_kexperts(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weight: torch.Tensor) -> torch.Tensor:
         return self.experts(x, topk_ids, topk_weight)
 
-    def forward(self, hidden_states, residual=None):
-        """`residual` (fusion hook of the decoder-layer glue): returns residual + mlp(hidden_states), the two adds riding in
-        the shared experts' down_proj epilogue when that operator supports it."""
-        out = self._forward(hidden_states, residual)
-        return out
+    def forward(self, hidden_states, residual=None, pre_norm=None):
+        """Fusion hooks of the decoder-layer glue: `residual` -> returns residual + mlp(hidden_states), the two adds riding
+        in the shared experts' down_proj epilogue; `pre_norm` (the layer's post_attention_layernorm module) ->
+        hidden_states is the un-normalised residual stream and the norm runs inside the router launch."""
+        return self._forward(hidden_states, residual, pre_norm)
 
     def _finish(self, y, identity, residual, orig_shape):
         shared = getattr(self.config, "n_shared_experts", None) is not None
@@ -271,11 +271,17 @@ class _KMoEBlock(BaseInjectedModule):
         y = y.view(*orig_shape)
         return y if residual is None else residual + y
 
-    def _forward(self, hidden_states, residual=None):
-        identity = hidden_states
+    def _forward(self, hidden_states, residual=None, pre_norm=None):
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
-        topk_idx, topk_weight = self.gate(hidden_states)
+        if pre_norm is not None and hasattr(self.gate, "_handle"):
+            topk_idx, topk_weight, xn = self.gate(hidden_states, norm=(pre_norm.weight, pre_norm.variance_epsilon))
+            hidden_states = xn.view(*orig_shape)
+        else:
+            if pre_norm is not None:
+                hidden_states = pre_norm(hidden_states)
+            topk_idx, topk_weight = self.gate(hidden_states)
+        identity = hidden_states
         hidden_states = hidden_states.view(-1, hidden_states.shape[-1])
         shared = getattr(self.config, "n_shared_experts", None) is not None
 

@@ -29,12 +29,14 @@ class KMoEGate(BaseInjectedModule):
                 float(getattr(c, "routed_scaling_factor", 1.0))))
         return self._gate
 
-    def forward(self, hidden_states) -> tuple[torch.Tensor, torch.Tensor]:
+    def forward(self, hidden_states, norm=None):
+        """(topk_idx, topk_weight) like MoEGate.forward; with norm=(weight, eps) the input is the un-normalised hidden
+        state, RMSNorm runs inside the router launch and the normalised rows come back as a third value."""
         h = hidden_states.shape[-1]
         x = hidden_states.reshape(-1, h)
         w = self.orig_module.weight
         bias = getattr(self.orig_module, "e_score_correction_bias", None)
-        return self._handle().forward(x.to(torch.bfloat16).contiguous(), w, bias)
+        return self._handle().forward(x.to(torch.bfloat16).contiguous(), w, bias, norm=norm)
 
     def load(self, w: dict | None = None, device: str | None = None):
         if device is None:

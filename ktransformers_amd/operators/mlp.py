@@ -14,7 +14,7 @@ from ktransformers_amd.operators.linear import KTransformersLinear, build_merged
 
 
 class KDeepseekV3MLP(BaseInjectedModule):
-    SUPPORTS_FUSION, RESIDUAL_KW = True, "add1"
+    SUPPORTS_FUSION, RESIDUAL_KW, PRE_NORM_KW = True, "add1", "pre_norm"
 
     def __init__(self, key: str, gguf_loader, config, orig_module: nn.Module, prefill_device: str = "cuda",
                  generate_device: str = "cuda", **kwargs):
@@ -41,9 +41,11 @@ class KDeepseekV3MLP(BaseInjectedModule):
             load_weights(up, self.gguf_loader, self.key + ".up_proj.")
 
     def forward(self, x: torch.Tensor, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
-                norm: tuple | None = None) -> torch.Tensor:
+                norm: tuple | None = None, pre_norm=None) -> torch.Tensor:
         from ktransformers_amd._native import rmsnorm, silu_mul
 
+        if pre_norm is not None:
+            norm = (pre_norm.weight, pre_norm.variance_epsilon)
         shape = x.shape
         x2 = x.reshape(-1, shape[-1])
         if self._gate_up is not None:       # one launch: merged GEMV with the SiLU * up epilogue
