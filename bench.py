@@ -256,7 +256,7 @@ class ModelDecodeRunner:
     tokens, cache append), RMSNorm, dense MLP (layer 0) | router + 6-of-64 int4 routed experts + shared experts] -> RMSNorm ->
     lm_head (W4) -> argmax.  The sampled token is fed back, so routing follows the model."""
 
-    def __init__(self, dev, ctx, max_new):
+    def __init__(self, dev, ctx, max_new, seed=0, use_graph=True):
         from ktransformers_amd.models.custom_cache import StaticCache
         from ktransformers_amd.models.modeling_deepseek import DeepseekForCausalLM, make_config
         from ktransformers_amd.optimize.optimize import optimize_and_load
@@ -288,11 +288,17 @@ class ModelDecodeRunner:
         self.cache.past_tokens = [ctx] * cfg.num_hidden_layers           # the prompt the cache pretends to hold
         self.step_mod = GreedyStep(model)
         self.pos = torch.tensor([[ctx]], device=dev, dtype=torch.long)
-        self.cur = torch.tensor([[1]], device=dev, dtype=torch.long)
-        self.runner = CUDAGraphRunner()
-        with torch.no_grad():
-            self.runner.capture(self.step_mod, self.cur, self.pos, self.pos[0], self.cache, main_device=str(dev))
-        self.tokens = []
+        self.cur = torch.tensor([[1 + 17 * seed]], device=dev, dtype=torch.long)
+        self.runner, self.graph_ok = None, False
+        if use_graph:
+            try:
+                r = CUDAGraphRunner()
+                with torch.no_grad():
+                    r.capture(self.step_mod, self.cur, self.pos, self.pos[0], self.cache, main_device=str(dev))
+                self.runner, self.graph_ok = r, True
+            except Exception as e:   # e.g. collectives that cannot be captured on this stack: stay eager, say so
+                log(f"[bench] graph capture failed ({type(e).__name__}: {e}); running eagerly")
+                torch.cuda.synchronize(dev)
 
     def moe_handles(self):
         return [l.mlp.experts.generate_experts.handle for l in self.model.model.layers if hasattr(l.mlp, "experts")]
@@ -305,8 +311,10 @@ class ModelDecodeRunner:
                 tot += h.weight_bytes()
         return tot
 
+    @torch.no_grad()
     def step(self, i):
-        nxt = self.runner(self.cur, self.pos, self.pos[0])
+        nxt = self.runner(self.cur, self.pos, self.pos[0]) if self.runner is not None else \
+            self.step_mod(self.cur, self.pos, self.cache, self.pos[0])
         self.cur.copy_(nxt)
         self.pos += 1
 
@@ -410,10 +418,11 @@ def main():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--cpu-baseline-only", action="store_true")
-    ap.add_argument("--hot-path", default="full", choices=["full", "moe"],
-                    help="full: MLA attention + router + routed experts per layer; moe: routed experts only")
+    ap.add_argument("--hot-path", default="model", choices=["model", "full", "moe"],
+                    help="model (default): the whole injected DeepSeek-V2-Lite decoder stack, greedy decode (every §8a row: "
+                         "linears, norms, RoPE, MLA attention operator, router, routed + shared experts, lm_head); "
+                         "full: only the MLA kernel + router + routed experts of every layer; moe: routed experts only")
     ap.add_argument("--ctx", type=int, default=4096, help="cached tokens the MLA decode attends over")
-    ap.add_argument("--no-model", action="store_true", help="skip the whole-model greedy-decode measurement (N=1 only)")
     args = ap.parse_args()
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(WORKLOADS[args.workload])), flush=True)
@@ -441,14 +450,27 @@ def main():
     assert E % world == 0
     e_local = E // world
     max_len = max(args.prefill_tokens if not args.no_prefill else 1, world, 1)
-    t0 = time.perf_counter()
-    layers = build_layers(wl, dev, max_len=max_len, expert_begin=rank * e_local, expert_num=e_local)
-    if rank == 0:
-        log(f"[bench] {L} layers x {e_local} experts resident: {sum(h.weight_bytes for h in layers) / 2**30:.2f} GiB packed, "
-            f"built in {time.perf_counter() - t0:.1f}s")
+    whole = args.hot_path == "model" and args.workload == "v2lite-int4"
+    layers = None
+    if not (whole and dist_on):   # stand-alone expert layers: the kernel-level measurements (and the non-model step types)
+        t0 = time.perf_counter()
+        layers = build_layers(wl, dev, max_len=max_len, expert_begin=rank * e_local, expert_num=e_local)
+        if rank == 0:
+            log(f"[bench] {L} layers x {e_local} experts resident: {sum(h.weight_bytes for h in layers) / 2**30:.2f} GiB packed, "
+                f"built in {time.perf_counter() - t0:.1f}s")
 
     # ---------------- decode ----------------
-    if dist_on and args.hot_path == "moe":
+    if whole:
+        if dist_on:   # experts sharded over the ranks, attention / dense parts replicated, one token stream per rank
+            from ktransformers_amd.parallel import enable_expert_parallel
+            enable_expert_parallel()
+        t0 = time.perf_counter()
+        mr = ModelDecodeRunner(dev, args.ctx, args.steps + args.warmup + 64, seed=rank, use_graph=not args.no_graph)
+        if rank == 0:
+            log(f"[bench] whole-model skeleton injected and loaded in {time.perf_counter() - t0:.1f}s"
+                + ("" if mr.graph_ok else " (graph capture failed: eager launches)"))
+        step = mr.step
+    elif dist_on and args.hot_path == "moe":
         runner = ExpertParallelMoE.bench_runner(wl, layers, dev, world, rank, use_graph=not args.no_graph)
         step = runner.step
     else:
@@ -463,18 +485,24 @@ def main():
     decode_tps = tokens_per_step * args.steps / dt
 
     out = {
-        "metric": "decode tokens/s (MoE + MLA hot path, int4 experts resident in HBM)",
+        "metric": "decode tokens/s (DeepSeek-V2-Lite, int4 experts + W4 linears + MLA resident in HBM, whole-model greedy decode)"
+                  if whole else "decode tokens/s (MoE + MLA hot path, int4 experts resident in HBM)",
         "value": round(decode_tps, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": "int8xint4->int32 (bf16 io)", "data": "synthetic",
         "config": {"workload": wl["desc"], "hidden": H, "intermediate": I, "experts": E, "top_k": k, "moe_layers": L,
                    "batch_per_gpu": 1, "parallelism": f"ep{world}" if dist_on else "single",
                    "hip_graph": not args.no_graph,
-                   "step": ("MLA cache-append + absorbed paged attention (ctx %d, %d heads, %d layers) + router + routed "
+                   "step": ("one greedy token through the YAML-injected DeepSeek-V2-Lite: embedding, 27 x [RMSNorm, MLA attention "
+                            "operator (W4-g64 q/kv_a/o projections, YaRN RoPE, absorb, paged MQA over ctx %d, cache append), "
+                            "RMSNorm, dense MLP | router + 6-of-64 AMXINT4 routed experts + W4 shared experts], RMSNorm, W4 "
+                            "lm_head, argmax; the sampled token is fed back; random weights" % args.ctx)
+                   if whole else
+                           ("MLA cache-append + absorbed paged attention (ctx %d, %d heads, %d layers) + router + routed "
                             "experts (%d layers)" % (args.ctx, wl["heads"], wl["attn_layers"], L))
                    + ("; routed experts sharded expert-parallel over %d ranks (all-gather + reduce-scatter per layer), "
                       "attention and router replicated, one token per rank" % world if dist_on else "")
-                   if args.hot_path == "full" else "router-less routed experts only"},
+                   if args.hot_path in ("full", "model") else "router-less routed experts only"},
     }
 
     if not dist_on:
@@ -502,6 +530,17 @@ def main():
             _native.lib.ktx_debug_set(2, 0)
             return tot / (R * L) * 1e3
 
+        if whole:
+            out["weight_bytes_streamed_per_token"] = int(mr.linear_bytes() + L * (k * 3 * H * I * 0.5))
+            del mr
+            torch.cuda.empty_cache()
+            # the MLA kernel + router + routed experts alone (the step this bench timed in its first profiles)
+            rf = FullDecodeRunner(wl, layers, dev, ctx=args.ctx)
+            rf.capture()
+            dtf = timed(rf.step, max(50, args.steps // 2), 10, dev, False)
+            out["mla_router_experts_only"] = {"value": round(max(50, args.steps // 2) / dtf, 2), "unit": "tok/s",
+                                              "ms_per_step": round(dtf / max(50, args.steps // 2) * 1e3, 4)}
+            del rf
         # routed-experts-only decode rate, for continuity with earlier profiles
         rm = DecodeRunner(wl, layers, T=1, dev=dev)
         rm.capture()
@@ -543,25 +582,6 @@ def main():
             out["prefill"] = {"value": round(Tp * psteps / dtp, 1), "unit": "tok/s", "tokens": Tp,
                               "ms_per_chunk": round(dtp / psteps * 1e3, 3),
                               "tflops": round(2 * 3 * H * I * k * Tp * L / (dtp / psteps) / 1e12, 1)}
-        # ---------------- whole model: every operator of the decoder stack, greedy decode -------------------------------
-        if not args.no_model and args.workload == "v2lite-int4":
-            try:
-                t0 = time.perf_counter()
-                msteps = max(50, args.steps // 2)
-                mr = ModelDecodeRunner(dev, args.ctx, msteps + 32)
-                log(f"[bench] whole-model skeleton injected and loaded in {time.perf_counter() - t0:.1f}s")
-                dtw = timed(mr.step, msteps, 10, dev, False)
-                out["whole_model"] = {
-                    "value": round(msteps / dtw, 2), "unit": "tok/s", "ms_per_token": round(dtw / msteps * 1e3, 4),
-                    "what": "DeepSeek-V2-Lite 27 layers end to end (embedding, RMSNorm, W4-g64 linears, MLA operator at ctx %d, "
-                            "router, int4 routed + shared experts, lm_head, greedy argmax), one HIP graph per token, random "
-                            "weights" % args.ctx,
-                    "weight_bytes_streamed_per_token": int(mr.linear_bytes() + L * (gu_bytes + dn_bytes)),
-                }
-                del mr
-                torch.cuda.empty_cache()
-            except Exception as e:   # the whole-model run is an extra; never lose the primary line over it
-                out["whole_model"] = {"error": f"{type(e).__name__}: {e}"}
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
 

@@ -86,6 +86,7 @@ class KExpertsHIP(KExpertsBase):
         self.expert_count = int(kwargs.get("expert_count", n_routed_experts))
         self.handle = None
         self._decode_out = None
+        self._ep = None          # ExpertParallelMoE when ktransformers_amd.parallel.enable_expert_parallel() is on
 
     # the device the kernels run on: "cpu" in a reference YAML means "where KExpertsCPU ran" -> use out_device
     def _hip_device(self) -> torch.device:
@@ -103,6 +104,13 @@ class KExpertsHIP(KExpertsBase):
         dev = self._hip_device()
         if w is None:
             w = self.load_weights(device=str(dev))[self.key]
+        from ktransformers_amd import parallel
+        ep_on = parallel.EP_STATE["enabled"] and torch.distributed.is_available() and torch.distributed.is_initialized()
+        if ep_on:   # shard the experts over the ranks; routing ids stay global
+            world = torch.distributed.get_world_size(parallel.EP_STATE["group"])
+            rank = torch.distributed.get_rank(parallel.EP_STATE["group"])
+            self.expert_begin, self.expert_count = parallel.expert_range(self.n_routed_experts, world, rank)
+            self.max_len = self.max_len * min(world, 8)      # decode gathers every rank's tokens; prefill receives rows
         cfg = self.config
         inter = getattr(cfg, "moe_intermediate_size", None) or cfg.intermediate_size
         if self.method == "GGUF" and "gate_type" not in w:
@@ -139,7 +147,9 @@ class KExpertsHIP(KExpertsBase):
                            prep(w["gate_scale"], torch.bfloat16), prep(w["up_scale"], torch.bfloat16),
                            prep(w["down_scale"], torch.bfloat16))
         self.handle = h
-        if warmup:
+        if ep_on:
+            self._ep = parallel.ExpertParallelMoE(h, parallel.EP_STATE["group"])
+        if warmup and not ep_on:
             x = torch.zeros((1, cfg.hidden_size), dtype=torch.bfloat16, device=dev)
             ids = torch.zeros((1, cfg.num_experts_per_tok), dtype=torch.int64, device=dev)
             self.handle.forward(x, ids, torch.zeros((1, cfg.num_experts_per_tok), dtype=torch.float32, device=dev))
@@ -158,7 +168,11 @@ class KExpertsHIP(KExpertsBase):
         w = weights.to(device=dev, dtype=torch.float32).contiguous()
         if x.dim() == 1:
             x, ids, w = x.unsqueeze(0), ids.unsqueeze(0), w.unsqueeze(0)
-        out = self.handle.forward(x, ids, w, bsz_tensor=bsz_tensor)
+        if self._ep is not None:
+            # decode-sized batches: all-gather + local partial + reduce-scatter; prompts: all-to-all-v dispatch / return
+            out = self._ep.forward(x, ids, w) if x.shape[0] <= 16 else self._ep.forward_prefill(x, ids, w)
+        else:
+            out = self.handle.forward(x, ids, w, bsz_tensor=bsz_tensor)
         return out.to(device=self.out_device if str(self.out_device) != "cuda" else dev)
 
     # reference fast path (experts.py:293-318): enqueue on the capturing stream, result later.  On the GPU both halves

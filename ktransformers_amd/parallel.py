@@ -22,6 +22,17 @@ import torch
 import torch.distributed as dist
 
 
+# Process-wide expert-parallel setting consulted by KExpertsHIP at load(): rule files cannot carry a process group.
+EP_STATE = {"enabled": False, "group": None}
+
+
+def enable_expert_parallel(group=None, enabled: bool = True) -> None:
+    """After torch.distributed.init_process_group: every KExpertsHIP loaded from now on owns experts
+    expert_range(E, world, rank) and runs its forward through the EP choreography below."""
+    EP_STATE["enabled"] = bool(enabled)
+    EP_STATE["group"] = group
+
+
 def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
                       x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, group=None) -> torch.Tensor:
     """x bf16 [T,H], ids int64 [T,k], w fp32 [T,k] (this rank's tokens) -> bf16 [T,H].
