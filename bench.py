@@ -1,18 +1,22 @@
 #!/usr/bin/env python3
-"""bench.py — hot-path throughput of the MI355X-native quantized-MoE path.
+"""bench.py — decode / prefill throughput of the MI355X-native quantized-MoE + MLA hot path.
 
 Contract (driver):  python bench.py --gpus N --steps K --warmup W      (N>1: launched under torch.distributed.run)
 prints ONE JSON line on rank 0.
 
-Workload (BASELINE.json configs[1], the largest configuration that fits one GPU with parity pinned):
-  DeepSeek-V2-Lite routed experts, AMXINT4 ("int4") weights resident in HBM: H=2048, I=1408, E=64, k=6, 26 MoE layers.
-  One decode "step" = one new token (batch 1) through the routed-expert hot path of all 26 MoE layers
-  (ktx_moe_forward per layer: bucket + activation quant + gate/up GEMM + SiLU*up + requant + down GEMM + combine),
-  replayed from one HIP graph; routing ids/weights change every step so successive steps hit different experts.
-  value = decode tokens/s (whole job).  `prefill` in the same line = tokens/s of one 2048-token prompt chunk through
-  the same 26 layers.
-N>1: experts are sharded E/N per rank (expert parallel), every rank decodes its own stream (weak scaling); per layer the
-  ranks all-gather [x, ids, w], run their local experts, and reduce-scatter the fp32-equivalent partial outputs (RCCL).
+Workload (BASELINE.json configs[1], the largest configuration that fits one GPU with parity pinned): DeepSeek-V2-Lite
+(27 layers, H=2048, 16 heads, MLA kv_lora 512 + rope 64, 64 routed experts top-6 + 2 shared, I=1408, vocab 102400) with
+AMXINT4 ("int4") routed experts and W4-g64 (Marlin semantics) linears, all resident in HBM; synthetic seeded weights.
+
+One "step" (default --hot-path model) = one greedy decode token (batch 1) through the WHOLE YAML-injected decoder stack —
+every §8(a) row: embedding, RMSNorm, MLA attention operator (projections, YaRN RoPE, absorb, paged MQA over --ctx cached
+tokens, cache append), router, routed + shared experts, lm_head, argmax — replayed as one HIP graph; the sampled token is
+fed back, so routing follows the model.  value = tokens/s of the whole job.
+N>1: every rank decodes its own token stream (weak scaling); attention / dense parts are replicated, the routed experts are
+sharded E/N per rank (expert parallel): per MoE layer all-gather [x, ids, w] -> local experts -> reduce-scatter (RCCL).
+Extra fields at N=1: `mla_router_experts_only` (the MLA kernel + router + routed experts of every layer, nothing else),
+`moe_only`, `prefill` (2048-token chunk through the routed experts), `roofline` (dominant decode kernel: algorithmic bytes
+/ launch time measured live with HIP events, + PMC traffic), `cpu_baseline` (the reference's own kernels on the host cores).
 """
 from __future__ import annotations
 
