@@ -113,3 +113,26 @@ def test_decode_with_fused_cache_append():
     torch.cuda.synchronize()
     torch.testing.assert_close(out.float().cpu(), ref.to(torch.bfloat16).float(), rtol=2.0 ** -7, atol=5e-3)
     assert torch.equal(kvd.cpu(), ref_buf), "the kernel must leave the appended rows in the cache"
+
+
+def test_decode_at_128k_context():
+    """BASELINE.json configs[4]: 128K-token paged latent cache (151 MB per layer), V3 head count.  The oracle's per-head
+    K replication would need 19 GB here, so the same math (scores = q . lat^T, fp32 softmax, P . ckv) is evaluated as two
+    plain fp32 matmuls over the latent rows."""
+    from ktransformers_amd._native import MLAWrapper
+    g = torch.Generator().manual_seed(9)
+    Hq, page, n = 128, 64, 131072 - 17
+    pages = (n + page - 1) // page
+    kv = (torch.randn((pages, page, 576), generator=g)).to(torch.bfloat16)
+    qn = torch.randn((1, Hq, 512), generator=g).to(torch.bfloat16)
+    qp = torch.randn((1, Hq, 64), generator=g).to(torch.bfloat16)
+    sm = 192 ** -0.5
+    lat = kv.reshape(-1, 576)[:n].float()
+    logits = (torch.cat([qn, qp], -1)[0].float() @ lat.T) * sm
+    ref = torch.softmax(logits, -1) @ lat[:, :512]
+    w = MLAWrapper(1, pages, device=DEV, max_q_tokens=1, max_splits=1024)
+    kvd = kv.to(DEV)
+    ckv, k_pe = torch.split(kvd, [512, 64], dim=-1)
+    w.plan(None, None, None, torch.tensor([n], dtype=torch.int32, device=DEV), None, Hq, 512, 64, page, sm, max_kv_len=n)
+    out = w.run(qn.to(DEV), qp.to(DEV), ckv, k_pe)
+    torch.testing.assert_close(out[0].float().cpu(), ref.to(torch.bfloat16).float(), rtol=5e-3, atol=5e-3)
