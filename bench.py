@@ -315,6 +315,10 @@ class ModelDecodeRunner:
                 tot += h.weight_bytes()
         return tot
 
+    def rewind(self, n):
+        """Forget n generated positions (pre-warm steps): the timed run starts at the configured context length again."""
+        self.pos -= n
+
     @torch.no_grad()
     def step(self, i):
         nxt = self.runner(self.cur, self.pos, self.pos[0]) if self.runner is not None else \
@@ -469,11 +473,21 @@ def main():
             from ktransformers_amd.parallel import enable_expert_parallel
             enable_expert_parallel()
         t0 = time.perf_counter()
-        mr = ModelDecodeRunner(dev, args.ctx, args.steps + args.warmup + 64, seed=rank, use_graph=not args.no_graph)
+        mr = ModelDecodeRunner(dev, args.ctx, args.steps + args.warmup + 464, seed=rank, use_graph=not args.no_graph)
         if rank == 0:
             log(f"[bench] whole-model skeleton injected and loaded in {time.perf_counter() - t0:.1f}s"
                 + ("" if mr.graph_ok else " (graph capture failed: eager launches)"))
         step = mr.step
+        # bring the GPU to its sustained clocks before the driver's W warm-up + K timed steps: a fresh process that has only
+        # loaded weights starts the first few hundred graph replays at idle clocks (measured: 390 vs 465 tok/s)
+        t_pre = time.perf_counter()
+        n_pre = 0
+        while time.perf_counter() - t_pre < 0.7 and n_pre < 400:
+            for _ in range(20):
+                mr.step(n_pre)
+                n_pre += 1
+            torch.cuda.synchronize(dev)
+        mr.rewind(n_pre)
     elif dist_on and args.hot_path == "moe":
         runner = ExpertParallelMoE.bench_runner(wl, layers, dev, world, rank, use_graph=not args.no_graph)
         step = runner.step

@@ -40,20 +40,19 @@ class KDeepseekV3MLP(BaseInjectedModule):
             load_weights(gate, self.gguf_loader, self.key + ".gate_proj.")
             load_weights(up, self.gguf_loader, self.key + ".up_proj.")
 
-    def forward(self, x: torch.Tensor, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
-                norm: tuple | None = None, pre_norm=None) -> torch.Tensor:
+    def gate_up(self, x: torch.Tensor, norm: tuple | None = None) -> torch.Tensor:
+        """First half: act_fn(gate_proj(x)) * up_proj(x) -> [T, intermediate] (one launch when merged)."""
         from ktransformers_amd._native import rmsnorm, silu_mul
 
-        if pre_norm is not None:
-            norm = (pre_norm.weight, pre_norm.variance_epsilon)
-        shape = x.shape
-        x2 = x.reshape(-1, shape[-1])
-        if self._gate_up is not None:       # one launch: merged GEMV with the SiLU * up epilogue
-            a = self._gate_up.forward(x2, norm=norm, glu=True)
-        else:
-            if norm is not None:
-                x2 = rmsnorm(x2, norm[0], norm[1], native_rounding=True)
-            a = silu_mul(torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1))
+        x2 = x.reshape(-1, x.shape[-1])
+        if self._gate_up is not None:       # merged GEMV with the SiLU * up epilogue
+            return self._gate_up.forward(x2, norm=norm, glu=True)
+        if norm is not None:
+            x2 = rmsnorm(x2, norm[0], norm[1], native_rounding=True)
+        return silu_mul(torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1))
+
+    def down(self, a: torch.Tensor, shape, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None) -> torch.Tensor:
+        """Second half: down_proj(a) (+ add1, + add2 in its epilogue)."""
         down = self.orig_module.down_proj
         fusion = {k: v.reshape(-1, shape[-1]) for k, v in (("add1", add1), ("add2", add2)) if v is not None}
         if isinstance(down, KTransformersLinear):
@@ -63,6 +62,12 @@ class KDeepseekV3MLP(BaseInjectedModule):
             for v in fusion.values():
                 y = v + y
         return y.reshape(*shape[:-1], y.shape[-1])
+
+    def forward(self, x: torch.Tensor, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
+                norm: tuple | None = None, pre_norm=None) -> torch.Tensor:
+        if pre_norm is not None:
+            norm = (pre_norm.weight, pre_norm.variance_epsilon)
+        return self.down(self.gate_up(x, norm), x.shape, add1, add2)
 
 
 kDeepseekV3MLP = KDeepseekV3MLP
