@@ -283,6 +283,9 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
   float* s_ad = reinterpret_cast<float*>(smem + 2 * BUF_BYTES);     // [MT*16]
   int* s_src = reinterpret_cast<int*>(s_ad + MT * 16);              // [MT*16]
 
+  // (an XCD-aware remap that runs the 3-4 token tiles sharing an expert's weight strips back to back on one XCD was
+  // measured: no change at T = 2048 — the re-reads are absorbed by the 256 MB Infinity Cache; the kernel is bound by the
+  // one-chunk prefetch distance)
   const int tile_idx = blockIdx.y;
   if (tile_idx >= p.counters[0]) return;
   const Tile tile = p.tiles[tile_idx];
@@ -361,16 +364,21 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
         v4i a[NMAT][2];
 #pragma unroll
         for (int m = 0; m < NMAT; m++) unpack_wfrag<WBITS>(w[s][m], a[m][0], a[m][1]);
+        // both halves of every (matrix, token-tile) accumulator are issued a full round apart: back-to-back MFMAs on the
+        // same accumulator would each wait out the previous one's latency
+        v4i b[MT][2];
 #pragma unroll
         for (int t = 0; t < MT; t++) {
-          const v4i b0 = *reinterpret_cast<const v4i*>(bb + ((t * COLS + s * 8) * 16) * 16);
-          const v4i b1 = *reinterpret_cast<const v4i*>(bb + ((t * COLS + s * 8 + 1) * 16) * 16);
-#pragma unroll
-          for (int m = 0; m < NMAT; m++) {
-            acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m][0], b0, acc[m][t], 0, 0, 0);
-            acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m][1], b1, acc[m][t], 0, 0, 0);
-          }
+          b[t][0] = *reinterpret_cast<const v4i*>(bb + ((t * COLS + s * 8) * 16) * 16);
+          b[t][1] = *reinterpret_cast<const v4i*>(bb + ((t * COLS + s * 8 + 1) * 16) * 16);
         }
+#pragma unroll
+        for (int hh = 0; hh < 2; hh++)
+#pragma unroll
+          for (int t = 0; t < MT; t++)
+#pragma unroll
+            for (int m = 0; m < NMAT; m++)
+              acc[m][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a[m][hh], b[t][hh], acc[m][t], 0, 0, 0);
       }
     }
   };
