@@ -520,10 +520,9 @@ class GateHandle:
                                        b.data_ptr() if b is not None else None, logits.data_ptr(), cnt.data_ptr(),
                                        idx.data_ptr(), wt.data_ptr(), st))
             return idx, wt
-        if False:
-            pass
-        else:  # F.linear in fp32, exactly the reference's expression (modeling_deepseek_v3.py:434-437)
-            logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
+        # large batches: F.linear in fp32, exactly the reference's expression (modeling_deepseek_v3.py:434-437) — a plain
+        # library GEMM — then the HIP selection kernel
+        logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
         idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
         w = torch.empty((T, self.k), dtype=torch.float32, device=dev)
         b = None

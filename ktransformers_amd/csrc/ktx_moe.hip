@@ -1687,15 +1687,12 @@ static int launch_gemm(const GemmParams& p, int max_tiles, hipStream_t st) {
   return 0;
 }
 
-extern int g_dbg_fwd[8];
 template <int WBITS, bool GATE_UP>
 static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_t st) {
   switch (mt) {
     case 1: return launch_gemm<WBITS, 1, 4, GATE_UP>(p, max_tiles, st);
     case 2: return launch_gemm<WBITS, 2, 4, GATE_UP>(p, max_tiles, st);
-    default:
-      if (g_dbg_fwd[3] == 1) return launch_gemm<WBITS, 4, 4, GATE_UP>(p, max_tiles, st);   // dev knob: 512-k chunks
-      return launch_gemm<WBITS, 4, 2, GATE_UP>(p, max_tiles, st);
+    default: return launch_gemm<WBITS, 4, 2, GATE_UP>(p, max_tiles, st);   // (512-k chunks, SPC = 4, measured slower)
   }
 }
 
@@ -1730,9 +1727,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
 static bool g_prof_on = false;
 static bool g_force_generic = false;  // tests: route small batches through the grouped (prefill) path too
 extern "C" int ktx_debug_force_generic(int on) { g_force_generic = on != 0; return 0; }
-int g_dbg_fwd[8] = {0};
-#define g_dbg g_dbg_fwd
-static int g_dbg_unused_[1] = {0};  // dev knobs: [0] waves/workgroup override of the decode gate/up kernel, [1] ablation bits
+static int g_dbg[8] = {0};  // dev knobs: [0] waves/workgroup override of the decode gate/up kernel, [1] ablation bits
 extern "C" int ktx_debug_set(int idx, int val) { if (idx >= 0 && idx < 8) g_dbg[idx] = val; return 0; }
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[5];
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;

@@ -1,4 +1,4 @@
-"""Dev probe: routed-expert prefill chunk (T tokens through L V2-Lite layers), optional knob ktx_debug_set(3, 1) = 512-k chunks."""
+"""Dev probe: routed-expert prefill chunk (T tokens through L V2-Lite layers); used for the PMC pass in profiles/r01_pmc_prefill.json."""
 import os
 import sys
 import time
@@ -13,8 +13,7 @@ wl = dict(bench.WORKLOADS["v2lite-int4"])
 wl["L"] = int(os.environ.get("L", "4"))
 T = int(os.environ.get("T", "2048"))
 layers = bench.build_layers(wl, dev, max_len=T)
-for knob in ([int(os.environ["KNOB"])] if "KNOB" in os.environ else [0, 1]):
-    _native.lib.ktx_debug_set(3, knob)
+for knob in (0,):
     rp = bench.DecodeRunner(wl, layers, T=T, dev=dev, nsets=2, seed=5)
     for i in range(3):
         rp.step(i)
