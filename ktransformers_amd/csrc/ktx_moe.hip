@@ -213,12 +213,50 @@ __global__ __launch_bounds__(1024) void moe_prep_kernel(PrepParams p) {
 // =====================================================================================================
 // Kq: per-row int8 quantisation of the activated intermediate (a11: down_ba_->from_mat, moe_base.hpp:378-384)
 // =====================================================================================================
-__global__ __launch_bounds__(256) void moe_actquant_kernel(const bf16_t* __restrict__ a, int K, int8_t* __restrict__ a_q,
+__device__ __forceinline__ uint2 quant8(const uint4& v, float id);
+__device__ __forceinline__ float amax8(const uint4& v, float m);
+// One workgroup per sorted row.  gu = [row][g | u] bf16 from the gate/up GEMM: a = bf16(act_fn(g, u)) (a10,
+// moe_base.hpp:693-726) is formed in registers (K <= 8192: four 8-element pieces per thread), then quantised per row exactly
+// like quant_row_block (d = amax/127, q = sat8(rne(a * (1/d)))).
+__global__ __launch_bounds__(256) void moe_actquant_kernel(const bf16_t* __restrict__ gu, int K, int8_t* __restrict__ a_q,
                                                            float* __restrict__ a_d, const int32_t* counters) {
   __shared__ float s_red[4];
   const int row = blockIdx.x;
   if (row >= counters[1]) return;
-  quant_row_block(a + (size_t)row * K, K, a_q + (size_t)row * K, a_d + row, s_red);
+  const int tid = threadIdx.x;
+  const bf16_t* gr = gu + (size_t)row * 2 * K;
+  uint4 av[4];
+  float amax = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = (tid + i * 256) * 8;
+    av[i] = make_uint4(0, 0, 0, 0);
+    if (j < K) {
+      const uint4 g = *reinterpret_cast<const uint4*>(gr + j), u = *reinterpret_cast<const uint4*>(gr + K + j);
+      const uint32_t gw[4] = {g.x, g.y, g.z, g.w}, uw[4] = {u.x, u.y, u.z, u.w};
+      uint32_t o[4];
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const bf16_t lo = f32_to_bf16(act_fn(bf16_to_f32((bf16_t)(gw[q] & 0xffffu)), bf16_to_f32((bf16_t)(uw[q] & 0xffffu))));
+        const bf16_t hi = f32_to_bf16(act_fn(bf16_to_f32((bf16_t)(gw[q] >> 16)), bf16_to_f32((bf16_t)(uw[q] >> 16))));
+        o[q] = (uint32_t)lo | ((uint32_t)hi << 16);
+      }
+      av[i] = make_uint4(o[0], o[1], o[2], o[3]);
+      amax = amax8(av[i], amax);
+    }
+  }
+  amax = wave_max(amax);
+  if ((tid & 63) == 0) s_red[tid >> 6] = amax;
+  __syncthreads();
+  const float m = fmaxf(fmaxf(s_red[0], s_red[1]), fmaxf(s_red[2], s_red[3]));
+  const float d = m / 127.0f;
+  const float id = d ? 1.0f / d : 0.0f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = (tid + i * 256) * 8;
+    if (j < K) *reinterpret_cast<uint2*>(a_q + (size_t)row * K + j) = quant8(av[i], id);
+  }
+  if (tid == 0) a_d[row] = d;
 }
 
 // =====================================================================================================
@@ -331,29 +369,36 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
       }
     }
   };
+  // staging unit `it` of this thread: a fixed (token row, 16-byte column) — its global row pointer and LDS slot are
+  // computed once, the chunk loop only adds c*KC (the per-chunk address arithmetic was ~1/4 of the kernel's instructions)
+  const int8_t* gsrc[UPT];
+  int gcol[UPT], lds_off[UPT];
+#pragma unroll
+  for (int it = 0; it < UPT; it++) {
+    const int g = it * 4 + wave;
+    gsrc[it] = nullptr;
+    gcol[it] = 0;
+    lds_off[it] = 0;
+    if (g < GROUPS) {
+      const int mt = g / (SPC * 2), col = (g % (SPC * 2)) * 4 + (lane >> 4);
+      const int src = s_src[mt * 16 + (lane & 15)];
+      gcol[it] = col * 16;
+      lds_off[it] = ((mt * COLS + col) * 16 + (lane & 15)) * 16;
+      if (src >= 0) gsrc[it] = p.act_q + (size_t)src * p.K + col * 16;
+    }
+  }
   auto load_b = [&](int c) {
 #pragma unroll
     for (int it = 0; it < UPT; it++) {
-      const int g = it * 4 + wave;
       uint4 v = make_uint4(0, 0, 0, 0);
-      if (g < GROUPS) {
-        const int mt = g / (SPC * 2), col = (g % (SPC * 2)) * 4 + (lane >> 4);
-        const int src = s_src[mt * 16 + (lane & 15)];
-        const int kb = c * KC + col * 16;
-        if (src >= 0 && kb < p.K) v = *reinterpret_cast<const uint4*>(p.act_q + (size_t)src * p.K + kb);
-      }
+      if (gsrc[it] && c * KC + gcol[it] < p.K) v = *reinterpret_cast<const uint4*>(gsrc[it] + c * KC);
       breg[it] = v;
     }
   };
   auto store_b = [&](int buf) {
 #pragma unroll
-    for (int it = 0; it < UPT; it++) {
-      const int g = it * 4 + wave;
-      if (g < GROUPS) {
-        const int mt = g / (SPC * 2), col = (g % (SPC * 2)) * 4 + (lane >> 4);
-        *reinterpret_cast<uint4*>(Bs + buf * BUF_BYTES + ((mt * COLS + col) * 16 + (lane & 15)) * 16) = breg[it];
-      }
-    }
+    for (int it = 0; it < UPT; it++)
+      if (it * 4 + wave < GROUPS) *reinterpret_cast<uint4*>(Bs + buf * BUF_BYTES + lds_off[it]) = breg[it];
   };
   auto compute = [&](WFrag<WBITS>(&w)[SPC][NMAT], int c, int buf) {
     if (!strip_ok) return;
@@ -415,20 +460,21 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
     const int row = t * 16 + tok;
     if (row < tile.nrows) {
       const float ad = s_ad[row];
-      bf16_t o[4];
+      bf16_t o[4], o2[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        // GemmKernel224Int4::apply_scale: (a_d * b_d) * float(acc)   (la/amx_kernels.hpp:1808-1846)
-        const bf16_t g = f32_to_bf16((ad * s0v[r]) * (float)acc[0][t][r]);
-        if constexpr (GATE_UP) {
-          const bf16_t u = f32_to_bf16((ad * s1v[r]) * (float)acc[1][t][r]);
-          o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
-        } else {
-          o[r] = g;
-        }
+        // GemmKernel224Int4::apply_scale: (a_d * b_d) * float(acc)   (la/amx_kernels.hpp:1808-1846), then bf16 (a9)
+        o[r] = f32_to_bf16((ad * s0v[r]) * (float)acc[0][t][r]);
+        if constexpr (GATE_UP) o2[r] = f32_to_bf16((ad * s1v[r]) * (float)acc[1][t][r]);
       }
-      uint2 pk = make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
-      *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * p.N + n0) = pk;
+      // gate/up: both bf16 results are stored ([row][g | u]); SiLU(g)*u (a10) is applied by moe_actquant_kernel, which has
+      // to read the row anyway — the ~40-instruction polynomial per element was a third of this kernel's issue slots
+      const int ld = GATE_UP ? 2 * p.N : p.N;
+      *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * ld + n0) =
+          make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+      if constexpr (GATE_UP)
+        *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * ld + p.N + n0) =
+            make_uint2((uint32_t)o2[0] | ((uint32_t)o2[1] << 16), (uint32_t)o2[2] | ((uint32_t)o2[3] << 16));
     }
   }
 }
@@ -1415,6 +1461,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_REQUIRE(cfg->hidden_size % 128 == 0 && cfg->intermediate_size % 128 == 0,
               "ktx_moe_create: hidden_size and intermediate_size must be multiples of 128 (reference: K % 128 == 0)");
   KTX_REQUIRE(cfg->max_len > 0, "ktx_moe_create: max_len must be positive");
+  KTX_REQUIRE(cfg->intermediate_size <= 8192 || cfg->format > KTX_FMT_AMXINT8, "ktx_moe_create: intermediate_size > 8192 is not supported for the int formats");
   KTX_HIP(hipSetDevice(cfg->device));
   ktx_moe_s* h = new ktx_moe_s();
   h->cfg = *cfg;
@@ -1447,7 +1494,8 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
     KTX_HIP(hipDeviceSynchronize());
     KTX_HIP(grow(w->x_q, w->cap[0], (size_t)cfg->max_len * H));
     KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? H / 32 : gguf ? H / 256 : 1)));
-    KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * (gguf ? sizeof(float) : sizeof(bf16_t))));
+    // int formats: the grouped gate/up GEMM stores g | u (2*I bf16 per row); GGUF: fp32 intermediates
+    KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * (gguf ? sizeof(float) : 2 * sizeof(bf16_t))));
     KTX_HIP(grow(w->a_q, w->cap[3], (size_t)h->max_pairs * I));
     KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? I / 32 : gguf ? I / 256 : 1)));
     KTX_HIP(grow(w->dn_buf, w->cap[5], (size_t)h->max_pairs * H * (gguf ? sizeof(float) : sizeof(bf16_t))));
