@@ -40,7 +40,7 @@ enum ktx_moe_format {
   KTX_FMT_RAWINT4 = 2, /* Kimi-K2 compressed-tensors int4, group 32, bf16 scales          (amx/k2-moe.hpp) */
   KTX_FMT_FP8 = 3,     /* DeepSeek e4m3 + 128x128 block scale_inv, bf16 activations       (amx/fp8-moe.hpp) */
   KTX_FMT_BF16 = 4,    /* bf16 weights                                                    (amx/bf16-moe.hpp) */
-  KTX_FMT_GGUF = 5,    /* GGUF k-quant blocks (Q4_K / Q6_K) x Q8_K activations — the llamafile backend (operators/llamafile/moe.hpp) */
+  KTX_FMT_GGUF = 5,    /* GGUF k-/i-quant blocks (Q4_K / Q6_K / IQ1_S) x Q8_K activations — the llamafile backend (operators/llamafile/moe.hpp) */
 };
 
 enum ktx_moe_matrix { KTX_MAT_GATE = 0, KTX_MAT_UP = 1, KTX_MAT_DOWN = 2 };
@@ -91,7 +91,8 @@ int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void* d_up, cons
 /* GGUF k-quant experts (the llamafile backend: LLAMA_MOE_TP::load_weights, operators/llamafile/moe.hpp:104-176; the
  * archive engine hands it mmap'ed `blk.N.ffn_{gate,up,down}_exps.weight`, archive/ktransformers/operators/experts.py:
  * 177-224): raw ggml blocks gate/up [expert_num][I][H/256 blocks], down [expert_num][H][I/256 blocks], DEVICE pointers,
- * with their ggml type ids (MOEConfig gate_type/up_type/down_type).  Supported: Q4_K (12), Q6_K (14) — the q4_k_m mix;
+ * with their ggml type ids (MOEConfig gate_type/up_type/down_type).  Supported: Q4_K (12), Q6_K (14) — the q4_k_m mix — and IQ1_S (19; its only in-tree definition is the reference's
+ * mul_mat_iq1_s_q8_K, third_party/llamafile/iqk_mul_mat.inc:2689-2770);
  * gate and up must share a type.  The handle re-tiles into its own layout.  Synchronous. */
 int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, int gate_type, int up_type,
                       int down_type);

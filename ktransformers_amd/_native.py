@@ -15,8 +15,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libktx_hip.so")
 
 FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4, "GGUF": 5}
-GGML_TYPE_Q4_K, GGML_TYPE_Q6_K = 12, 14
-GGML_BLOCK_BYTES = {12: 144, 14: 210}
+GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 14, 19
+GGML_BLOCK_BYTES = {12: 144, 14: 210, 19: 50}
 MAT_GATE, MAT_UP, MAT_DOWN = 0, 1, 2
 
 
@@ -219,7 +219,7 @@ class MoEHandle:
         """Raw GGUF blocks (uint8 device tensors): gate/up [E, I, H/256*blk], down [E, H, I/256*blk]; ggml type ids."""
         for t, n, kdim, ty in ((gate, self.I, self.H, gate_type), (up, self.I, self.H, up_type), (down, self.H, self.I, down_type)):
             if ty not in GGML_BLOCK_BYTES:
-                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q4_K=12, Q6_K=14)")
+                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q4_K=12, Q6_K=14, IQ1_S=19)")
             shape = (self.E, n, kdim // 256 * GGML_BLOCK_BYTES[ty])
             if t.dtype != torch.uint8 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
                 raise KtxError(f"load_gguf: expected contiguous uint8 {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")

@@ -1540,7 +1540,7 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
   KTX_REQUIRE(h->cfg.format == KTX_FMT_GGUF, "ktx_moe_load_gguf: handle was not created with KTX_FMT_GGUF");
   const int types[3] = {gate_type, up_type, down_type};
   for (int t : types)
-    KTX_REQUIRE(t == GG_Q4K || t == GG_Q6K, "ktx_moe_load_gguf: supported ggml types are Q4_K (12) and Q6_K (14)");
+    KTX_REQUIRE(t == GG_Q4K || t == GG_Q6K || t == GG_IQ1S, "ktx_moe_load_gguf: supported ggml types are Q4_K (12), Q6_K (14) and IQ1_S (19)");
   KTX_HIP(hipSetDevice(h->cfg.device));
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
@@ -1556,6 +1556,8 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
     for (int e = 0; e < E; e++) {
       if (types[m] == GG_Q4K)
         hipLaunchKernelGGL(gg_pack_q4k_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
+      else if (types[m] == GG_IQ1S)
+        hipLaunchKernelGGL(gg_pack_iq1s_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
       else
         hipLaunchKernelGGL(gg_pack_q6k_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
     }
@@ -2109,8 +2111,8 @@ extern "C" int ktx_moe_combine(int qlen, int k, int hidden, const void* d_rows, 
 
 template <int WT, int MT, bool GATE_UP>
 static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
-  constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = WT == GG_Q4K ? 8 : 16;
-  const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4;
+  constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = WT == GG_Q6K ? 16 : 8;
+  const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4 + (WT == GG_IQ1S ? 2048 * 8 : 0);
   hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
@@ -2152,7 +2154,9 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   int rc;
   {
     ProfScope ps(1, st);
-    rc = h->gg_type[0] == GG_Q4K ? launch_gguf_mt<GG_Q4K, true>(mt, g1, max_tiles, st) : launch_gguf_mt<GG_Q6K, true>(mt, g1, max_tiles, st);
+    rc = h->gg_type[0] == GG_Q4K ? launch_gguf_mt<GG_Q4K, true>(mt, g1, max_tiles, st)
+         : h->gg_type[0] == GG_Q6K ? launch_gguf_mt<GG_Q6K, true>(mt, g1, max_tiles, st)
+                                   : launch_gguf_mt<GG_IQ1S, true>(mt, g1, max_tiles, st);
   }
   if (rc) return rc;
   {
@@ -2167,7 +2171,9 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   g2.counters = ws->counters; g2.out = reinterpret_cast<float*>(ws->dn_buf);
   {
     ProfScope ps(3, st);
-    rc = h->gg_type[2] == GG_Q4K ? launch_gguf_mt<GG_Q4K, false>(mt, g2, max_tiles, st) : launch_gguf_mt<GG_Q6K, false>(mt, g2, max_tiles, st);
+    rc = h->gg_type[2] == GG_Q4K ? launch_gguf_mt<GG_Q4K, false>(mt, g2, max_tiles, st)
+         : h->gg_type[2] == GG_Q6K ? launch_gguf_mt<GG_Q6K, false>(mt, g2, max_tiles, st)
+                                   : launch_gguf_mt<GG_IQ1S, false>(mt, g2, max_tiles, st);
   }
   if (rc) return rc;
   CombineParams cp{};

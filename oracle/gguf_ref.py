@@ -11,8 +11,8 @@ import ctypes as C
 
 import numpy as np
 
-GGML_TYPE_Q4_K, GGML_TYPE_Q6_K = 12, 14
-BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q6_K: 210}
+GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 14, 19
+BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
 
 
 def dequantize_q4_k(data: np.ndarray) -> np.ndarray:
@@ -97,8 +97,77 @@ def quantize_q6_k(w: np.ndarray) -> np.ndarray:
     return out.reshape(*lead, -1)
 
 
-QUANT = {GGML_TYPE_Q4_K: quantize_q4_k, GGML_TYPE_Q6_K: quantize_q6_k}
-DEQUANT = {GGML_TYPE_Q4_K: dequantize_q4_k, GGML_TYPE_Q6_K: dequantize_q6_k}
+_GRID = None
+
+
+def iq1s_grid() -> np.ndarray:
+    """[2048, 8] int8 grid points in {-1, 0, +1} (the codebook the C oracle compiles in; format constant)."""
+    global _GRID
+    if _GRID is None:
+        from oracle.oracle import Oracle
+        lib = Oracle().lib
+        lib.ktxo_iq1s_grid.restype = C.POINTER(C.c_uint16)
+        packed = np.ctypeslib.as_array(lib.ktxo_iq1s_grid(), shape=(2048,)).astype(np.int32)
+        _GRID = np.stack([((packed >> (2 * e)) & 3) - 1 for e in range(8)], axis=1).astype(np.int8)
+    return _GRID
+
+
+def dequantize_iq1_s(data: np.ndarray) -> np.ndarray:
+    """uint8 [..., nblk*50] -> float32 [..., nblk*256]:  w = d * (2s+1) * (g +- 0.125)."""
+    lead = data.shape[:-1]
+    b = np.ascontiguousarray(data).reshape(-1, 50)
+    nb = b.shape[0]
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32).reshape(nb, 1, 1, 1)
+    qs = b[:, 2:34].reshape(nb, 8, 4).astype(np.int32)
+    qh = b[:, 34:50].copy().view(np.uint16).astype(np.int32).reshape(nb, 8)
+    idx = qs | (((qh[:, :, None] >> (3 * np.arange(4))[None, None, :]) & 7) << 8)
+    g = iq1s_grid()[idx].astype(np.float32)                                 # [nb, 8, 4, 8]
+    scale = (2 * ((qh >> 12) & 7) + 1).astype(np.float32)[:, :, None, None]
+    delta = np.where(qh & 0x8000, -0.125, 0.125).astype(np.float32)[:, :, None, None]
+    return (d * scale * (g + delta)).astype(np.float32).reshape(*lead, -1)
+
+
+def quantize_iq1_s(w: np.ndarray) -> np.ndarray:
+    """Simple test encoder: per 32-weight sub-block pick scale s in 0..7 and delta sign, per 8 weights the nearest grid
+    point (brute force over the 2048 entries)."""
+    lead = w.shape[:-1]
+    x = np.ascontiguousarray(w, dtype=np.float32).reshape(-1, 8, 4, 8)        # [nb, ib, l, e]
+    nb = x.shape[0]
+    grid = iq1s_grid().astype(np.float32)                                       # [2048, 8]
+    amax = np.abs(x).reshape(nb, -1).max(axis=1)
+    d = (amax / 15.0 / 1.125).astype(np.float16)
+    df = np.maximum(d.astype(np.float32), 1e-30)
+    sub = np.abs(x).reshape(nb, 8, -1).max(axis=2) / 1.125                      # wanted d*(2s+1)
+    s = np.clip(np.rint((sub / df[:, None] - 1) / 2), 0, 7).astype(np.int32)
+    dl = df[:, None] * (2 * s + 1)
+    out = np.zeros((nb, 50), np.uint8)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    qh = (s << 12).astype(np.int32)
+    choice = {}
+    g2 = (grid ** 2).sum(-1)                                                    # [2048]
+    for sign, delta in ((0, 0.125), (1, -0.125)):
+        t = (x / dl[:, :, None, None] - delta).reshape(-1, 8)                   # target grid values, one row per 8 weights
+        idx = np.empty(t.shape[0], np.int64)
+        err = np.empty(t.shape[0], np.float32)
+        for s0 in range(0, t.shape[0], 1 << 16):                                # nearest grid point: |t-g|^2 = |t|^2 - 2 t.g + |g|^2
+            tt = t[s0:s0 + (1 << 16)]
+            dist = g2[None, :] - 2.0 * (tt @ grid.T)
+            ii = dist.argmin(-1)
+            idx[s0:s0 + len(tt)] = ii
+            err[s0:s0 + len(tt)] = dist[np.arange(len(tt)), ii] + (tt ** 2).sum(-1)
+        choice[sign] = (idx.reshape(nb, 8, 4), err.reshape(nb, 8, 4).sum(-1))
+    use_neg = choice[1][1] < choice[0][1]
+    idx = np.where(use_neg[:, :, None], choice[1][0], choice[0][0])              # [nb, 8, 4]
+    qh |= np.where(use_neg, 0x8000, 0)
+    for l in range(4):
+        qh |= ((idx[:, :, l] >> 8) & 7) << (3 * l)
+    out[:, 2:34] = (idx & 0xFF).astype(np.uint8).reshape(nb, 32)
+    out[:, 34:50] = qh.astype(np.uint16).view(np.uint8).reshape(nb, 16)
+    return out.reshape(*lead, -1)
+
+
+QUANT = {GGML_TYPE_Q4_K: quantize_q4_k, GGML_TYPE_Q6_K: quantize_q6_k, GGML_TYPE_IQ1_S: quantize_iq1_s}
+DEQUANT = {GGML_TYPE_Q4_K: dequantize_q4_k, GGML_TYPE_Q6_K: dequantize_q6_k, GGML_TYPE_IQ1_S: dequantize_iq1_s}
 
 
 class _GgufMoe(C.Structure):

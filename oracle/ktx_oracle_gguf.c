@@ -26,6 +26,12 @@
 #define QK_K 256
 #define GGML_TYPE_Q4_K 12
 #define GGML_TYPE_Q6_K 14
+#define GGML_TYPE_IQ1_S 19
+
+/* IQ1_S codebook (format constant), packed 2 bits per weight: see tests/golden/make_iq1s_grid.py */
+static const uint16_t iq1s_grid_packed[2048] = {
+#include "iq1s_grid.inc"
+};
 
 float ktxo_bf16_to_f32(uint16_t h);
 uint16_t ktxo_f32_to_bf16(float f);
@@ -124,9 +130,62 @@ float ktxo_vec_dot_q6_K(const uint8_t* wrow, int K, const int8_t* q8, const floa
   return acc;
 }
 
-static size_t row_bytes(int type, int K) { return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : 210); }
+/* block_iq1_s: { fp16 d, uint8 qs[32], uint16 qh[8] } = 50 B.  The only in-tree definition of its arithmetic is the
+ * reference's AVX2 kernel mul_mat_iq1_s_q8_K (third_party/llamafile/iqk_mul_mat.inc:2689-2770), restated here op for op in
+ * scalar form: per 32-weight sub-block ib: scale = 2*((qh[ib]>>12)&7)+1, delta = (qh[ib]&0x8000) ? -9 : -7, the four grid
+ * points idx_l = qs[4*ib+l] | (((qh[ib] >> 3*l) & 7) << 8) give 8 unsigned weights (0,1,2) each;
+ *   sumi = sum_ib 8*scale*dot(grid_us, q8) + sum_ib scale*delta*bsum32;  acc = fma(d*d8, float(sumi), acc);  result = 0.125*acc
+ * i.e. w = d * scale * (g +- 0.125), g in {-1,0,+1}.  (iqk accumulates the 8 AVX lanes of sumi separately in fp32 and adds
+ * them at the end; here the lanes are added in int32 first.) */
+float ktxo_vec_dot_iq1_s(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 50, q8 += QK_K, bs += 16) {
+    uint16_t dh; memcpy(&dh, wrow, 2);
+    const float d = fp16_to_f32(dh);
+    const uint8_t* qs = wrow + 2;
+    uint16_t qh[8]; memcpy(qh, wrow + 34, 16);
+    int32_t sumi = 0;
+    for (int ib = 0; ib < 8; ib++) {
+      const int scale = 2 * ((qh[ib] >> 12) & 7) + 1;
+      const int delta = (qh[ib] & 0x8000) ? -9 : -7;
+      int32_t dot = 0;
+      for (int l = 0; l < 4; l++) {
+        const uint16_t g = iq1s_grid_packed[qs[4 * ib + l] | (((qh[ib] >> (3 * l)) & 7) << 8)];
+        for (int e = 0; e < 8; e++) dot += (int32_t)((g >> (2 * e)) & 3) * q8[ib * 32 + l * 8 + e];
+      }
+      sumi += 8 * scale * dot + scale * delta * ((int32_t)bs[2 * ib] + bs[2 * ib + 1]);
+    }
+    acc = fmaf(d * d8[b], (float)sumi, acc);
+  }
+  return 0.125f * acc;
+}
+
+/* de-quantised values of IQ1_S rows (tests): w = d * scale * (g +- 0.125) */
+void ktxo_dequant_iq1_s(const uint8_t* blocks, int nblocks, float* out) {
+  for (int b = 0; b < nblocks; b++, blocks += 50, out += QK_K) {
+    uint16_t dh; memcpy(&dh, blocks, 2);
+    const float d = fp16_to_f32(dh);
+    const uint8_t* qs = blocks + 2;
+    uint16_t qh[8]; memcpy(qh, blocks + 34, 16);
+    for (int ib = 0; ib < 8; ib++) {
+      const float dl = d * (float)(2 * ((qh[ib] >> 12) & 7) + 1);
+      const float delta = (qh[ib] & 0x8000) ? -0.125f : 0.125f;
+      for (int l = 0; l < 4; l++) {
+        const uint16_t g = iq1s_grid_packed[qs[4 * ib + l] | (((qh[ib] >> (3 * l)) & 7) << 8)];
+        for (int e = 0; e < 8; e++) out[ib * 32 + l * 8 + e] = dl * ((float)((int)((g >> (2 * e)) & 3) - 1) + delta);
+      }
+    }
+  }
+}
+
+const uint16_t* ktxo_iq1s_grid(void) { return iq1s_grid_packed; }
+
+static size_t row_bytes(int type, int K) {
+  return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : type == GGML_TYPE_Q6_K ? 210 : 50);
+}
 
 static float vec_dot(int type, const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  if (type == GGML_TYPE_IQ1_S) return ktxo_vec_dot_iq1_s(wrow, K, q8, d8, bs);
   return type == GGML_TYPE_Q4_K ? ktxo_vec_dot_q4_K(wrow, K, q8, d8, bs) : ktxo_vec_dot_q6_K(wrow, K, q8, d8, bs);
 }
 
@@ -142,7 +201,7 @@ int ktxo_moe_forward_gguf(const ktxo_gguf_moe* m, int T, int k, const int64_t* i
                           uint16_t* y, float* inter_out) {
   const int H = m->H, I = m->I;
   const int types[3] = {m->gate_type, m->up_type, m->down_type};
-  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q6_K) return -1;
+  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q6_K && types[i] != GGML_TYPE_IQ1_S) return -1;
   float* xf = malloc(sizeof(float) * H);
   int8_t* xq = malloc(H); float* xd = malloc(sizeof(float) * (H / QK_K)); int16_t* xbs = malloc(2 * (H / 16));
   float* inter = malloc(sizeof(float) * I);

@@ -7,7 +7,8 @@ import numpy as np
 import pytest
 
 from helpers import bf16_to_f32
-from oracle.gguf_ref import (DEQUANT, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle, dequantize_q4_k, dequantize_q6_k)
+from oracle.gguf_ref import (DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle, dequantize_iq1_s,
+                             dequantize_q4_k, dequantize_q6_k, iq1s_grid, quantize_iq1_s)
 from oracle.oracle import f32_to_bf16
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gguf_blocks_golden.npz")
@@ -41,7 +42,8 @@ def test_q8k_quantiser():
     assert np.abs(q[:256] * d[0] - x[:256]).max() <= abs(d[0]) * 0.5 + 1e-6
 
 
-@pytest.mark.parametrize("types", [(GGML_TYPE_Q4_K, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K), (GGML_TYPE_Q6_K, GGML_TYPE_Q4_K, GGML_TYPE_Q4_K)])
+@pytest.mark.parametrize("types", [(GGML_TYPE_Q4_K, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K), (GGML_TYPE_Q6_K, GGML_TYPE_Q4_K, GGML_TYPE_Q4_K),
+                                   (GGML_TYPE_IQ1_S, GGML_TYPE_IQ1_S, GGML_TYPE_IQ1_S)])
 def test_gguf_forward_tracks_dequantised_math(types):
     o = GgufOracle()
     E, k, H, I, T = 4, 2, 256, 512, 3
@@ -75,3 +77,31 @@ def test_gguf_forward_tracks_dequantised_math(types):
         g, u = gd[e] @ xq, ud[e] @ xq
         want = (g / (1 + np.exp(-g))) * u
         assert np.abs(inter[j] - want).max() <= 2e-5 * np.abs(want).max() + 1e-7
+
+
+def test_iq1s_codebook_and_block_layout():
+    """The IQ1_S codebook transcribed from the reference (tests/golden/make_iq1s_grid.py): 2048 distinct ternary points; the
+    numpy de-quantiser (w = d * (2s+1) * (g +- 1/8)) and the C restatement of the reference's mul_mat_iq1_s_q8_K agree."""
+    import ctypes as C
+    g = iq1s_grid()
+    assert g.shape == (2048, 8) and set(np.unique(g)) == {-1, 0, 1} and np.unique(g, axis=0).shape[0] == 2048
+    rng = np.random.default_rng(4)
+    blocks = rng.integers(0, 256, (6, 50), dtype=np.uint8)
+    blocks[:, 0:2] = (rng.random(6).astype(np.float16) * np.float16(0.02)).view(np.uint8).reshape(6, 2)
+    want = dequantize_iq1_s(blocks)
+    lib = GgufOracle().lib
+    out = np.empty(6 * 256, np.float32)
+    lib.ktxo_dequant_iq1_s(blocks.ctypes.data_as(C.c_void_p), C.c_int(6), out.ctypes.data_as(C.c_void_p))
+    assert np.array_equal(out.reshape(6, 256), want)
+    # dot product of a block row with Q8_K codes == de-quantised math (fp32 rounding only)
+    o = GgufOracle()
+    x = rng.standard_normal(256 * 6).astype(np.float32)
+    q, d8, bs = o.quantize_row_q8_K(x)
+    lib.ktxo_vec_dot_iq1_s.restype = C.c_float
+    got = lib.ktxo_vec_dot_iq1_s(blocks.ctypes.data_as(C.c_void_p), C.c_int(256 * 6), q.ctypes.data_as(C.c_void_p),
+                                 d8.ctypes.data_as(C.c_void_p), bs.ctypes.data_as(C.c_void_p))
+    xq = (q.astype(np.float64).reshape(-1, 256) * d8.astype(np.float64)[:, None]).reshape(-1)
+    ref = float(want.reshape(-1).astype(np.float64) @ xq)
+    assert abs(got - ref) <= 2e-5 * abs(ref) + 1e-6
+    w = (rng.standard_normal((4, 512)) / 10).astype(np.float32)
+    assert np.linalg.norm(dequantize_iq1_s(quantize_iq1_s(w)) - w) / np.linalg.norm(w) < 0.75     # ~1.6 bits per weight

@@ -11,10 +11,10 @@ import torch
 pytestmark = pytest.mark.gpu
 
 from helpers import bf16_to_f32  # noqa: E402
-from oracle.gguf_ref import GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle  # noqa: E402
+from oracle.gguf_ref import GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle  # noqa: E402
 from oracle.oracle import f32_to_bf16  # noqa: E402
 
-Q4, Q6 = GGML_TYPE_Q4_K, GGML_TYPE_Q6_K
+Q4, Q6, IQ1 = GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S
 
 
 def make(E, H, I, types, seed):
@@ -25,10 +25,23 @@ def make(E, H, I, types, seed):
     return gate, up, down
 
 
-def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None):
+def random_iq1s(E, N, K, rng):
+    """Random but valid IQ1_S blocks (any byte pattern is a legal block; d kept small): the encoder in oracle/gguf_ref.py is a
+    brute-force nearest-grid search, far too slow for V3-sized matrices."""
+    b = rng.integers(0, 256, (E, N, K // 256, 50), dtype=np.uint8)
+    d = (rng.random((E, N, K // 256)).astype(np.float16) * np.float16(0.004) + np.float16(0.001))
+    b[..., 0:2] = d.view(np.uint8).reshape(E, N, K // 256, 2)
+    return b.reshape(E, N, -1)
+
+
+def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None, random_blocks=False):
     from ktransformers_amd import _native as n
     o = GgufOracle()
-    gate, up, down = make(E, H, I, types, seed)
+    if random_blocks:
+        r0 = np.random.default_rng(seed)
+        gate, up, down = random_iq1s(E, I, H, r0), random_iq1s(E, I, H, r0), random_iq1s(E, H, I, r0)
+    else:
+        gate, up, down = make(E, H, I, types, seed)
     rng = np.random.default_rng(seed + 1)
     x = f32_to_bf16(rng.standard_normal((T, H)).astype(np.float32))
     ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
@@ -49,7 +62,7 @@ def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None):
     return h
 
 
-@pytest.mark.parametrize("types", [(Q4, Q4, Q6), (Q4, Q4, Q4), (Q6, Q6, Q6), (Q6, Q6, Q4)])
+@pytest.mark.parametrize("types", [(Q4, Q4, Q6), (Q4, Q4, Q4), (Q6, Q6, Q6), (Q6, Q6, Q4), (IQ1, IQ1, IQ1), (IQ1, IQ1, Q4)])
 @pytest.mark.parametrize("T", [1, 3, 19])
 def test_small(types, T):
     run_case(4, 2, 256, 512, T, types, seed=T)
@@ -63,6 +76,12 @@ def test_invalid_ids_and_ragged_tiles():
 def test_mixtral_like_shape(T):
     """q4_k_m mix at a Mixtral-like aspect (H % 256 == 0, I % 256 == 0), prefill tile sizes MT = 1 / 4."""
     run_case(8, 2, 1024, 3584, T, (Q4, Q4, Q6), seed=9)
+
+
+def test_iq1s_v3_expert_shape():
+    """BASELINE.json configs[4] (DeepSeek-R1, IQ1_S experts): the V3 expert shape, a few experts, decode and a small batch."""
+    run_case(4, 2, 7168, 2048, 1, (IQ1, IQ1, IQ1), seed=11, random_blocks=True)
+    run_case(4, 2, 7168, 2048, 9, (IQ1, IQ1, IQ1), seed=12, random_blocks=True)
 
 
 def test_errors():
