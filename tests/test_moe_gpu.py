@@ -64,6 +64,33 @@ def test_parity_with_oracle_both_paths(oracle, dev, method, shape):
         h.close()
 
 
+@pytest.mark.parametrize("method", ["AMXINT4", "AMXINT8"])
+@pytest.mark.parametrize("shape", [
+    (4, 2, 256, 256, 700),     # one k-chunk, K a multiple of the ring depth, ragged last tiles + invalid ids
+    (4, 2, 1152, 640, 300),    # 9 / 5 k-steps: ring tails; 40 strips: half-empty last strip group
+    (2, 2, 4352, 384, 200),    # K = 4352 > 2048: three LDS chunks (16 + 16 + 2 k-steps)
+])
+def test_streaming_prompt_kernels(oracle, dev, method, shape):
+    """The LDS-resident / register-ring grouped GEMM for prompts (moe_gemm_stream_kernel) forced on (dev knob 4 = 2), against
+    the oracle and against the chunk-pipelined kernels (knob 4 = 1) on the same input: bit-exact."""
+    from ktransformers_amd import _native
+    E, k, H, I, T = shape
+    c = make_case(3, E, k, H, I, T, invalid_ids=True)
+    mo = oracle.make_moe(FMT[method], c["gate"], c["up"], c["down"])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = make_handle(method, c, E, k, H, I, T, dev)
+    try:
+        got = {}
+        for knob in (1, 2):
+            _native.lib.ktx_debug_set(4, knob)
+            got[knob] = run(h, c, dev)
+        assert np.array_equal(got[2], want), f"{int((got[2] != want).sum())} bf16 outputs differ (streaming kernels)"
+        assert np.array_equal(got[1], want)
+    finally:
+        _native.lib.ktx_debug_set(4, 0)
+        h.close()
+
+
 @pytest.mark.parametrize("fname,method", [("int4", "AMXINT4"), ("int8", "AMXINT8")])
 @pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
 def test_parity_with_reference_golden(dev, fname, method, case):
