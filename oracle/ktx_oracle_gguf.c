@@ -1,22 +1,28 @@
-/* ktx_oracle_gguf.c — TEST INFRASTRUCTURE ONLY.  *** PARITY UNPINNED ***
+/* ktx_oracle_gguf.c — TEST INFRASTRUCTURE ONLY.  Parity: GEMM kernels PINNED against the reference's own code,
+ * activation quantiser restated from ggml's published algorithm (*** that part unpinned ***).
  *
  * CPU restatement of the reference's llamafile/GGUF expert path:
  *   LLAMA_MOE_TP::forward_one / forward_many   kt-kernel/operators/llamafile/moe.hpp:271-460, 461-747
  *     bf16 input -> fp32 -> from_float(vec_dot_type = Q8_K) -> llamafile_sgemm(weights x Q8_K) -> fp32
  *     act_fn(g) * u in fp32 with expf (moe.hpp:269, 374) -> from_float(Q8_K) -> down sgemm -> fp32
  *     output[i] += down[i] * w in slot order (moe.hpp:447-449, 715-721) -> bf16 (moe-tp.hpp merge)
- * The GEMM arithmetic itself lives in un-vendored dependencies that are NOT under /root/reference:
- *   ggerganov/llama.cpp (submodule third_party/llama.cpp, pin not recorded in the tree; the reference's numpy
- *   dequantisers cite ggml commit fca1caafea7de9fbd7efc733b9818f9cf2da3050, archive/ktransformers/util/custom_gguf.py:326)
- *   — quantize_row_q8_K, block_q4_K / block_q6_K / block_q8_K, get_scale_min_k4, ggml_vec_dot_q{4,6}_K_q8_K —
- *   and third_party/llamafile/iqk_mul_mat.inc (present) whose AVX2/AVX512 kernels the reference actually runs.
- * What is restated here is ggml's PUBLISHED scalar algorithm for those functions.  The integer parts (Q8_K codes,
- * sub-block dot products, 6-bit scale/min products) are exact in every implementation; the fp32 combine order across
- * 256-blocks differs between ggml's scalar code, its SIMD paths and iqk — here it is one sequential FMA chain per
- * output (acc = fma(d8*d, isum, acc); acc = fma(-(d8*dmin), msum, acc)), which is also what the HIP kernel does.
- * Pins available in-tree: the block LAYOUTS (dequantised values) are checked against the reference's own numpy
- * dequantize_q4_k / dequantize_q6_k (tests/golden/make_gguf_golden.py); the reference's only numeric test for this
- * path is `diff < 0.5` against torch (kt-kernel/examples/test_moe.py:203-206), which needs the built extension.
+ *
+ * Where the arithmetic lives and how each piece is pinned:
+ *   * weights x Q8_K products (ktxo_vec_dot_q4_K / q6_K / iq1_s): the kernels the reference actually runs are in-tree,
+ *     third_party/llamafile/iqk_mul_mat.inc (reached through llamafile_sgemm, tinyblas_cpu_sgemm.inc:331-335).  They are
+ *     compiled UNMODIFIED into oracle/_ref/libiqk_ref_{avx2,zen4}.so (oracle/Makefile `iqk`; the empty llama.cpp submodule's
+ *     type definitions come from oracle/shim_iqk/) and tests/test_gguf_ref_pin_cpu.py drives both variants and these
+ *     functions on the same blocks: identical integer sub-block sums by construction, fp32 results within the stated
+ *     re-association bound of the exact value and within 3e-7 of the output scale of each other (median 2-3 ulp) — the
+ *     order of the fp32 adds differs (iqk: 8 AVX lanes of partial sums per output, added at the end; here, as in the HIP
+ *     kernel, one fma per 256-block: acc = fma(d8*d, isum, acc); acc = fma(-(d8*dmin), msum, acc)).
+ *   * block LAYOUTS (de-quantised values): checked against the reference's own numpy dequantize_q4_k / dequantize_q6_k
+ *     (tests/golden/make_gguf_golden.py -> tests/golden/gguf_blocks_golden.npz); IQ1_S through the iqk kernel above.
+ *   * quantize_row_q8_K (activations -> Q8_K): lives in the un-vendored ggerganov/llama.cpp submodule (third_party/llama.cpp
+ *     is empty; pin not recorded in the tree — the reference's numpy dequantisers cite ggml commit
+ *     fca1caafea7de9fbd7efc733b9818f9cf2da3050, archive/ktransformers/util/custom_gguf.py:326).  Restated from ggml's
+ *     published quantize_row_q8_K_ref; no in-tree code or vector pins it.  The reference's only numeric test for this path
+ *     is `diff < 0.5` against torch (kt-kernel/examples/test_moe.py:203-206), which needs the built extension.
  */
 #include <math.h>
 #include <stdint.h>

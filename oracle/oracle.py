@@ -26,6 +26,8 @@ def build(ref: bool = True) -> None:
     subprocess.run(["make", "-s", "-C", _HERE, "oracle"], check=True)
     if ref and os.path.isdir("/root/reference/kt-kernel"):
         subprocess.run(["make", "-s", "-C", _HERE, "ref"], check=True)
+    if ref and os.path.isfile("/root/reference/third_party/llamafile/iqk_mul_mat.inc"):
+        subprocess.run(["make", "-s", "-C", _HERE, "iqk"], check=True)
 
 
 def host_has_avx512_vnni() -> bool:

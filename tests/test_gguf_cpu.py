@@ -1,5 +1,6 @@
 """CPU: GGUF k-quant block codec vs the reference's own numpy dequantisers (golden fixture), Q8_K quantiser properties,
-and the restated llamafile expert forward (oracle/ktx_oracle_gguf.c — parity unpinned, see its header) against fp64 math
+and the restated llamafile expert forward (oracle/ktx_oracle_gguf.c; its GEMM kernels are pinned against the reference's iqk
+kernels in test_gguf_ref_pin_cpu.py, its Q8_K quantiser is restated from ggml's published algorithm) against fp64 math
 on the de-quantised weights (the only kind of check the reference itself has for this path: kt-kernel/examples/test_moe.py)."""
 import os
 

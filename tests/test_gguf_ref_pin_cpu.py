@@ -1,0 +1,111 @@
+"""CPU: pins the GGUF restatement (oracle/ktx_oracle_gguf.c) against the reference's OWN k-/i-quant GEMM kernels —
+third_party/llamafile/iqk_mul_mat.inc compiled unmodified into oracle/_ref/libiqk_ref_{avx2,zen4}.so (oracle/Makefile `iqk`);
+these are the kernels LLAMA_MOE_TP reaches through llamafile_sgemm (tinyblas_cpu_sgemm.inc:331-335 ->
+iqk_mul_mat(m, n, k*blck, Atype, A, lda, Btype=Q8_K, B, ldb, C, ldc, ith, nth)).
+
+The integer parts are identical by construction; the fp32 combination differs in ORDER only (iqk keeps 8 AVX lanes of
+partial sums per output and adds them at the end, the restatement — like the HIP kernel — folds each 256-block with one
+fma).  So the bar is: both agree with the exact (float64) value of the same quantised product to within the fp32
+reordering bound `4 ulp_f32 x sum_b |block term|`, and with each other to twice that."""
+import ctypes as C
+import os
+
+import numpy as np
+import pytest
+
+from oracle.gguf_ref import DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle
+
+REF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
+GGML_TYPE_Q8_K = 15
+BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
+VARIANTS = {"avx2": ("libiqk_ref_avx2.so", "iqk_mul_mat", "avx2"), "zen4": ("libiqk_ref_zen4.so", "iqk_mul_mat_zen4", "avx512_vnni")}
+
+
+def cpu_has(flag):
+    try:
+        with open("/proc/cpuinfo") as f:
+            return any(flag in line.split() for line in f if line.startswith("flags"))
+    except OSError:
+        return False
+
+
+def load(variant):
+    so, sym, flag = VARIANTS[variant]
+    path = os.path.join(REF_DIR, so)
+    if not os.path.exists(path):
+        pytest.skip(f"{so} not built (needs /root/reference at build time: make -C oracle iqk)")
+    if not cpu_has(flag):
+        pytest.skip(f"host CPU lacks {flag}")
+    fn = getattr(C.CDLL(path), sym)
+    fn.restype = C.c_bool
+    fn.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
+                   C.c_long, C.c_int, C.c_int]
+    return fn
+
+
+def random_blocks(t, N, K, rng):
+    """Valid blocks of type t: Q4_K / Q6_K through the test quantisers; IQ1_S as random bit patterns with a small d."""
+    if t != GGML_TYPE_IQ1_S:
+        return QUANT[t]((rng.standard_normal((N, K)) / 10).astype(np.float32))
+    b = rng.integers(0, 256, (N, K // 256, 50), dtype=np.uint8)
+    d = rng.random((N, K // 256)).astype(np.float16) * np.float16(0.004) + np.float16(0.001)
+    b[..., 0:2] = d.view(np.uint8).reshape(N, K // 256, 2)
+    return b.reshape(N, -1)
+
+
+def q8k_rows(o, x):
+    """x fp32 [T][K] -> (block_q8_K bytes [T][K/256*292], q int8 [T][K], d fp32 [T][K/256], bsums int16 [T][K/16])."""
+    T, K = x.shape
+    nb = K // 256
+    rec = np.zeros((T, nb), dtype=np.dtype([("d", "<f4"), ("qs", "i1", 256), ("bsums", "<i2", 16)]))
+    assert rec.dtype.itemsize == 292
+    qs, ds, bss = [], [], []
+    for t in range(T):
+        q, d, bs = o.quantize_row_q8_K(x[t])
+        rec["d"][t], rec["qs"][t], rec["bsums"][t] = d, q.reshape(nb, 256), bs.reshape(nb, 16)
+        qs.append(q); ds.append(d); bss.append(bs)
+    return rec, np.stack(qs), np.stack(ds), np.stack(bss)
+
+
+@pytest.mark.parametrize("variant", ["avx2", "zen4"])
+@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S])
+@pytest.mark.parametrize("shape", [(48, 512, 1), (40, 2048, 5), (24, 1536, 19)])
+def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
+    iqk = load(variant)
+    N, K, T = shape
+    o = GgufOracle()
+    rng = np.random.default_rng(N * 1000 + K + T + t)
+    wb = np.ascontiguousarray(random_blocks(t, N, K, rng))
+    x = rng.standard_normal((T, K)).astype(np.float32)
+    x[0, :256] = 0  # an all-zero activation block (d = 0)
+    rec, q8, d8, bs = q8k_rows(o, x)
+
+    out = np.full((T, N), np.nan, np.float32)
+    ok = iqk(N, T, K, t, wb.ctypes.data, K // 256, GGML_TYPE_Q8_K, rec.ctypes.data, K // 256, out.ctypes.data, N, 0, 1)
+    if not ok:
+        pytest.skip(f"the reference's {variant} build has no kernel for ggml type {t}")
+
+    vec_dot = {GGML_TYPE_Q4_K: o.lib.ktxo_vec_dot_q4_K, GGML_TYPE_Q6_K: o.lib.ktxo_vec_dot_q6_K, GGML_TYPE_IQ1_S: o.lib.ktxo_vec_dot_iq1_s}[t]
+    vec_dot.restype = C.c_float
+    mine = np.empty((T, N), np.float32)
+    rb = BLOCK_BYTES[t] * (K // 256)
+    for ti in range(T):
+        for n in range(N):
+            mine[ti, n] = vec_dot(C.c_void_p(wb.ctypes.data + n * rb), C.c_int(K), C.c_void_p(q8[ti].ctypes.data),
+                                  C.c_void_p(d8[ti].ctypes.data), C.c_void_p(bs[ti].ctypes.data))
+
+    # exact value of the quantised product and the size of its per-block terms, in float64
+    wd = DEQUANT[t](wb).astype(np.float64).reshape(N, K // 256, 256)
+    xd = (q8.astype(np.float64).reshape(T, K // 256, 256) * d8.astype(np.float64)[:, :, None])
+    terms = np.einsum("nbk,tbk->tnb", wd, xd)
+    exact = terms.sum(-1)
+    # fp32 re-association bound: 16 ulp of the per-block terms, plus 1 ulp of the largest magnitudes an implementation may
+    # round separately before they cancel (Q4_K: d*sum(s*dot) and dmin*sum(m*bsum); Q6_K: the -32 offset; IQ1_S: the delta term)
+    bound = 2.0 ** -23 * (16 * np.abs(terms).sum(-1) + np.einsum("nb,tb->tn", np.abs(wd).max(-1), np.abs(xd).sum(-1))) + 1e-30
+    assert np.isfinite(out).all()
+    assert (np.abs(out.astype(np.float64) - exact) <= bound).all(), f"reference kernel off by {np.abs(out - exact).max()}"
+    assert (np.abs(mine.astype(np.float64) - exact) <= bound).all(), f"restatement off by {np.abs(mine - exact).max()}"
+    assert (np.abs(mine.astype(np.float64) - out) <= 2 * bound).all()
+    # measured agreement: 2-3e-7 of the output scale, median 2-3 ulp
+    assert np.abs(mine - out).max() <= 1e-6 * np.abs(out).max()
+    assert np.mean(np.abs(mine - out) <= 4 * np.spacing(np.abs(out).astype(np.float32))) > 0.5
