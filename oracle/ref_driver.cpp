@@ -189,4 +189,28 @@ int ktref_quant_roundtrip(int kind, int n, int k, const void* src_bf16, void* ds
   });
 }
 
+// The packed bytes themselves: what the reference's converter writes per expert matrix and NUMA part
+// ("<layer>.ffn_*_exps.E.numa.N.weight" = BufferB::b, ".scale" = BufferB::d; operators/amx/moe.hpp:103-124, 271-296).
+// kind 0 = AMXINT4 (n*k/2 bytes), 1 = AMXINT8 (n*k bytes).  Pins ktransformers_amd/kt_kernel/utils/amx_packed.py.
+int ktref_pack_b(int kind, int n, int k, const void* src_bf16, void* packed, float* scales) {
+  return guarded([&] {
+    auto run = [&](auto tag) {
+      using K = decltype(tag);
+      size_t sz = K::BufferB::required_size(n, k);
+      void* buf = std::aligned_alloc(64, (sz + 63) / 64 * 64);
+      {
+        typename K::BufferB bb(n, k, buf);
+        int nth = K::recommended_nth(n);
+        for (int ith = 0; ith < nth; ith++) bb.from_mat((ggml_bf16_t*)src_bf16, ith, nth);
+        memcpy(packed, bb.b, sz - sizeof(float) * n);
+        memcpy(scales, bb.d, sizeof(float) * n);
+      }
+      std::free(buf);
+    };
+    if (kind == KIND_INT4) run(amx::GemmKernel224Int4{});
+    else if (kind == KIND_INT8) run(amx::GemmKernel224Int8{});
+    else throw std::runtime_error("pack_b: kind not supported");
+  });
+}
+
 }  // extern "C"

@@ -26,7 +26,8 @@ def _save(folder, shards):
 
 
 def fp8_block(folder, prefix="model.layers.{L}.mlp.experts", names=("gate_proj", "up_proj", "down_proj"),
-              scale="weight_scale_inv", per_channel=False, layers=(1, 2), seed=0):
+              scale="weight_scale_inv", per_channel=False, layers=(1, 2), seed=0, dims=None):
+    E, H, I = dims or (globals()["E"], globals()["H"], globals()["I"])
     g = _rng(seed)
     shards = {}
     for L in layers:
@@ -41,7 +42,8 @@ def fp8_block(folder, prefix="model.layers.{L}.mlp.experts", names=("gate_proj",
     _save(folder, shards)
 
 
-def bf16_per_expert(folder, prefix="model.layers.{L}.mlp.experts", names=("gate_proj", "up_proj", "down_proj"), seed=1):
+def bf16_per_expert(folder, prefix="model.layers.{L}.mlp.experts", names=("gate_proj", "up_proj", "down_proj"), seed=1, dims=None):
+    E, H, I = dims or (globals()["E"], globals()["H"], globals()["I"])
     g = _rng(seed)
     t = {}
     for e in range(E):
@@ -58,7 +60,8 @@ def bf16_packed(folder, vl=False, seed=2):
         f"{base}.mlp.experts.down_proj": torch.randn(E, H, I, generator=g).to(torch.bfloat16)}})
 
 
-def compressed_int4(folder, int32=True, with_shape=True, prefix="model.layers.5.mlp.experts", seed=3):
+def compressed_int4(folder, int32=True, with_shape=True, prefix="model.layers.5.mlp.experts", seed=3, dims=None):
+    E, H, I = dims or (globals()["E"], globals()["H"], globals()["I"])
     g = _rng(seed)
     t = {}
     for e in range(E):
