@@ -7,6 +7,8 @@ Reference surface kept (file:line in archive/ktransformers/operators/experts.py)
   EXPERTS_MAP                 :680-684
   KTransformersExperts        :686-757  prefill_op / generate_op switch, load / unload / set_inference_mode
   KDeepseekV2MoE / KDeepseekV3MoE   :874-971 / :972-1012   gate -> routed experts (+ shared experts) orchestration
+  KMistralSparseMoEBlock      :1074-1170  Mixtral (BASELINE config C1): nn.Linear router, softmax -> top-k -> renormalise
+  KDeepseekV3MoEV2 / KTransformersExpertsV2  :1172-1350  batched-serving variants: forward(..., bsz_tensor, cuda_graph_idx)
 
 What changed underneath: the reference copies hidden states to pinned host memory, runs the experts on the CPU
 (cpuinfer_ext MOE / AMX*_MOE) and copies the result back, ordered by cudaLaunchHostFunc; here the quantized experts
@@ -245,13 +247,16 @@ class KTransformersExperts(BaseInjectedModule, KExpertsBase):
         if self.generate_experts is not None:
             self.device = self.generate_experts.device
 
-    def forward(self, input_tensor, expert_ids, weights):
+    def forward(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0):
+        """`bsz_tensor` / `cuda_graph_idx`: the batched-serving contract of KTransformersExpertsV2 (experts.py:1331-1339) — an
+        int32 device scalar holding the number of valid rows, read by the kernels at execution time so one captured graph
+        serves every batch size up to the captured one; rows beyond it are left untouched."""
         if self.mode == InferenceState.GENERATE:
             assert self.generate_experts is not None, "generate_experts is None"
-            return self.generate_experts.forward(input_tensor, expert_ids, weights)
+            return self.generate_experts.forward(input_tensor, expert_ids, weights, bsz_tensor, cuda_graph_idx)
         elif self.mode == InferenceState.PREFILL:
             assert self.prefill_experts is not None, "prefill_experts is None"
-            return self.prefill_experts.forward(input_tensor, expert_ids, weights)
+            return self.prefill_experts.forward(input_tensor, expert_ids, weights, bsz_tensor, cuda_graph_idx)
         raise ValueError("load or set_inference_mode before forward")
 
     def set_inference_mode(self, mode: InferenceState):
@@ -320,3 +325,50 @@ class KDeepseekV2MoE(_KMoEBlock):
 
 class KDeepseekV3MoE(_KMoEBlock):
     """archive/ktransformers/operators/experts.py:972-1012 ("V3 MoE" block; sigmoid noaux_tc gate in front)."""
+
+
+class KTransformersExpertsV2(KTransformersExperts):
+    """archive/ktransformers/operators/experts.py:1273-1350: the balance_serve engine's expert switch; its forward always
+    carries (bsz_tensor, cuda_graph_idx) — KTransformersExperts.forward accepts both spellings."""
+
+
+class KDeepseekV3MoEV2(_KMoEBlock):
+    """archive/ktransformers/operators/experts.py:1172-1213: forward(hidden_states, bsz_tensor, cuda_graph_idx=0) of the
+    batched-serving engine.  hidden_states [1, T_max, H] with `bsz_tensor[0]` valid rows; the router and the shared experts
+    run over all T_max rows (the reference's shared_experts(identity, bsz_tensor) skips the padding rows, whose values
+    nobody reads), the routed experts honour bsz_tensor on the device."""
+
+    def forward(self, hidden_states, bsz_tensor=None, cuda_graph_idx=0):
+        orig_shape = hidden_states.shape
+        identity = hidden_states
+        topk_idx, topk_weight = self.gate(hidden_states)
+        x = hidden_states.view(-1, hidden_states.shape[-1])
+        y = self.experts(x, topk_idx, topk_weight, bsz_tensor, cuda_graph_idx).view(*orig_shape).to(device=hidden_states.device)
+        return self._finish(y, identity, None, orig_shape)
+
+
+class KMistralSparseMoEBlock(BaseInjectedModule):
+    """archive/ktransformers/operators/experts.py:1074-1128 (Mixtral-8x7B, BASELINE config C1): router logits from the
+    original nn.Linear gate, fp32 softmax over all experts, top-k, renormalise, weights cast to the activation dtype (the
+    reference does, :1090, so they reach the experts bf16-rounded) -> routed experts.  Returns (y, router_logits)."""
+
+    def moe_kexperts(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weight: torch.Tensor) -> torch.Tensor:
+        return self.experts(x, topk_ids, topk_weight)
+
+    def forward(self, hidden_states: torch.Tensor):
+        orig_shape = hidden_states.shape
+        sequence_length = orig_shape[1]
+        x = hidden_states.view(-1, orig_shape[-1])
+        router_logits = self.gate(x)
+        routing_weights = torch.nn.functional.softmax(router_logits, dim=1, dtype=torch.float)
+        routing_weights, selected_experts = torch.topk(routing_weights, self.top_k, dim=-1)
+        routing_weights = routing_weights / routing_weights.sum(dim=-1, keepdim=True)
+        routing_weights = routing_weights.to(x.dtype)
+        gen = getattr(self.experts, "generate_experts", None)
+        if (sequence_length == 1 and x.shape[0] == 1 and gen is not None and hasattr(gen, "submit_for_one_decode")
+                and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
+            gen.submit_for_one_decode(x[0], selected_experts[0], routing_weights[0])
+            y = gen.sync_for_one_decode()
+        else:
+            y = self.moe_kexperts(x, selected_experts, routing_weights)
+        return y.view(*orig_shape).to(device=hidden_states.device), router_logits

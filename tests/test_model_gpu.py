@@ -94,3 +94,24 @@ def test_generation_through_a_captured_graph_equals_eager(model_and_gold):
     ref_last = torch.from_numpy(g["logits_f32"])[-1]
     if float(g["margin_f32"][-1]) > 0.1:
         assert int(eager[0]) == int(ref_last.argmax())
+
+
+def test_serving_variant_block_honours_bsz_tensor(model_and_gold):
+    """KDeepseekV3MoEV2.forward(hidden, bsz_tensor, cuda_graph_idx) (experts.py:1172-1213) on the injected MoE block: with all
+    rows valid it equals the single-request block, with fewer the valid rows are unchanged."""
+    from ktransformers_amd.operators.experts import KDeepseekV3MoEV2
+    from ktransformers_amd.util.generate import set_inference_mode
+    from ktransformers_amd.util.utils import InferenceState
+    model, _, _ = model_and_gold
+    set_inference_mode(model, InferenceState.GENERATE)
+    blk = model.model.layers[1].mlp
+    T, H = 6, CFG["hidden_size"]
+    x = (torch.randn(1, T, H, generator=torch.Generator().manual_seed(0)) * 0.5).to(torch.bfloat16).cuda()
+    with torch.no_grad():
+        full = blk(x).clone()
+        allrows = KDeepseekV3MoEV2.forward(blk, x, torch.tensor([T], dtype=torch.int32, device="cuda"), 0).clone()
+        part = KDeepseekV3MoEV2.forward(blk, x, torch.tensor([4], dtype=torch.int32, device="cuda"), 0).clone()
+    torch.cuda.synchronize()
+    assert torch.isfinite(full.float()).all() and full.float().abs().max() > 0
+    assert torch.equal(allrows, full)
+    assert torch.equal(part[:, :4], full[:, :4])
