@@ -67,7 +67,7 @@ class StaticCache:
         return self.past_tokens[layer_idx]
 
     def get_usable_length(self, kv_seq_len: int, layer_idx: Optional[int] = 0) -> int:
-        return self.past_tokens[layer_idx]
+        return 0                                                                 # custom_cache.py:225-226 (callers add it to q_len)
 
     def change_seq_length(self, bias: Optional[int] = 0) -> None:
         for i in range(self.num_hidden_layers):
@@ -80,3 +80,13 @@ class StaticCache:
         for i in range(self.num_hidden_layers):
             self.key_cache[i].zero_()
             self.past_tokens[i] = 0
+
+    def remove_suffix(self, start_pos: int) -> None:
+        """Forget everything from token `start_pos` on (prefix reuse between requests, custom_cache.py:240-250)."""
+        for i in range(self.num_hidden_layers):
+            k = self.key_cache[i]
+            k.view(-1, k.shape[-1])[start_pos:].zero_()
+            self.past_tokens[i] = start_pos
+
+    def get_max_cache_shape(self):
+        return self.max_cache_len                                                # custom_cache.py:252-254

@@ -118,3 +118,31 @@ def test_linear_injection_and_registry(injected):
         KLinearMarlin("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), num_bits=8)
     with pytest.raises(ValueError):
         lin.set_inference_mode("bogus")
+
+
+def test_static_cache_bookkeeping_on_cpu():
+    """The parts of StaticCache that need no kernel: page table, length bookkeeping, prefix truncation
+    (archive/ktransformers/models/custom_cache.py:45-254)."""
+    import types
+
+    import torch
+
+    from ktransformers_amd.models.custom_cache import StaticCache
+    cfg = types.SimpleNamespace(max_position_embeddings=4096, kv_lora_rank=512, qk_rope_head_dim=64, num_hidden_layers=3)
+    c = StaticCache(cfg, 2, 200, "cpu", torch.bfloat16)
+    assert c.page_size == 64 and c.max_pages == 4 and c.key_cache[0].shape == (4, 64, 1, 576) and c.value_cache[0] is None
+    assert c.page_table_list[0].tolist() == [[0, 1, 2, 3], [4, 5, 6, 7]] and c.page_table_list[1] is c.page_table_list[0]
+    assert c.max_cache_len == 200 and c.get_max_length() == 200 and c.get_max_cache_shape() == 200 and c.max_batch_size == 2
+    assert StaticCache(cfg, 1, None, "cpu").max_cache_len == 4096
+    c.note_appended(1, 5)
+    c.change_seq_length(2)
+    assert [c.get_seq_length(i) for i in range(3)] == [2, 7, 2] and c.get_usable_length(9, 1) == 0
+    c.key_cache[2].fill_(1)
+    c.remove_suffix(70)
+    flat = c.key_cache[2].view(-1, 576).float()
+    assert bool((flat[:70] == 1).all()) and bool((flat[70:] == 0).all()) and c.get_seq_length(2) == 70
+    c.reset()
+    assert c.get_seq_length(0) == 0 and float(c.key_cache[2].float().abs().sum()) == 0
+    import pytest
+    with pytest.raises(ValueError):
+        StaticCache(cfg, 1, 64, "cpu", torch.float16)
