@@ -139,7 +139,8 @@ int ktx_debug_force_generic(int on);
 /* Development knobs for timing experiments and tests (never set by the product path): idx 0 = waves per workgroup of the
  * decode gate/up kernel (0 = auto), idx 1 = ablation bits (bit0: skip the weight stream; results are then meaningless),
  * idx 2 = run only one decode kernel (1 gate/up, 2 down; bench.py's per-kernel timing), idx 4 = prompt (64-row tile) GEMM
- * implementation: 0 auto (streaming kernels for hidden*intermediate >= 4M), 1 chunk-pipelined only, 2 streaming only. */
+ * implementation: 0 auto (streaming kernels for hidden*intermediate >= 4M), 1 chunk-pipelined only, 2 streaming only,
+ * 3 the register-tile kernels (256-row tiles; bit-exact in the tests, not yet timed, hence not selected by default). */
 int ktx_debug_set(int idx, int val);
 int ktx_profile_collect(double* ms5, long long* count5);
 

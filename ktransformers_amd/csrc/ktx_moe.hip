@@ -666,6 +666,161 @@ __global__ __launch_bounds__(512) void moe_gemm_stream_kernel(GemmParams p, int 
 }
 
 // =====================================================================================================
+// K1r / K2r: register-tile grouped GEMM for prompts (dev knob 4 = 3).  Written at the end of round 1 from the PMC evidence in
+// bit-exact on hardware (tests/test_moe_gpu.py::test_register_tile_prompt_kernels) but NOT yet timed —
+// the GPU budget was spent — so the product path does not select it yet.
+// The 64-row kernels move ~4x the unique operand bytes across the fabric; here one workgroup owns a 256-row x 16-unit
+// (256-feature) int32 accumulator tile in registers (8 waves = 4 row groups x 2 unit groups, 128 accumulator VGPRs each)
+// and walks K one 128-wide step at a time with BOTH operands double-buffered in LDS (activations gathered + swizzled as in
+// the streaming kernel, weights stored un-packed to int8 so the loop has no VALU): 350 op per fabric byte instead of 210.
+// Tiles come from moe_prep_kernel with rows_per_tile = 256.  Arithmetic and epilogue as in moe_gemm_kernel.
+// =====================================================================================================
+template <int WBITS, bool GATE_UP>
+__global__ __launch_bounds__(512) void moe_gemm_rt_kernel(GemmParams p) {
+  constexpr int ROWS = 256, UNITS = 16, WU = 8, WT = 4;      // workgroup tile; per-wave units / 16-row token tiles
+  constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
+  constexpr int ACT_BYTES = 8 * ROWS * 16;                   // one k-step of activations: 8 x 16-byte columns x 256 rows
+  constexpr int W_BYTES = UNITS * 2048;                      // one k-step of weights, int8: [unit][half][lane][16 B]
+  constexpr int BUF = ACT_BYTES + W_BYTES;                   // 64 KB per buffer, two buffers
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float* s_ad = reinterpret_cast<float*>(smem + 2 * BUF);    // [ROWS]
+  int* s_src = reinterpret_cast<int*>(s_ad + ROWS);          // [ROWS]
+
+  const int tile_idx = blockIdx.y;
+  if (tile_idx >= p.counters[0]) return;
+  const Tile tile = p.tiles[tile_idx];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;                   // row group (64 rows), unit group (8 units)
+  const int NKS = p.K / 128, nstrips = p.N / 16;
+
+  if (tid < ROWS) {
+    int src = -1;
+    float ad = 0.0f;
+    if (tid < tile.nrows) {
+      src = p.row_src ? p.row_src[tile.row0 + tid] : (tile.row0 + tid);
+      ad = p.act_d[src];
+    }
+    s_src[tid] = src;
+    s_ad[tid] = ad;
+  }
+  __syncthreads();
+
+  // ---- staging roles.  activations: 4 x (row, column) per thread; weights: units tid>>6 and 8 + (tid>>6), lane tid&63
+  const int8_t* a_src[4];
+  int a_off[4];
+  bool a_live[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int idx = tid + i * 512, row = idx >> 3, col = idx & 7;
+    const int src = s_src[row];
+    a_live[i] = src >= 0;
+    a_src[i] = p.act_q + (size_t)(src >= 0 ? src : 0) * p.K + col * 16;
+    a_off[i] = col * (ROWS * 16) + (((row & ~15) | ((row & 15) ^ ((col & 3) | ((col & 4) ? 12 : 0)))) << 4);
+  }
+  const uint8_t* w_src[2];
+#pragma unroll
+  for (int i = 0; i < 2; i++) {
+    const int u = (tid >> 6) + i * 8;
+    const int strip = GATE_UP ? blockIdx.x * 8 + (u >> 1) : blockIdx.x * 16 + u;
+    const uint8_t* base = (GATE_UP && (u & 1)) ? p.w1 : p.w0;
+    w_src[i] = base + (size_t)tile.expert * p.expert_stride + (size_t)(strip < nstrips ? strip : 0) * NKS * TILE_BYTES + lane * 16;
+  }
+  uint4 ra[4];
+  WFrag<WBITS> rw[2];
+  auto load_regs = [&](int ks) {
+#pragma unroll
+    for (int i = 0; i < 4; i++) ra[i] = *reinterpret_cast<const uint4*>(a_src[i] + (size_t)ks * 128);
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      const uint8_t* t = w_src[i] + (size_t)ks * TILE_BYTES;
+      rw[i].v[0] = *reinterpret_cast<const uint4*>(t);
+      if constexpr (WBITS == 8) rw[i].v[1] = *reinterpret_cast<const uint4*>(t + 1024);
+    }
+  };
+  auto store_lds = [&](int buf) {
+    uint8_t* ab = smem + buf * BUF;
+#pragma unroll
+    for (int i = 0; i < 4; i++) *reinterpret_cast<uint4*>(ab + a_off[i]) = a_live[i] ? ra[i] : make_uint4(0, 0, 0, 0);
+    uint8_t* wb = ab + ACT_BYTES;
+#pragma unroll
+    for (int i = 0; i < 2; i++) {
+      v4i h0, h1;
+      unpack_wfrag<WBITS>(rw[i], h0, h1);
+      const int u = (tid >> 6) + i * 8;
+      *reinterpret_cast<v4i*>(wb + u * 2048 + lane * 16) = h0;
+      *reinterpret_cast<v4i*>(wb + u * 2048 + 1024 + lane * 16) = h1;
+    }
+  };
+
+  v4i acc[WU][WT];
+#pragma unroll
+  for (int u = 0; u < WU; u++)
+#pragma unroll
+    for (int t = 0; t < WT; t++) acc[u][t] = v4i{0, 0, 0, 0};
+  // this wave's fragment addresses inside a buffer
+  const int kc = lane >> 4;
+  const int fsw = ((kc & 1) << 1) | ((kc & 2) ? 12 : 0);
+  const int b_off0 = (kc * 2) * (ROWS * 16) + (wm * 64) * 16 + (((lane & 15) ^ fsw) << 4);
+  const int b_off1 = (kc * 2 + 1) * (ROWS * 16) + (wm * 64) * 16 + (((lane & 15) ^ (fsw | 1)) << 4);
+  const int w_off = ACT_BYTES + (wn * WU) * 2048 + lane * 16;
+  const bool rows_live = wm * 64 < tile.nrows;  // wave-uniform: a row group past the tile only keeps the barriers company
+
+  load_regs(0);
+  store_lds(0);
+  __syncthreads();
+  for (int c = 0; c < NKS; c++) {
+    if (c + 1 < NKS) load_regs(c + 1);
+    if (rows_live) {
+      const uint8_t* buf = smem + (c & 1) * BUF;
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++) {
+        v4i b[WT];
+#pragma unroll
+        for (int t = 0; t < WT; t++) b[t] = *reinterpret_cast<const v4i*>(buf + (hh ? b_off1 : b_off0) + t * 256);
+#pragma unroll
+        for (int u = 0; u < WU; u++) {
+          const v4i a = *reinterpret_cast<const v4i*>(buf + w_off + u * 2048 + hh * 1024);
+#pragma unroll
+          for (int t = 0; t < WT; t++) acc[u][t] = __builtin_amdgcn_mfma_i32_16x16x64_i8(a, b[t], acc[u][t], 0, 0, 0);
+        }
+      }
+    }
+    if (c + 1 < NKS) store_lds((c + 1) & 1);
+    __syncthreads();
+  }
+  if (!rows_live) return;
+
+  // ---- epilogue (GemmKernel224Int4::apply_scale, la/amx_kernels.hpp:1808-1846; bf16 rounding a9)
+  const int tok = lane & 15;
+  const int ld = GATE_UP ? 2 * p.N : p.N;
+#pragma unroll
+  for (int u = 0; u < WU; u++) {
+    const int gu = wn * WU + u;
+    const int strip = GATE_UP ? blockIdx.x * 8 + (gu >> 1) : blockIdx.x * 16 + gu;
+    if (strip < nstrips) {
+      const int n0 = strip * 16 + (lane >> 4) * 4;
+      const float* sp = (GATE_UP && (gu & 1)) ? p.s1 : p.s0;
+      const float4 sc = *reinterpret_cast<const float4*>(sp + (size_t)tile.expert * p.N + n0);
+      const float sv[4] = {sc.x, sc.y, sc.z, sc.w};
+      const int coff = (GATE_UP && (gu & 1)) ? p.N : 0;
+#pragma unroll
+      for (int t = 0; t < WT; t++) {
+        const int row = wm * 64 + t * 16 + tok;
+        if (row < tile.nrows) {
+          const float ad = s_ad[row];
+          bf16_t o[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[r] = f32_to_bf16((ad * sv[r]) * (float)acc[u][t][r]);
+          *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * ld + coff + n0) =
+              make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+        }
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 // Decode fast path (qlen*k <= KTX_DEC_MAX_PAIRS): two launches per layer instead of five.
 //   moe_dec_gateup_kernel : one workgroup per ((t,j) pair, 4 strips); quantises x[t] itself (a6), streams the gate/up
 //                           strips of expert ids[t][j] through a D-deep register ring (every wave keeps D KiB-sized
@@ -1943,6 +2098,22 @@ static int launch_gemm_stream(const GemmParams& p, int max_tiles, hipStream_t st
 }
 
 template <int WBITS, bool GATE_UP>
+static int launch_gemm_rt(const GemmParams& p, int max_tiles, hipStream_t st) {
+  const size_t lds = 2 * (8 * 256 * 16 + 16 * 2048) + 256 * 8;
+  auto kern = moe_gemm_rt_kernel<WBITS, GATE_UP>;
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+  });
+  KTX_HIP(attr_err);
+  const int strips_per_wg = GATE_UP ? 8 : 16;
+  hipLaunchKernelGGL(kern, dim3((p.N / 16 + strips_per_wg - 1) / strips_per_wg, max_tiles), dim3(512), lds, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+template <int WBITS, bool GATE_UP>
 static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_t st) {
   switch (mt) {
     case 1: return launch_gemm<WBITS, 1, 4, GATE_UP>(p, max_tiles, st);
@@ -2121,7 +2292,9 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     return forward_rawint4(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   if (h->cfg.format == KTX_FMT_GGUF)
     return forward_gguf(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
-  const int mt = pick_mt(qlen, k, E);
+  int mt = pick_mt(qlen, k, E);
+  const bool use_rt = mt == 4 && g_dbg[4] == 3;   // register-tile kernels (256-row tiles): parity-tested, not yet timed
+  if (use_rt) mt = 16;
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
   // 64-row tiles (prompts) of large expert matrices take the streaming kernels: measured 1.35x (gate/up) - 1.55x (down) on
@@ -2146,7 +2319,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   int rc;
   {
     ProfScope ps(1, st);
-    if (use_stream) rc = h->wbits == 4 ? launch_gemm_stream<4, true>(g1, max_tiles, st) : launch_gemm_stream<8, true>(g1, max_tiles, st);
+    if (use_rt) rc = h->wbits == 4 ? launch_gemm_rt<4, true>(g1, max_tiles, st) : launch_gemm_rt<8, true>(g1, max_tiles, st);
+    else if (use_stream) rc = h->wbits == 4 ? launch_gemm_stream<4, true>(g1, max_tiles, st) : launch_gemm_stream<8, true>(g1, max_tiles, st);
     else rc = h->wbits == 4 ? launch_gemm_mt<4, true>(mt, g1, max_tiles, st) : launch_gemm_mt<8, true>(mt, g1, max_tiles, st);
   }
   if (rc) return rc;
@@ -2163,7 +2337,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   g2.counters = ws->counters; g2.out = ws->dn_buf;
   {
     ProfScope ps(3, st);
-    if (use_stream) rc = h->wbits == 4 ? launch_gemm_stream<4, false>(g2, max_tiles, st) : launch_gemm_stream<8, false>(g2, max_tiles, st);
+    if (use_rt) rc = h->wbits == 4 ? launch_gemm_rt<4, false>(g2, max_tiles, st) : launch_gemm_rt<8, false>(g2, max_tiles, st);
+    else if (use_stream) rc = h->wbits == 4 ? launch_gemm_stream<4, false>(g2, max_tiles, st) : launch_gemm_stream<8, false>(g2, max_tiles, st);
     else rc = h->wbits == 4 ? launch_gemm_mt<4, false>(mt, g2, max_tiles, st) : launch_gemm_mt<8, false>(mt, g2, max_tiles, st);
   }
   if (rc) return rc;

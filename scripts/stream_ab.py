@@ -1,4 +1,5 @@
-"""Dev probe: chunk-pipelined vs streaming grouped GEMM (ktx_debug_set(4, 0|2)) — bit-exact comparison + per-kernel HIP-event timing."""
+"""Dev probe: chunk-pipelined vs streaming vs register-tile grouped GEMM (ktx_debug_set(4, 1|2|3)) — bit-exact comparison +
+per-kernel HIP-event timing."""
 import os
 import sys
 
@@ -26,9 +27,8 @@ def run_case(name, E, H, I, k, T, fmt, reps=6, uniform=False):
     ids = torch.multinomial(p.expand(T, E), k, generator=g).to(torch.int64).to(dev)
     w = torch.rand(T, k, generator=g).to(dev)
     outs = {}
-    for knob in (0, 2, 12, 22):
-        _native.lib.ktx_debug_set(4, 2 if knob else 0)
-        _native.lib.ktx_debug_set(5, knob // 10)
+    for knob in (1, 2, 3):   # chunk-pipelined, streaming, register-tile
+        _native.lib.ktx_debug_set(4, knob)
         y = torch.empty(T, H, dtype=torch.bfloat16, device=dev)
         for _ in range(2):
             h.forward(x, ids, w, out=y)
@@ -43,10 +43,9 @@ def run_case(name, E, H, I, k, T, fmt, reps=6, uniform=False):
         s = " ".join(f"{n}={ms / max(c, 1) * 1e3:.1f}us" for n, (ms, c) in prof.items())
         tot = sum(ms / max(c, 1) for ms, c in prof.values())
         print(f"{name} knob={knob}: {s} total={tot * 1e3:.1f}us  ({2 * 3 * H * I * k * T / tot / 1e9:.0f} TOP/s)", flush=True)
-    same = all(torch.equal(outs[0].view(torch.int16), outs[kk].view(torch.int16)) for kk in (2, 12, 22))
+    same = all(torch.equal(outs[1].view(torch.int16), outs[kk].view(torch.int16)) for kk in (2, 3))
     print(f"{name}: bit-exact={same} finite={bool(torch.isfinite(outs[2].float()).all())}", flush=True)
     _native.lib.ktx_debug_set(4, 0)
-    _native.lib.ktx_debug_set(5, 0)
     return same
 
 

@@ -91,6 +91,33 @@ def test_streaming_prompt_kernels(oracle, dev, method, shape):
         h.close()
 
 
+@pytest.mark.parametrize("method", ["AMXINT4", "AMXINT8"])
+@pytest.mark.parametrize("shape", [
+    (4, 2, 256, 256, 700),     # 350 rows per expert: one full 256-row tile + a ragged one
+    (4, 2, 1152, 640, 300),    # 9 / 5 k-steps; 40 strips: half-empty last strip group
+    (8, 6, 2048, 1408, 600),   # DeepSeek-V2-Lite expert shape
+])
+def test_register_tile_prompt_kernels(oracle, dev, method, shape):
+    """moe_gemm_rt_kernel (256-row register tiles; dev knob 4 = 3 — not selected by default until it has been timed) against the
+    chunk-pipelined kernels (knob 4 = 1) and the oracle: bit-exact."""
+    from ktransformers_amd import _native
+    E, k, H, I, T = shape
+    c = make_case(5, E, k, H, I, T, invalid_ids=True)
+    h = make_handle(method, c, E, k, H, I, T, dev)
+    try:
+        got = {}
+        for knob in (1, 3):
+            _native.lib.ktx_debug_set(4, knob)
+            got[knob] = run(h, c, dev)
+        assert np.array_equal(got[3], got[1]), f"{int((got[3] != got[1]).sum())} bf16 outputs differ (register-tile kernels)"
+        if T * k * H * I <= 2 ** 31:
+            mo = oracle.make_moe(FMT[method], c["gate"], c["up"], c["down"])
+            assert np.array_equal(got[1], oracle.moe_forward(mo, c["ids"], c["w"], c["x"]))
+    finally:
+        _native.lib.ktx_debug_set(4, 0)
+        h.close()
+
+
 @pytest.mark.parametrize("fname,method", [("int4", "AMXINT4"), ("int8", "AMXINT8")])
 @pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
 def test_parity_with_reference_golden(dev, fname, method, case):
