@@ -60,11 +60,42 @@ class CUDAGraphRunner:
     __call__ = forward
 
 
+def warp_logits(scores: torch.Tensor, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+                min_tokens_to_keep: int = 1) -> torch.Tensor:
+    """The reference's `tf_logits_warper` chain for the settings its chat front end exposes (utils.py:356-396 builds HF's
+    TemperatureLogitsWarper -> TopKLogitsWarper -> TopPLogitsWarper in this order): scores [..., vocab] -> scores with the
+    excluded tokens at -inf.  Same arithmetic as the HF classes (tests/test_generate_cpu.py compares with them)."""
+    if temperature is not None and temperature != 1.0:
+        scores = scores / temperature
+    if top_k is not None and top_k != 0:
+        k = min(max(int(top_k), min_tokens_to_keep), scores.size(-1))
+        scores = scores.masked_fill(scores < torch.topk(scores, k)[0][..., -1, None], -float("inf"))
+    if top_p is not None and top_p < 1.0:
+        sorted_logits, sorted_indices = torch.sort(scores, descending=False)
+        cumulative = sorted_logits.softmax(dim=-1).cumsum(dim=-1)
+        remove = cumulative <= (1 - top_p)
+        remove[..., -min_tokens_to_keep:] = 0
+        scores = scores.masked_fill(remove.scatter(-1, sorted_indices, remove), -float("inf"))
+    return scores
+
+
+def sample_next_token(scores: torch.Tensor, do_sample: bool = False, temperature: float = 1.0, top_k: int = 0, top_p: float = 1.0,
+                      generator: torch.Generator | None = None) -> torch.Tensor:
+    """decode_one_tokens' tail (utils.py:486-491): warp, then multinomial over the softmax when sampling, argmax otherwise."""
+    scores = warp_logits(scores.float(), temperature, top_k, top_p) if do_sample else scores
+    if not do_sample:
+        return scores.argmax(dim=-1)
+    return torch.multinomial(torch.softmax(scores, dim=-1), num_samples=1, generator=generator).squeeze(-1)
+
+
 @torch.no_grad()
 def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_new_tokens: int = 16, use_cuda_graph: bool = True,
-                         chunk_size: int = 8192, return_logits: bool = False):
-    """Greedy generation (utils.py:356-540 with do_sample=False): returns the generated token ids [max_new_tokens]
-    (and the fp32 logits of every generated position when return_logits)."""
+                         chunk_size: int = 8192, return_logits: bool = False, do_sample: bool = False, temperature: float = 1.0,
+                         top_k: int = 0, top_p: float = 1.0, generator: torch.Generator | None = None, eos_token_id=None):
+    """Generation loop (utils.py:356-540): chunked prefill, then one token per step through a captured HIP graph; greedy by
+    default, temperature / top-k / top-p sampling with do_sample.  Returns the generated token ids [<= max_new_tokens]
+    (generation stops after `eos_token_id`), and the fp32 logits of every generated position when return_logits."""
+    pick = lambda lg: sample_next_token(lg[0, -1], do_sample, temperature, top_k, top_p, generator)
     dev = input_ids.device
     T = input_ids.shape[1]
     set_inference_mode(model, InferenceState.PREFILL)
@@ -75,13 +106,13 @@ def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_ne
         logits = model(input_ids[:, s:e], pos, past_key_values, pos[0], last_token_only=True)
     set_inference_mode(model, InferenceState.GENERATE)
     tokens, all_logits = [], []
-    nxt = logits[0, -1].argmax(dim=-1)
+    nxt = pick(logits)
     runner = None
     for i in range(max_new_tokens):
         tokens.append(nxt.clone())
         if return_logits:
             all_logits.append(logits[0, -1].clone())
-        if i == max_new_tokens - 1:
+        if i == max_new_tokens - 1 or (eos_token_id is not None and int(nxt) == eos_token_id):
             break
         cur = nxt.view(1, 1)
         pos = torch.tensor([[T + i]], device=dev, dtype=torch.long)
@@ -92,6 +123,6 @@ def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_ne
             logits = runner(cur, pos, pos[0])
         else:
             logits = model(cur, pos, past_key_values, pos[0])
-        nxt = logits[0, -1].argmax(dim=-1)
+        nxt = pick(logits)
     out = torch.stack(tokens)
     return (out, torch.stack(all_logits)) if return_logits else out
