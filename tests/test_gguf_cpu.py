@@ -51,7 +51,16 @@ def test_gguf_forward_tracks_dequantised_math(types):
     rng = np.random.default_rng(1)
     gate_f, up_f = (rng.standard_normal((E, I, H)) / 10).astype(np.float32), (rng.standard_normal((E, I, H)) / 10).astype(np.float32)
     down_f = (rng.standard_normal((E, H, I)) / 10).astype(np.float32)
-    gate, up, down = QUANT[types[0]](gate_f), QUANT[types[1]](up_f), QUANT[types[2]](down_f)
+    def blocks(t, w):
+        if t != GGML_TYPE_IQ1_S:
+            return QUANT[t](w)
+        # any bit pattern is a valid IQ1_S block: random ones (small d) instead of the slow nearest-grid encoder, whose own
+        # round trip is covered at the end of test_iq1s_codebook_and_block_layout
+        b = rng.integers(0, 256, w.shape[:-1] + (w.shape[-1] // 256, 50), dtype=np.uint8)
+        d = rng.random(w.shape[:-1] + (w.shape[-1] // 256,)).astype(np.float16) * np.float16(0.02) + np.float16(0.005)
+        b[..., 0:2] = d.view(np.uint8).reshape(d.shape + (2,))
+        return b.reshape(w.shape[:-1] + (-1,))
+    gate, up, down = blocks(types[0], gate_f), blocks(types[1], up_f), blocks(types[2], down_f)
     x = f32_to_bf16(rng.standard_normal((T, H)).astype(np.float32))
     ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
     ids[1, 0] = -1                                                # skipped slot
