@@ -37,18 +37,32 @@ class _Leaf(nn.Module):
                            "ktransformers_amd has no torch fallback for the hot path")
 
 
-class DeepseekRMSNorm(_Leaf):
+class DeepseekRMSNorm(nn.Module):
+    """Several of the reference's rule files leave the norms (and, for V2, the router) un-replaced and rely on the HF module's
+    own forward; here those modules run the library's HIP kernels themselves — the same calls the injected operators make
+    (operators/layernorm.py, operators/gate.py) — so such a rule file works unmodified.  Still no torch math."""
+
     def __init__(self, hidden_size, eps=1e-6):
         super().__init__()
         self.weight = nn.Parameter(torch.ones(hidden_size))
         self.variance_epsilon, self.hidden_size = eps, hidden_size
+
+    def forward(self, x, batch_size_tensor=None, residual=None):
+        from ktransformers_amd._native import fused_add_rmsnorm, rmsnorm
+        w = self.weight if self.weight.dtype == torch.bfloat16 else self.weight.to(torch.bfloat16)
+        if batch_size_tensor is None:
+            return rmsnorm(x, w, self.variance_epsilon, native_rounding=True)
+        if residual is not None:
+            fused_add_rmsnorm(x, residual, w, self.variance_epsilon, batch_size_tensor)
+            return x, residual
+        return rmsnorm(x, w, self.variance_epsilon, native_rounding=False, bsz_tensor=batch_size_tensor)
 
 
 class DeepseekRotaryEmbedding(_Leaf):
     pass
 
 
-class MoEGate(_Leaf):
+class MoEGate(nn.Module):
     def __init__(self, config):
         super().__init__()
         self.config = config
@@ -56,6 +70,19 @@ class MoEGate(_Leaf):
         self.weight = nn.Parameter(torch.empty((config.n_routed_experts, config.hidden_size)))
         if config.topk_method == "noaux_tc":
             self.e_score_correction_bias = nn.Parameter(torch.empty((config.n_routed_experts)))
+        self._router = None
+
+    def forward(self, hidden_states):
+        """(topk_idx, topk_weight): the router kernels of csrc/ktx_gate.hip, as KMoEGate.forward (see DeepseekRMSNorm)."""
+        if self._router is None:
+            from ktransformers_amd._native import GateHandle
+            c = self.config
+            self._router = GateHandle(c.n_routed_experts, c.hidden_size, c.num_experts_per_tok, getattr(c, "n_group", 1) or 1,
+                                      getattr(c, "topk_group", 1) or 1, getattr(c, "scoring_func", "softmax"),
+                                      getattr(c, "topk_method", "greedy"), bool(getattr(c, "norm_topk_prob", False)),
+                                      float(getattr(c, "routed_scaling_factor", 1.0)))
+        x = hidden_states.reshape(-1, hidden_states.shape[-1]).to(torch.bfloat16).contiguous()
+        return self._router.forward(x, self.weight, getattr(self, "e_score_correction_bias", None), norm=None)
 
 
 class DeepseekMLP(nn.Module):

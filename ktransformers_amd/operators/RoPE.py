@@ -78,3 +78,7 @@ class YarnRotaryEmbeddingV3(RotaryEmbeddingV3):
 RotaryEmbedding = RotaryEmbeddingV3
 YarnRotaryEmbedding = YarnRotaryEmbeddingV3
 DeepSeekV3YarnRotaryEmbedding = YarnRotaryEmbeddingV3
+
+
+# archive/ktransformers/operators/RoPE.py:367-416 is RotaryEmbeddingV3 again under another name (Moonlight serve rules)
+RotaryEmbeddingV4 = RotaryEmbeddingV3

@@ -146,3 +146,48 @@ def test_static_cache_bookkeeping_on_cpu():
     import pytest
     with pytest.raises(ValueError):
         StaticCache(cfg, 1, 64, "cpu", torch.float16)
+
+
+REF_RULES = "/root/reference/archive/ktransformers/optimize/optimize_rules"
+
+
+@pytest.mark.skipif(not os.path.isdir(REF_RULES), reason="needs the reference checkout (build container only)")
+@pytest.mark.parametrize("rule_file,v3", [("DeepSeek-V3-Chat.yaml", True), ("DeepSeek-V3-Chat-amx.yaml", True),
+                                          ("DeepSeek-V3-Chat-fp8-linear-ggml-experts.yaml", True), ("Moonlight-16B-A3B.yaml", True),
+                                          ("DeepSeek-V2-Lite-Chat.yaml", False), ("DeepSeek-V2-Chat.yaml", False)])
+def test_reference_rule_files_inject_unmodified(rule_file, v3):
+    """The drop-in claim at the YAML level: the reference's OWN single-GPU DeepSeek rule files, read where they lie, resolve
+    every class to this package's mirrors and inject into the skeleton model (meta device, no weights)."""
+    import contextlib
+    import io
+
+    from ktransformers_amd.models.modeling_deepseek import DeepseekForCausalLM, make_config
+    from ktransformers_amd.operators.attention import KDeepseekV2Attention
+    from ktransformers_amd.operators.experts import KDeepseekV2MoE
+    from ktransformers_amd.operators.linear import KTransformersLinear
+    from ktransformers_amd.operators.models import KDeepseekV2Model
+    base = dict(vocab_size=512, hidden_size=128, intermediate_size=256, moe_intermediate_size=128, num_hidden_layers=2,
+                num_attention_heads=2, n_shared_experts=1, n_routed_experts=8, num_experts_per_tok=2, first_k_dense_replace=1,
+                moe_layer_freq=1, n_group=2, topk_group=1, routed_scaling_factor=2.5, kv_lora_rank=512, qk_rope_head_dim=64,
+                qk_nope_head_dim=128, v_head_dim=128, max_position_embeddings=4096, rope_theta=10000.0, rms_norm_eps=1e-6,
+                attention_bias=False, rope_scaling={"type": "yarn", "factor": 40, "mscale": 1.0, "mscale_all_dim": 1.0,
+                                                    "original_max_position_embeddings": 4096, "beta_fast": 32, "beta_slow": 1})
+    if v3:
+        base.update(topk_method="noaux_tc", scoring_func="sigmoid", norm_topk_prob=True, q_lora_rank=64, architectures=["DeepseekV3ForCausalLM"])
+    else:
+        base.update(topk_method="group_limited_greedy", scoring_func="softmax", norm_topk_prob=False, q_lora_rank=None,
+                    architectures=["DeepseekV2ForCausalLM"])
+    cfg = make_config(**base)
+    with torch.device("meta"):
+        model = DeepseekForCausalLM(cfg)
+    with contextlib.redirect_stdout(io.StringIO()):
+        optimize_and_load(model, os.path.join(REF_RULES, rule_file), DictLoader({}), cfg, default_device="cuda:0", load=False)
+    moe_layer = model.model.layers[1]
+    assert isinstance(model.model, KDeepseekV2Model) and model.model.per_layer_prefill_intput_threshold == 0
+    assert isinstance(moe_layer.mlp, KDeepseekV3MoE if v3 else KDeepseekV2MoE)
+    assert isinstance(moe_layer.mlp.experts, KTransformersExperts)
+    assert isinstance(moe_layer.mlp.gate, KMoEGate) == v3     # the V2 rule files leave the router to the model's own module
+    assert isinstance(moe_layer.self_attn, KDeepseekV2Attention)
+    assert isinstance(moe_layer.self_attn.o_proj, KTransformersLinear)
+    assert isinstance(model.model.layers[0].mlp.down_proj, KTransformersLinear)
+    assert not isinstance(moe_layer.self_attn.kv_b_proj, KTransformersLinear)     # kept dense for the absorb (rule regex)
