@@ -90,3 +90,60 @@ class StaticCache:
 
     def get_max_cache_shape(self):
         return self.max_cache_len                                                # custom_cache.py:252-254
+
+
+class KDeepSeekV3Cache:
+    """The batched-serving latent cache (archive/ktransformers/models/custom_cache.py:387-466): per layer one
+    [pages, page_size, 1, kv_lora_rank + rope] bf16 tensor, pages handed out by the scheduler.  The reference takes the tensors
+    from its kvc2 `InferenceContext`; here `allocate(num_pages)` creates them (the storage engine is out of scope) and `load`
+    accepts any object with the same `k_cache[0][layer]` shape of attribute."""
+
+    def __init__(self, config, page_size: int = 256, dtype=torch.bfloat16, device="cuda:0"):
+        if dtype != torch.bfloat16:
+            raise ValueError("the HIP MLA kernels read a bf16 latent cache")
+        self.config, self.dtype, self.device = config, dtype, torch.device(device)
+        self.kv_lora_rank, self.qk_rope_head_dim, self.page_size = config.kv_lora_rank, config.qk_rope_head_dim, page_size
+        self.k_caches, self.v_caches = [], []
+        self.max_cache_len = 0
+
+    def allocate(self, num_pages: int) -> None:
+        shape = (num_pages, self.page_size, 1, self.kv_lora_rank + self.qk_rope_head_dim)
+        self.k_caches = [torch.zeros(shape, dtype=self.dtype, device=self.device) for _ in range(self.config.num_hidden_layers)]
+        self.max_cache_len = num_pages * self.page_size
+
+    def load(self, inference_context) -> None:
+        self.k_caches = [inference_context.k_cache[0][i] for i in range(self.config.num_hidden_layers)]
+        self.max_cache_len = self.k_caches[0].shape[0] * self.k_caches[0].shape[1]
+
+    def update(self, key_states: torch.Tensor, value_states: torch.Tensor, layer_idx: int, page_idx: torch.Tensor,
+               page_offset: torch.Tensor, cache_kwargs: Optional[Dict[str, Any]] = None) -> torch.Tensor:
+        """Scatter the new latent rows (key_states = compressed_kv, value_states = k_pe) to [page_idx, page_offset]; returns the
+        layer's whole cache tensor (custom_cache.py:413-443)."""
+        from ktransformers_amd._native import mla_cache_append
+
+        k_out = self.k_caches[layer_idx]
+        mla_cache_append(k_out, key_states.reshape(-1, self.kv_lora_rank), value_states.reshape(-1, self.qk_rope_head_dim),
+                         page_idx, page_offset)
+        return k_out
+
+    def get_page_table(self, cache_position: torch.Tensor, q_indptr: torch.Tensor, kv_indptr: torch.Tensor, kv_indices: torch.Tensor,
+                       bsz_tensors: torch.Tensor):
+        """(page_idx, page_offset) of every scheduled token (custom_cache.py:446-463): token i of request r at position p lives
+        in that request's p // page_size-th page, kv_indices[kv_indptr[r] + p // page_size]; tokens beyond bsz_tensors[0], and
+        positions beyond the request's allotted pages, get page 0 like the reference's zero initialisation.  Vectorised: the
+        reference loops over tokens on the host."""
+        page_offset = cache_position % self.page_size
+        local = cache_position // self.page_size
+        n = cache_position.numel()
+        counts = (q_indptr[1:] - q_indptr[:-1]).to(torch.long)
+        query_ids = torch.repeat_interleave(torch.arange(counts.numel(), device=cache_position.device), counts, output_size=int(q_indptr[-1]))
+        if query_ids.numel() < n:   # tokens past the last request keep request 0, as torch.zeros_like does in the reference
+            query_ids = torch.cat([query_ids, query_ids.new_zeros(n - query_ids.numel())])
+        query_ids = query_ids[:n]
+        start = kv_indptr[query_ids].to(torch.long)
+        have = (kv_indptr[query_ids + 1] - kv_indptr[query_ids]).to(torch.long)
+        ok = (local < have) & (torch.arange(n, device=cache_position.device) < int(bsz_tensors[0]))
+        idx = (start + torch.where(ok, local.to(torch.long), torch.zeros_like(start))).clamp_(max=max(kv_indices.numel() - 1, 0))
+        page_idx = torch.where(ok, kv_indices[idx].to(local.dtype), torch.zeros_like(local))
+        return page_idx, page_offset
+

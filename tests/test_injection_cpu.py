@@ -154,7 +154,9 @@ REF_RULES = "/root/reference/archive/ktransformers/optimize/optimize_rules"
 @pytest.mark.skipif(not os.path.isdir(REF_RULES), reason="needs the reference checkout (build container only)")
 @pytest.mark.parametrize("rule_file,v3", [("DeepSeek-V3-Chat.yaml", True), ("DeepSeek-V3-Chat-amx.yaml", True),
                                           ("DeepSeek-V3-Chat-fp8-linear-ggml-experts.yaml", True), ("Moonlight-16B-A3B.yaml", True),
-                                          ("DeepSeek-V2-Lite-Chat.yaml", False), ("DeepSeek-V2-Chat.yaml", False)])
+                                          ("DeepSeek-V2-Lite-Chat.yaml", False), ("DeepSeek-V2-Chat.yaml", False),
+                                          ("DeepSeek-V3-Chat-serve.yaml", True), ("Moonlight-16B-A3B-serve.yaml", True),
+                                          ("DeepSeek-V3-Chat-fp8-linear-ggml-experts-serve.yaml", True)])
 def test_reference_rule_files_inject_unmodified(rule_file, v3):
     """The drop-in claim at the YAML level: the reference's OWN single-GPU DeepSeek rule files, read where they lie, resolve
     every class to this package's mirrors and inject into the skeleton model (meta device, no weights)."""
@@ -184,6 +186,13 @@ def test_reference_rule_files_inject_unmodified(rule_file, v3):
         optimize_and_load(model, os.path.join(REF_RULES, rule_file), DictLoader({}), cfg, default_device="cuda:0", load=False)
     moe_layer = model.model.layers[1]
     assert isinstance(model.model, KDeepseekV2Model) and model.model.per_layer_prefill_intput_threshold == 0
+    if "serve" in rule_file:   # the balance_serve engine's operator set (bsz_tensor / page-table contracts)
+        from ktransformers_amd.operators.balance_serve_attention import flashinfer_attn
+        from ktransformers_amd.operators.experts import KDeepseekV3MoEV2, KTransformersExpertsV2
+        from ktransformers_amd.operators.layernorm import RMSNorm
+        assert isinstance(moe_layer.mlp, KDeepseekV3MoEV2) and isinstance(moe_layer.mlp.experts, KTransformersExpertsV2)
+        assert isinstance(moe_layer.self_attn, flashinfer_attn) and isinstance(moe_layer.input_layernorm, RMSNorm)
+        return
     assert isinstance(moe_layer.mlp, KDeepseekV3MoE if v3 else KDeepseekV2MoE)
     assert isinstance(moe_layer.mlp.experts, KTransformersExperts)
     assert isinstance(moe_layer.mlp.gate, KMoEGate) == v3     # the V2 rule files leave the router to the model's own module
@@ -191,3 +200,29 @@ def test_reference_rule_files_inject_unmodified(rule_file, v3):
     assert isinstance(moe_layer.self_attn.o_proj, KTransformersLinear)
     assert isinstance(model.model.layers[0].mlp.down_proj, KTransformersLinear)
     assert not isinstance(moe_layer.self_attn.kv_b_proj, KTransformersLinear)     # kept dense for the absorb (rule regex)
+
+
+def test_serving_cache_page_table_matches_reference():
+    """KDeepSeekV3Cache.get_page_table (vectorised here) against the reference's own function on seeded scheduler states
+    (tests/golden/serve_cache_golden.npz from tests/golden/make_serve_cache_golden.py)."""
+    import types
+
+    import numpy as np
+
+    from ktransformers_amd.models.custom_cache import KDeepSeekV3Cache
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "serve_cache_golden.npz"))
+    cfg = types.SimpleNamespace(kv_lora_rank=512, qk_rope_head_dim=64, num_hidden_layers=2)
+    keys = sorted(k[:-3] for k in g.files if k.endswith("_in"))
+    assert len(keys) == 9
+    for key in keys:
+        page_size, b = (int(v) for v in g[key + "_in"])
+        c = KDeepSeekV3Cache(cfg, page_size=page_size, device="cpu")
+        t = lambda n: torch.from_numpy(g[f"{key}_{n}"])
+        pi, po = c.get_page_table(t("pos"), t("q_indptr"), t("kv_indptr"), t("kv_indices"), torch.tensor([b]))
+        assert torch.equal(pi, t("page_idx")) and torch.equal(po, t("page_offset")), key
+    c.allocate(3)
+    assert len(c.k_caches) == 2 and c.k_caches[0].shape == (3, 256, 1, 576) and c.max_cache_len == 768
+    c.load(types.SimpleNamespace(k_cache=[[torch.zeros(2, 256, 1, 576, dtype=torch.bfloat16)] * 2]))
+    assert c.max_cache_len == 512
+    assert resolve_class("ktransformers.operators.balance_serve_attention.flashinfer_attn").__name__ == "flashinfer_attn"
+    assert resolve_class("ktransformers.models.custom_cache.KDeepSeekV3Cache") is KDeepSeekV3Cache
