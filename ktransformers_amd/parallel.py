@@ -42,12 +42,16 @@ def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch
     world = dist.get_world_size(group)
     T, H = x.shape
     k = ids.shape[1]
-    xg = torch.empty((world * T, H), dtype=x.dtype, device=x.device)
-    idsg = torch.empty((world * T, k), dtype=ids.dtype, device=ids.device)
-    wg = torch.empty((world * T, k), dtype=w.dtype, device=w.device)
-    dist.all_gather_into_tensor(xg, x.contiguous(), group=group)
-    dist.all_gather_into_tensor(idsg, ids.contiguous(), group=group)
-    dist.all_gather_into_tensor(wg, w.contiguous(), group=group)
+    # one all-gather per layer instead of three: the token's activation row, expert ids and routing weights travel as one
+    # byte row (decode collectives are latency-bound: ~20 us each on xGMI, 26 MoE layers per token)
+    nx, ni = H * x.element_size(), k * ids.element_size()
+    row = torch.cat([x.contiguous().view(torch.uint8).view(T, nx), ids.contiguous().view(torch.uint8).view(T, ni),
+                     w.contiguous().view(torch.uint8).view(T, k * w.element_size())], dim=1)
+    g = torch.empty((world * T, row.shape[1]), dtype=torch.uint8, device=x.device)
+    dist.all_gather_into_tensor(g, row, group=group)
+    xg = g[:, :nx].contiguous().view(x.dtype).view(world * T, H)
+    idsg = g[:, nx:nx + ni].contiguous().view(ids.dtype).view(world * T, k)
+    wg = g[:, nx + ni:].contiguous().view(w.dtype).view(world * T, k)
     part = local_partial(xg, idsg, wg)
     out = torch.empty((T, H), dtype=torch.float32, device=x.device)
     dist.reduce_scatter_tensor(out, part, op=dist.ReduceOp.SUM, group=group)
