@@ -482,7 +482,8 @@ def main():
         # loaded weights starts the first few hundred graph replays at idle clocks (measured: 390 vs 465 tok/s)
         t_pre = time.perf_counter()
         n_pre = 0
-        while time.perf_counter() - t_pre < 0.7 and n_pre < 400:
+        # (N > 1: every step issues collectives, so all ranks must run the SAME number of steps — a fixed count, not a time box)
+        while n_pre < 200 if dist_on else (time.perf_counter() - t_pre < 0.7 and n_pre < 400):
             for _ in range(20):
                 mr.step(n_pre)
                 n_pre += 1
