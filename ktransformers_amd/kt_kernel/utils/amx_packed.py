@@ -15,7 +15,7 @@ GemmKernel224Int4 / Int8 (amx_kernels.hpp:960-985, 1559-1585):
 Pinned bit-for-bit against the reference's own packer: tests/test_amx_packed_cpu.py (oracle/_ref `ktref_pack_b`)."""
 from __future__ import annotations
 
-from typing import List, Sequence, Tuple
+from typing import Sequence, Tuple
 
 import numpy as np
 
