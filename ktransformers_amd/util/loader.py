@@ -24,29 +24,41 @@ class DictLoader:
     def load_tensor(self, name: str, device: str = "cpu") -> torch.Tensor:
         return self.state[name].to(device)
 
+    def _expert_stems(self, key: str):
+        """Per-expert tensor name stems: HF `<key>.<e>.{gate,up,down}_proj` or the short `<key>.<e>.{gate,up,down}` some
+        checkpoints use (custom_loader.py:149-173)."""
+        short = f"{key}.0.up.weight" in self.state
+        return {p: (p if short else p + "_proj") for p in ("gate", "up", "down")}
+
     def get_expert_count(self, key: str) -> int:
-        pat = re.compile(re.escape(key) + r"\.(\d+)\.gate_proj\.weight(_packed)?$")
-        ids = [int(m.group(1)) for k in self.state for m in [pat.match(k)] if m]
-        return max(ids) + 1 if ids else 0
+        stem = self._expert_stems(key)["up"]
+        n = 0
+        while any(f"{key}.{n}.{stem}.{suffix}" in self.state for suffix in ("weight", "weight_packed")):
+            n += 1
+        return n
 
     def load_experts(self, key: str, device: str = "cpu") -> dict:
+        """Stacked per-expert tensors: gate/up [E, I, H(/2)], down [E, H, I(/2)] (+ `<proj>_scale` for block-fp8
+        `weight_scale_inv`, kt-kernel/python/utils/loader.py:296-508, and compressed-tensors int4 `weight_packed` +
+        `weight_scale`, :683-777).  The reference returns numpy views + ggml type ids for its CPU backend
+        (custom_loader.py:113-223); the HIP operator takes the tensors as they are."""
         n = self.get_expert_count(key)
         if n == 0:
-            raise ValueError(f"Experts {key} not found in the weight source")
+            raise ValueError(f"No experts found for key {key}")
         out = {}
-        for proj in ("gate", "up", "down"):
-            out[proj] = torch.stack([self.state[f"{key}.{e}.{proj}_proj.weight"] for e in range(n)]).to(device)
-            # DeepSeek block-fp8 checkpoints carry weight_scale_inv (kt-kernel/python/utils/loader.py:296-508); Kimi-K2
-            # compressed-tensors int4 carries weight_packed + weight_scale (:683-777)
+        for proj, stem in self._expert_stems(key).items():
+            packed = f"{key}.0.{stem}.weight_packed" in self.state
+            name = "weight_packed" if packed else "weight"
+            out[proj] = torch.stack([self.state[f"{key}.{e}.{stem}.{name}"] for e in range(n)]).to(device)
             for suffix in ("weight_scale_inv", "weight_scale"):
-                k0 = f"{key}.0.{proj}_proj.{suffix}"
-                if k0 in self.state:
-                    out[proj + "_scale"] = torch.stack(
-                        [self.state[f"{key}.{e}.{proj}_proj.{suffix}"] for e in range(n)]).to(device)
-            kp = f"{key}.0.{proj}_proj.weight_packed"
-            if kp in self.state:
-                out[proj] = torch.stack([self.state[f"{key}.{e}.{proj}_proj.weight_packed"] for e in range(n)]).to(device)
+                if f"{key}.0.{stem}.{suffix}" in self.state:
+                    out[proj + "_scale"] = torch.stack([self.state[f"{key}.{e}.{stem}.{suffix}"] for e in range(n)]).to(device)
         return out
+
+    def load_gate(self, key: str, device: str = "cpu") -> dict:
+        """{'weight', 'e_score_correction_bias'} of a router, None where absent (custom_loader.py:225-250)."""
+        return {k: (self.state[f"{key}.{k}"].to(device) if f"{key}.{k}" in self.state else None)
+                for k in ("weight", "e_score_correction_bias")}
 
 
 class SafeTensorLoader(DictLoader):

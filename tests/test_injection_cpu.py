@@ -226,3 +226,41 @@ def test_serving_cache_page_table_matches_reference():
     assert c.max_cache_len == 512
     assert resolve_class("ktransformers.operators.balance_serve_attention.flashinfer_attn").__name__ == "flashinfer_attn"
     assert resolve_class("ktransformers.models.custom_cache.KDeepSeekV3Cache") is KDeepSeekV3Cache
+
+
+def test_dict_and_safetensor_loaders(tmp_path):
+    """The archive-style weight sources (custom_loader.py:96-250 protocol): per-expert stacking for bf16, block-fp8 and
+    compressed-tensors int4 checkpoints, the short `up/gate/down` stems, load_gate, and the lazy safetensors variant."""
+    from safetensors.torch import save_file
+
+    from ktransformers_amd.util.loader import SafeTensorLoader
+    g = torch.Generator().manual_seed(0)
+    E, H, I = 3, 64, 32
+    st = {}
+    for e in range(E):
+        for p, (n, k) in (("gate", (I, H)), ("up", (I, H)), ("down", (H, I))):
+            st[f"L.mlp.experts.{e}.{p}_proj.weight"] = torch.randn(n, k, generator=g).to(torch.bfloat16)
+            st[f"F.mlp.experts.{e}.{p}_proj.weight"] = torch.randint(0, 255, (n, k), generator=g, dtype=torch.uint8)
+            st[f"F.mlp.experts.{e}.{p}_proj.weight_scale_inv"] = torch.rand(1, 1, generator=g)
+            st[f"Q.mlp.experts.{e}.{p}_proj.weight_packed"] = torch.randint(0, 255, (n, k // 2), generator=g, dtype=torch.uint8)
+            st[f"Q.mlp.experts.{e}.{p}_proj.weight_scale"] = torch.rand(n, k // 32, generator=g).to(torch.bfloat16)
+            st[f"S.experts.{e}.{p}.weight"] = torch.randn(n, k, generator=g).to(torch.bfloat16)
+    st["L.mlp.gate.weight"] = torch.randn(E, H, generator=g)
+    st["L.mlp.gate.e_score_correction_bias"] = torch.randn(E, generator=g)
+    save_file(st, str(tmp_path / "m.safetensors"))
+    for ld in (DictLoader(st), SafeTensorLoader(str(tmp_path))):
+        w = ld.load_experts("L.mlp.experts")
+        assert w["gate"].shape == (E, I, H) and w["down"].shape == (E, H, I) and set(w) == {"gate", "up", "down"}
+        assert torch.equal(w["up"][2], st["L.mlp.experts.2.up_proj.weight"])
+        f = ld.load_experts("F.mlp.experts")
+        assert f["gate"].dtype == torch.uint8 and f["down_scale"].shape == (E, 1, 1)
+        q = ld.load_experts("Q.mlp.experts")                     # no `.weight` key at all: only weight_packed
+        assert q["gate"].shape == (E, I, H // 2) and q["gate_scale"].dtype == torch.bfloat16 and ld.get_expert_count("Q.mlp.experts") == E
+        s2 = ld.load_experts("S.experts")
+        assert torch.equal(s2["down"][1], st["S.experts.1.down.weight"])
+        gate = ld.load_gate("L.mlp.gate")
+        assert torch.equal(gate["weight"], st["L.mlp.gate.weight"]) and gate["e_score_correction_bias"].shape == (E,)
+        assert ld.load_gate("F.mlp.gate") == {"weight": None, "e_score_correction_bias": None}
+        with pytest.raises(ValueError, match="No experts found"):
+            ld.load_experts("nope")
+        assert ld.has_tensor("L.mlp.gate.weight") and not ld.has_tensor("zzz")
