@@ -1,4 +1,4 @@
-"""Expert-parallel choreography on CPU: world_size 2, gloo.  Each rank owns half the experts and its own tokens; the
+"""Expert-parallel choreography on CPU: world_size 2 and 4, gloo.  Each rank owns half the experts and its own tokens; the
 local-expert compute is stood in by the oracle (tests only), so this exercises the all-gather / partial / reduce-scatter
 path of ktransformers_amd/parallel.py against the single-process oracle result."""
 import os
@@ -50,11 +50,11 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_expert_parallel_decode_matches_single_process():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_expert_parallel_decode_matches_single_process(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 29500 + (os.getpid() % 2000)
+    port = 29500 + (os.getpid() % 2000) + world
     procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
@@ -119,11 +119,11 @@ def _prefill_worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
-def test_expert_parallel_prefill_all_to_all_is_bit_identical():
-    world = 2
+@pytest.mark.parametrize("world", [2, 4])
+def test_expert_parallel_prefill_all_to_all_is_bit_identical(world):
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
-    port = 31500 + (os.getpid() % 2000)
+    port = 31500 + (os.getpid() % 2000) + world
     procs = [ctx.Process(target=_prefill_worker, args=(r, world, port, q)) for r in range(world)]
     for p in procs:
         p.start()
