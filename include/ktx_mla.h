@@ -55,10 +55,12 @@ int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_nope, const
                           void* d_out, float* d_lse, void* d_workspace, size_t workspace_bytes, void* stream);
 
 /* cache.update(): scatter T new latent rows [ckv(512) | k_pe(64)] to cache[page_idx[t]][page_offset[t]]
- * (custom_cache.py:189-195 / :433-441).  kv_cache bf16 [pages][page_size][token_stride]. */
+ * (custom_cache.py:189-195 / :433-441).  kv_cache bf16 [pages][page_size][token_stride].  num_pages > 0: rows whose
+ * page_idx / page_offset fall outside [0, num_pages) x [0, page_size) are dropped instead of written (the reference's
+ * indexed assignment raises; a device-side scatter cannot, so it must not corrupt HBM); 0 = unchecked. */
 int ktx_mla_cache_append(const ktx_mla_config* cfg, void* d_kv_cache, int64_t token_stride, const void* d_ckv_new,
                          const void* d_kpe_new, const int32_t* d_page_idx, const int32_t* d_page_offset,
-                         const int32_t* d_ntokens, int max_tokens, void* stream);
+                         const int32_t* d_ntokens, int max_tokens, int num_pages, void* stream);
 
 #ifdef __cplusplus
 }

@@ -140,8 +140,17 @@ int ktx_debug_force_generic(int on);
  * decode gate/up kernel (0 = auto), idx 1 = ablation bits (bit0: skip the weight stream; results are then meaningless),
  * idx 2 = run only one decode kernel (1 gate/up, 2 down; bench.py's per-kernel timing), idx 4 = prompt (64-row tile) GEMM
  * implementation: 0 auto (streaming kernels for hidden*intermediate >= 4M), 1 chunk-pipelined only, 2 streaming only,
- * 3 the register-tile kernels (256-row tiles; bit-exact in the tests, not yet timed, hence not selected by default). */
+ * 3 the register-tile kernels (256-row tiles; bit-exact in the tests, not yet timed, hence not selected by default),
+ * idx 5 = run only one kernel of ktx_mla_decode* (1 the split-KV kernel, 2 the merge; per-kernel timing). */
 int ktx_debug_set(int idx, int val);
+int ktx_debug_get(int idx);
+/* Per-launch timing of every kernel of the library (bench.py's per-kernel table; ktx_prof.hip).  mode 1: each launch is
+ * bracketed by two HIP events on its stream; mode 2: labels only (rocprofv3 --pmc passes map dispatches to classes with
+ * it); 0: off.  collect synchronises the device and writes one line per launch since the previous collect, in launch order:
+ * "<kernel and shape>\t<algorithmic bytes>\t<microseconds, -1 in mode 2>\n".  *needed receives the size the text needs; call
+ * with buf = NULL to query it.  Launches made while timing is on are not graph-capturable. */
+int ktx_timing_enable(int mode);
+int ktx_timing_collect(char* buf, size_t cap, size_t* needed);
 int ktx_profile_collect(double* ms5, long long* count5);
 
 #ifdef __cplusplus

@@ -83,7 +83,7 @@ def _load() -> C.CDLL:
     lib.ktx_mla_decode_append.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.ktx_mla_cache_append.argtypes = [C.POINTER(_MlaConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
-                                         C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+                                         C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.ktx_linear_create.argtypes = [C.POINTER(_LinearConfig), C.POINTER(C.c_void_p)]
     lib.ktx_linear_destroy.argtypes = [C.c_void_p]
     lib.ktx_linear_load_bf16.argtypes = [C.c_void_p] * 3
@@ -108,13 +108,77 @@ def _load() -> C.CDLL:
     lib.ktx_profile_enable.argtypes = [C.c_int]
     lib.ktx_debug_force_generic.argtypes = [C.c_int]
     lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
+    lib.ktx_debug_get.argtypes = [C.c_int]
+    lib.ktx_timing_enable.argtypes = [C.c_int]
+    lib.ktx_timing_collect.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
     lib.ktx_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     return lib
 
 
-lib = _load()
+# ---- call tracing (measurement support, used by bench.py) ---------------------------------------------------------------
+# Every entry point that ENQUEUES work takes the HIP stream as its last argument.  While TRACE is a list, each such call is
+# appended to it as (name, args) right before it is made; replay_call() re-issues one on the current stream.  bench.py
+# records one decode step during graph capture (all pointers then stay valid for the life of the graph) and replays the
+# calls of ONE kernel class alone to time that kernel on distinct layers' weights.  Not used by the product path.
+STREAM_CALLS = frozenset((
+    "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
+    "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_linear_forward",
+    "ktx_linear_forward_batched", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
+    "ktx_mla_prep", "ktx_argmax"))
+TRACE: list | None = None
+HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
+
+
+class _TracedLib:
+    def __init__(self, raw):
+        object.__setattr__(self, "_raw", raw)
+        object.__setattr__(self, "_wrapped", {})
+
+    def __getattr__(self, name):
+        fn = getattr(self._raw, name)
+        if name not in STREAM_CALLS:
+            return fn
+        w = self._wrapped.get(name)
+        if w is None:
+            def w(*args, _fn=fn, _name=name):
+                if TRACE is not None:
+                    TRACE.append((_name, args))
+                return _fn(*args)
+            self._wrapped[name] = w
+        return w
+
+
+def replay_call(name: str, args: tuple, device) -> None:
+    """Re-issue a traced call on the current stream of `device` (its recorded stream argument is replaced)."""
+    check(getattr(lib._raw, name)(*args[:-1], _stream_ptr(device)))
+
+
+def _register(handle_obj) -> None:
+    import weakref
+    HANDLES[handle_obj._h.value] = weakref.ref(handle_obj)
+
+
+lib = _TracedLib(_load())
 
 PROFILE_SLOTS = ("prep", "gate_up_gemm", "act_quant", "down_gemm", "combine")
+
+
+def timing_enable(mode: int) -> None:
+    """Per-launch timing of every library kernel (include/ktx_moe.h): 0 off, 1 HIP events around each launch, 2 labels only."""
+    check(lib.ktx_timing_enable(int(mode)))
+
+
+def timing_collect() -> list:
+    """[(label, algorithmic_bytes, microseconds | None)] for every launch since the previous collect, in launch order."""
+    need = C.c_size_t(0)
+    check(lib.ktx_timing_collect(None, 0, C.byref(need)))
+    buf = C.create_string_buffer(max(int(need.value), 1))
+    check(lib.ktx_timing_collect(buf, len(buf), C.byref(need)))
+    out = []
+    for line in buf.value.decode("utf-8", "replace").splitlines():
+        label, nbytes, us = line.rsplit("\t", 2)
+        out.append((label, float(nbytes), float(us) if float(us) >= 0 else None))
+    return out
 
 
 def profile_enable(on: bool) -> None:
@@ -162,6 +226,7 @@ class MoEHandle:
         h = C.c_void_p()
         check(lib.ktx_moe_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        _register(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -336,6 +401,7 @@ class LinearHandle:
         h = C.c_void_p()
         check(lib.ktx_linear_create(C.byref(cfg), C.byref(h)))
         self._h = h
+        _register(self)
 
     def close(self) -> None:
         if getattr(self, "_h", None):
@@ -618,7 +684,7 @@ def mla_cache_append(kv_cache: torch.Tensor, ckv_new: torch.Tensor, kpe_new: tor
     pi, po = page_idx.to(torch.int32).contiguous(), page_offset.to(torch.int32).contiguous()
     check(lib.ktx_mla_cache_append(C.byref(cfg), kv_cache.data_ptr(), ts, c.data_ptr(), r.data_ptr(), pi.data_ptr(),
                                    po.data_ptr(), ntokens.data_ptr() if ntokens is not None else None, T,
-                                   _stream_ptr(kv_cache.device)))
+                                   int(kv_cache.shape[0]), _stream_ptr(kv_cache.device)))
 
 
 # ---- small fused ops (include/ktx_ops.h) ---------------------------------------------------------------------------

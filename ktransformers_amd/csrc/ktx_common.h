@@ -27,6 +27,19 @@ int ktx_fail(const std::string& msg);
     if (!(cond)) return ktx_fail(std::string(msg));                                                     \
   } while (0)
 
+// ---- per-launch timing (ktx_prof.hip; measurement aid, off unless bench.py turns it on) -------------------------------
+int ktx_timing_mode();
+std::string ktx_fmt(const char* fmt, ...);
+struct KtxTimeScope {
+  KtxTimeScope(hipStream_t st, double bytes, std::string label);
+  ~KtxTimeScope();
+  hipStream_t st_;
+  long idx_;
+};
+// brackets the rest of the enclosing block: KTX_TIMED(stream, algorithmic_bytes, "kernel<%d> %d->%d", ...)
+#define KTX_TIMED(st, bytes, ...) \
+  KtxTimeScope _ktx_ts((st), (double)(bytes), ktx_timing_mode() ? ktx_fmt(__VA_ARGS__) : std::string())
+
 // ---- bf16 <-> fp32 (device + host) ----------------------------------------------------------------------------
 // Reference: kt-kernel/operators/amx/la/utils.hpp:14-52.  fp32->bf16 is round-to-nearest-even with input denormals
 // and denormal results flushed to (signed) zero and NaN quieted — the behaviour of VCVTNE2PS2BF16, which is what
@@ -43,6 +56,27 @@ __host__ __device__ __forceinline__ bf16_t f32_to_bf16(float f) {
   if ((u & 0x7f800000u) == 0) return (bf16_t)((u >> 16) & 0x8000u);
   if ((u & 0x7fffffffu) > 0x7f800000u) return (bf16_t)((u >> 16) | 0x0040u);
   return (bf16_t)((u + (0x7fffu + ((u >> 16) & 1u))) >> 16);
+}
+
+// ---- torch-semantics bf16 helpers for the glue ops (router, RMSNorm prologues): plain IEEE round-to-nearest-even as
+// torch's .to(bfloat16) — one v_cvt_pk_bf16_f32 for two values — and the packed bf16 dot product v_dot2c_f32_bf16
+// (d += a.lo*b.lo + a.hi*b.hi).  NOT for the expert path, whose parity contract pins the AVX512 rounding above.
+typedef __bf16 ktx_bf2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ uint32_t ktx_pk_bf16(float lo, float hi) {
+  ktx_bf2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return __builtin_bit_cast(uint32_t, v);
+}
+__device__ __forceinline__ float ktx_lo_f32(uint32_t pk) { return __uint_as_float(pk << 16); }
+__device__ __forceinline__ float ktx_hi_f32(uint32_t pk) { return __uint_as_float(pk & 0xffff0000u); }
+__device__ __forceinline__ float ktx_dot2_bf16(uint32_t a, uint32_t b, float acc) {
+  return __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(ktx_bf2, a), __builtin_bit_cast(ktx_bf2, b), acc, false);
+}
+// DeepseekV3RMSNorm.forward on a packed pair: weight * bf16(x * r), both roundings (modeling_deepseek_v3.py:98-103)
+__device__ __forceinline__ uint32_t ktx_norm_pk(uint32_t x, float r, uint32_t w) {
+  const uint32_t h = ktx_pk_bf16(ktx_lo_f32(x) * r, ktx_hi_f32(x) * r);
+  return ktx_pk_bf16(ktx_lo_f32(h) * ktx_lo_f32(w), ktx_hi_f32(h) * ktx_hi_f32(w));
 }
 
 // _mm512_cvtps_epi32 + _mm512_cvtsepi32_epi8: round-to-nearest-even then signed saturation to int8.

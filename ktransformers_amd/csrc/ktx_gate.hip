@@ -31,12 +31,9 @@ __global__ __launch_bounds__(256) void gate_logits_kernel(const int32_t* d_bsz, 
     const uint4 b = *reinterpret_cast<const uint4*>(wr + j);
     const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b.x, b.y, b.z, b.w};
 #pragma unroll
-    for (int q = 0; q < 4; q++) {
-      acc = fmaf(bf16_to_f32((bf16_t)(av[q] & 0xffffu)), bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
-      acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
-    }
+    for (int q = 0; q < 4; q++) acc = ktx_dot2_bf16(av[q], bv[q], acc);   // v_dot2c_f32_bf16: two products per instruction
   }
-  acc = wave_sum(acc);   // same tree as gate_fused_kernel: the two paths give identical logits
+  acc = wave_sum(acc);   // same order and tree as gate_fused_kernel: the two paths give identical logits
   if (lane == 0) logits[(size_t)t * E + e] = acc;
 }
 
@@ -111,37 +108,72 @@ __device__ __forceinline__ void gate_select_token(const ktx_gate_config& c, int 
   // group limitation (modeling_deepseek_v3.py:449-468 / modeling_deepseek.py:431-448)
   if (c.topk_method != KTX_GATE_GREEDY && c.n_group > 1) {
     const int gsz = E / c.n_group;
-    // group score: noaux_tc = sum of the group's top-2 choice scores; group_limited_greedy = group max
-    float gscore = NEG;  // lane g < n_group holds group g's score
-    for (int g = 0; g < c.n_group; g++) {
-      float v1 = NEG, v2 = NEG;  // per-lane top-2 inside group g
+    const bool top2 = c.topk_method == KTX_GATE_NOAUX_TC;   // group score: sum of the group's top-2 (V3) | group max (V2)
+    unsigned long long keep = 0ull;
+    if (gsz == 32 && 2 * EPL <= 64) {
+      // DeepSeek-V3 / R1 (256 experts, 8 groups): the group of expert (slot s, lane) is 2s + (lane >> 5), so every slot
+      // yields two group scores from 16-lane DPP reductions — no loop over groups, no per-group argmax passes.
+      float gsc[2 * EPL];
 #pragma unroll
       for (int s = 0; s < EPL; s++) {
-        const int e = s * 64 + lane;
-        if (e < E && e / gsz == g) {
-          const float v = choice[s];
-          if (v > v1) { v2 = v1; v1 = v; } else if (v > v2) { v2 = v; }
+        const float v = choice[s];
+        const int r1 = __float_as_int(row16_max(v));
+        const float h0 = fmaxf(__int_as_float(__builtin_amdgcn_readlane(r1, 0)), __int_as_float(__builtin_amdgcn_readlane(r1, 16)));
+        const float h1 = fmaxf(__int_as_float(__builtin_amdgcn_readlane(r1, 32)), __int_as_float(__builtin_amdgcn_readlane(r1, 48)));
+        float q0 = 0.0f, q1 = 0.0f;
+        if (top2) {   // second largest = max after retiring ONE instance of the largest (a tied pair counts twice, like topk(2))
+          const unsigned long long hit = __ballot(v == (lane < 32 ? h0 : h1));
+          const int f0 = __ffs((int)(unsigned)(hit & 0xffffffffull)) - 1, f1 = 32 + __ffs((int)(unsigned)(hit >> 32)) - 1;
+          const float v2 = (lane == (lane < 32 ? f0 : f1)) ? NEG : v;
+          const int r2 = __float_as_int(row16_max(v2));
+          q0 = fmaxf(__int_as_float(__builtin_amdgcn_readlane(r2, 0)), __int_as_float(__builtin_amdgcn_readlane(r2, 16)));
+          q1 = fmaxf(__int_as_float(__builtin_amdgcn_readlane(r2, 32)), __int_as_float(__builtin_amdgcn_readlane(r2, 48)));
         }
+        gsc[2 * s] = top2 ? h0 + q0 : h0;
+        gsc[2 * s + 1] = top2 ? h1 + q1 : h1;
       }
-      // wave top-2 via two argmax passes
-      float m1 = v1; int i1 = lane;
-      wave_argmax(m1, i1);
-      float cand = (lane == i1) ? v2 : v1;
-      int i2 = lane;
-      wave_argmax(cand, i2);
-      const float gs = (c.topk_method == KTX_GATE_NOAUX_TC) ? (m1 + cand) : m1;
-      if (lane == g) gscore = gs;
+      // the topk_group best groups by rank (ties -> lower index); wave-uniform arithmetic
+#pragma unroll
+      for (int g = 0; g < 2 * EPL; g++) {
+        int rank = 0;
+#pragma unroll
+        for (int o = 0; o < 2 * EPL; o++)
+          rank += (o < c.n_group && o != g && (gsc[o] > gsc[g] || (gsc[o] == gsc[g] && o < g))) ? 1 : 0;
+        if (g < c.n_group && rank < c.topk_group) keep |= 1ull << g;
+      }
+    } else {
+      int grp[EPL];
+#pragma unroll
+      for (int s = 0; s < EPL; s++) grp[s] = (s * 64 + lane) / gsz;
+      float gscore = NEG;  // lane g < n_group holds group g's score
+      for (int g = 0; g < c.n_group; g++) {
+        float v1 = NEG, v2 = NEG;  // per-lane top-2 inside group g
+#pragma unroll
+        for (int s = 0; s < EPL; s++) {
+          if (s * 64 + lane < E && grp[s] == g) {
+            const float v = choice[s];
+            if (v > v1) { v2 = v1; v1 = v; } else if (v > v2) { v2 = v; }
+          }
+        }
+        // wave top-2 via two argmax passes
+        float m1 = v1; int i1 = lane;
+        wave_argmax(m1, i1);
+        float cand = (lane == i1) ? v2 : v1;
+        int i2 = lane;
+        wave_argmax(cand, i2);
+        const float gs = top2 ? (m1 + cand) : m1;
+        if (lane == g) gscore = gs;
+      }
+      // pick topk_group groups; everything outside them is masked out
+      float gs = (lane < c.n_group) ? gscore : NEG;
+      for (int r = 0; r < c.topk_group; r++) {
+        float v = gs; int i = lane;
+        wave_argmax(v, i);
+        keep |= 1ull << i;
+        if (lane == i) gs = NEG;
+      }
     }
-    // pick topk_group groups; everything outside them is masked out
-    unsigned long long keep = 0ull;
-    float gs = (lane < c.n_group) ? gscore : NEG;
-    for (int r = 0; r < c.topk_group; r++) {
-      float v = gs; int i = lane;
-      wave_argmax(v, i);
-      keep |= 1ull << i;
-      if (lane == i) gs = NEG;
-    }
-    const float masked = (c.topk_method == KTX_GATE_NOAUX_TC) ? NEG : 0.0f;  // V3 fills -inf, V2 fills 0.0
+    const float masked = top2 ? NEG : 0.0f;  // V3 fills -inf, V2 fills 0.0
 #pragma unroll
     for (int s = 0; s < EPL; s++) {
       const int e = s * 64 + lane;
@@ -215,7 +247,10 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
                                                          float* __restrict__ topk_w, const bf16_t* __restrict__ norm_w,
                                                          float norm_eps, bf16_t* __restrict__ xn_out) {
   __shared__ int s_last;
+  __shared__ float s_red[4];
   __shared__ float s_logits[KTX_GATE_MAX_E];
+  extern __shared__ __attribute__((aligned(16))) uint8_t gate_smem[];   // NJ > 0: the normalised row, bf16 [H]
+  uint4* xs = reinterpret_cast<uint4*>(gate_smem);
   int T = qlen;
   if (d_bsz) T = min(max(*d_bsz, 0), qlen);
   const int t = blockIdx.y;
@@ -223,28 +258,39 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
   const int E = c.n_routed_experts, H = c.hidden_size;
   const int lane = threadIdx.x & 63;
   const int e = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (e < E) {
+  // (NJ > 0: the workgroup-wide barriers below need every wavefront, so an out-of-range expert clamps to the last row and
+  //  simply does not store its logit)
+  const bool e_ok = e < E;
+  if (e_ok || NJ > 0) {
     const bf16_t* xr = x + (size_t)t * H;
-    const bf16_t* wr = w + (size_t)e * H;
+    const bf16_t* wr = w + (size_t)(e_ok ? e : E - 1) * H;
     float acc = 0.0f;
     if constexpr (NJ > 0) {
-      // fused post_attention_layernorm (H <= 512*NJ): the wavefront holds the whole row (112 elements per lane at H = 7168),
-      // so the inverse RMS is one wave reduction; the normalised row (DeepseekV3RMSNorm: w * bf16(x * r)) feeds the dot
-      // products and is written once (workgroup 0, wavefront 0) for the experts that run after the router.
-      uint4 xa[NJ], wn[NJ], b[NJ];
-      float ss = 0.f;
-      // every load of the kernel (x, norm weight, router weights) is issued before the first use
+      // fused post_attention_layernorm (H <= 512*NJ).  The workgroup normalises the row ONCE into LDS — 256 threads x <= 4
+      // pieces of 8 (DeepseekV3RMSNorm: w * bf16(x * r), both roundings) — and each wavefront then takes its expert's dot
+      // product against the LDS copy.  (The first version had every wavefront normalise the whole row in registers: 112
+      // elements per lane at H = 7168 unrolled into ~12k instructions — 100 KB of code, more than the instruction cache,
+      // fetched cold by every launch: 78 us per call inside a DeepSeek-V3 decode step.)  Workgroup 0 writes the normalised
+      // row out for the experts that run after the router.  The router-row loads are issued first: they depend on nothing.
+      uint4 b[NJ];
 #pragma unroll
       for (int u = 0; u < NJ; u++) {
         const int j = lane * 8 + u * 512;
-        const bool ok = j < H;
-        xa[u] = ok ? *reinterpret_cast<const uint4*>(xr + j) : make_uint4(0, 0, 0, 0);
-        wn[u] = ok ? *reinterpret_cast<const uint4*>(norm_w + j) : make_uint4(0, 0, 0, 0);
-        b[u] = ok ? *reinterpret_cast<const uint4*>(wr + j) : make_uint4(0, 0, 0, 0);
+        b[u] = j < H ? *reinterpret_cast<const uint4*>(wr + j) : make_uint4(0, 0, 0, 0);
+      }
+      const int npiece = H >> 3;
+      uint4 xa[4], wn[4];
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int p = threadIdx.x + i * 256;
+        const bool ok = p < npiece;
+        xa[i] = ok ? *reinterpret_cast<const uint4*>(xr + p * 8) : make_uint4(0, 0, 0, 0);
+        wn[i] = ok ? *reinterpret_cast<const uint4*>(norm_w + p * 8) : make_uint4(0, 0, 0, 0);
       }
 #pragma unroll
-      for (int u = 0; u < NJ; u++) {
-        const uint32_t av[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w};
+      for (int i = 0; i < 4; i++) {
+        const uint32_t av[4] = {xa[i].x, xa[i].y, xa[i].z, xa[i].w};
 #pragma unroll
         for (int q = 0; q < 4; q++) {
           const float lo = bf16_to_f32((bf16_t)(av[q] & 0xffffu)), hi = bf16_to_f32((bf16_t)(av[q] >> 16));
@@ -252,26 +298,28 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
         }
       }
       ss = wave_sum(ss);
-      const float r = 1.0f / sqrtf(ss / (float)H + norm_eps);
+      if (lane == 0) s_red[threadIdx.x >> 6] = ss;
+      __syncthreads();
+      const float r = 1.0f / sqrtf((((s_red[0] + s_red[1]) + s_red[2]) + s_red[3]) / (float)H + norm_eps);
+#pragma unroll
+      for (int i = 0; i < 4; i++) {
+        const int p = threadIdx.x + i * 256;
+        if (p < npiece) {
+          const uint4 ov = make_uint4(ktx_norm_pk(xa[i].x, r, wn[i].x), ktx_norm_pk(xa[i].y, r, wn[i].y),
+                                      ktx_norm_pk(xa[i].z, r, wn[i].z), ktx_norm_pk(xa[i].w, r, wn[i].w));
+          xs[p] = ov;
+          if (xn_out && blockIdx.x == 0) *reinterpret_cast<uint4*>(xn_out + (size_t)t * H + p * 8) = ov;
+        }
+      }
+      __syncthreads();
 #pragma unroll
       for (int u = 0; u < NJ; u++) {
         const int j = lane * 8 + u * 512;
         if (j < H) {
-          const uint32_t av[4] = {xa[u].x, xa[u].y, xa[u].z, xa[u].w}, wv[4] = {wn[u].x, wn[u].y, wn[u].z, wn[u].w};
-          const uint32_t bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
-          uint32_t o[4];
+          const uint4 a = xs[lane + u * 64];
+          const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
 #pragma unroll
-          for (int q = 0; q < 4; q++) {
-            const float lo = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(bf16_to_f32((bf16_t)(av[q] & 0xffffu)) * r)) *
-                                                     bf16_to_f32((bf16_t)(wv[q] & 0xffffu))));
-            const float hi = bf16_to_f32(f32_to_bf16(bf16_to_f32(f32_to_bf16(bf16_to_f32((bf16_t)(av[q] >> 16)) * r)) *
-                                                     bf16_to_f32((bf16_t)(wv[q] >> 16))));
-            o[q] = (__float_as_uint(lo) >> 16) | (__float_as_uint(hi) & 0xffff0000u);
-            acc = fmaf(lo, bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
-            acc = fmaf(hi, bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
-          }
-          if (xn_out && blockIdx.x == 0 && threadIdx.x < 64)
-            *reinterpret_cast<uint4*>(xn_out + (size_t)t * H + j) = make_uint4(o[0], o[1], o[2], o[3]);
+          for (int q = 0; q < 4; q++) acc = ktx_dot2_bf16(av[q], bv[q], acc);
         }
       }
     } else
@@ -287,14 +335,11 @@ __global__ __launch_bounds__(256) void gate_fused_kernel(ktx_gate_config c, cons
       for (int u = 0; u < 8; u++) {
         const uint32_t av[4] = {a[u].x, a[u].y, a[u].z, a[u].w}, bv[4] = {b[u].x, b[u].y, b[u].z, b[u].w};
 #pragma unroll
-        for (int q = 0; q < 4; q++) {
-          acc = fmaf(bf16_to_f32((bf16_t)(av[q] & 0xffffu)), bf16_to_f32((bf16_t)(bv[q] & 0xffffu)), acc);
-          acc = fmaf(bf16_to_f32((bf16_t)(av[q] >> 16)), bf16_to_f32((bf16_t)(bv[q] >> 16)), acc);
-        }
+        for (int q = 0; q < 4; q++) acc = ktx_dot2_bf16(av[q], bv[q], acc);
       }
     }
     acc = wave_sum(acc);
-    if (lane == 0) __hip_atomic_store(&logits[(size_t)t * E + e], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 store
+    if (lane == 0 && e_ok) __hip_atomic_store(&logits[(size_t)t * E + e], acc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // sc1 store
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -338,7 +383,7 @@ static int gate_forward_impl(const ktx_gate_config* cfg, const int32_t* d_bsz, i
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((E + 3) / 4, qlen);
   const int epl = (E + 63) / 64;
-#define KTX_FUSED2(N, J) hipLaunchKernelGGL((gate_fused_kernel<N, J>), grid, dim3(256), 0, st, *cfg, d_bsz, qlen, (const bf16_t*)d_x, (const bf16_t*)d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight, (const bf16_t*)d_norm_w, norm_eps, (bf16_t*)d_xn_out)
+#define KTX_FUSED2(N, J) hipLaunchKernelGGL((gate_fused_kernel<N, J>), grid, dim3(256), (J) > 0 ? (size_t)cfg->hidden_size * 2 : 0, st, *cfg, d_bsz, qlen, (const bf16_t*)d_x, (const bf16_t*)d_w, d_bias, d_logits, d_counters, d_topk_idx, d_topk_weight, (const bf16_t*)d_norm_w, norm_eps, (bf16_t*)d_xn_out)
 #define KTX_FUSED(N)                                                          \
   do {                                                                        \
     if (!d_norm_w) KTX_FUSED2(N, 0);                                          \
@@ -347,6 +392,8 @@ static int gate_forward_impl(const ktx_gate_config* cfg, const int32_t* d_bsz, i
     else KTX_FUSED2(N, 16);                                                   \
   } while (0)
   KTX_REQUIRE(!d_norm_w || cfg->hidden_size <= 8192, "ktx_gate_forward_norm: the fused RMSNorm needs hidden_size <= 8192");
+  KTX_TIMED(st, (double)E * cfg->hidden_size * 2.0 + (double)qlen * cfg->hidden_size * (d_norm_w ? 6.0 : 2.0) + E * 8.0,
+            "gate_fused_kernel%s T=%d E=%d H=%d", d_norm_w ? "+rmsnorm" : "", qlen, E, cfg->hidden_size);
   if (epl <= 1) KTX_FUSED(1);
   else if (epl <= 2) KTX_FUSED(2);
   else if (epl <= 4) KTX_FUSED(4);

@@ -200,18 +200,10 @@ __device__ __forceinline__ bf16_t lin_glu(float g, float u) {
   const float sb = bf16_to_f32(f32_to_bf16(gb / (1.0f + expf(-gb))));
   return f32_to_bf16(sb * ub);
 }
-// 8 bf16 of an input row -> RMSNorm'ed (DeepseekV3RMSNorm.forward: w * bf16(x * r), both roundings)
+// 8 bf16 of an input row -> RMSNorm'ed (DeepseekV3RMSNorm.forward: w * bf16(x * r), both roundings as torch's bf16 cast)
 __device__ __forceinline__ uint4 lin_norm8(const uint4& v, float r, const bf16_t* __restrict__ w8) {
   const uint4 wv = *reinterpret_cast<const uint4*>(w8);
-  const uint32_t d[4] = {v.x, v.y, v.z, v.w}, wd[4] = {wv.x, wv.y, wv.z, wv.w};
-  uint32_t o[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const float a = bf16_to_f32(f32_to_bf16(__uint_as_float(d[i] << 16) * r)) * __uint_as_float(wd[i] << 16);
-    const float b = bf16_to_f32(f32_to_bf16(__uint_as_float(d[i] & 0xffff0000u) * r)) * __uint_as_float(wd[i] & 0xffff0000u);
-    o[i] = (uint32_t)f32_to_bf16(a) | ((uint32_t)f32_to_bf16(b) << 16);
-  }
-  return make_uint4(o[0], o[1], o[2], o[3]);
+  return make_uint4(ktx_norm_pk(v.x, r, wv.x), ktx_norm_pk(v.y, r, wv.y), ktx_norm_pk(v.z, r, wv.z), ktx_norm_pk(v.w, r, wv.w));
 }
 
 // =====================================================================================================
@@ -219,7 +211,11 @@ __device__ __forceinline__ uint4 lin_norm8(const uint4& v, float r, const bf16_t
 // one k-slice through a D-deep register ring; the 8 wavefronts of a workgroup are SW strips x 8/SW k-slices and meet in
 // LDS (fixed summation order).
 // =====================================================================================================
-template <int FMT, int G, int D>
+// EXACT: every k-slice holds a multiple of D k-steps, so the hot loop is branch-free straight-line code and the compiler
+// keeps exact `s_waitcnt vmcnt(D-1..)` counts: D KiB-sized loads stay in flight per wave.  With guards in the loop
+// (`if (ks < ks1)` around a load) it cannot count the outstanding loads and drains the ring with vmcnt(0) at every step:
+// one KiB per memory round trip per wave — measured 1.7-2.7 TB/s on 60-500 MB matrices before this variant existed.
+template <int FMT, int G, int D, bool EXACT>
 __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   using F = Fmt<FMT, G>;
   lin_select_batch(p, blockIdx.y);
@@ -234,50 +230,75 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sw = wave % p.SW, sl = wave / p.SW;
-  const int strip = blockIdx.x * p.SW + sw;
-  const bool strip_ok = strip < p.nstrips;
-  const int ks0 = sl * p.SPS, ks1 = strip_ok ? min(ks0 + p.SPS, NKS) : ks0;
+  const int strip_raw = blockIdx.x * p.SW + sw;
+  const bool strip_ok = strip_raw < p.nstrips;
+  const int strip = strip_ok ? strip_raw : p.nstrips - 1;   // a surplus wave streams a valid strip and stores nothing
+  const int ks0 = sl * p.SPS, ks1 = EXACT ? ks0 + p.SPS : (strip_ok ? min(ks0 + p.SPS, NKS) : ks0);
   int bsz = p.T;
   if (p.d_bsz) bsz = min(max(*p.d_bsz, 0), p.T);
 
-  // ---- weight ring: issue the first D k-steps before anything else
+  // ---- the activation rows first (vmcnt retires in order and they are needed first): up to XPRE 16-byte pieces per
+  // thread go to registers now, the (rare) rest of a long multi-token block is fetched in the staging loops below
+  constexpr int XPRE = 4;
+  const int npiece = NKS * 16;   // 8-element pieces per token
+  const int ntot = TP * npiece;
+  uint4 xpre[XPRE];
+#pragma unroll
+  for (int i = 0; i < XPRE; i++) {
+    const int idx = tid + i * 512;
+    xpre[i] = make_uint4(0, 0, 0, 0);
+    if (idx < ntot) {
+      const int tok = idx / npiece, col = idx - tok * npiece;
+      if (tok < bsz && col * 8 < p.Kx) xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
+    }
+  }
+  auto piece = [&](int it, int idx) -> uint4 {   // piece `idx` of the block: register copy for the first XPRE rounds
+    if (it < XPRE) return xpre[it < XPRE ? it : 0];
+    const int tok = idx / npiece, col = idx - tok * npiece;
+    if (tok < bsz && col * 8 < p.Kx) return *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
+    return make_uint4(0, 0, 0, 0);
+  };
+
+  // ---- weight ring: the first D k-steps are in flight while the activations are staged
   uint4 wr[D][F::NQ];
   uint2 sr[D];
   const uint8_t* wp = p.w + (size_t)strip * NKS * F::TILE + lane * 16;
   const bf16_t* sp4 = reinterpret_cast<const bf16_t*>(p.sc) + ((size_t)strip * NKS * 16 + (lane & 15)) * F::GPK;
   const float* sp8 = reinterpret_cast<const float*>(p.sc) + (size_t)(strip >> 3) * NKS;
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
   auto load_step = [&](int d, int ks) {
 #pragma unroll
-    for (int q = 0; q < F::NQ; q++)
-      wr[d][q] = *reinterpret_cast<const uint4*>(wp + (size_t)ks * F::TILE + q * 1024);
+    for (int q = 0; q < F::NQ; q++) {   // non-temporal: every weight byte is read once per token by one CU
+      const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + (size_t)ks * F::TILE + q * 1024));
+      wr[d][q] = make_uint4(v.x, v.y, v.z, v.w);
+    }
     if constexpr (FMT == F_W4) sr[d] = load_w4_scales<F::GPK>(sp4 + (size_t)ks * 16 * F::GPK);
     else if constexpr (FMT == F_FP8) sr[d] = make_uint2(__float_as_uint(sp8[ks]), 0);
     else sr[d] = make_uint2(0, 0);
   };
 #pragma unroll
   for (int d = 0; d < D; d++)
-    if (ks0 + d < ks1) load_step(d, ks0 + d);
+    if (EXACT || ks0 + d < ks1) load_step(d, ks0 + d);
 
   // ---- stage the activations (every workgroup its own copy), group sums / fp8 quantisation on the way
-  const int npiece = NKS * 16;   // 8-element pieces per token
   float rnorm[4] = {1.f, 1.f, 1.f, 1.f};
-  if (p.norm_w) {   // fused input RMSNorm: first the inverse RMS of every token row (rows are re-read below from L1/L2)
-    float ss[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int idx = tid; idx < TP * npiece; idx += 512) {
-      const int tok = idx / npiece, col = idx - tok * npiece;
-      if (tok < bsz && col * 8 < p.Kx) {
-        const uint4 v = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
-        const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-        float q = 0.f;
+  auto sumsq_piece = [&](int idx, const uint4& v, float (&ss)[4]) {
+    const int tok = idx / npiece;
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+    float q = 0.f;
 #pragma unroll
-        for (int i = 0; i < 4; i++) {
-          const float a = __uint_as_float(d[i] << 16), b = __uint_as_float(d[i] & 0xffff0000u);
-          q += a * a + b * b;
-        }
-#pragma unroll
-        for (int t4 = 0; t4 < 4; t4++) ss[t4] += tok == t4 ? q : 0.f;
-      }
+    for (int i = 0; i < 4; i++) {
+      const float a = __uint_as_float(d[i] << 16), b = __uint_as_float(d[i] & 0xffff0000u);
+      q += a * a + b * b;
     }
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) ss[t4] += tok == t4 ? q : 0.f;   // pieces beyond the block are all-zero
+  };
+  if (p.norm_w) {   // fused input RMSNorm: first the inverse RMS of every token row
+    float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int i = 0; i < XPRE; i++) sumsq_piece(tid + i * 512, xpre[i], ss);
+    for (int idx = tid + XPRE * 512; idx < ntot; idx += 512) sumsq_piece(idx, piece(XPRE, idx), ss);
     float* nred = red;   // [8 waves][4], free until the epilogue
 #pragma unroll
     for (int t4 = 0; t4 < 4; t4++) {
@@ -293,13 +314,10 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
     }
     __syncthreads();
   }
-  for (int idx = tid; idx < TP * npiece; idx += 512) {
+  auto stage_piece = [&](int idx, uint4 v) {
     const int tok = idx / npiece, col = idx - tok * npiece;
-    uint4 v = make_uint4(0, 0, 0, 0);
-    if (tok < bsz && col * 8 < p.Kx) {
-      v = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
-      if (p.norm_w) v = lin_norm8(v, tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3], p.norm_w + col * 8);
-    }
+    if (p.norm_w && tok < bsz && col * 8 < p.Kx)
+      v = lin_norm8(v, tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3], p.norm_w + col * 8);
     if constexpr (FMT == F_FP8) {
       float am = amax8_bf16(v);
 #pragma unroll
@@ -318,7 +336,12 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
           for (int r = tok; r < 4; r += TP) aux[(col / (G / 8)) * 4 + r] = s;
       }
     }
-  }
+  };
+  // (the shuffles inside stage_piece need whole 16-lane groups: ntot is a multiple of 16 and idx advances by 512)
+#pragma unroll
+  for (int i = 0; i < XPRE; i++)
+    if (tid + i * 512 < ntot) stage_piece(tid + i * 512, xpre[i]);
+  for (int idx = tid + XPRE * 512; idx < ntot; idx += 512) stage_piece(idx, piece(XPRE, idx));
   __syncthreads();
 
   // ---- stream
@@ -326,13 +349,30 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   const int kc = lane >> 4, tokp = (lane & 15) & (TP - 1);
   const uint8_t* xb0 = xs + tokp * 16 + (FMT == F_FP8 ? kc * 2 : FMT == F_W4 ? kc : kc * 4) * cs;
   const int xstep = (FMT == F_FP8 ? 8 : 16) * cs;
-  for (int base = ks0; base < ks1; base += D) {
+  if constexpr (EXACT) {
+    const int ngrp = p.SPS / D;
+    for (int g = 0; g < ngrp - 1; g++) {
+      const int base = ks0 + g * D;
 #pragma unroll
-    for (int d = 0; d < D; d++) {
-      const int ks = base + d;
-      if (ks < ks1) {
-        lin_step<FMT, G>(wr[d], sr[d], xb0 + (size_t)ks * xstep, cs, aux + ks * F::GPK * 4, 4, acc);
-        if (ks + D < ks1) load_step(d, ks + D);
+      for (int d = 0; d < D; d++) {
+        lin_step<FMT, G>(wr[d], sr[d], xb0 + (size_t)(base + d) * xstep, cs, aux + (base + d) * F::GPK * 4, 4, acc);
+        load_step(d, base + D + d);
+        __builtin_amdgcn_sched_barrier(0);   // keep the refill right behind its slot's use: D loads stay in flight
+      }
+    }
+    const int base = ks0 + (ngrp - 1) * D;
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      lin_step<FMT, G>(wr[d], sr[d], xb0 + (size_t)(base + d) * xstep, cs, aux + (base + d) * F::GPK * 4, 4, acc);
+  } else {
+    for (int base = ks0; base < ks1; base += D) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int ks = base + d;
+        if (ks < ks1) {
+          lin_step<FMT, G>(wr[d], sr[d], xb0 + (size_t)ks * xstep, cs, aux + ks * F::GPK * 4, 4, acc);
+          if (ks + D < ks1) load_step(d, ks + D);
+        }
       }
     }
   }
@@ -346,7 +386,7 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   if (tid < p.SW * 64) {
     const int swo = tid >> 6, r = (tid >> 4) & 3, f = tid & 15;
     const int n = (blockIdx.x * p.SW + swo) * 16 + f;
-    if (r < bsz && n < p.N) {
+    if (r < bsz && n < p.N && blockIdx.x * p.SW + swo < p.nstrips) {
       const int nsl = 8 / p.SW;
       float v = 0.f;
       for (int s = 0; s < nsl; s++) v += red[((s * p.SW + swo) * 4 + r) * 16 + f];
@@ -670,10 +710,25 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
     KTX_HIP(hipGetLastError());
     return 0;
   };
-  constexpr int DMAX = FMT == F_BF16 ? 4 : 8;
-  if (p.SPS >= DMAX) return go(lin_dec_kernel<FMT, G, DMAX>);
-  if (p.SPS >= 4) return go(lin_dec_kernel<FMT, G, 4>);
-  return go(lin_dec_kernel<FMT, G, 2>);
+  constexpr int DMAX = FMT == F_BF16 ? 4 : 8;   // ring depth bound by registers: a BF16 k-step is 4 KiB per wave
+  KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
+            "lin_dec_kernel<%s> %d->%d%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", p.Kx, p.N,
+            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
+  // branch-free variant whenever every k-slice is the same whole number of D-step groups (all DeepSeek / Kimi shapes)
+  if (nsl * p.SPS == NKS) {
+    if constexpr (DMAX >= 8) {
+      if (p.SPS % 8 == 0) return go(lin_dec_kernel<FMT, G, 8, true>);
+      if (p.SPS % 7 == 0) return go(lin_dec_kernel<FMT, G, 7, true>);
+      if (p.SPS % 6 == 0) return go(lin_dec_kernel<FMT, G, 6, true>);
+    }
+    if (p.SPS % 4 == 0) return go(lin_dec_kernel<FMT, G, 4, true>);
+    if (p.SPS % 3 == 0) return go(lin_dec_kernel<FMT, G, 3, true>);
+    if (p.SPS % 2 == 0) return go(lin_dec_kernel<FMT, G, 2, true>);
+    if (p.SPS == 1) return go(lin_dec_kernel<FMT, G, 1, true>);
+  }
+  if (p.SPS >= DMAX) return go(lin_dec_kernel<FMT, G, DMAX, false>);
+  if (p.SPS >= 4) return go(lin_dec_kernel<FMT, G, 4, false>);
+  return go(lin_dec_kernel<FMT, G, 2, false>);
 }
 
 template <int FMT, int G, int MT>
@@ -683,6 +738,9 @@ int launch_gemm(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
   const size_t smem = 2 * (size_t)(2 * C16 * CS) + 2 * (size_t)(2 * F::GPK * TOK * 4);
   const dim3 grid((h->nstrips + 3) / 4, (p.T + TOK - 1) / TOK, h->batch);
   auto kern = lin_gemm_kernel<FMT, G, MT>;
+  KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
+            "lin_gemm_kernel<%s,MT%d> T=%d %d->%d%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", MT, p.T, p.Kx, p.N,
+            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
   static bool attr_set = false;
   if (!attr_set) {
     KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));

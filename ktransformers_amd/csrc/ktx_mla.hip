@@ -19,6 +19,8 @@
 #include "../../include/ktx_mla.h"
 #include "ktx_common.h"
 
+extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
+
 typedef __bf16 v8bf __attribute__((ext_vector_type(8)));
 
 #define MLA_TILE 32
@@ -100,7 +102,12 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   for (int b0 = 0; b0 < B && req < 0; b0 += 64) {
     const int i = b0 + lane;
     int q0 = 0x7fffffff, q1 = 0, kl = 0, kp = 0;
-    if (i < B) { q0 = p.qo_indptr[i]; q1 = p.qo_indptr[i + 1]; kl = p.kv_len[i]; kp = p.kv_indptr[i]; }
+    if (i < B) {
+      q0 = p.qo_indptr[i]; q1 = p.qo_indptr[i + 1]; kl = p.kv_len[i]; kp = p.kv_indptr[i];
+      // never index past the pages the request owns: a sequence that outgrew its cache attends to (and appends within)
+      // its last page instead of reading kv_indices / writing HBM out of bounds
+      kl = min(kl, (p.kv_indptr[i + 1] - kp) * p.page_size);
+    }
     const unsigned long long hit = __ballot(qt >= q0 && qt < q1);
     if (hit) {
       const int src = __ffsll((long long)hit) - 1;
@@ -356,11 +363,12 @@ __global__ __launch_bounds__(256) void mla_merge_kernel(MlaParams p, bf16_t* out
 
 __global__ void mla_cache_append_kernel(bf16_t* cache, long long ts, int page_size, const bf16_t* ckv, const bf16_t* kpe,
                                         const int32_t* page_idx, const int32_t* page_off, const int32_t* ntok,
-                                        int max_tokens) {
+                                        int max_tokens, int num_pages) {
   int T = max_tokens;
   if (ntok) T = min(max(*ntok, 0), max_tokens);
   const int t = blockIdx.x;
   if (t >= T) return;
+  if (num_pages > 0 && ((unsigned)page_idx[t] >= (unsigned)num_pages || (unsigned)page_off[t] >= (unsigned)page_size)) return;
   bf16_t* dst = cache + ((size_t)page_idx[t] * page_size + page_off[t]) * ts;
   const int i = threadIdx.x;  // 72 threads x 16 B = 576 bf16
   if (i < 64) *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(ckv + (size_t)t * MLA_DC + i * 8);
@@ -402,15 +410,26 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   KTX_REQUIRE(ckv_token_stride % 8 == 0 && kpe_token_stride % 8 == 0, "ktx_mla_decode: token strides must be multiples of 8 elements");
   hipStream_t st = (hipStream_t)stream;
   const int Hq = cfg->num_heads;
-  // workgroup shape: (head blocks x dim slices) = 4x2 for head counts that are multiples of 64, 1x4 otherwise
-  const bool wide = (Hq % 64 == 0);
-  const int hbw = wide ? 4 : 1, nwv = wide ? 8 : 4;
+  // workgroup shape (head blocks x dim slices): decode-sized calls of many-headed models take 2x4 (32 heads share one staged
+  // KV tile, 128 output dims per wave), prompts of those models 4x2, everything else 1x4
+  const bool decode_sized = total_q_tokens <= 16;
+  const int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized) ? 2 : (Hq % 64 == 0) ? 4 : 1;
+  const bool wide = shape == 4;
+  const int hbw = shape, nwv = shape == 1 ? 4 : 8;
   const int hblocks = Hq / (16 * hbw);
-  // KV splits: one 32-token tile per workgroup whenever the grid stays under ~2048 workgroups (measured: extra tiles per
-  // workgroup cost more than the extra partials cost the merge kernel), bounded by the workspace
+  // KV splits: one 32-token tile per workgroup whenever the grid stays under ~2048 workgroups (measured on 16 heads: extra
+  // tiles per workgroup cost more than the extra partials cost the merge kernel), bounded by the workspace — and by the
+  // partials themselves: every split writes Hq x 514 floats per token that the merge kernel reads back (at 128 heads and 144
+  // splits that was 38 MB per layer, 8x the 4.7 MB of latent rows the attention actually needs), so the split count is
+  // capped where the partials reach ~16 MB and at about one workgroup per CU
   int nsplit = std::max(1, 2048 / std::max(1, hblocks * total_q_tokens));
+  const size_t per_split_bytes = (size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float);
+  nsplit = std::min<int>(nsplit, std::max<size_t>(16, ((size_t)16 << 20) / per_split_bytes));
+  if (shape == 2) nsplit = std::min(nsplit, std::max(16, 256 / std::max(1, hblocks * total_q_tokens)));
   if (cfg->kv_len_hint > 0) nsplit = std::min(nsplit, std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE));
-  nsplit = std::min(nsplit, std::min(1024, std::max(1, cfg->max_splits)));
+  // <= 256 splits: the merge kernel keeps splits/16 partial rows per thread in registers (NS = 16 is its largest, spill-free
+  // instantiation); longer contexts simply put more 32-token tiles into each split
+  nsplit = std::min(nsplit, std::min(256, std::max(1, cfg->max_splits)));
   nsplit = (int)std::min<size_t>((size_t)nsplit, workspace_bytes / ((size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float)));
   KTX_REQUIRE(nsplit >= 1, "ktx_mla_decode: workspace too small");
   const size_t need = (size_t)total_q_tokens * Hq * nsplit * (MLA_DC + 2) * sizeof(float);
@@ -426,26 +445,40 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   p.app_ckv = (const bf16_t*)d_new_ckv; p.app_kpe = (const bf16_t*)d_new_kpe; p.ckv_w = (bf16_t*)d_ckv; p.kpe_w = (bf16_t*)d_k_pe;
   const size_t lds = (size_t)(2 * MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
   const dim3 grid(nsplit, hblocks, total_q_tokens);
-  if (wide) {
+  const int only = ktx_debug_get(5);   // measurement knob (include/ktx_moe.h): 1 = split-KV kernel only, 2 = merge only
+  // algorithmic bytes: the latent rows of the context (hint) + q / out rows; the split partials are an implementation artefact
+  const double kv_bytes = (double)std::max(cfg->kv_len_hint, 1) * (MLA_DC + MLA_DR) * 2.0 * batch;
+  if (only == 2) {
+  } else if (shape == 2) {
+    KTX_TIMED(st, kv_bytes + (double)total_q_tokens * Hq * (MLA_DC + MLA_DR + MLA_DC) * 2.0,
+              "mla_decode_kernel<2,4> T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
+    static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<2, 4>),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    KTX_HIP(e2);
+    hipLaunchKernelGGL((mla_decode_kernel<2, 4>), grid, dim3(512), lds, st, p);
+  } else if (wide) {
+    KTX_TIMED(st, kv_bytes + (double)total_q_tokens * Hq * (MLA_DC + MLA_DR + MLA_DC) * 2.0,
+              "mla_decode_kernel<4,2> T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
     static hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<4, 2>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     KTX_HIP(e4);
     hipLaunchKernelGGL((mla_decode_kernel<4, 2>), grid, dim3(512), lds, st, p);
   } else {
+    KTX_TIMED(st, kv_bytes + (double)total_q_tokens * Hq * (MLA_DC + MLA_DR + MLA_DC) * 2.0,
+              "mla_decode_kernel<1,4> T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
     static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<1, 4>),
                                                hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
     KTX_HIP(e1);
     hipLaunchKernelGGL((mla_decode_kernel<1, 4>), grid, dim3(256), lds, st, p);
   }
   KTX_HIP(hipGetLastError());
-  {
+  if (only != 1) {
+    KTX_TIMED(st, (double)total_q_tokens * Hq * MLA_DC * 2.0, "mla_merge_kernel T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
     const dim3 mg(Hq, total_q_tokens, 4);
     if (p.nsplit <= 32) hipLaunchKernelGGL(mla_merge_kernel<2>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
     else if (p.nsplit <= 64) hipLaunchKernelGGL(mla_merge_kernel<4>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
     else if (p.nsplit <= 144) hipLaunchKernelGGL(mla_merge_kernel<9>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
-    else if (p.nsplit <= 256) hipLaunchKernelGGL(mla_merge_kernel<16>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
-    else if (p.nsplit <= 512) hipLaunchKernelGGL(mla_merge_kernel<32>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
-    else hipLaunchKernelGGL(mla_merge_kernel<64>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
+    else hipLaunchKernelGGL(mla_merge_kernel<16>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
   }
   KTX_HIP(hipGetLastError());
   return 0;
@@ -453,13 +486,14 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
 
 extern "C" int ktx_mla_cache_append(const ktx_mla_config* cfg, void* d_kv_cache, int64_t token_stride,
                                     const void* d_ckv_new, const void* d_kpe_new, const int32_t* d_page_idx,
-                                    const int32_t* d_page_offset, const int32_t* d_ntokens, int max_tokens, void* stream) {
+                                    const int32_t* d_page_offset, const int32_t* d_ntokens, int max_tokens, int num_pages,
+                                    void* stream) {
   KTX_REQUIRE(cfg && d_kv_cache && d_ckv_new && d_kpe_new && d_page_idx && d_page_offset && max_tokens > 0,
               "ktx_mla_cache_append: bad argument");
   KTX_REQUIRE(token_stride >= MLA_DC + MLA_DR && token_stride % 8 == 0, "ktx_mla_cache_append: bad token stride");
   hipLaunchKernelGGL(mla_cache_append_kernel, dim3(max_tokens), dim3(128), 0, (hipStream_t)stream, (bf16_t*)d_kv_cache,
                      (long long)token_stride, cfg->page_size, (const bf16_t*)d_ckv_new, (const bf16_t*)d_kpe_new,
-                     d_page_idx, d_page_offset, d_ntokens, max_tokens);
+                     d_page_idx, d_page_offset, d_ntokens, max_tokens, num_pages);
   KTX_HIP(hipGetLastError());
   return 0;
 }

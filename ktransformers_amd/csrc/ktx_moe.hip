@@ -29,6 +29,7 @@
 #include <algorithm>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <mutex>
 #include <string>
 #include <vector>
@@ -1741,8 +1742,12 @@ __global__ void pack_rawint4_scales_kernel(const bf16_t* __restrict__ src, int N
 // host side
 // =====================================================================================================
 // Scratch for one forward.  Like the reference's shared_mem_buffer arena (cpu_backend/shared_mem_buffer.h:37-55) it is
-// shared by every MoE layer on a device: forwards of different layers are ordered on the caller's stream, so one
-// arena (grown to the largest request at create time, never inside forward) serves them all.
+// shared by the MoE layers of a device: forwards of different layers are ordered on ONE stream (the caller's decode /
+// prefill stream — handles that run concurrently on different streams of one device must not share an arena and are not
+// supported), so one arena sized for the largest request serves them all.  An arena is NEVER grown in place or freed
+// while a handle refers to it: captured HIP graphs bake its addresses in.  A handle that needs more than the device's
+// current arena holds gets a NEW arena (which becomes the device's current one); the old one lives on for the handles
+// (and graphs) that already use it and is released with the last of them.
 struct Workspace {
   int8_t *x_q = nullptr, *a_q = nullptr;
   float *x_d = nullptr, *a_d = nullptr;
@@ -1751,18 +1756,35 @@ struct Workspace {
   Tile* tiles = nullptr;
   int16_t *x_bs = nullptr, *a_bs = nullptr;   // Q8_K 16-sums (GGUF path)
   size_t cap[12] = {0};
+  int device = 0;
+  ~Workspace() {
+    int cur = 0;
+    const bool have = hipGetDevice(&cur) == hipSuccess;
+    (void)hipSetDevice(device);
+    (void)hipDeviceSynchronize();
+    void* ptrs[] = {x_q, a_q, x_d, a_d, a_buf, dn_buf, row_of_pair, src_of_row, counters, tiles, x_bs, a_bs};
+    for (void* q : ptrs)
+      if (q) (void)hipFree(q);
+    if (have) (void)hipSetDevice(cur);
+  }
 };
 static std::mutex g_ws_mu;
-static Workspace g_ws[64];
+static std::shared_ptr<Workspace> g_ws[64];
 
-template <class T>
-static hipError_t grow(T*& p, size_t& cap, size_t bytes) {
-  if (bytes <= cap) return hipSuccess;
-  if (p) { hipError_t e = hipFree(p); if (e != hipSuccess) return e; p = nullptr; }
-  hipError_t e = hipMalloc(&p, bytes);
-  if (e == hipSuccess) cap = bytes;
-  return e;
-}
+// current device saved on entry, restored on exit (callers with several GPUs in one process keep their own current device)
+struct DeviceGuard {
+  int prev = -1;
+  hipError_t err;
+  explicit DeviceGuard(int dev) {
+    err = hipGetDevice(&prev);
+    if (err == hipSuccess && prev != dev) err = hipSetDevice(dev);
+  }
+  ~DeviceGuard() {
+    int cur = -1;
+    if (prev >= 0 && hipGetDevice(&cur) == hipSuccess && cur != prev) (void)hipSetDevice(prev);
+  }
+};
+#define KTX_ON_DEVICE(dev) DeviceGuard _dg(dev); KTX_HIP(_dg.err)
 
 struct ktx_moe_s {
   ktx_moe_config cfg;
@@ -1771,6 +1793,7 @@ struct ktx_moe_s {
   uint8_t *gate_w = nullptr, *up_w = nullptr, *down_w = nullptr;
   float *gate_s = nullptr, *up_s = nullptr, *down_s = nullptr;
   uint8_t* mask = nullptr;
+  std::shared_ptr<Workspace> ws_own;   // keeps the arena alive as long as this handle (and graphs captured through it)
   Workspace* ws = nullptr;
   int max_pairs = 0, max_tiles = 0;
   int gg_type[3] = {0, 0, 0};     // GGUF: ggml type of gate / up / down
@@ -1803,7 +1826,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
               "ktx_moe_create: hidden_size and intermediate_size must be multiples of 128 (reference: K % 128 == 0)");
   KTX_REQUIRE(cfg->max_len > 0, "ktx_moe_create: max_len must be positive");
   KTX_REQUIRE(cfg->intermediate_size <= 8192 || cfg->format > KTX_FMT_AMXINT8, "ktx_moe_create: intermediate_size > 8192 is not supported for the int formats");
-  KTX_HIP(hipSetDevice(cfg->device));
+  KTX_ON_DEVICE(cfg->device);
   ktx_moe_s* h = new ktx_moe_s();
   h->cfg = *cfg;
   if (h->cfg.global_expert_num <= 0) h->cfg.global_expert_num = cfg->expert_num;
@@ -1828,30 +1851,47 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_HIP(hipMalloc(&h->down_s, dn_sbytes));
   }
   {
-    // Growing the arena frees the old blocks: only legal while no forward using them is in flight.
     std::lock_guard<std::mutex> lk(g_ws_mu);
     KTX_REQUIRE(cfg->device >= 0 && cfg->device < 64, "ktx_moe_create: device ordinal out of range");
-    Workspace* w = &g_ws[cfg->device];
-    KTX_HIP(hipDeviceSynchronize());
-    KTX_HIP(grow(w->x_q, w->cap[0], (size_t)cfg->max_len * H));
-    KTX_HIP(grow(w->x_d, w->cap[1], (size_t)cfg->max_len * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? H / 32 : gguf ? H / 256 : 1)));
+    const bool raw = cfg->format == KTX_FMT_RAWINT4;
+    size_t need[12] = {0};
+    need[0] = (size_t)cfg->max_len * H;
+    need[1] = (size_t)cfg->max_len * sizeof(float) * (raw ? H / 32 : gguf ? H / 256 : 1);
     // int formats: the grouped gate/up GEMM stores g | u (2*I bf16 per row); GGUF: fp32 intermediates
-    KTX_HIP(grow(w->a_buf, w->cap[2], (size_t)h->max_pairs * I * (gguf ? sizeof(float) : 2 * sizeof(bf16_t))));
-    KTX_HIP(grow(w->a_q, w->cap[3], (size_t)h->max_pairs * I));
-    KTX_HIP(grow(w->a_d, w->cap[4], (size_t)h->max_pairs * sizeof(float) * (cfg->format == KTX_FMT_RAWINT4 ? I / 32 : gguf ? I / 256 : 1)));
-    KTX_HIP(grow(w->dn_buf, w->cap[5], (size_t)h->max_pairs * H * (gguf ? sizeof(float) : sizeof(bf16_t))));
+    need[2] = (size_t)h->max_pairs * I * (gguf ? sizeof(float) : 2 * sizeof(bf16_t));
+    need[3] = (size_t)h->max_pairs * I;
+    need[4] = (size_t)h->max_pairs * sizeof(float) * (raw ? I / 32 : gguf ? I / 256 : 1);
+    need[5] = (size_t)h->max_pairs * H * (gguf ? sizeof(float) : sizeof(bf16_t));
+    need[6] = need[7] = (size_t)h->max_pairs * sizeof(int32_t);
+    need[8] = (size_t)h->max_tiles * sizeof(Tile);
+    need[9] = 4 * sizeof(int32_t);
     if (gguf) {
-      KTX_HIP(grow(w->x_bs, w->cap[10], (size_t)cfg->max_len * (H / 16) * sizeof(int16_t)));
-      KTX_HIP(grow(w->a_bs, w->cap[11], (size_t)h->max_pairs * (I / 16) * sizeof(int16_t)));
+      need[10] = (size_t)cfg->max_len * (H / 16) * sizeof(int16_t);
+      need[11] = (size_t)h->max_pairs * (I / 16) * sizeof(int16_t);
     }
-    KTX_HIP(grow(w->row_of_pair, w->cap[6], (size_t)h->max_pairs * sizeof(int32_t)));
-    KTX_HIP(grow(w->src_of_row, w->cap[7], (size_t)h->max_pairs * sizeof(int32_t)));
-    KTX_HIP(grow(w->tiles, w->cap[8], (size_t)h->max_tiles * sizeof(Tile)));
-    if (!w->counters) {
-      KTX_HIP(grow(w->counters, w->cap[9], 4 * sizeof(int32_t)));
-      KTX_HIP(hipMemset(w->counters, 0, 4 * sizeof(int32_t)));
+    std::shared_ptr<Workspace> cur = g_ws[cfg->device];
+    bool fits = cur != nullptr;
+    for (int i = 0; fits && i < 12; i++) fits = need[i] <= cur->cap[i];
+    if (!fits) {
+      auto w = std::make_shared<Workspace>();
+      w->device = cfg->device;
+      for (int i = 0; i < 12; i++) w->cap[i] = std::max(need[i], cur ? cur->cap[i] : (size_t)0);
+      hipError_t e = hipSuccess;
+      auto alloc = [&](auto*& ptr, int i) {
+        if (e == hipSuccess && w->cap[i]) e = hipMalloc(reinterpret_cast<void**>(&ptr), w->cap[i]);
+      };
+      alloc(w->x_q, 0); alloc(w->x_d, 1); alloc(w->a_buf, 2); alloc(w->a_q, 3); alloc(w->a_d, 4); alloc(w->dn_buf, 5);
+      alloc(w->row_of_pair, 6); alloc(w->src_of_row, 7); alloc(w->tiles, 8); alloc(w->counters, 9);
+      alloc(w->x_bs, 10); alloc(w->a_bs, 11);
+      if (e == hipSuccess) e = hipMemset(w->counters, 0, 4 * sizeof(int32_t));
+      if (e != hipSuccess) {
+        ktx_moe_destroy(h);
+        return ktx_fail(std::string("ktx_moe_create: workspace: ") + hipGetErrorString(e));
+      }
+      g_ws[cfg->device] = cur = w;
     }
-    h->ws = w;
+    h->ws_own = cur;
+    h->ws = cur.get();
   }
   *out = h;
   return 0;
@@ -1859,7 +1899,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
 
 extern "C" int ktx_moe_destroy(ktx_moe_t h) {
   if (!h) return 0;
-  hipSetDevice(h->cfg.device);
+  DeviceGuard _dg(h->cfg.device);
   void* ptrs[] = {h->gate_w, h->up_w, h->down_w, h->gate_s, h->up_s, h->down_s, h->mask};
   for (void* p : ptrs)
     if (p) hipFree(p);
@@ -1882,7 +1922,7 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
   const int types[3] = {gate_type, up_type, down_type};
   for (int t : types)
     KTX_REQUIRE(t == GG_Q4K || t == GG_Q6K || t == GG_IQ1S, "ktx_moe_load_gguf: supported ggml types are Q4_K (12), Q6_K (14) and IQ1_S (19)");
-  KTX_HIP(hipSetDevice(h->cfg.device));
+  KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
   const uint8_t* src[3] = {(const uint8_t*)d_gate, (const uint8_t*)d_up, (const uint8_t*)d_down};
@@ -1925,7 +1965,7 @@ static int pack_matrix(ktx_moe_s* h, const int8_t* d_q, int N, int K, uint8_t* d
 
 extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down) {
   KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_bf16: null argument");
-  KTX_HIP(hipSetDevice(h->cfg.device));
+  KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   KTX_REQUIRE(h->cfg.format != KTX_FMT_FP8 && h->cfg.format != KTX_FMT_RAWINT4,
               "ktx_moe_load_bf16: FP8 / RAWINT4 handles take pre-quantised weights (ktx_moe_load_fp8 / ktx_moe_load_rawint4)");
@@ -1969,7 +2009,7 @@ extern "C" int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const 
   KTX_REQUIRE(h->cfg.format == KTX_FMT_AMXINT4 || h->cfg.format == KTX_FMT_AMXINT8,
               "ktx_moe_load_quantized: AMXINT4 / AMXINT8 handles only");
   KTX_REQUIRE(which >= 0 && which <= 2, "ktx_moe_load_quantized: bad matrix selector");
-  KTX_HIP(hipSetDevice(h->cfg.device));
+  KTX_ON_DEVICE(h->cfg.device);
   const int H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const int N = which == KTX_MAT_DOWN ? H : I, K = which == KTX_MAT_DOWN ? I : H;
   uint8_t* dst = which == KTX_MAT_GATE ? h->gate_w + expert * h->gu_stride
@@ -1992,7 +2032,7 @@ extern "C" int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_u
                                 const float* d_gate_scale, const float* d_up_scale, const float* d_down_scale) {
   KTX_REQUIRE(h && d_gate && d_up && d_down && d_gate_scale && d_up_scale && d_down_scale, "ktx_moe_load_fp8: null argument");
   KTX_REQUIRE(h->cfg.format == KTX_FMT_FP8, "ktx_moe_load_fp8: handle was not created with KTX_FMT_FP8");
-  KTX_HIP(hipSetDevice(h->cfg.device));
+  KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const size_t pieces = (size_t)I * H / 16, nsc = (size_t)(I / 128) * (H / 128);
   for (int e = 0; e < E; e++) {
@@ -2016,7 +2056,7 @@ extern "C" int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void*
                                     const void* d_gate_scale, const void* d_up_scale, const void* d_down_scale) {
   KTX_REQUIRE(h && d_gate && d_up && d_down && d_gate_scale && d_up_scale && d_down_scale, "ktx_moe_load_rawint4: null argument");
   KTX_REQUIRE(h->cfg.format == KTX_FMT_RAWINT4, "ktx_moe_load_rawint4: handle was not created with KTX_FMT_RAWINT4");
-  KTX_HIP(hipSetDevice(h->cfg.device));
+  KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const size_t dwords = (size_t)I * H / 8, nsc = (size_t)I * (H / 32);
   for (int e = 0; e < E; e++) {
@@ -2041,7 +2081,7 @@ extern "C" int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void*
 
 extern "C" int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask) {
   KTX_REQUIRE(h, "ktx_moe_set_expert_mask: null handle");
-  KTX_HIP(hipSetDevice(h->cfg.device));
+  KTX_ON_DEVICE(h->cfg.device);
   if (!mask) {
     if (h->mask) { KTX_HIP(hipFree(h->mask)); h->mask = nullptr; }
     return 0;
@@ -2154,6 +2194,7 @@ static bool g_prof_on = false;
 static bool g_force_generic = false;  // tests: route small batches through the grouped (prefill) path too
 extern "C" int ktx_debug_force_generic(int on) { g_force_generic = on != 0; return 0; }
 extern "C" int ktx_debug_set(int idx, int val) { if (idx >= 0 && idx < 8) g_dbg[idx] = val; return 0; }
+extern "C" int ktx_debug_get(int idx) { return idx >= 0 && idx < 8 ? g_dbg[idx] : 0; }
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[5];
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
@@ -2180,12 +2221,17 @@ extern "C" int ktx_profile_collect(double* ms5, long long* count5) {
   return 0;
 }
 
+static const char* const kProfSlotName[5] = {"moe_prep_kernel (bucket + x-quant)", "moe grouped gate|up GEMM", "moe_actquant_kernel",
+                                             "moe grouped down GEMM", "moe_combine_kernel"};
 struct ProfScope {
   int slot;
   hipStream_t st;
   std::pair<hipEvent_t, hipEvent_t> ev;
   bool on;
-  ProfScope(int slot_, hipStream_t st_) : slot(slot_), st(st_), on(g_prof_on) {
+  KtxTimeScope ts;   // the library-wide per-launch log (ktx_prof.hip); the decode kernels label themselves
+  ProfScope(int slot_, hipStream_t st_, bool timed = true)
+      : slot(slot_), st(st_), on(g_prof_on),
+        ts(st_, 0.0, timed && ktx_timing_mode() ? std::string(kProfSlotName[slot_]) : std::string()) {
     if (!on) return;
     if (!g_prof_free.empty()) { ev = g_prof_free.back(); g_prof_free.pop_back(); }
     else { hipEventCreate(&ev.first); hipEventCreate(&ev.second); }
@@ -2214,6 +2260,7 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
   KTX_REQUIRE(qlen > 0 && qlen <= h->cfg.max_len, "ktx_moe_forward: qlen exceeds max_len");
   KTX_REQUIRE(k > 0 && k <= h->cfg.num_experts_per_tok, "ktx_moe_forward: k exceeds num_experts_per_tok");
   KTX_REQUIRE(d_expert_ids && d_weights && d_input && d_output, "ktx_moe_forward: null pointer");
+  KTX_ON_DEVICE(h->cfg.device);   // the handle's device, whatever the caller's current one is (restored on return)
   hipStream_t st = (hipStream_t)stream;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   Workspace* ws = h->ws;
@@ -2256,8 +2303,11 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
       KTX_HIP(err);                                                                                                 \
       hipLaunchKernelGGL((moe_dec_down_kernel<WB, DD, EX>), g2, dim3(64 * k), lds2, st, dp);                        \
     } while (0)
+    const double wb = h->wbits / 8.0;
     if (only != 2) {
-      ProfScope ps(1, st);
+      ProfScope ps(1, st, false);
+      KTX_TIMED(st, qlen * k * (2.0 * I * H * wb + 2.0 * I * 4 + I * 2.0) + qlen * H * 2.0,
+                "moe_dec_gateup_kernel<W%d> T=%d k=%d H=%d I=%d", h->wbits, qlen, k, H, I);
       if (h->wbits == 4) {
         if (nks1 % 16 == 0) KTX_LAUNCH_GU(4, 16, true);
         else if (nks1 % 14 == 0) KTX_LAUNCH_GU(4, 14, true);
@@ -2271,7 +2321,9 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     }
     KTX_HIP(hipGetLastError());
     if (only != 1) {
-      ProfScope ps(3, st);
+      ProfScope ps(3, st, false);
+      KTX_TIMED(st, qlen * k * ((double)H * I * wb + H * 4.0 + I * 2.0) + qlen * H * 2.0,
+                "moe_dec_down_kernel<W%d> T=%d k=%d H=%d I=%d", h->wbits, qlen, k, H, I);
       if (h->wbits == 4) {
         if (nks2 % 16 == 0) KTX_LAUNCH_DN(4, 16, true);
         else if (nks2 % 14 == 0) KTX_LAUNCH_DN(4, 14, true);

@@ -171,6 +171,7 @@ extern "C" int ktx_rmsnorm(const void* d_x, int64_t ldx, const void* d_w, void* 
   KTX_REQUIRE(ldx % 8 == 0 && ldy % 8 == 0, "ktx_rmsnorm: row strides must be multiples of 8 elements");
   if (T <= 0) return 0;
   hipStream_t st = (hipStream_t)stream;
+  KTX_TIMED(st, (double)T * dim * 4.0 + dim * 2.0, "rmsnorm_kernel T=%d dim=%d", T, dim);
   if (native_rounding)
     hipLaunchKernelGGL(rmsnorm_kernel<1>, dim3(T), dim3(256), 0, st, (const bf16_t*)d_x, (long)ldx, (bf16_t*)nullptr,
                        (const bf16_t*)d_w, (bf16_t*)d_y, (long)ldy, T, dim, eps, d_bsz);
@@ -197,6 +198,7 @@ extern "C" int ktx_silu_mul(const void* d_gu, int64_t ldg, void* d_y, int T, int
   KTX_REQUIRE(d_gu && d_y, "ktx_silu_mul: null argument");
   KTX_REQUIRE(inter > 0 && inter % 8 == 0 && ldg % 8 == 0, "ktx_silu_mul: sizes must be multiples of 8");
   if (T <= 0) return 0;
+  KTX_TIMED((hipStream_t)stream, (double)T * inter * 6.0, "silu_mul_kernel T=%d I=%d", T, inter);
   hipLaunchKernelGGL(silu_mul_kernel, dim3((inter / 8 + 255) / 256, T), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)d_gu, (long)ldg, (bf16_t*)d_y, T, inter, d_bsz);
   KTX_HIP(hipGetLastError());
@@ -220,6 +222,7 @@ extern "C" int ktx_mla_prep(int T, int num_heads, int nope_dim, int rope_dim, in
   p.ckv = (bf16_t*)d_ckv_out; p.kpe = (bf16_t*)d_kpe_out;
   p.pos = d_pos; p.inv_freq = d_inv_freq; p.mscale = mscale;
   const int per = 256 / (rope_dim / 2);
+  KTX_TIMED((hipStream_t)stream, (double)T * (num_heads * rope_dim * 4.0 + (kv_lora + rope_dim) * 4.0), "mla_prep_kernel T=%d Hq=%d", T, num_heads);
   hipLaunchKernelGGL(mla_prep_kernel, dim3(T, 1 + (d_q ? (num_heads + per - 1) / per : 0)), dim3(256), 0, (hipStream_t)stream, p);
   KTX_HIP(hipGetLastError());
   return 0;

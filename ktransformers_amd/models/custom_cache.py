@@ -52,6 +52,10 @@ class StaticCache:
 
         cache_position = cache_kwargs.get("cache_position")
         k_out = self.key_cache[layer_idx]
+        if self.past_tokens[layer_idx] + cache_position.size(0) > self.max_pages * self.page_size:
+            # the reference's indexed assignment raises on an out-of-range position (custom_cache.py:189-195)
+            raise IndexError(f"StaticCache.update: {self.past_tokens[layer_idx]} + {cache_position.size(0)} tokens exceed the "
+                             f"cache ({self.max_pages * self.page_size} tokens)")
         self.past_tokens[layer_idx] += cache_position.size(0)
         page_idx = cache_position // self.page_size
         page_offset = cache_position % self.page_size

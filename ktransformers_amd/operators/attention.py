@@ -25,6 +25,44 @@ from torch import nn
 from ktransformers_amd.operators.base_operator import BaseInjectedModule
 from ktransformers_amd.operators.RoPE import yarn_get_mscale
 
+# One decode wrapper and one prompt wrapper per device, shared by every attention layer (the layers of a model run
+# serially on one stream, so they can share the split-KV workspace).  The workspace scales with the QUERY tokens of one
+# call (prefill chunk), never with max_position_embeddings: a per-layer wrapper sized by the context length would need
+# ~43 GB per layer at DeepSeek-V3's 163840 positions.  The decode wrapper is never re-allocated (captured graphs hold
+# its workspace pointer); the prompt wrapper grows on demand (prompts are not graph-captured).
+_DECODE_WRAPPERS: dict = {}
+_PREFILL_WRAPPERS: dict = {}
+PREFILL_Q_GRANULE = 1024
+
+
+def _decode_wrapper(dev: torch.device):
+    from ktransformers_amd._native import MLAWrapper
+    w = _DECODE_WRAPPERS.get(dev)
+    if w is None:
+        w = _DECODE_WRAPPERS[dev] = MLAWrapper(1, 1, use_cuda_graph=True, device=dev, max_q_tokens=1)
+    return w
+
+
+def _prefill_wrapper(dev: torch.device, q_len: int):
+    from ktransformers_amd._native import MLAWrapper
+    w = _PREFILL_WRAPPERS.get(dev)
+    if w is None or w.max_q_tokens < q_len:
+        need = (q_len + PREFILL_Q_GRANULE - 1) // PREFILL_Q_GRANULE * PREFILL_Q_GRANULE
+        w = _PREFILL_WRAPPERS[dev] = MLAWrapper(1, 1, use_cuda_graph=False, device=dev, max_q_tokens=need)
+    return w
+
+
+def _cache_page_arrays(cache, layer_idx: int, dev: torch.device):
+    """(kv_indptr [2], kv_indices [max_pages]) of the single-request cache passed to THIS call: the page table comes from
+    the cache object itself (custom_cache.py:99-104), so a larger cache handed in later is indexed with its own table."""
+    memo = getattr(cache, "_ktx_kv_indptr", None)
+    if memo is None:
+        memo = cache._ktx_kv_indptr = {}
+    key = (dev, cache.max_pages)
+    if key not in memo:
+        memo[key] = torch.tensor([0, cache.max_pages], dtype=torch.int32, device=dev)
+    return memo[key], cache.page_table_list[layer_idx][0]
+
 
 class KDeepseekV2Attention(BaseInjectedModule):
     SUPPORTS_FUSION = True     # forward(..., pre_norm=, residual=)
@@ -112,7 +150,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
         """`pre_norm` (an RMSNorm module: the layer's input_layernorm, applied to hidden_states here instead of by the
         caller) and `residual` (added to the output) are fusion hooks used by the decoder-layer glue; without them the
         signature and behaviour are the reference's."""
-        from ktransformers_amd._native import MLAWrapper, mla_prep, rmsnorm
+        from ktransformers_amd._native import mla_prep, rmsnorm
 
         bsz, q_len, _ = hidden_states.size()
         if bsz != 1:
@@ -158,9 +196,9 @@ class KDeepseekV2Attention(BaseInjectedModule):
         cache = past_key_value.key_cache[self.layer_idx]                   # [pages, page, 1, lora + rope]
         ckv_pages = cache[:, :, 0, :lora]
         kpe_pages = cache[:, :, 0, lora:]
-        if self.mla_wrapper is None:
-            object.__setattr__(self, "mla_wrapper", MLAWrapper(1, past_key_value.max_pages, use_cuda_graph=True, device=dev,
-                                                               max_q_tokens=self._max_len()))
+        capacity = past_key_value.max_pages * past_key_value.page_size
+        kv_indptr, kv_indices = _cache_page_arrays(past_key_value, self.layer_idx, dev)
+        object.__setattr__(self, "mla_wrapper", _decode_wrapper(dev) if q_len == 1 else _prefill_wrapper(dev, q_len))
         if q_len == 1:
             # kv_len is read on the device: positions + 1 (attention.py:430-433); the kernel appends the new row itself.
             # Every layer of a step sees the same position tensor: derive kv_len once per step, not once per layer.
@@ -174,8 +212,11 @@ class KDeepseekV2Attention(BaseInjectedModule):
                 past_key_value._kv_len_memo = (key, position_ids, kv_len)
             # split count: a launch-grid constant of the captured graph — size it for the context seen now plus headroom
             # (longer contexts later just put several tiles in a split)
-            hint = int(past_key_value.get_seq_length(self.layer_idx)) + 512
-            self.mla_wrapper.plan(None, None, None, kv_len, None, Hp, lora, rope, past_key_value.page_size,
+            seen = int(past_key_value.get_seq_length(self.layer_idx))
+            if seen + 1 > capacity:     # the reference's indexed assignment raises here (custom_cache.py:189-195)
+                raise IndexError(f"KDeepseekV2Attention: position {seen} is beyond the cache ({capacity} tokens)")
+            hint = min(seen + 512, capacity)
+            self.mla_wrapper.plan(None, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16, max_kv_len=hint)
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
             past_key_value.note_appended(self.layer_idx, 1)
@@ -185,7 +226,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
             past_key_value.update(ckv_new, kpe_new, self.layer_idx, {"cache_position": cp})
             qo_indptr = torch.tensor([0, q_len], dtype=torch.int32, device=dev)
             kv_len = (pos[-1:] + 1).to(torch.int32)
-            self.mla_wrapper.plan(qo_indptr, None, None, kv_len, None, Hp, lora, rope, past_key_value.page_size,
+            self.mla_wrapper.plan(qo_indptr, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16)
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]

@@ -9,8 +9,7 @@ plan/run signature is the flashinfer wrapper's) with the batch's qo_indptr / kv_
 each token's latent row goes (`page_idx`, `page_offset`; KDeepSeekV3Cache.get_page_table).  The arithmetic is
 KDeepseekV2Attention's — merged projections, fused RMSNorm + YaRN RoPE (`ktx_mla_prep`), cache append, batched absorb, paged
 MQA over the latent cache, batched un-absorb, o_proj — only the batching contract differs, so it re-uses that operator's
-pieces and kernels.  STATUS: written after round 1's GPU budget was spent — index logic tested on CPU, the operator itself
-not yet run on hardware (tests/test_serve_attention_gpu.py is opt-in via KTX_EXPERIMENTAL=1)."""
+pieces and kernels (tests/test_serve_attention_gpu.py)."""
 from __future__ import annotations
 
 import torch

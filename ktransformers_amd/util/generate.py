@@ -29,7 +29,10 @@ class CUDAGraphRunner:
         self.input_buffers = {}
         self.output_buffers = {}
 
-    def capture(self, model, cur_token, position_ids, cache_position, past_key_values, main_device="cuda:0", **kwargs):
+    def capture(self, model, cur_token, position_ids, cache_position, past_key_values, main_device="cuda:0", trace=None,
+                **kwargs):
+        """`trace` (a list, measurement only): receives the (name, args) of every library call issued during the capture
+        (ktransformers_amd._native.TRACE); their pointers stay valid as long as this runner's graph lives."""
         assert self.graph is None
         self.model = model
         dev = torch.device(main_device)
@@ -44,8 +47,13 @@ class CUDAGraphRunner:
         torch.cuda.current_stream(dev).wait_stream(stream)
         torch.cuda.synchronize(dev)
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph, stream=stream):
-            logits = model(ib["cur_token"], ib["position_ids"], past_key_values, ib["cache_position"])
+        from ktransformers_amd import _native
+        _native.TRACE = trace
+        try:
+            with torch.cuda.graph(self.graph, stream=stream):
+                logits = model(ib["cur_token"], ib["position_ids"], past_key_values, ib["cache_position"])
+        finally:
+            _native.TRACE = None
         torch.cuda.synchronize(dev)
         self.output_buffers = {"logits": logits}
 
@@ -98,6 +106,11 @@ def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_ne
     pick = lambda lg: sample_next_token(lg[0, -1], do_sample, temperature, top_k, top_p, generator)
     dev = input_ids.device
     T = input_ids.shape[1]
+    cap = getattr(past_key_values, "max_cache_len", None)
+    if hasattr(past_key_values, "max_pages"):
+        cap = past_key_values.max_pages * past_key_values.page_size
+    if cap is not None and T + max_new_tokens > cap:
+        raise ValueError(f"prefill_and_generate: {T} prompt + {max_new_tokens} new tokens exceed the cache ({cap} tokens)")
     set_inference_mode(model, InferenceState.PREFILL)
     logits = None
     for s in range(0, T, chunk_size):                                    # chunk_prefill (utils.py:496-511)

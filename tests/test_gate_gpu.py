@@ -76,3 +76,29 @@ def test_fused_router_handoff_is_never_stale_under_load():
             n.check(n.lib.ktx_gate_select(C.byref(g.cfg), None, 3, logits.data_ptr(), bias.data_ptr() if bias is not None else None,
                                           idx.data_ptr(), wt.data_ptr(), torch.cuda.current_stream().cuda_stream))
             assert torch.equal(outs[i][0], idx) and torch.equal(outs[i][1], wt), f"launch {i} differs"
+
+
+@pytest.mark.parametrize("name", ["v3", "k2", "v3_ties", "v2lite", "v2", "v2_ties"])
+def test_router_matches_reference_module_golden(name):
+    """The HIP router against outputs of the reference's OWN MoEGate modules (tests/golden/make_router_golden.py imports
+    modeling_deepseek_v3.py / modeling_deepseek.py), incl. duplicated router rows whose scores tie exactly."""
+    import os
+    from ktransformers_amd._native import GateHandle
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "router_golden.npz"))
+    E, H, k, ng, tg, norm = (int(v) for v in g[f"{name}.cfg"])
+    scoring, method = (str(v) for v in g[f"{name}.func"])
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(g[f"{name}.x"]).view(torch.bfloat16).to(dev)
+    w = torch.from_numpy(g[f"{name}.w"]).view(torch.bfloat16).to(dev)
+    bias = torch.from_numpy(g[f"{name}.bias"]).to(dev) if f"{name}.bias" in g.files else None
+    gh = GateHandle(E, H, k, ng, tg, scoring, method, bool(norm), float(g[f"{name}.scale"]))
+    idx, wt = gh.forward(x, w, bias)
+    torch.cuda.synchronize()
+    idx, wt, ridx, rwt = idx.cpu().numpy(), wt.cpu().numpy(), g[f"{name}.idx"], g[f"{name}.wt"]
+    for t in range(idx.shape[0]):
+        if name.endswith("ties"):    # whichever tied expert was picked, the score multiset is the reference's
+            np.testing.assert_allclose(np.sort(wt[t]), np.sort(rwt[t]), rtol=2e-6, atol=1e-9)
+        else:
+            assert set(idx[t].tolist()) == set(ridx[t].tolist()), f"token {t}: routed expert set differs"
+            ref = dict(zip(ridx[t].tolist(), rwt[t].tolist()))
+            np.testing.assert_allclose(wt[t], np.array([ref[e] for e in idx[t].tolist()], np.float32), rtol=2e-6, atol=1e-9)

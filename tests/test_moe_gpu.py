@@ -390,3 +390,23 @@ def test_rawint4_bit_exact(oracle, dev, shape):
         assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
     finally:
         h.close()
+
+
+@pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
+def test_rawint4_against_reference_golden(dev, case):
+    """Bit-exact against outputs of the reference's OWN Kimi-K2 class (TP_MOE<AMX_K2_MOE_TP<GemmKernel224Int4SmallKGroup>>,
+    k2-moe.hpp:124-191) on weights quantised by the reference test's own rawint4_quantize (tests/golden/make_golden.py)."""
+    from ktransformers_amd._native import MoEHandle
+    g = np.load(GOLDEN)
+    E, k, H, I = int(g["k2_E"]), int(g["k2_k"]), int(g["k2_H"]), int(g["k2_I"])
+    c = dict(x=g[f"k2_{case}_x"], ids=g[f"k2_{case}_ids"], w=g[f"k2_{case}_w"])
+    h = MoEHandle(E, k, H, I, max_len=64, method="RAWINT4", device=0, group_size=32)
+    try:
+        h.load_rawint4(*[torch.from_numpy(g[f"k2_{n}_p"]).to(dev) for n in ("gate", "up", "down")],
+                       *[torch_bf16(g[f"k2_{n}_s"], dev) for n in ("gate", "up", "down")])
+        want = g[f"k2_{case}_y"]
+        got = run(h, c, dev)
+        assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ"
+        assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), g[f"k2_{case}_yinc"])
+    finally:
+        h.close()

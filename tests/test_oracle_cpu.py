@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 
 from helpers import bf16_to_f32, f32_to_bf16, make_case
-from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, Reference, reference_available
+from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, FMT_RAWINT4, Reference, reference_available
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "moe_amx_golden.npz")
 
@@ -57,6 +57,45 @@ def test_oracle_fp_formats_match_live_reference(oracle, shape):
     mb = ref.make_moe(FMT_BF16, c["gate"], c["up"], c["down"], k=k, max_len=64)
     assert np.array_equal(oracle.moe_forward(oracle.make_moe_bf16(c["gate"], c["up"], c["down"]), c["ids"], c["w"], c["x"]),
                           ref.moe_forward(mb, c["ids"], c["w"], c["x"]))
+
+
+@pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
+def test_oracle_rawint4_matches_reference_golden(oracle, golden, case):
+    """RAWINT4 (Kimi-K2) restatement against outputs of the reference's own K2 class (k2-moe.hpp:124-191) — vec_mul path
+    (t1, t7), mat_mul path (t33), invalid ids, incremental merge."""
+    g = golden
+    moe = oracle.make_moe_rawint4(g["k2_gate_p"], g["k2_up_p"], g["k2_down_p"], g["k2_gate_s"], g["k2_up_s"], g["k2_down_s"])
+    x, ids, w = g[f"k2_{case}_x"], g[f"k2_{case}_ids"], g[f"k2_{case}_w"]
+    y = oracle.moe_forward(moe, ids, w, x)
+    assert np.array_equal(y, g[f"k2_{case}_y"]), "RAWINT4 oracle differs from the reference K2 kernels' golden output"
+    assert np.array_equal(oracle.moe_forward(moe, ids, w, x, y_prev=y), g[f"k2_{case}_yinc"])
+
+
+def test_rawint4_quantiser_helper_matches_reference_golden(golden):
+    """tests/helpers.rawint4_quantize (vectorised) reproduces the packed bytes / bf16 scales stored by make_golden.py, whose
+    first expert was checked there against the reference test's own scalar rawint4_quantize."""
+    from helpers import rawint4_quantize
+    base = make_case(20260922, int(golden["k2_E"]), int(golden["k2_k"]), int(golden["k2_H"]), int(golden["k2_I"]), 1)
+    for nm in ("gate", "up", "down"):
+        p, s = rawint4_quantize(bf16_to_f32(base[nm]))
+        assert np.array_equal(p, golden[f"k2_{nm}_p"]) and np.array_equal(s, golden[f"k2_{nm}_s"])
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref not built or host lacks AVX512-VNNI/BF16")
+@pytest.mark.parametrize("shape", [(8, 2, 512, 512, 1), (8, 2, 512, 512, 5), (8, 3, 1024, 512, 40), (8, 2, 512, 1024, 70)])
+def test_oracle_rawint4_matches_live_reference(oracle, shape):
+    from helpers import rawint4_quantize
+    E, k, H, I, T = shape
+    c = make_case(3, E, k, H, I, T, invalid_ids=T >= 5)
+    q = [rawint4_quantize(bf16_to_f32(c[n])) for n in ("gate", "up", "down")]
+    ref = Reference(threads=4)
+    mr = ref.make_moe_quant(FMT_RAWINT4, E, H, I, k, q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1], max_len=128, group_size=32)
+    mo = oracle.make_moe_rawint4(q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1])
+    yr = ref.moe_forward(mr, c["ids"], c["w"], c["x"])
+    yo = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    assert np.array_equal(yo, yr)
+    assert np.array_equal(oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=yo), ref.moe_forward(mr, c["ids"], c["w"], c["x"], y_prev=yr))
+    ref.free_moe(mr)
 
 
 def test_oracle_int4_quantiser_matches_reference_golden(oracle, golden):

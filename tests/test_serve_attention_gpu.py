@@ -1,13 +1,9 @@
-"""GPU (opt-in: KTX_EXPERIMENTAL=1): the batched-serving attention operator `flashinfer_attn` — two requests flattened into one
-call, paged latent cache with a scattered page table — against the single-request operator run on each request alone.
-Written after round 1's GPU budget was spent; not yet run on hardware, hence not part of the default GPU suite."""
-import os
-
+"""GPU: the batched-serving attention operator `flashinfer_attn` — two requests flattened into one call, paged latent cache
+with a scattered page table — against the single-request operator run on each request alone."""
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.skipif(os.environ.get("KTX_EXPERIMENTAL") != "1",
-                                                  reason="not yet run on hardware; set KTX_EXPERIMENTAL=1")]
+pytestmark = pytest.mark.gpu
 
 from test_model_gpu import CFG, model_and_gold  # noqa: E402,F401  (fixture)
 
