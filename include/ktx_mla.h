@@ -62,6 +62,10 @@ int ktx_mla_cache_append(const ktx_mla_config* cfg, void* d_kv_cache, int64_t to
                          const void* d_kpe_new, const int32_t* d_page_idx, const int32_t* d_page_offset,
                          const int32_t* d_ntokens, int max_tokens, int num_pages, void* stream);
 
+/* Tuning aid (scripts/mla_sweep.py): while a device buffer of >= 16 * workgroups int64 entries is set, every workgroup of the
+ * split-KV kernel stamps the wall clock (100 MHz) at its phase boundaries into it; NULL (the default) turns it off. */
+int ktx_mla_debug_stamps(long long* d_buf);
+
 #ifdef __cplusplus
 }
 #endif

@@ -84,6 +84,7 @@ def _load() -> C.CDLL:
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.ktx_mla_cache_append.argtypes = [C.POINTER(_MlaConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
+    lib.ktx_mla_debug_stamps.argtypes = [C.c_void_p]
     lib.ktx_linear_create.argtypes = [C.POINTER(_LinearConfig), C.POINTER(C.c_void_p)]
     lib.ktx_linear_destroy.argtypes = [C.c_void_p]
     lib.ktx_linear_load_bf16.argtypes = [C.c_void_p] * 3

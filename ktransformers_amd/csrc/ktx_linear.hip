@@ -33,6 +33,8 @@
 
 typedef __bf16 lv8bf __attribute__((ext_vector_type(8)));
 
+extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
+
 namespace {
 
 constexpr int F_BF16 = KTX_LIN_BF16, F_W4 = KTX_LIN_W4, F_FP8 = KTX_LIN_FP8;
@@ -215,8 +217,59 @@ __device__ __forceinline__ uint4 lin_norm8(const uint4& v, float r, const bf16_t
 // keeps exact `s_waitcnt vmcnt(D-1..)` counts: D KiB-sized loads stay in flight per wave.  With guards in the loop
 // (`if (ks < ks1)` around a load) it cannot count the outstanding loads and drains the ring with vmcnt(0) at every step:
 // one KiB per memory round trip per wave — measured 1.7-2.7 TB/s on 60-500 MB matrices before this variant existed.
-template <int FMT, int G, int D, bool EXACT>
+//
+// MODE 0: guarded register ring (any shape).  MODE 1 ("exact"): branch-free register ring, see above.  MODE 2 (W4): the ring
+// lives in LDS and is filled by LDS-DMA (global_load_lds, 1 KiB per wave-instruction, no VGPR destination), D slots per wave;
+// the consumer waits with an explicit `s_waitcnt vmcnt(D-1)` — loads retire in order, so the oldest slot has landed — reads
+// the slot back with one ds_read_b128 and refills it at once.  The compiler cannot sink or batch these refills (there is no
+// register dependency for it to schedule around), so D KiB stay in flight per wave for the WHOLE stream instead of arriving
+// in bursts separated by a full memory round trip; the scales of the wave's k-slice are fetched the same way up front.
+constexpr int M_GUARD = 0, M_EXACT = 1, M_DMA = 2;
+#define KTX_VMCNT(n) __builtin_amdgcn_s_waitcnt(0x0f70 | ((n) & 0xf) | ((((n) >> 4) & 3) << 14))   /* gfx9 encoding: vmcnt only */
+// One LDS-DMA wave-instruction: lane l's 16 bytes at gsrc_lane land at LDS byte address lds_addr + 16 l (M0 carries the
+// wave-uniform LDS base; recipe of cdna_hip_programming.md §5.7).  Issued through inline asm ON PURPOSE: for an LDS-DMA it
+// knows about, the compiler drains every pending DMA (vmcnt(0)) in front of any LDS read it cannot prove disjoint from the
+// destination — here the activation / scale reads of every step — which would turn the ring back into one KiB per memory
+// round trip.  Unseen by the compiler, completion is tracked by the explicit KTX_VMCNT waits below (loads retire in order);
+// the compiler's own waits for ITS loads can only wait longer than needed, never shorter.  `nt`: every weight byte is read
+// once per token by one CU.
+__device__ __forceinline__ void lin_dma_1k(const uint8_t* gsrc_lane, uint32_t lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off nt\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_addr)
+               : "memory");
+}
+__device__ __forceinline__ uint32_t lds_addr_of(const void* p) {   // wave-uniform LDS byte address of a __shared__ pointer
+  return __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)p);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..15 (the instruction takes an immediate: a scalar branch picks it)
+__device__ __forceinline__ void lin_vmcnt_rt(int n) {
+  switch (n) {
+    case 0: KTX_VMCNT(0); break;
+    case 1: KTX_VMCNT(1); break;
+    case 2: KTX_VMCNT(2); break;
+    case 3: KTX_VMCNT(3); break;
+    case 4: KTX_VMCNT(4); break;
+    case 5: KTX_VMCNT(5); break;
+    case 6: KTX_VMCNT(6); break;
+    case 7: KTX_VMCNT(7); break;
+    case 8: KTX_VMCNT(8); break;
+    case 9: KTX_VMCNT(9); break;
+    case 10: KTX_VMCNT(10); break;
+    case 11: KTX_VMCNT(11); break;
+    case 12: KTX_VMCNT(12); break;
+    case 13: KTX_VMCNT(13); break;
+    case 14: KTX_VMCNT(14); break;
+    default: KTX_VMCNT(15); break;
+  }
+}
+
+template <int FMT, int G, int D, int MODE>
 __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
+  constexpr bool EXACT = MODE != M_GUARD;
+  static_assert(MODE != M_DMA || FMT == F_W4, "the LDS-DMA ring is built for the W4 format");
   using F = Fmt<FMT, G>;
   lin_select_batch(p, blockIdx.y);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -260,8 +313,11 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   };
 
   // ---- weight ring: the first D k-steps are in flight while the activations are staged
-  uint4 wr[D][F::NQ];
-  uint2 sr[D];
+  uint4 wr[MODE == M_DMA ? 1 : D][F::NQ];
+  uint2 sr[MODE == M_DMA ? 1 : D];
+  uint8_t* ring = reinterpret_cast<uint8_t*>(red + 8 * 4 * 16) + (size_t)wave * (D * 1024 + ((p.SPS * 16 * F::GPK * 2 + 1023) & ~1023));
+  uint8_t* scl = ring + D * 1024;                           // this wave's scales: [SPS][16][GPK] bf16
+  const uint32_t ring_a = MODE == M_DMA ? lds_addr_of(ring) : 0;
   const uint8_t* wp = p.w + (size_t)strip * NKS * F::TILE + lane * 16;
   const bf16_t* sp4 = reinterpret_cast<const bf16_t*>(p.sc) + ((size_t)strip * NKS * 16 + (lane & 15)) * F::GPK;
   const float* sp8 = reinterpret_cast<const float*>(p.sc) + (size_t)(strip >> 3) * NKS;
@@ -276,9 +332,20 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
     else if constexpr (FMT == F_FP8) sr[d] = make_uint2(__float_as_uint(sp8[ks]), 0);
     else sr[d] = make_uint2(0, 0);
   };
+  if constexpr (MODE == M_DMA) {
+    // scales of the slice first (they must have landed when the first slot has), then the first D weight tiles
+    const uint8_t* sg = reinterpret_cast<const uint8_t*>(sp4 - (lane & 15) * F::GPK) + (size_t)ks0 * 16 * F::GPK * 2;
+    const int sbytes = p.SPS * 16 * F::GPK * 2;
+    const uint32_t scl_a = lds_addr_of(scl);
+    for (int o = 0; o < sbytes; o += 1024)
+      if (o + lane * 16 < sbytes) lin_dma_1k(sg + o + lane * 16, scl_a + o);
 #pragma unroll
-  for (int d = 0; d < D; d++)
-    if (EXACT || ks0 + d < ks1) load_step(d, ks0 + d);
+    for (int d = 0; d < D; d++) lin_dma_1k(wp + (size_t)(ks0 + d) * F::TILE, ring_a + d * 1024);
+  } else {
+#pragma unroll
+    for (int d = 0; d < D; d++)
+      if (EXACT || ks0 + d < ks1) load_step(d, ks0 + d);
+  }
 
   // ---- stage the activations (every workgroup its own copy), group sums / fp8 quantisation on the way
   float rnorm[4] = {1.f, 1.f, 1.f, 1.f};
@@ -349,7 +416,33 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   const int kc = lane >> 4, tokp = (lane & 15) & (TP - 1);
   const uint8_t* xb0 = xs + tokp * 16 + (FMT == F_FP8 ? kc * 2 : FMT == F_W4 ? kc : kc * 4) * cs;
   const int xstep = (FMT == F_FP8 ? 8 : 16) * cs;
-  if constexpr (EXACT) {
+  if constexpr (MODE == M_DMA) {
+    // SPS - D steps that consume the oldest slot and refill it, then D steps that drain the ring.  Both loops stay ROLLED:
+    // unrolled, the compiler hoists the activation reads of all D steps to the top and spills — and a scratch access is a
+    // VMEM operation of its own, which would break the wait counts.
+    auto consume = [&](int i, int slot) {   // step ks0 + i sits in ring slot `slot`
+      wr[0][0] = *reinterpret_cast<const uint4*>(ring + slot * 1024 + lane * 16);
+      sr[0] = load_w4_scales<F::GPK>(reinterpret_cast<const bf16_t*>(scl) + ((size_t)i * 16 + (lane & 15)) * F::GPK);
+      lin_step<FMT, G>(wr[0], sr[0], xb0 + (size_t)(ks0 + i) * xstep, cs, aux + (ks0 + i) * F::GPK * 4, 4, acc);
+    };
+    // steady state: one step per iteration (rolled: a handful of live registers, no spills — a scratch access would be a
+    // VMEM operation of its own and break the wait counts), the slot index wraps at run time
+    const int nmain = p.SPS - D;
+    int slot = 0;
+#pragma unroll 1
+    for (int i = 0; i < nmain; i++) {
+      KTX_VMCNT(D - 1);
+      consume(i, slot);
+      lin_dma_1k(wp + (size_t)(ks0 + i + D) * F::TILE, ring_a + slot * 1024);   // the slot's data is in registers by now
+      slot = slot + 1 == D ? 0 : slot + 1;
+    }
+#pragma unroll 1
+    for (int j = 0; j < D; j++) {   // drain: D - 1 - j loads may still be outstanding when step j's slot is read
+      lin_vmcnt_rt(D - 1 - j);
+      consume(nmain + j, slot);
+      slot = slot + 1 == D ? 0 : slot + 1;
+    }
+  } else if constexpr (EXACT) {
     const int ngrp = p.SPS / D;
     for (int g = 0; g < ngrp - 1; g++) {
       const int base = ks0 + g * D;
@@ -690,16 +783,50 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
   using F = Fmt<FMT, G>;
   const int NKS = h->NKS;
   p.TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
+  // Strips per workgroup (SW; the other 8/SW wavefronts split K).  A CU pulls ~11 B/clk whatever runs on it, so a launch
+  // takes as long as its busiest CU: ceil(workgroups / CUs) workgroups' worth of bytes — c strips of weights, the
+  // activation block every workgroup stages for itself, and a fixed prologue.  Pick the c that minimises that (measured on
+  // the DeepSeek-V3 shapes, scripts/lin_sweep.py: 224 workgroups of 2 strips beat 448 of 1 for o_proj, 576 of 4 beat 288
+  // of 8 for the dense MLP, ...).
+  static int ncu = 0;
+  if (!ncu) {
+    hipDeviceProp_t prop;
+    ncu = (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+  }
+  const double strip_bytes = (double)NKS * (F::TILE + (FMT == F_W4 ? 16 * F::GPK * 2 : 0));
+  const double x_bytes = (double)NKS * 128 * 2 * p.TP + 30.0 * 1024;
   int SW = 1;
-  for (int c = 8; c > 1; c >>= 1)
-    if ((h->nstrips + c - 1) / c >= 384) { SW = c; break; }
-  while (SW < 8 && NKS < 8 / SW) SW <<= 1;   // at least one k-step per slice
+  double best = 1e30;
+  for (int c = 1; c <= 8; c <<= 1) {
+    if (NKS < 8 / c) continue;   // at least one k-step per slice
+    const int nwg = (h->nstrips + c - 1) / c * h->batch;
+    const double cost = (double)((nwg + ncu - 1) / ncu) * (c * strip_bytes + x_bytes);
+    if (cost < best) { best = cost; SW = c; }
+  }
+  {   // tuning knob 8 (scripts/lin_sweep.py): force the strips-per-workgroup split (1, 2, 4 or 8)
+    const int f = ktx_debug_get(8);
+    if ((f == 1 || f == 2 || f == 4 || f == 8) && NKS >= 8 / f) SW = f;
+  }
   p.SW = SW;
   const int nsl = 8 / SW;
   p.SPS = (NKS + nsl - 1) / nsl;
   const int ncol16 = FMT == F_FP8 ? NKS * 8 : NKS * 16;
-  const size_t smem = (size_t)ncol16 * p.TP * 16 + (size_t)NKS * F::GPK * 16 + 8 * 4 * 16 * 4;
+  size_t smem = (size_t)ncol16 * p.TP * 16 + (size_t)NKS * F::GPK * 16 + 8 * 4 * 16 * 4;
   const dim3 grid((h->nstrips + SW - 1) / SW, h->batch);
+  // W4, whole slices, OPT-IN (ktx_debug_set(9, 2)): the LDS-DMA ring, as deep as the slice and the LDS allow.  Measured on
+  // MI355X (scripts/lin_sweep.py, DeepSeek-V3 shapes) it is 10-30 % SLOWER than the branch-free register ring below —
+  // the 16-slot ring plus the slice's scales take ~140 KB of LDS, i.e. one workgroup per CU, and every step serialises a
+  // DMA wait, an LDS round trip and the MFMAs inside one wave, where the register ring runs two workgroups per CU whose
+  // bursts overlap each other — so the register ring stays the default and this path is kept for tuning.
+  int dma_depth = 0;
+  if constexpr (FMT == F_W4) {
+    if (nsl * p.SPS == NKS && ktx_debug_get(9) == 2) {
+      const size_t scl_bytes = ((size_t)p.SPS * 16 * F::GPK * 2 + 1023) & ~(size_t)1023;
+      for (int d : {16, 12, 8, 6, 4, 2, 1})
+        if (d <= p.SPS && smem + 8 * (d * 1024 + scl_bytes) <= 156 * 1024) { dma_depth = d; break; }
+      if (dma_depth) smem += 8 * (dma_depth * 1024 + scl_bytes);
+    }
+  }
   auto go = [&](auto kern) -> int {
     static bool attr_set = false;   // one flag per kernel instantiation
     if (!attr_set) {
@@ -714,21 +841,33 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
             "lin_dec_kernel<%s> %d->%d%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", p.Kx, p.N,
             h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
-  // branch-free variant whenever every k-slice is the same whole number of D-step groups (all DeepSeek / Kimi shapes)
+  if constexpr (FMT == F_W4) {
+    switch (dma_depth) {
+      case 16: return go(lin_dec_kernel<FMT, G, 16, M_DMA>);
+      case 12: return go(lin_dec_kernel<FMT, G, 12, M_DMA>);
+      case 8: return go(lin_dec_kernel<FMT, G, 8, M_DMA>);
+      case 6: return go(lin_dec_kernel<FMT, G, 6, M_DMA>);
+      case 4: return go(lin_dec_kernel<FMT, G, 4, M_DMA>);
+      case 2: return go(lin_dec_kernel<FMT, G, 2, M_DMA>);
+      case 1: return go(lin_dec_kernel<FMT, G, 1, M_DMA>);
+      default: break;
+    }
+  }
+  // branch-free register ring whenever every k-slice is the same whole number of D-step groups
   if (nsl * p.SPS == NKS) {
     if constexpr (DMAX >= 8) {
-      if (p.SPS % 8 == 0) return go(lin_dec_kernel<FMT, G, 8, true>);
-      if (p.SPS % 7 == 0) return go(lin_dec_kernel<FMT, G, 7, true>);
-      if (p.SPS % 6 == 0) return go(lin_dec_kernel<FMT, G, 6, true>);
+      if (p.SPS % 8 == 0) return go(lin_dec_kernel<FMT, G, 8, M_EXACT>);
+      if (p.SPS % 7 == 0) return go(lin_dec_kernel<FMT, G, 7, M_EXACT>);
+      if (p.SPS % 6 == 0) return go(lin_dec_kernel<FMT, G, 6, M_EXACT>);
     }
-    if (p.SPS % 4 == 0) return go(lin_dec_kernel<FMT, G, 4, true>);
-    if (p.SPS % 3 == 0) return go(lin_dec_kernel<FMT, G, 3, true>);
-    if (p.SPS % 2 == 0) return go(lin_dec_kernel<FMT, G, 2, true>);
-    if (p.SPS == 1) return go(lin_dec_kernel<FMT, G, 1, true>);
+    if (p.SPS % 4 == 0) return go(lin_dec_kernel<FMT, G, 4, M_EXACT>);
+    if (p.SPS % 3 == 0) return go(lin_dec_kernel<FMT, G, 3, M_EXACT>);
+    if (p.SPS % 2 == 0) return go(lin_dec_kernel<FMT, G, 2, M_EXACT>);
+    if (p.SPS == 1) return go(lin_dec_kernel<FMT, G, 1, M_EXACT>);
   }
-  if (p.SPS >= DMAX) return go(lin_dec_kernel<FMT, G, DMAX, false>);
-  if (p.SPS >= 4) return go(lin_dec_kernel<FMT, G, 4, false>);
-  return go(lin_dec_kernel<FMT, G, 2, false>);
+  if (p.SPS >= DMAX) return go(lin_dec_kernel<FMT, G, DMAX, M_GUARD>);
+  if (p.SPS >= 4) return go(lin_dec_kernel<FMT, G, 4, M_GUARD>);
+  return go(lin_dec_kernel<FMT, G, 2, M_GUARD>);
 }
 
 template <int FMT, int G, int MT>

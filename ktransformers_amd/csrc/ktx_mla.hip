@@ -39,7 +39,13 @@ struct MlaParams {
   // optional fused cache append for decode (one new token per request): latent rows [batch][512], [batch][64]
   const bf16_t *app_ckv, *app_kpe;
   bf16_t *ckv_w, *kpe_w;
+  long long* dbg;   // tuning aid (scripts/mla_sweep.py): 16 wall-clock stamps per workgroup, NULL in normal use
 };
+#define MLA_TS(k)                                                                                             \
+  do {                                                                                                        \
+    if (p.dbg && threadIdx.x == 0)                                                                            \
+      p.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); \
+  } while (0)
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
@@ -79,6 +85,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   const int split = blockIdx.x, hb = blockIdx.y, qt = blockIdx.z;
   int B = p.batch;
   if (p.d_bsz) B = min(max(*p.d_bsz, 0), p.batch);
+  MLA_TS(0);
 
   // ---- Q fragments first: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope).  Their
   // addresses depend on nothing but the block indices, so they are in flight while the request lookup below resolves.
@@ -127,6 +134,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   app_pos = __builtin_amdgcn_readfirstlane(app_pos);
   const size_t pidx = ((size_t)qt * p.Hq + head0) * p.nsplit + split;  // + head*nsplit per head
   if (req < 0) return;
+  MLA_TS(1);
 
   const int ntiles = (kv_end + MLA_TILE - 1) / MLA_TILE;
   const int per = (ntiles + p.nsplit - 1) / p.nsplit;
@@ -202,6 +210,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     stage_ckv(t_begin, Kt);
     load_kpe(t_begin);
     store_kpe(Kt);
+    MLA_TS(2);
     bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
 
     for (int tile = t_begin; tile < t_end; tile++) {
@@ -213,6 +222,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       // One barrier per tile: it drains this tile's LDS-DMA (the compiler emits vmcnt(0) ahead of it), publishes the k_pe
       // stores, and proves every wave is done reading the other buffer, which the next tile's DMA may now overwrite.
       __syncthreads();
+      if (tile == t_begin) MLA_TS(3);
       const bool more = tile + 1 < t_end;
       if (more) { stage_ckv(tile + 1, Kn); load_kpe(tile + 1); }
 
@@ -227,6 +237,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b0, s0, 0, 0, 0);
         s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b1, s1, 0, 0, 0);
       }
+      if (tile == t_begin) MLA_TS(4);
       // lane holds S[head = (lane>>4)*4 + r][token = tok0 + (lane&15) (+16)]
       const bool v0 = (lane & 15) < ntok, v1 = 16 + (lane & 15) < ntok;
       float alpha[4];
@@ -260,8 +271,10 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
       }
       if (more) store_kpe(Kn);
+      if (tile == t_begin) MLA_TS(5);
     }
   }
+  MLA_TS(6);
 
   // ---- partial results: un-normalised O plus (m, l) per head ------------------------------------------------------------
 #pragma unroll
@@ -278,6 +291,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       for (int i = 0; i < NDT; i++) po[i * 16 + (lane & 15)] = o[i][r];
     }
   }
+  MLA_TS(7);
 }
 
 // merge the KV splits: one 256-thread workgroup per (query token, head, quarter of the 512 output dims) — a workgroup
@@ -375,6 +389,12 @@ __global__ void mla_cache_append_kernel(bf16_t* cache, long long ts, int page_si
   else if (i < 72) *reinterpret_cast<uint4*>(dst + i * 8) = *reinterpret_cast<const uint4*>(kpe + (size_t)t * MLA_DR + (i - 64) * 8);
 }
 
+static long long* g_mla_dbg = nullptr;
+extern "C" int ktx_mla_debug_stamps(long long* d_buf) {   // device buffer of >= 16 * workgroups entries, or NULL to stop
+  g_mla_dbg = d_buf;
+  return 0;
+}
+
 extern "C" size_t ktx_mla_workspace_bytes(const ktx_mla_config* cfg, int max_q_tokens) {
   if (!cfg || max_q_tokens <= 0) return 0;
   // one (O[512], m, l) record per (token, head, split).  The launcher never uses more than ~2048 workgroups, so beyond
@@ -413,7 +433,11 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   // workgroup shape (head blocks x dim slices): decode-sized calls of many-headed models take 2x4 (32 heads share one staged
   // KV tile, 128 output dims per wave), prompts of those models 4x2, everything else 1x4
   const bool decode_sized = total_q_tokens <= 16;
-  const int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized) ? 2 : (Hq % 64 == 0) ? 4 : 1;
+  int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized) ? 2 : (Hq % 64 == 0) ? 4 : 1;
+  {   // tuning knobs (scripts/mla_sweep.py): 6 = force the workgroup shape, 7 = force the split count
+    const int fs = ktx_debug_get(6);
+    if ((fs == 1) || (fs == 2 && Hq % 32 == 0) || (fs == 4 && Hq % 64 == 0)) shape = fs;
+  }
   const bool wide = shape == 4;
   const int hbw = shape, nwv = shape == 1 ? 4 : 8;
   const int hblocks = Hq / (16 * hbw);
@@ -426,6 +450,7 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   const size_t per_split_bytes = (size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float);
   nsplit = std::min<int>(nsplit, std::max<size_t>(16, ((size_t)16 << 20) / per_split_bytes));
   if (shape == 2) nsplit = std::min(nsplit, std::max(16, 256 / std::max(1, hblocks * total_q_tokens)));
+  if (ktx_debug_get(7) > 0) nsplit = ktx_debug_get(7);
   if (cfg->kv_len_hint > 0) nsplit = std::min(nsplit, std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE));
   // <= 256 splits: the merge kernel keeps splits/16 partial rows per thread in registers (NS = 16 is its largest, spill-free
   // instantiation); longer contexts simply put more 32-token tiles into each split
@@ -442,6 +467,7 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   p.sm_scale = cfg->sm_scale;
   p.part_o = (float*)d_workspace;
   p.part_ml = p.part_o + (size_t)total_q_tokens * Hq * nsplit * MLA_DC;
+  p.dbg = g_mla_dbg;
   p.app_ckv = (const bf16_t*)d_new_ckv; p.app_kpe = (const bf16_t*)d_new_kpe; p.ckv_w = (bf16_t*)d_ckv; p.kpe_w = (bf16_t*)d_k_pe;
   const size_t lds = (size_t)(2 * MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
   const dim3 grid(nsplit, hblocks, total_q_tokens);
