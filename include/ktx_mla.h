@@ -35,7 +35,8 @@ size_t ktx_mla_workspace_bytes(const ktx_mla_config* cfg, int max_q_tokens);
 
 /* run(q_nope[T,Hq,512], q_pe[T,Hq,64], ckv[pages,page,512], k_pe[pages,page,64]) -> out[T,Hq,512]
  * (BatchMLAPagedAttentionWrapper.run; the plan() arguments are passed here as device arrays):
- *   qo_indptr int32 [batch+1], kv_indptr int32 [batch+1], kv_indices int32 [*] (page ids), kv_len_arr int32 [batch];
+ *   qo_indptr int32 [batch+1], kv_indptr int32 [batch+1], kv_indices int32 [*] (page ids; NULL = identity page table: request
+ *   r owns pages kv_indptr[r] .. kv_indptr[r+1]-1 in order, which spares the kernel a dependent load), kv_len_arr int32 [batch];
  *   d_bsz int32* or NULL: number of live requests (<= batch), read on the device;
  *   ckv_token_stride / kpe_token_stride: elements between consecutive tokens of a page (576 for the fused cache view);
  *   lse float [T,Hq] or NULL (natural-log sum-exp * log2(e), like flashinfer's return_lse). */

@@ -624,12 +624,15 @@ class MLAWrapper:
         self.need_plan = True
 
     def plan(self, qo_indptr, kv_indptr, kv_indices, kv_len_arr, bsz_tensor, num_heads, head_dim_ckv, head_dim_kpe,
-             page_size, sm_scale, q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16, max_kv_len: int = 0):
+             page_size, sm_scale, q_data_type=torch.bfloat16, kv_data_type=torch.bfloat16, max_kv_len: int = 0,
+             identity_pages: bool = False):
+        """identity_pages: the page table is the identity (request r owns pages kv_indptr[r] .. kv_indptr[r+1]-1 in order, as
+        in the single-request StaticCache): the kernel then skips the page-table load (include/ktx_mla.h)."""
         if q_data_type != torch.bfloat16 or kv_data_type != torch.bfloat16:
             raise KtxError("MLAWrapper: bf16 q/kv only")
         self.qo_indptr = qo_indptr if qo_indptr is not None else self.qo_indptr_buf
         self.kv_indptr = kv_indptr if kv_indptr is not None else self.kv_indptr_buf
-        self.kv_indices = kv_indices if kv_indices is not None else self.kv_indices_buf
+        self.kv_indices = None if identity_pages else (kv_indices if kv_indices is not None else self.kv_indices_buf)
         self.bsz_tensor = bsz_tensor if bsz_tensor is not None else getattr(self, "batch_size_tensor_buf", None)
         self.kv_len_arr = kv_len_arr
         self.cfg = _MlaConfig(num_heads, head_dim_ckv, head_dim_kpe, page_size, float(sm_scale), self.max_splits,
@@ -664,7 +667,7 @@ class MLAWrapper:
             raise KtxError("MLAWrapper.run: new_ckv/new_kpe must be contiguous bf16")
         check(lib.ktx_mla_decode_append(C.byref(self.cfg), q_nope.data_ptr(), q_pe.data_ptr(), ckv.data_ptr(), k_pe.data_ptr(),
                                         ckv_ts, kpe_ts, self.qo_indptr.data_ptr(), self.kv_indptr.data_ptr(),
-                                        self.kv_indices.data_ptr(), self.kv_len_arr.data_ptr(),
+                                        self.kv_indices.data_ptr() if self.kv_indices is not None else None, self.kv_len_arr.data_ptr(),
                                         self.bsz_tensor.data_ptr() if self.bsz_tensor is not None else None, batch, T,
                                         new_ckv.data_ptr() if new_ckv is not None else None,
                                         new_kpe.data_ptr() if new_kpe is not None else None,

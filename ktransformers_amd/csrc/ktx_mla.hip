@@ -83,8 +83,6 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, hb = blockIdx.y, qt = blockIdx.z;
-  int B = p.batch;
-  if (p.d_bsz) B = min(max(*p.d_bsz, 0), p.batch);
   MLA_TS(0);
 
   // ---- Q fragments first: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope).  Their
@@ -103,19 +101,21 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   }
 
   // which request owns query token qt?  Every wavefront resolves it on its own with ONE round of independent loads
-  // (lane i looks at request i), instead of a serial scan by one lane followed by dependent loads and a barrier: after a
-  // kernel boundary every one of those loads is an L2 miss (~1-2 us each).
+  // (lane i looks at request i) — the live-request count *d_bsz is fetched in the same round and applied afterwards, not
+  // waited for first: right after a kernel boundary each dependent load is another 1.5-3 us (measured with the phase stamps)
   int req = -1, kv_end = 0, page_base = 0, app_pos = -1;
-  for (int b0 = 0; b0 < B && req < 0; b0 += 64) {
+  const int bsz_raw = p.d_bsz ? *p.d_bsz : p.batch;
+  for (int b0 = 0; b0 < p.batch && req < 0; b0 += 64) {
     const int i = b0 + lane;
     int q0 = 0x7fffffff, q1 = 0, kl = 0, kp = 0;
-    if (i < B) {
+    if (i < p.batch) {
       q0 = p.qo_indptr[i]; q1 = p.qo_indptr[i + 1]; kl = p.kv_len[i]; kp = p.kv_indptr[i];
       // never index past the pages the request owns: a sequence that outgrew its cache attends to (and appends within)
       // its last page instead of reading kv_indices / writing HBM out of bounds
       kl = min(kl, (p.kv_indptr[i + 1] - kp) * p.page_size);
     }
-    const unsigned long long hit = __ballot(qt >= q0 && qt < q1);
+    const int B = min(max(bsz_raw, 0), p.batch);
+    const unsigned long long hit = __ballot(i < B && qt >= q0 && qt < q1);
     if (hit) {
       const int src = __ffsll((long long)hit) - 1;
       q0 = __builtin_amdgcn_readlane(q0, src); q1 = __builtin_amdgcn_readlane(q1, src);
@@ -158,11 +158,13 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     auto stage_ckv = [&](int tile, bf16_t* dst) {
       const int tok0 = tile * MLA_TILE;
       const int ntok = min(MLA_TILE, kv_end - tok0);
-      const int page0 = p.kv_indices[page_base + tok0 / p.page_size];
+      // kv_indices == NULL: the request's pages are page_base, page_base + 1, ... (the single-request cache's identity table,
+      // custom_cache.py:99-104) — no dependent page-table load in front of the latent rows
+      const int page0 = p.kv_indices ? p.kv_indices[page_base + tok0 / p.page_size] : page_base + tok0 / p.page_size;
       for (int r = wave; r < MLA_TILE; r += NWV) {
         if (r < ntok) {
           const int pos = tok0 + r;
-          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
+          const int page = tile_in_page ? page0 : (p.kv_indices ? p.kv_indices[page_base + pos / p.page_size] : page_base + pos / p.page_size);
           const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
           const bf16_t* src = p.ckv + trow * p.ckv_ts;
           if (pos == app_pos) {
@@ -179,14 +181,14 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     auto load_kpe = [&](int tile) {   // k_pe: 32 rows x 8 pieces of 16 B through registers
       const int tok0 = tile * MLA_TILE;
       const int ntok = min(MLA_TILE, kv_end - tok0);
-      const int page0 = p.kv_indices[page_base + tok0 / p.page_size];
+      const int page0 = p.kv_indices ? p.kv_indices[page_base + tok0 / p.page_size] : page_base + tok0 / p.page_size;
 #pragma unroll
       for (int i = 0; i < KPE_PER_THREAD; i++) {
         const int u = tid + i * NWV * 64, r = u >> 3, piece = u & 7;
         uint4 v = make_uint4(0, 0, 0, 0);
         if (u < MLA_TILE * 8 && r < ntok) {
           const int pos = tok0 + r;
-          const int page = tile_in_page ? page0 : p.kv_indices[page_base + pos / p.page_size];
+          const int page = tile_in_page ? page0 : (p.kv_indices ? p.kv_indices[page_base + pos / p.page_size] : page_base + pos / p.page_size);
           const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
           if (pos == app_pos) {
             v = *reinterpret_cast<const uint4*>(p.app_kpe + (size_t)req * MLA_DR + piece * 8);
@@ -423,7 +425,7 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
                                      void* d_workspace, size_t workspace_bytes, void* stream) {
   KTX_REQUIRE((d_new_ckv == nullptr) == (d_new_kpe == nullptr), "ktx_mla_decode_append: give both new_ckv and new_kpe or neither");
   KTX_REQUIRE(cfg && d_q_nope && d_q_pe && d_ckv && d_k_pe && d_out && d_workspace, "ktx_mla_decode: null pointer");
-  KTX_REQUIRE(d_qo_indptr && d_kv_indptr && d_kv_indices && d_kv_len_arr, "ktx_mla_decode: null index array");
+  KTX_REQUIRE(d_qo_indptr && d_kv_indptr && d_kv_len_arr, "ktx_mla_decode: null index array");
   KTX_REQUIRE(cfg->head_dim_ckv == MLA_DC && cfg->head_dim_kpe == MLA_DR, "ktx_mla_decode: only kv_lora_rank 512 + rope 64");
   KTX_REQUIRE(cfg->num_heads > 0 && cfg->num_heads % 16 == 0, "ktx_mla_decode: num_heads must be a multiple of 16");
   KTX_REQUIRE(batch > 0 && total_q_tokens > 0 && cfg->page_size > 0, "ktx_mla_decode: bad sizes");

@@ -900,12 +900,18 @@ __device__ __forceinline__ void dec_step2(const WFrag<WBITS>& fg, const WFrag<WB
 // D = ring depth (k-steps in flight per wave).  EXACT: NKS is a multiple of D, so the hot loop is branch-free
 // straight-line code (the guarded variant costs ~2x in the loop: every predicate becomes an exec-mask branch that
 // fences the scheduler, exposing LDS and MFMA latency with one wave per SIMD).
-template <int WBITS, int D, int NW, bool EXACT>
-__global__ __launch_bounds__(NW * 64) void moe_dec_gateup_kernel(DecParams p) {
+// KS = k-slices per strip: the workgroup is NW strips x KS slices of K, wave (strip, slice) streams NKS/KS k-steps and the
+// slices' int32 partial sums meet in LDS (exact: integer adds).  Twice the waves per CU means twice the KiB in flight on a
+// CU whose single workgroup otherwise has four waves waiting on one burst each.
+template <int WBITS, int D, int NW, bool EXACT, int KS = 1>
+__global__ __launch_bounds__(NW * KS * 64) void moe_dec_gateup_kernel(DecParams p) {
   constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
+  constexpr int NWV = NW * KS;
+  static_assert(KS == 1 || EXACT, "k-slices are built for the branch-free variant");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   uint8_t* xq = smem;                                              // [H + 128]
-  float* s_red = reinterpret_cast<float*>(smem + p.H + 128);       // [NW]
+  float* s_red = reinterpret_cast<float*>(smem + p.H + 128);       // [NWV]
+  int* s_part = reinterpret_cast<int*>(s_red + NWV);               // KS > 1: [NW][KS-1][8][64] int32 partial sums
   int T = p.qlen;
   if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
   const int pair = blockIdx.y, t = pair / p.k;
@@ -915,23 +921,25 @@ __global__ __launch_bounds__(NW * 64) void moe_dec_gateup_kernel(DecParams p) {
   const int e = (int)idl;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform => scalar branches
-  const int strip = blockIdx.x * NW + wave;
+  const int sw = wave % NW, slice = wave / NW;
+  const int strip = blockIdx.x * NW + sw;
   const bool strip_ok = strip * 16 < p.I;
-  const int NKS = p.H / 128;
+  const int NKS_ALL = p.H / 128;
+  const int NKS = NKS_ALL / KS;          // k-steps of this wave's slice
 
   // ---- a6 part 1: this token's activations (issued first: vmcnt retires in order, and x is needed first) ----------
   const bf16_t* xr = p.x + (size_t)t * p.H;
   uint4 xv[4];
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int j = tid * 8 + i * NW * 512;
+    const int j = tid * 8 + i * NWV * 512;
     xv[i] = make_uint4(0, 0, 0, 0);
     if (j < p.H) xv[i] = *reinterpret_cast<const uint4*>(xr + j);
   }
   // ---- weight ring: D k-steps of (gate, up) in flight --------------------------------------------------------------
   const int strip_c = strip_ok ? strip : 0;
-  const uint8_t* wg = p.gate_w + (size_t)e * p.gu_stride + (size_t)strip_c * NKS * TILE_BYTES;
-  const uint8_t* wu = p.up_w + (size_t)e * p.gu_stride + (size_t)strip_c * NKS * TILE_BYTES;
+  const uint8_t* wg = p.gate_w + (size_t)e * p.gu_stride + ((size_t)strip_c * NKS_ALL + (size_t)slice * NKS) * TILE_BYTES;
+  const uint8_t* wu = p.up_w + (size_t)e * p.gu_stride + ((size_t)strip_c * NKS_ALL + (size_t)slice * NKS) * TILE_BYTES;
   WFrag<WBITS> ring[D][2];
 #pragma unroll
   for (int d = 0; d < D; d++) {
@@ -949,25 +957,25 @@ __global__ __launch_bounds__(NW * 64) void moe_dec_gateup_kernel(DecParams p) {
 #pragma unroll
   for (int i = 0; i < 4; i++) amax = amax8(xv[i], amax);
   amax = wave_max(amax);
-  if constexpr (NW > 1) {
+  if constexpr (NWV > 1) {
     if (lane == 0) s_red[wave] = amax;
     __syncthreads();
     amax = s_red[0];
 #pragma unroll
-    for (int w = 1; w < NW; w++) amax = fmaxf(amax, s_red[w]);
+    for (int w = 1; w < NWV; w++) amax = fmaxf(amax, s_red[w]);
   }
   const float xd = amax / 127.0f;
   const float xid = xd ? 1.0f / xd : 0.0f;
 #pragma unroll
   for (int i = 0; i < 4; i++) {
-    const int j = tid * 8 + i * NW * 512;
+    const int j = tid * 8 + i * NWV * 512;
     if (j < p.H) *reinterpret_cast<uint2*>(xq + j) = quant8(xv[i], xid);
   }
   __syncthreads();
-  if (!strip_ok) return;
+  if (KS == 1 && !strip_ok) return;   // (with k-slices every wave stays for the barrier below)
 
   v4i accg = {0, 0, 0, 0}, accu = {0, 0, 0, 0};
-  const uint8_t* bb = xq + (lane >> 4) * 32;
+  const uint8_t* bb = xq + (lane >> 4) * 32 + (size_t)slice * NKS * 128;
   if constexpr (EXACT) {
     const int G = NKS / D;
     for (int g = 0; g < G - 1; g++) {
@@ -1005,6 +1013,21 @@ __global__ __launch_bounds__(NW * 64) void moe_dec_gateup_kernel(DecParams p) {
           }
         }
       }
+    }
+  }
+  if constexpr (KS > 1) {   // the slices' exact int32 partial sums meet in LDS; slice 0 finishes the strip
+    if (slice > 0) {
+      int* dst = s_part + ((sw * (KS - 1) + slice - 1) * 8) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { dst[r * 64] = accg[r]; dst[(4 + r) * 64] = accu[r]; }
+    }
+    __syncthreads();
+    if (slice > 0 || !strip_ok) return;
+#pragma unroll
+    for (int sl = 1; sl < KS; sl++) {
+      const int* src = s_part + ((sw * (KS - 1) + sl - 1) * 8) * 64 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { accg[r] += src[r * 64]; accu[r] += src[(4 + r) * 64]; }
     }
   }
   if ((lane & 15) == 0) {  // all 16 columns are the same token: column 0 stores
@@ -2284,7 +2307,10 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     if (g_dbg[0] == 2 && H <= 4096) nw = 2;
     if (g_dbg[0] == 4) nw = 4;
     const dim3 g1((strips + nw - 1) / nw, qlen * k), g2(H / 16, qlen);
-    const size_t lds1 = (size_t)H + 128 + 16;
+    // two k-slices per strip when a single-token launch would otherwise leave one 4-wave workgroup per CU (DeepSeek-V3 /
+    // Kimi-K2: 32 strip groups x 8 pairs = 256 workgroups): knob 10 = 1 turns the split off for A/B timing
+    const bool ksplit = h->wbits == 4 && nw == 4 && (H / 128) % 28 == 0 && g1.x * g1.y <= 512 && g_dbg[10] != 1;
+    const size_t lds1 = (size_t)H + 128 + 16 + (ksplit ? 8 * sizeof(float) + (size_t)4 * 8 * 64 * sizeof(int) : 4 * sizeof(float));
     const size_t lds2 = (size_t)k * (I + 128) + (size_t)k * 16 * sizeof(float) + (size_t)k * 2 * sizeof(int);
     KTX_REQUIRE(lds2 <= 160 * 1024, "ktx_moe_forward: k*I too large for the decode path");
     const int nks1 = H / 128, nks2 = I / 128;
@@ -2308,7 +2334,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
       ProfScope ps(1, st, false);
       KTX_TIMED(st, qlen * k * (2.0 * I * H * wb + 2.0 * I * 4 + I * 2.0) + qlen * H * 2.0,
                 "moe_dec_gateup_kernel<W%d> T=%d k=%d H=%d I=%d", h->wbits, qlen, k, H, I);
-      if (h->wbits == 4) {
+      if (ksplit) hipLaunchKernelGGL((moe_dec_gateup_kernel<4, 14, 4, true, 2>), g1, dim3(512), lds1, st, dp);
+      else if (h->wbits == 4) {
         if (nks1 % 16 == 0) KTX_LAUNCH_GU(4, 16, true);
         else if (nks1 % 14 == 0) KTX_LAUNCH_GU(4, 14, true);
         else if (nks1 % 11 == 0) KTX_LAUNCH_GU(4, 11, true);

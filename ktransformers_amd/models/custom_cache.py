@@ -24,6 +24,7 @@ class StaticCache:
         self.qk_rope_head_dim = config.qk_rope_head_dim
         self.num_hidden_layers = config.num_hidden_layers
         self.is_MLA, self.is_page = True, True
+        self.identity_page_table = True      # page_table_list[i] = arange (custom_cache.py:99-104): pages are used in order
         latent_shape = (self.max_pages, self.page_size, 1, self.kv_lora_rank + self.qk_rope_head_dim)
         self.key_cache, self.value_cache, self.page_table_list, self.past_tokens = [], [], [], []
         self.page_table_map: Dict[Any, torch.Tensor] = {}

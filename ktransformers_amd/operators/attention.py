@@ -217,7 +217,8 @@ class KDeepseekV2Attention(BaseInjectedModule):
                 raise IndexError(f"KDeepseekV2Attention: position {seen} is beyond the cache ({capacity} tokens)")
             hint = min(seen + 512, capacity)
             self.mla_wrapper.plan(None, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
-                                  self.softmax_scale, torch.bfloat16, torch.bfloat16, max_kv_len=hint)
+                                  self.softmax_scale, torch.bfloat16, torch.bfloat16, max_kv_len=hint,
+                                  identity_pages=bool(getattr(past_key_value, "identity_page_table", False)))
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
             past_key_value.note_appended(self.layer_idx, 1)
             object.__setattr__(self, "_decode_plan", kv_len)
@@ -227,7 +228,8 @@ class KDeepseekV2Attention(BaseInjectedModule):
             qo_indptr = torch.tensor([0, q_len], dtype=torch.int32, device=dev)
             kv_len = (pos[-1:] + 1).to(torch.int32)
             self.mla_wrapper.plan(qo_indptr, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
-                                  self.softmax_scale, torch.bfloat16, torch.bfloat16)
+                                  self.softmax_scale, torch.bfloat16, torch.bfloat16,
+                                  identity_pages=bool(getattr(past_key_value, "identity_page_table", False)))
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
         out = out.reshape(q_len, H * self.v_head_dim)

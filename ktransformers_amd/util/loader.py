@@ -62,7 +62,16 @@ class DictLoader:
 
 
 class SafeTensorLoader(DictLoader):
-    """Directory of *.safetensors shards, loaded lazily per tensor."""
+    """Directory of *.safetensors shards, loaded lazily per tensor (archive/ktransformers/util/custom_loader.py:44-275).
+
+    Also reads the reference's HYBRID checkpoints — the output of archive/merge_tensors/merge_safetensor_gguf.py (DeepSeek-V3 /
+    R1 with fp8 linears and GGUF-quantised experts, the format its DeepSeek-V3-Chat-fp8-linear-ggml-experts.yaml rule file
+    expects; BASELINE config C5).  That script stores EVERY tensor under its GGUF name (`translate_name_to_gguf`:
+    model.layers.3.self_attn.q_a_proj.weight -> blk.3.attn_q_a.weight, ...), the linears as e4m3 `weight` +
+    `weight_scale_inv`, and per MoE layer the experts as the raw ggml blocks of all experts in one uint8 tensor
+    `blk.N.ffn_{gate,up,down}_exps.weight` next to an int `blk.N.ffn_*_exps.ggml_type`.  Like the reference's loader, every
+    lookup tries the name as given and then its GGUF translation (custom_loader.py:96-111,272-275), and load_experts /
+    load_gate take the "legacy hybrid" branch when the translated expert tensor exists (:122-146, :236-243)."""
 
     def __init__(self, path: str):
         from safetensors import safe_open
@@ -70,14 +79,60 @@ class SafeTensorLoader(DictLoader):
         self.tensor_device_map = {}
         self._files = {}
         self._index: Dict[str, str] = {}
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"Path not found: {path}")
         files = [path] if os.path.isfile(path) else sorted(
-            os.path.join(path, f) for f in os.listdir(path) if f.endswith(".safetensors"))
+            os.path.join(root, f) for root, _, fs in os.walk(path) for f in sorted(fs) if f.endswith(".safetensors"))
         for f in files:
             h = safe_open(f, framework="pt", device="cpu")
             self._files[f] = h
             for k in h.keys():
                 self._index[k] = f
         self.state = _LazyState(self)
+
+    @staticmethod
+    def _gguf_name(name: str) -> str:
+        from ktransformers_amd.util.gguf_loader import translate_name_to_gguf
+        return translate_name_to_gguf(name)
+
+    def _resolve(self, name: str):
+        t = self._gguf_name(name)
+        return t if t in self._index else (name if name in self._index else None)
+
+    def has_tensor(self, name: str) -> bool:
+        return self._resolve(name) is not None
+
+    def load_tensor(self, name: str, device: str = "cpu") -> torch.Tensor:
+        k = self._resolve(name)
+        if k is None:
+            raise KeyError(f"Key {name} not found in Safetensor files")
+        return self.state[k].to(device)
+
+    def is_hybrid_experts(self, key: str) -> bool:
+        return self._gguf_name(key) + ".ffn_gate_exps.weight" in self._index
+
+    def get_expert_count(self, key: str) -> int:
+        if self.is_hybrid_experts(key):
+            raise ValueError("a hybrid checkpoint stores all experts of a layer in one ggml tensor: take the count from the config")
+        return DictLoader.get_expert_count(self, key)
+
+    def load_experts(self, key: str, device: str = "cpu") -> dict:
+        if not self.is_hybrid_experts(key):
+            return DictLoader.load_experts(self, key, device)
+        base = self._gguf_name(key)                     # "blk.N": raw ggml blocks + type ids, as the reference returns them
+        out = {}
+        for proj in ("gate", "up", "down"):
+            out[proj] = self.state[f"{base}.ffn_{proj}_exps.weight"].to(device)
+            out[proj + "_type"] = int(self.state[f"{base}.ffn_{proj}_exps.ggml_type"].item())
+        return out
+
+    def load_gate(self, key: str, device: str = "cpu") -> dict:
+        res = {"weight": None, "e_score_correction_bias": None}
+        for k in res:          # both branches of the reference's load_gate reduce to has_tensor / load_tensor with translation
+            name = self._resolve(f"{key}.{k}")
+            if name is not None:
+                res[k] = self.state[name].to(device)
+        return res
 
 
 class _LazyState(dict):
