@@ -242,17 +242,25 @@ class ModelDecodeRunner:
         self.cache = StaticCache(cfg, 1, ctx + max_new + 64, str(dev), torch.bfloat16)
         for kc in self.cache.key_cache:
             kc.normal_()
-        self.cache.past_tokens = [ctx] * cfg.num_hidden_layers           # the prompt the cache pretends to hold
         self.step_mod = GreedyFeedbackStep(model)
-        self.pos = torch.tensor([[ctx]], device=dev, dtype=torch.long)
-        self.cur = torch.tensor([[1 + 17 * seed]], device=dev, dtype=torch.long)
+        self.seed = seed
         self.runner, self.graph_ok, self.graph_error = None, False, None
+        self.capture(use_graph)
+
+    def capture(self, use_graph=True):
+        """(Re-)capture the decode step: launch-time choices (tuning knobs) are baked into the graph at this point."""
+        from ktransformers_amd.util.generate import CUDAGraphRunner
+
+        dev, ctx = self.dev, self.ctx
+        self.runner, self.graph_ok, self.graph_error = None, False, None
+        self.cache.past_tokens = [ctx] * self.cfg.num_hidden_layers
+        self.pos = torch.tensor([[ctx]], device=dev, dtype=torch.long)
+        self.cur = torch.tensor([[1 + 17 * self.seed]], device=dev, dtype=torch.long)
         if use_graph:
             try:
                 r = CUDAGraphRunner()
                 with torch.no_grad():
-                    r.capture(self.step_mod, self.cur, self.pos, self.pos[0].clone(), self.cache, main_device=str(dev),
-                              trace=trace)
+                    r.capture(self.step_mod, self.cur, self.pos, self.pos[0].clone(), self.cache, main_device=str(dev))
                 self.runner, self.graph_ok = r, True
                 self.pos = r.input_buffers["position_ids"]               # advanced inside the graph
                 self.cur = r.input_buffers["cur_token"]

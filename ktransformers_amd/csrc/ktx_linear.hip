@@ -803,6 +803,12 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
     const double cost = (double)((nwg + ncu - 1) / ncu) * (c * strip_bytes + x_bytes);
     if (cost < best) { best = cost; SW = c; }
   }
+  if (ktx_debug_get(11) == 1) {   // A/B knob: the first rule (largest split that still leaves >= 384 workgroups)
+    SW = 1;
+    for (int c = 8; c > 1; c >>= 1)
+      if ((h->nstrips + c - 1) / c >= 384) { SW = c; break; }
+    while (SW < 8 && NKS < 8 / SW) SW <<= 1;
+  }
   {   // tuning knob 8 (scripts/lin_sweep.py): force the strips-per-workgroup split (1, 2, 4 or 8)
     const int f = ktx_debug_get(8);
     if ((f == 1 || f == 2 || f == 4 || f == 8) && NKS >= 8 / f) SW = f;

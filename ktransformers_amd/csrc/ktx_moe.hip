@@ -1521,6 +1521,237 @@ __global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
   }
 }
 
+// =====================================================================================================
+// Decode fast path of the FP8 / BF16 experts (qlen*k <= KTX_DEC_MAX_PAIRS): the two-launch structure of the int formats
+// (moe_dec_gateup_kernel / moe_dec_down_kernel) with the arithmetic of moe_gemm_fp_kernel — bf16 activations as they are,
+// weights widened to bf16 exactly, bf16 MFMA, fp32 accumulation (per 128-K group for FP8, then c = fma(group, scale, c)),
+// every stage rounded to bf16.  Reference analogue: forward_decode of operators/amx/moe_base.hpp:464-654 over
+// GemmKernel224FP8 / GemmKernel224BF16 (la/amx_raw_kernels.hpp:334-566, :17-256).  Before this path existed a decode token
+// of these formats went bucket -> grouped GEMM -> grouped GEMM -> combine: four launches of M-tiled kernels at M = 1.
+// All 16 B-operand columns of the MFMA carry the same token, so no lane masking is needed.
+// =====================================================================================================
+struct DecFpParams {
+  const int32_t* d_bsz;
+  int qlen, k, E, expert_begin, H, I;
+  const int64_t* ids;
+  const uint8_t* mask;
+  const bf16_t* x;
+  const float* weights;
+  const uint8_t *gate_w, *up_w, *down_w;
+  const float *gate_s, *up_s, *down_s;   // FP8: scale_inv [E][N/128][K/128]
+  size_t gu_stride, dn_stride;           // bytes per expert matrix
+  bf16_t* a_buf;                         // [qlen*k][I]
+  void* y;
+  int incremental, partial_f32;
+};
+
+template <bool FP8>
+struct FpSlot {   // one k-step of one matrix in registers: the lane's 32 weights (+ the group's scale)
+  uint4 q[FP8 ? 2 : 4];
+  float sc;
+};
+template <bool FP8>
+__device__ __forceinline__ FpSlot<FP8> fp_load_slot(const uint8_t* tile, const float* sc, int lane) {
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  FpSlot<FP8> s;
+#pragma unroll
+  for (int q = 0; q < (FP8 ? 2 : 4); q++) {
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(tile + q * 1024 + lane * 16));
+    s.q[q] = make_uint4(v.x, v.y, v.z, v.w);
+  }
+  s.sc = FP8 ? *sc : 1.0f;
+  return s;
+}
+// acc += W_slot (16 features x 128 k) . x (128 k, one token); xs = LDS address of this lane's part of the k-step
+template <bool FP8>
+__device__ __forceinline__ void fp_dec_step(const FpSlot<FP8>& w, const uint8_t* xs, v4f& acc) {
+  v8bf a[4];
+  if constexpr (FP8) {
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+      const uint2 e0 = fp8x4_to_bf16x4(w.q[q].x), e1 = fp8x4_to_bf16x4(w.q[q].y);
+      const uint2 e2 = fp8x4_to_bf16x4(w.q[q].z), e3 = fp8x4_to_bf16x4(w.q[q].w);
+      a[q * 2] = u4_as_v8bf(make_uint4(e0.x, e0.y, e1.x, e1.y));
+      a[q * 2 + 1] = u4_as_v8bf(make_uint4(e2.x, e2.y, e3.x, e3.y));
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = u4_as_v8bf(w.q[j]);
+  }
+  v4f tmp = FP8 ? v4f{0.f, 0.f, 0.f, 0.f} : acc;
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+    tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a[j], u4_as_v8bf(*reinterpret_cast<const uint4*>(xs + j * 16)), tmp, 0, 0, 0);
+  if constexpr (FP8) {
+#pragma unroll
+    for (int r = 0; r < 4; r++) acc[r] = fmaf(tmp[r], w.sc, acc[r]);   // apply_scale_kgroup
+  } else {
+    acc = tmp;
+  }
+}
+
+// one workgroup per ((t,j) pair, NW strips): x[t] staged in LDS as bf16, gate and up strips of expert ids[t][j] through a
+// D-deep register ring (NKS % D == 0: branch-free), SiLU*up epilogue -> a_buf[pair]
+template <bool FP8, int D, int NW>
+__global__ __launch_bounds__(NW * 64) void moe_dec_fp_gateup_kernel(DecFpParams p) {
+  constexpr int TILE_BYTES = FP8 ? 2048 : 4096;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [H] bf16
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int pair = blockIdx.y, t = pair / p.k;
+  if (t >= T) return;
+  const long long idl = p.ids[pair] - p.expert_begin;
+  if (idl < 0 || idl >= p.E || (p.mask && p.mask[idl])) return;
+  const int e = (int)idl;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = blockIdx.x * NW + wave;
+  const bool strip_ok = strip * 16 < p.I;
+  const int strip_c = strip_ok ? strip : 0;
+  const int NKS = p.H / 128;
+  // activations first (vmcnt retires in order), then the ring
+  const bf16_t* xr = p.x + (size_t)t * p.H;
+  uint4 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = tid * 8 + i * NW * 512;
+    xv[i] = make_uint4(0, 0, 0, 0);
+    if (j < p.H) xv[i] = *reinterpret_cast<const uint4*>(xr + j);
+  }
+  const uint8_t* wg = p.gate_w + (size_t)e * p.gu_stride + (size_t)strip_c * NKS * TILE_BYTES;
+  const uint8_t* wu = p.up_w + (size_t)e * p.gu_stride + (size_t)strip_c * NKS * TILE_BYTES;
+  const size_t sstride = (size_t)(p.I / 128) * NKS;
+  const float* sg = FP8 ? p.gate_s + (size_t)e * sstride + (size_t)(strip_c * 16 / 128) * NKS : nullptr;
+  const float* su = FP8 ? p.up_s + (size_t)e * sstride + (size_t)(strip_c * 16 / 128) * NKS : nullptr;
+  FpSlot<FP8> ring[D][2];
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    ring[d][0] = fp_load_slot<FP8>(wg + (size_t)d * TILE_BYTES, sg + d, lane);
+    ring[d][1] = fp_load_slot<FP8>(wu + (size_t)d * TILE_BYTES, su + d, lane);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int j = tid * 8 + i * NW * 512;
+    if (j < p.H) *reinterpret_cast<uint4*>(smem + j * 2) = xv[i];
+  }
+  __syncthreads();
+  if (!strip_ok) return;
+  v4f accg = {0.f, 0.f, 0.f, 0.f}, accu = {0.f, 0.f, 0.f, 0.f};
+  const uint8_t* xb = smem + (lane >> 4) * 64;
+  const int G = NKS / D;
+  for (int g = 0; g < G - 1; g++) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const int ks = g * D + d;
+      fp_dec_step<FP8>(ring[d][0], xb + ks * 256, accg);
+      fp_dec_step<FP8>(ring[d][1], xb + ks * 256, accu);
+      ring[d][0] = fp_load_slot<FP8>(wg + (size_t)(ks + D) * TILE_BYTES, sg + ks + D, lane);
+      ring[d][1] = fp_load_slot<FP8>(wu + (size_t)(ks + D) * TILE_BYTES, su + ks + D, lane);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    const int ks = (G - 1) * D + d;
+    fp_dec_step<FP8>(ring[d][0], xb + ks * 256, accg);
+    fp_dec_step<FP8>(ring[d][1], xb + ks * 256, accu);
+  }
+  if ((lane & 15) == 0) {
+    const int n0 = strip * 16 + (lane >> 4) * 4;
+    bf16_t o[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const bf16_t gq = f32_to_bf16(accg[r]), uq = f32_to_bf16(accu[r]);
+      o[r] = f32_to_bf16(act_fn(bf16_to_f32(gq), bf16_to_f32(uq)));
+    }
+    *reinterpret_cast<uint2*>(p.a_buf + (size_t)pair * p.I + n0) =
+        make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
+  }
+}
+
+// one workgroup per (token, 16-row strip of H), wave j = slot j: the activated row of pair (t,j) staged (wave-private) in
+// LDS, the down strip of its expert streamed, then the slot-ordered weighted combine (a12) and the merge step (a4)
+template <bool FP8, int D>
+__global__ __launch_bounds__(512) void moe_dec_fp_down_kernel(DecFpParams p) {
+  constexpr int TILE_BYTES = FP8 ? 2048 : 4096;
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // [k][I] bf16 activations | [k][16] fp32 down outputs | [k] valid flags | [k] routing weights
+  uint8_t* a_all = smem;
+  float* s_dn = reinterpret_cast<float*>(smem + (size_t)p.k * p.I * 2);
+  int* s_valid = reinterpret_cast<int*>(s_dn + p.k * 16);
+  float* s_wt = reinterpret_cast<float*>(s_valid + p.k);
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int j = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = t * p.k + j, strip = blockIdx.x;
+  const long long idl = p.ids[pair] - p.expert_begin;
+  const bool valid = !(idl < 0 || idl >= p.E || (p.mask && p.mask[idl]));
+  const int e = valid ? (int)idl : 0;
+  const int NKS = p.I / 128;
+  if (valid) {
+    const bf16_t* ar = p.a_buf + (size_t)pair * p.I;
+    uint8_t* aw = a_all + (size_t)j * p.I * 2;
+    uint4 av[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = lane * 8 + i * 512;
+      av[i] = make_uint4(0, 0, 0, 0);
+      if (c < p.I) av[i] = *reinterpret_cast<const uint4*>(ar + c);
+    }
+    const uint8_t* wd = p.down_w + (size_t)e * p.dn_stride + (size_t)strip * NKS * TILE_BYTES;
+    const float* sd = FP8 ? p.down_s + (size_t)e * (size_t)(p.H / 128) * NKS + (size_t)(strip * 16 / 128) * NKS : nullptr;
+    FpSlot<FP8> ring[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) ring[d] = fp_load_slot<FP8>(wd + (size_t)d * TILE_BYTES, sd + d, lane);
+    const float wt = p.weights[pair];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = lane * 8 + i * 512;
+      if (c < p.I) *reinterpret_cast<uint4*>(aw + c * 2) = av[i];
+    }
+    if (lane == 0) { s_valid[j] = 1; s_wt[j] = wt; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back its own LDS row: order only
+    __builtin_amdgcn_wave_barrier();
+    v4f acc = {0.f, 0.f, 0.f, 0.f};
+    const uint8_t* xb = aw + (lane >> 4) * 64;
+    const int G = NKS / D;
+    for (int g = 0; g < G - 1; g++) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int ks = g * D + d;
+        fp_dec_step<FP8>(ring[d], xb + ks * 256, acc);
+        ring[d] = fp_load_slot<FP8>(wd + (size_t)(ks + D) * TILE_BYTES, sd + ks + D, lane);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) fp_dec_step<FP8>(ring[d], xb + ((G - 1) * D + d) * 256, acc);
+    if ((lane & 15) == 0) {
+      const int r0 = (lane >> 4) * 4;
+#pragma unroll
+      for (int r = 0; r < 4; r++) s_dn[j * 16 + r0 + r] = bf16_to_f32(f32_to_bf16(acc[r]));
+    }
+  } else if (lane == 0) {
+    s_valid[j] = 0;
+    s_wt[j] = 0.0f;
+  }
+  __syncthreads();
+  if (tid < 16) {  // a12: weighted combine in slot order, then a4
+    float acc = 0.0f;
+    for (int jj = 0; jj < p.k; jj++)
+      if (s_valid[jj]) acc = fmaf(s_dn[jj * 16 + tid], s_wt[jj], acc);
+    const size_t o = (size_t)t * p.H + strip * 16 + tid;
+    if (p.partial_f32) {
+      reinterpret_cast<float*>(p.y)[o] = acc;
+    } else {
+      bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + o;
+      if (p.incremental) acc = acc + bf16_to_f32(*yp);
+      *yp = f32_to_bf16(acc);
+    }
+  }
+}
+
 // row-major [N][K] (fp8 bytes or bf16) -> W tiles of the fp formats; one thread per 16-byte piece
 __global__ void pack_wfp_kernel(const uint8_t* __restrict__ src, int N, int K, int fp8, uint4* __restrict__ out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2444,6 +2675,69 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
   const int mt = std::min(4, pick_mt(qlen, k, E));
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
+
+  // ---- decode fast path: two launches (see moe_dec_fp_gateup_kernel) ------------------------------------------------------
+  const int nks1 = H / 128, nks2 = I / 128;
+  const int d1 = fp8 ? (nks1 % 8 == 0 ? 8 : nks1 % 7 == 0 ? 7 : nks1 % 4 == 0 ? 4 : nks1 % 2 == 0 ? 2 : 1)
+                     : (nks1 % 4 == 0 ? 4 : nks1 % 2 == 0 ? 2 : 1);
+  const int d2 = fp8 ? (nks2 % 16 == 0 ? 16 : nks2 % 8 == 0 ? 8 : nks2 % 4 == 0 ? 4 : nks2 % 2 == 0 ? 2 : 1)
+                     : (nks2 % 8 == 0 ? 8 : nks2 % 4 == 0 ? 4 : nks2 % 2 == 0 ? 2 : 1);
+  const size_t lds_dn = (size_t)k * I * 2 + (size_t)k * 16 * sizeof(float) + (size_t)k * 2 * sizeof(int);
+  if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && H <= 16384 && I <= 4096 && lds_dn <= 160 * 1024 && !g_force_generic) {
+    DecFpParams dp;
+    dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
+    dp.ids = d_expert_ids; dp.mask = h->mask; dp.x = (const bf16_t*)d_input; dp.weights = d_weights;
+    dp.gate_w = h->gate_w; dp.up_w = h->up_w; dp.down_w = h->down_w;
+    dp.gate_s = h->gate_s; dp.up_s = h->up_s; dp.down_s = h->down_s;
+    dp.gu_stride = h->gu_stride; dp.dn_stride = h->dn_stride; dp.a_buf = ws->a_buf; dp.y = d_output;
+    dp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+    const dim3 g1((I / 16 + 3) / 4, npairs), g2(H / 16, qlen);
+    const size_t lds_gu = (size_t)H * 2;
+    const double wb = fp8 ? 1.0 : 2.0;
+    const int only = g_dbg[2];
+#define KTX_FP_GU(F8, DD)                                                                                            \
+    do {                                                                                                             \
+      static std::once_flag once; static hipError_t err = hipSuccess;                                                \
+      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_fp_gateup_kernel<F8, DD, 4>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+      KTX_HIP(err);                                                                                                  \
+      hipLaunchKernelGGL((moe_dec_fp_gateup_kernel<F8, DD, 4>), g1, dim3(256), lds_gu, st, dp);                      \
+    } while (0)
+#define KTX_FP_DN(F8, DD)                                                                                            \
+    do {                                                                                                             \
+      static std::once_flag once; static hipError_t err = hipSuccess;                                                \
+      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_fp_down_kernel<F8, DD>), \
+                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+      KTX_HIP(err);                                                                                                  \
+      hipLaunchKernelGGL((moe_dec_fp_down_kernel<F8, DD>), g2, dim3(64 * k), lds_dn, st, dp);                        \
+    } while (0)
+    if (only != 2) {
+      KTX_TIMED(st, npairs * (2.0 * I * H * wb + I * 2.0) + qlen * H * 2.0, "moe_dec_fp_gateup_kernel<%s> T=%d k=%d H=%d I=%d",
+                fp8 ? "FP8" : "BF16", qlen, k, H, I);
+      if (fp8) {
+        switch (d1) { case 8: KTX_FP_GU(true, 8); break; case 7: KTX_FP_GU(true, 7); break; case 4: KTX_FP_GU(true, 4); break;
+                      case 2: KTX_FP_GU(true, 2); break; default: KTX_FP_GU(true, 1); break; }
+      } else {
+        switch (d1) { case 4: KTX_FP_GU(false, 4); break; case 2: KTX_FP_GU(false, 2); break; default: KTX_FP_GU(false, 1); break; }
+      }
+    }
+    KTX_HIP(hipGetLastError());
+    if (only != 1) {
+      KTX_TIMED(st, npairs * ((double)H * I * wb + I * 2.0) + qlen * H * 2.0, "moe_dec_fp_down_kernel<%s> T=%d k=%d H=%d I=%d",
+                fp8 ? "FP8" : "BF16", qlen, k, H, I);
+      if (fp8) {
+        switch (d2) { case 16: KTX_FP_DN(true, 16); break; case 8: KTX_FP_DN(true, 8); break; case 4: KTX_FP_DN(true, 4); break;
+                      case 2: KTX_FP_DN(true, 2); break; default: KTX_FP_DN(true, 1); break; }
+      } else {
+        switch (d2) { case 8: KTX_FP_DN(false, 8); break; case 4: KTX_FP_DN(false, 4); break; case 2: KTX_FP_DN(false, 2); break;
+                      default: KTX_FP_DN(false, 1); break; }
+      }
+    }
+    KTX_HIP(hipGetLastError());
+#undef KTX_FP_GU
+#undef KTX_FP_DN
+    return 0;
+  }
 
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;

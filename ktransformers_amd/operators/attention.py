@@ -30,6 +30,11 @@ from ktransformers_amd.operators.RoPE import yarn_get_mscale
 # call (prefill chunk), never with max_position_embeddings: a per-layer wrapper sized by the context length would need
 # ~43 GB per layer at DeepSeek-V3's 163840 positions.  The decode wrapper is never re-allocated (captured graphs hold
 # its workspace pointer); the prompt wrapper grows on demand (prompts are not graph-captured).
+def _NO_IDENTITY() -> bool:      # A/B switch for timing experiments (scripts/ab_decode.py)
+    import os
+    return os.environ.get("KTX_MLA_NO_IDENTITY") == "1"
+
+
 _DECODE_WRAPPERS: dict = {}
 _PREFILL_WRAPPERS: dict = {}
 PREFILL_Q_GRANULE = 1024
@@ -218,7 +223,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
             hint = min(seen + 512, capacity)
             self.mla_wrapper.plan(None, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16, max_kv_len=hint,
-                                  identity_pages=bool(getattr(past_key_value, "identity_page_table", False)))
+                                  identity_pages=bool(getattr(past_key_value, "identity_page_table", False)) and not _NO_IDENTITY())
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
             past_key_value.note_appended(self.layer_idx, 1)
             object.__setattr__(self, "_decode_plan", kv_len)
@@ -229,7 +234,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
             kv_len = (pos[-1:] + 1).to(torch.int32)
             self.mla_wrapper.plan(qo_indptr, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16,
-                                  identity_pages=bool(getattr(past_key_value, "identity_page_table", False)))
+                                  identity_pages=bool(getattr(past_key_value, "identity_page_table", False)) and not _NO_IDENTITY())
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
         out = out.reshape(q_len, H * self.v_head_dim)

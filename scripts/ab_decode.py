@@ -1,0 +1,55 @@
+"""Dev tool: A/B timing of launch-time choices on the SAME box and the SAME resident model — boxes of the pool differ by
+10-30 % on latency-bound kernels, so two bench runs cannot be compared.  The whole-model decode graph is re-captured per
+configuration (knobs are read at launch time) and the configurations are timed interleaved, several rounds.
+
+    python scripts/ab_decode.py [--layers 32] [--rounds 3] [--steps 60]
+"""
+import argparse, os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+import bench
+from ktransformers_amd import _native as n
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--workload", default="v3-int4")
+ap.add_argument("--layers", type=int, default=0)
+ap.add_argument("--rounds", type=int, default=3)
+ap.add_argument("--steps", type=int, default=60)
+ap.add_argument("--ctx", type=int, default=4096)
+args = ap.parse_args()
+dev = torch.device("cuda", 0)
+torch.cuda.set_device(dev)
+wl = bench.WORKLOADS[args.workload]
+mr = bench.ModelDecodeRunner(wl, args.layers or wl["layers"], dev, args.ctx, 4096)
+
+CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
+    "default": ({}, {}),
+    "lin: first split rule": ({11: 1}, {}),
+    "moe gate/up: no k-slices": ({10: 1}, {}),
+    "mla: page table load": ({}, {"KTX_MLA_NO_IDENTITY": "1"}),
+    "mla: 4x2 shape, 128 splits": ({6: 4, 7: 128}, {}),
+    "lin: LDS-DMA ring": ({9: 2}, {}),
+}
+res = {k: [] for k in CONFIGS}
+for r in range(args.rounds):
+    for name, (knobs, env) in CONFIGS.items():
+        for i, v in knobs.items():
+            n.lib.ktx_debug_set(i, v)
+        for k, v in env.items():
+            os.environ[k] = v
+        try:
+            mr.capture(True)
+            for _ in range(40):
+                mr.step()
+            mr.set_position(args.ctx)
+            dt = bench.timed(mr.step, args.steps, 10, dev, False)
+            res[name].append(dt / args.steps * 1e3)
+        finally:
+            for i in knobs:
+                n.lib.ktx_debug_set(i, 0)
+            for k in env:
+                os.environ.pop(k, None)
+        print(f"round {r} {name:32s} {res[name][-1]:.3f} ms/step", flush=True)
+base = min(res["default"])
+for name, v in res.items():
+    print(f"{name:32s} best {min(v):.3f} ms  median {sorted(v)[len(v) // 2]:.3f} ms  vs default {min(v) / base:.3f}x", flush=True)

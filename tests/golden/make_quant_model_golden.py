@@ -132,7 +132,10 @@ def build(seed, dtype):
     sd["lm_head.weight"] = head_w
     eff = dict(sd)                                               # what the quantised back-ends compute with
     for name in sd:
-        if name.endswith("_proj.weight") and ".mlp.experts." not in name and "kv_b_proj" not in name or name == "lm_head.weight":
+        # every nn.Linear of the decoder layers except kv_b_proj, plus lm_head (DeepSeek-V3-Chat.yaml:10-30); the router's
+        # weight is a plain Parameter of MoEGate, not a Linear, and stays as it is
+        is_linear = sd[name].dim() == 2 and "embed_tokens" not in name and not name.endswith("mlp.gate.weight")
+        if is_linear and ".mlp.experts." not in name and "kv_b_proj" not in name:
             eff[name] = marlin_weights(sd[name])
     root.load_state_dict({k: v.to(dtype) for k, v in eff.items()}, strict=True)
     root.eval()
@@ -162,6 +165,20 @@ def logits_of(root, ids, dtype):
     return root.lm_head(root.model.norm(h)).float()[0]
 
 
+@torch.no_grad()
+def hidden_states(root, ids, dtype):
+    """The residual stream after every decoder layer (+ the final norm) for the whole sequence `ids`."""
+    h = root.model.embed_tokens(ids)
+    n = ids.shape[1]
+    pos = torch.arange(n).unsqueeze(0)
+    mask = torch.full((n, n), float("-inf")).triu(1)[None, None].to(dtype)
+    out = [h[0].float().numpy().copy()]
+    for layer in root.model.layers:
+        h = layer(h, attention_mask=mask, position_ids=pos)[0]
+        out.append(h[0].float().numpy().copy())
+    return np.stack(out)
+
+
 def generate(root, prompt, dtype):
     ids, toks, lg, margins = prompt.clone(), [], [], []
     for _ in range(N_NEW):
@@ -186,13 +203,17 @@ for seed in range(100, 140):
           f"logit std {lg32.std():.2f}, rel(bf16 vs fp32 logits) {np.linalg.norm(lg - lg32) / np.linalg.norm(lg32):.4f} -> "
           f"{'KEEP' if ok else 'skip'}", flush=True)
     if ok:
-        chosen = (seed, cfg, sd, prompt, toks, lg, lg32, margins, margins32, rec_bf16)
+        full = torch.cat([prompt, torch.tensor([toks[:-1]])], dim=1)       # the sequence whose last position yields toks[-1]
+        hid16, hid32 = hidden_states(root_bf16, full, torch.bfloat16), hidden_states(root_f32, full, torch.float32)
+        chosen = (seed, cfg, sd, prompt, toks, lg, lg32, margins, margins32, rec_bf16, hid16, hid32)
         break
 assert chosen is not None, "no seed in range met the stability criterion"
-seed, cfg, sd, prompt, toks, lg, lg32, margins, margins32, recs = chosen
+seed, cfg, sd, prompt, toks, lg, lg32, margins, margins32, recs, hid16, hid32 = chosen
 out = {f"w.{k}": v.view(torch.uint16).numpy() for k, v in sd.items()}
 out.update(seed=np.int64(seed), prompt=prompt[0].numpy(), tokens=np.array(toks, np.int64), logits_bf16=lg, logits_f32=lg32,
-           margin_bf16=margins, margin_f32=margins32, min_margin=np.float32(MIN_MARGIN))
+           margin_bf16=margins, margin_f32=margins32, min_margin=np.float32(MIN_MARGIN),
+           # residual stream after the embedding and after each layer over the whole 48-token sequence (bf16 run as bf16 bits)
+           hidden_f32=hid32.astype(np.float32), hidden_bf16=torch.from_numpy(hid16).to(torch.bfloat16).view(torch.uint16).numpy())
 for i, rec in enumerate(recs):        # the expert block's last call (all positions of the final step) per MoE layer
     x, ids, w, y = rec["last"]
     out[f"moe{i}.x"], out[f"moe{i}.ids"], out[f"moe{i}.w"], out[f"moe{i}.y"] = x, ids, w, y

@@ -326,6 +326,31 @@ def _check_fp(got_u16, want_u16):
     assert np.abs(a - b).mean() / max(np.abs(b).mean(), 1e-30) < 1e-3
 
 
+def test_fp8_decode_at_deepseek_v3_expert_shape(oracle, dev):
+    """BASELINE config C3 (DeepSeek-V3 fp8 experts, 7168 x 2048, top-8): the two-launch decode path against the oracle that is
+    pinned to the reference's own AMX_FP8_MOE_TP, and against the grouped path on the same input."""
+    from helpers import fp8_block_quant
+    from ktransformers_amd._native import MoEHandle, force_generic_path
+    E, k, H, I, T = 8, 8, 7168, 2048, 2
+    c = make_case(11, E, k, H, I, T)
+    q = [fp8_block_quant(bf16_to_f32(c[n])) for n in ("gate", "up", "down")]
+    mo = oracle.make_moe_fp8(q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = MoEHandle(E, k, H, I, max_len=8, method="FP8", device=0, group_size=128)
+    try:
+        h.load_fp8(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch.from_numpy(x[1]).to(dev) for x in q])
+        got = run(h, c, dev)
+        _check_fp(got, want)
+        force_generic_path(True)
+        try:
+            grouped = run(h, c, dev)
+        finally:
+            force_generic_path(False)
+        _check_fp(got, grouped)
+    finally:
+        h.close()
+
+
 @pytest.mark.parametrize("fmt", ["FP8", "BF16"])
 @pytest.mark.parametrize("shape", [(8, 2, 512, 256, 1), (8, 2, 512, 256, 5), (8, 6, 2048, 1408, 2), (8, 2, 256, 512, 40),
                                    (8, 2, 256, 512, 300), (4, 2, 256, 256, 700)])

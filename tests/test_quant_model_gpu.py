@@ -70,8 +70,8 @@ def test_greedy_token_ids_identical_to_the_reference_cpu_backend(quant_model, us
     ref32, ref16 = torch.from_numpy(g["logits_f32"]), torch.from_numpy(g["logits_bf16"])
     per_pos = lambda x: ((x - ref32).norm(dim=1) / ref32.norm(dim=1)).numpy()
     e_ref, e = per_pos(ref16), per_pos(logits.float().cpu())
-    assert np.median(e) < max(1.5 * np.median(e_ref), 3e-2), (np.median(e), np.median(e_ref), np.round(e, 3).tolist())
-    assert (e > 0.12).mean() <= 0.25, np.round(e, 3).tolist()
+    assert np.median(e) < 2.5 * np.median(e_ref) + 1e-2, (np.median(e), np.median(e_ref), np.round(e, 3).tolist())
+    assert (e > 0.2).mean() <= 0.25, np.round(e, 3).tolist()
     # and the winning margin the reference saw survives here with room to spare
     top2 = logits.float().cpu().topk(2, dim=-1).values
     assert float((top2[:, 0] - top2[:, 1]).min()) > 0.25 * float(g["margin_bf16"].min())
@@ -96,3 +96,37 @@ def test_expert_blocks_bit_exact_on_the_reference_inputs(quant_model):
         assert np.array_equal(got, want), f"MoE layer {li}: {int((got != want).sum())} of {want.size} bf16 outputs differ"
         n += 1
     assert n == 3
+
+
+def test_residual_stream_tracks_the_reference_layer_by_layer(quant_model):
+    """The whole 48-token sequence as ONE prompt pass, residual stream compared after every decoder layer with the reference's
+    fp32-arithmetic run.  The yardstick per layer is the reference's own bf16 run (stored next to it): the quantised experts
+    amplify any bf16-level difference in their input (int8 row quantisation, router near-ties), so both pipelines drift from
+    0.3 % after the dense layer to a few per cent after three MoE layers; this path must stay within 2.5x of that drift."""
+    from ktransformers_amd.util.generate import set_inference_mode
+    from ktransformers_amd.util.utils import InferenceState
+    model, cache, g = quant_model
+    ids = torch.from_numpy(np.concatenate([g["prompt"], g["tokens"][:-1]])).cuda()[None]
+    ref32 = torch.from_numpy(g["hidden_f32"])
+    ref16 = torch.from_numpy(g["hidden_bf16"].view(np.int16).copy()).view(torch.bfloat16).float()
+    got = []
+    hooks = [layer.register_forward_hook(lambda m, a, out: got.append((out[0] if isinstance(out, tuple) else out).detach().float().cpu()))
+             for layer in model.model.layers]
+    try:
+        set_inference_mode(model, InferenceState.PREFILL)
+        cache.reset()
+        pos = torch.arange(ids.shape[1], device="cuda")[None]
+        with torch.no_grad():
+            model(ids, pos, cache, pos[0])
+        torch.cuda.synchronize()
+    finally:
+        for h in hooks:
+            h.remove()
+        set_inference_mode(model, InferenceState.GENERATE)
+    med = lambda a, b: float(((a - b).norm(dim=1) / b.norm(dim=1)).median())
+    report = []
+    for li, h in enumerate(got):
+        h = h.reshape(-1, h.shape[-1])
+        report.append((li, round(med(h, ref32[li + 1]), 4), round(med(ref16[li + 1], ref32[li + 1]), 4)))
+    for li, ours, theirs in report:
+        assert ours < 2.5 * theirs + 5e-3, report
