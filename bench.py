@@ -376,11 +376,11 @@ def kernel_table(mr, dev, ms_per_step, reps=4):
                      "GBs": round(nbytes / (us * 1e-6) / 1e9, 1) if us > 0 else None,
                      "frac_of_hbm_peak": round(nbytes / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if us > 0 else None})
     rows.sort(key=lambda r: -r["us_per_step"])
-    # kernel time of ONE MoE layer: cut a step's log at every mla_prep (one per layer; a segment then holds one layer's
+    # kernel time of ONE MoE layer: cut a step's log at every mla_prep (one per layer, fused into the q-absorb launch in decode; a segment then holds one layer's
     # launches, its first GEMVs borrowed from the next layer, whose shapes are the same); average the MoE segments
     segs = []
     for log in logs:
-        cuts = [i for i, (label, _, _) in enumerate(log) if label.startswith("mla_prep_kernel")]
+        cuts = [i for i, (label, _, _) in enumerate(log) if label.startswith("mla_prep_kernel") or label.endswith("+mla_prep")]
         for a, b in zip(cuts, cuts[1:]):
             seg = log[a:b]
             if any(l.startswith("moe_dec_") for l, _, _ in seg):
@@ -555,13 +555,32 @@ def whole_model_prefill(mr, T, dev, reps=3):
             torch.cuda.synchronize(dev)
             if r:
                 times.append(time.perf_counter() - t0)
+    # one more pass with the library's per-launch log on: where a prompt chunk spends its time
+    from ktransformers_amd import _native
+    per_kernel = []
+    try:
+        _native.timing_enable(1)
+        with torch.no_grad():
+            mr.cache.past_tokens = [0] * mr.cfg.num_hidden_layers
+            mr.model(ids, pos, mr.cache, pos[0], last_token_only=True)
+        agg = {}
+        for label, nbytes, us in _native.timing_collect():
+            key = label.split(" T=")[0] if label.startswith(("lin_gemm", "lin_dec")) else label
+            a = agg.setdefault(key, [0, 0.0])
+            a[0] += 1
+            a[1] += us or 0.0
+        tot = sum(v[1] for v in agg.values())
+        per_kernel = [{"kernel": k2, "launches": v[0], "total_ms": round(v[1] / 1e3, 3), "share": round(v[1] / tot, 4)}
+                      for k2, v in sorted(agg.items(), key=lambda kv: -kv[1][1])][:12]
+    finally:
+        _native.timing_enable(0)
     set_inference_mode(mr.model, InferenceState.GENERATE)
     dt = sum(times) / len(times)
     cfg = mr.cfg
     n_moe = cfg.num_hidden_layers - min(cfg.first_k_dense_replace, cfg.num_hidden_layers)
     moe_flop = 2 * 3 * cfg.hidden_size * cfg.moe_intermediate_size * cfg.num_experts_per_tok * T * n_moe
     return {"value": round(T / dt, 1), "unit": "tok/s", "tokens": T, "ms_per_chunk": round(dt * 1e3, 3),
-            "layers": cfg.num_hidden_layers, "routed_expert_TOPs_share": round(moe_flop / dt / 1e12, 1),
+            "layers": cfg.num_hidden_layers, "routed_expert_TOPs_share": round(moe_flop / dt / 1e12, 1), "per_kernel": per_kernel,
             "what": "whole resident model, one prompt chunk from an empty cache (absorbed MLA, grouped int8-MFMA expert GEMMs, "
                     "W4 MFMA linears), last-token logits"}
 

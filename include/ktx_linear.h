@@ -102,6 +102,15 @@ int ktx_linear_forward_batched(ktx_linear_t h, const int32_t* d_bsz, int T, cons
                                int64_t x_batch_stride, void* d_y, int64_t ldy, int64_t y_batch_stride,
                                ktx_stream_t stream);
 
+/* ktx_linear_forward_batched for a decode step (T <= 4) with ktx_mla_prep (include/ktx_ops.h) riding in the same launch: the
+ * q-absorb products need only q_nope, the prep only q_pe / the kv_a row — independent work between the projections and the
+ * MLA kernel (attention.py:360-418), one kernel boundary instead of two.  Arguments after y_batch_stride are ktx_mla_prep's. */
+int ktx_linear_forward_batched_prep(ktx_linear_t h, int T, const void* d_x, int64_t ldx, int64_t x_batch_stride, void* d_y,
+                                    int64_t ldy, int64_t y_batch_stride, int num_heads, int nope_dim, int rope_dim, int kv_lora,
+                                    const void* d_q, int64_t q_row_stride, void* d_q_pe_out, const void* d_kv,
+                                    int64_t kv_row_stride, const void* d_kv_norm_w, float eps, void* d_ckv_out, void* d_kpe_out,
+                                    const int64_t* d_pos, const float* d_inv_freq, float mscale, ktx_stream_t stream);
+
 /* bytes of HBM held for the weights (tiles + scales) — the algorithmic bytes one decode launch streams */
 size_t ktx_linear_weight_bytes(ktx_linear_t h);
 

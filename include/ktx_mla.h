@@ -63,6 +63,20 @@ int ktx_mla_cache_append(const ktx_mla_config* cfg, void* d_kv_cache, int64_t to
                          const void* d_kpe_new, const int32_t* d_page_idx, const int32_t* d_page_offset,
                          const int32_t* d_ntokens, int max_tokens, int num_pages, void* stream);
 
+/* Non-absorbed prompt attention — the prefill branch of KDeepseekV2Attention (archive/ktransformers/operators/attention.py:
+ * 349-523, forward_chunck :58-164): kv_b_proj has expanded the context's latents to per-head keys and values, and a causal
+ * attention runs over qk dim 192 (128 nope + 64 rope) with v dim 128 — 3.4x fewer flop per (query, key) than the absorbed
+ * form, which stays the decode path.  The T query tokens are the LAST T of the kv_len keys (chunked prefill: kv_len > T).
+ *   q_nope bf16 [T][H][128] and q_pe bf16 [T][H][64] (RoPE applied) with explicit element strides (views of one q tensor);
+ *   k_nope bf16 [H][kv_pad][128]; k_pe bf16 [kv_len][64] rows `kpe_token_stride` apart (the latent cache itself);
+ *   v_t bf16 [H][128][kv_pad] (V TRANSPOSED: keys contiguous — it is a GEMM output either way); out bf16 [T][H][128].
+ * kv_pad: multiple of 64 >= kv_len; k_nope rows and v_t columns in [kv_len, kv_pad) must be ZERO (they are, when the latent
+ * rows fed to the expansion GEMMs are zero-padded). */
+int ktx_mla_prefill(int T, int num_heads, int kv_len, int kv_pad, float sm_scale, const void* d_q_nope, int64_t qn_token_stride,
+                    int64_t qn_head_stride, const void* d_q_pe, int64_t qp_token_stride, int64_t qp_head_stride,
+                    const void* d_k_nope, const void* d_k_pe, int64_t kpe_token_stride, const void* d_v_t, void* d_out,
+                    void* stream);
+
 /* Tuning aid (scripts/mla_sweep.py): while a device buffer of >= 16 * workgroups int64 entries is set, every workgroup of the
  * split-KV kernel stamps the wall clock (100 MHz) at its phase boundaries into it; NULL (the default) turns it off. */
 int ktx_mla_debug_stamps(long long* d_buf);

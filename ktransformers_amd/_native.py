@@ -82,6 +82,8 @@ def _load() -> C.CDLL:
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
     lib.ktx_mla_decode_append.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.c_void_p]
+    lib.ktx_mla_prefill.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
+                                    C.c_int64, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_mla_cache_append.argtypes = [C.POINTER(_MlaConfig), C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
                                          C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]
     lib.ktx_mla_debug_stamps.argtypes = [C.c_void_p]
@@ -93,6 +95,10 @@ def _load() -> C.CDLL:
     lib.ktx_linear_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_linear_forward_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
                                                C.c_int64, C.c_int64, C.c_void_p]
+    lib.ktx_linear_forward_batched_prep.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p, C.c_int64,
+                                                    C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64,
+                                                    C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p,
+                                                    C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.ktx_linear_forward_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
                                              C.c_void_p]
     lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
@@ -123,8 +129,8 @@ def _load() -> C.CDLL:
 # calls of ONE kernel class alone to time that kernel on distinct layers' weights.  Not used by the product path.
 STREAM_CALLS = frozenset((
     "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
-    "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_linear_forward",
-    "ktx_linear_forward_batched", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
+    "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_mla_prefill", "ktx_linear_forward",
+    "ktx_linear_forward_batched", "ktx_linear_forward_batched_prep", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
     "ktx_mla_prep", "ktx_argmax"))
 TRACE: list | None = None
 HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
@@ -523,6 +529,33 @@ class LinearHandle:
         return out
 
 
+def absorb_and_prep(qabs: "LinearHandle", q: torch.Tensor, kv: torch.Tensor, kv_norm_weight: torch.Tensor, eps: float,
+                    positions: torch.Tensor, inv_freq: torch.Tensor, mscale: float, num_heads: int, nope_dim: int, rope_dim: int,
+                    kv_lora: int):
+    """Decode step (T <= 4): the per-head q-absorb products AND mla_prep in one launch (ktx_linear_forward_batched_prep).
+    q: bf16 [T, H*(nope+rope)] (unit inner stride), kv: bf16 [T, kv_lora+rope].  Returns (q_nope [T,H,lora], q_pe, ckv, k_pe)."""
+    T, dev = positions.numel(), positions.device
+    _bf16_rows(q, "absorb_and_prep q")
+    _bf16_rows(kv, "absorb_and_prep kv")
+    q = q.reshape(T, -1)
+    kv = kv.reshape(T, -1)
+    if positions.dtype != torch.int64 or inv_freq.dtype != torch.float32:
+        raise KtxError("absorb_and_prep: positions must be int64 and inv_freq fp32")
+    if qabs.batch != num_heads or qabs.K != nope_dim:
+        raise KtxError("absorb_and_prep: the handle is not the per-head q-absorb linear of this attention")
+    q3 = q.unflatten(1, (num_heads, nope_dim + rope_dim))
+    q_nope = torch.empty((T, num_heads, qabs.N), dtype=torch.bfloat16, device=dev)
+    q_pe = torch.empty((T, num_heads, rope_dim), dtype=torch.bfloat16, device=dev)
+    ckv = torch.empty((T, kv_lora), dtype=torch.bfloat16, device=dev)
+    kpe = torch.empty((T, rope_dim), dtype=torch.bfloat16, device=dev)
+    check(lib.ktx_linear_forward_batched_prep(qabs._h, T, q3.data_ptr(), q3.stride(0), q3.stride(1), q_nope.data_ptr(),
+                                              q_nope.stride(0), q_nope.stride(1), num_heads, nope_dim, rope_dim, kv_lora,
+                                              q.data_ptr(), q.stride(0), q_pe.data_ptr(), kv.data_ptr(), kv.stride(0),
+                                              kv_norm_weight.data_ptr(), float(eps), ckv.data_ptr(), kpe.data_ptr(),
+                                              positions.data_ptr(), inv_freq.data_ptr(), float(mscale), _stream_ptr(dev)))
+    return q_nope, q_pe, ckv, kpe
+
+
 def linear_force_gemm(on: bool) -> None:
     check(lib.ktx_linear_debug_force_gemm(1 if on else 0))
 
@@ -689,6 +722,25 @@ def mla_cache_append(kv_cache: torch.Tensor, ckv_new: torch.Tensor, kpe_new: tor
     check(lib.ktx_mla_cache_append(C.byref(cfg), kv_cache.data_ptr(), ts, c.data_ptr(), r.data_ptr(), pi.data_ptr(),
                                    po.data_ptr(), ntokens.data_ptr() if ntokens is not None else None, T,
                                    int(kv_cache.shape[0]), _stream_ptr(kv_cache.device)))
+
+
+def mla_prefill(q_nope: torch.Tensor, q_pe: torch.Tensor, k_nope: torch.Tensor, k_pe: torch.Tensor, v_t: torch.Tensor,
+                kv_len: int, sm_scale: float) -> torch.Tensor:
+    """Causal non-absorbed prompt attention (include/ktx_mla.h, ktx_mla_prefill).  q_nope [T,H,128] / q_pe [T,H,64] (strided
+    views allowed, unit inner stride), k_nope [H,kv_pad,128] contiguous, k_pe [kv_len(+),64] rows with a token stride,
+    v_t [H,128,kv_pad] contiguous -> bf16 [T,H,128]; the T queries are the last T of the kv_len keys."""
+    T, H, _ = q_nope.shape
+    kv_pad = k_nope.shape[1]
+    for t, what in ((q_nope, "q_nope"), (q_pe, "q_pe"), (k_nope, "k_nope"), (k_pe, "k_pe"), (v_t, "v_t")):
+        _bf16_rows(t, f"mla_prefill {what}")
+    if q_nope.shape[2] != 128 or q_pe.shape[2] != 64 or k_nope.shape != (H, kv_pad, 128) or v_t.shape != (H, 128, kv_pad) \
+            or not k_nope.is_contiguous() or not v_t.is_contiguous() or k_pe.shape[-1] != 64 or k_pe.dim() != 2:
+        raise KtxError("mla_prefill: bad operand shapes")
+    out = torch.empty((T, H, 128), dtype=torch.bfloat16, device=q_nope.device)
+    check(lib.ktx_mla_prefill(T, H, int(kv_len), kv_pad, float(sm_scale), q_nope.data_ptr(), q_nope.stride(0), q_nope.stride(1),
+                              q_pe.data_ptr(), q_pe.stride(0), q_pe.stride(1), k_nope.data_ptr(), k_pe.data_ptr(), k_pe.stride(0),
+                              v_t.data_ptr(), out.data_ptr(), _stream_ptr(q_nope.device)))
+    return out
 
 
 # ---- small fused ops (include/ktx_ops.h) ---------------------------------------------------------------------------

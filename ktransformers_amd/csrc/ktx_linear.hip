@@ -32,6 +32,7 @@
 #include "../../include/ktx_linear.h"
 
 typedef __bf16 lv8bf __attribute__((ext_vector_type(8)));
+#include "ktx_prep.inc"
 
 extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
 
@@ -106,6 +107,10 @@ struct LinParams {
   const bf16_t *add1, *add2;
   long ld1, ld2;
   int glu;   // rows interleaved per strip as [8 gate | 8 up]: the epilogue writes act_fn(gate) * up, N/2 columns
+  // ktx_linear_forward_batched_prep: one extra row of workgroups (blockIdx.y == 0, the products shift up by one) runs the MLA prep of the same decode
+  // step (latent RMSNorm + RoPE) beside the per-head absorb products — independent work, one launch instead of two
+  int prep_on;
+  MlaPrepParams prep;
 };
 
 // batch b of a batched linear: shift the base pointers once
@@ -270,9 +275,14 @@ template <int FMT, int G, int D, int MODE>
 __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   constexpr bool EXACT = MODE != M_GUARD;
   static_assert(MODE != M_DMA || FMT == F_W4, "the LDS-DMA ring is built for the W4 format");
-  using F = Fmt<FMT, G>;
-  lin_select_batch(p, blockIdx.y);
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (p.prep_on && blockIdx.y == 0) {   // the prep row, dispatched FIRST so it overlaps the products: workgroup x handles tokens x, x + gridDim.x, ...
+    float* s_cs = reinterpret_cast<float*>(smem);   // (static LDS here would push the kernel past the 160 KB attribute)
+    for (int t = blockIdx.x; t < p.prep.T; t += gridDim.x) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
+    return;
+  }
+  using F = Fmt<FMT, G>;
+  lin_select_batch(p, blockIdx.y - (p.prep_on ? 1 : 0));
   const int NKS = p.NKS, TP = p.TP;
   const int ncol16 = FMT == F_FP8 ? NKS * 8 : NKS * 16;   // 16-byte LDS columns per token
   const int cs = TP * 16;
@@ -817,8 +827,9 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
   const int nsl = 8 / SW;
   p.SPS = (NKS + nsl - 1) / nsl;
   const int ncol16 = FMT == F_FP8 ? NKS * 8 : NKS * 16;
-  size_t smem = (size_t)ncol16 * p.TP * 16 + (size_t)NKS * F::GPK * 16 + 8 * 4 * 16 * 4;
-  const dim3 grid((h->nstrips + SW - 1) / SW, h->batch);
+  size_t smem = (size_t)ncol16 * p.TP * 16 + (size_t)NKS * F::GPK * 16 + 8 * 4 * 16 * 4;   // >= 2 KiB: covers the prep row's 520 floats
+  if (p.prep_on && smem < 520 * 4) smem = 520 * 4;
+  const dim3 grid((h->nstrips + SW - 1) / SW, h->batch + (p.prep_on ? 1 : 0));
   // W4, whole slices, OPT-IN (ktx_debug_set(9, 2)): the LDS-DMA ring, as deep as the slice and the LDS allow.  Measured on
   // MI355X (scripts/lin_sweep.py, DeepSeek-V3 shapes) it is 10-30 % SLOWER than the branch-free register ring below —
   // the 16-slot ring plus the slice's scales take ~140 KB of LDS, i.e. one workgroup per CU, and every step serialises a
@@ -845,8 +856,8 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
   };
   constexpr int DMAX = FMT == F_BF16 ? 4 : 8;   // ring depth bound by registers: a BF16 k-step is 4 KiB per wave
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
-            "lin_dec_kernel<%s> %d->%d%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", p.Kx, p.N,
-            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
+            "lin_dec_kernel<%s> %d->%d%s%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", p.Kx, p.N,
+            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "", p.prep_on ? " +mla_prep" : "");
   if constexpr (FMT == F_W4) {
     switch (dma_depth) {
       case 16: return go(lin_dec_kernel<FMT, G, 16, M_DMA>);
@@ -1036,7 +1047,8 @@ bool dec_fits(const ktx_linear_s* h, int T) {
 }  // namespace
 
 static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, long ldx, long xbs, void* d_y,
-                               long ldy, long ybs, ktx_stream_t stream, const ktx_linear_fusion* fu = nullptr) {
+                               long ldy, long ybs, ktx_stream_t stream, const ktx_linear_fusion* fu = nullptr,
+                               const MlaPrepParams* prep = nullptr) {
   KTX_REQUIRE(h && d_x && d_y, "ktx_linear_forward: null argument");
   KTX_REQUIRE(h->loaded, "ktx_linear_forward: weights not loaded");
   KTX_REQUIRE(T >= 0 && T <= h->cfg.max_len, "ktx_linear_forward: T exceeds max_len");
@@ -1048,6 +1060,7 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   p.T = T; p.N = h->cfg.out_features; p.Kx = h->cfg.in_features; p.NKS = h->NKS; p.nstrips = h->nstrips;
   p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
   p.wbs = h->w_bytes / h->batch; p.scbs = h->sc_bytes / h->batch;
+  if (prep) { p.prep_on = 1; p.prep = *prep; }
   if (fu) {
     KTX_REQUIRE(h->batch == 1, "ktx_linear_forward_fused: not for batched handles");
     KTX_REQUIRE(!fu->norm_weight || dec_eligible(h, T),
@@ -1092,6 +1105,25 @@ extern "C" int ktx_linear_forward_batched(ktx_linear_t h, const int32_t* d_bsz, 
                                           int64_t x_batch_stride, void* d_y, int64_t ldy, int64_t y_batch_stride,
                                           ktx_stream_t stream) {
   return linear_forward_impl(h, d_bsz, T, d_x, ldx, x_batch_stride, d_y, ldy, y_batch_stride, stream);
+}
+
+extern "C" int ktx_linear_forward_batched_prep(ktx_linear_t h, int T, const void* d_x, int64_t ldx, int64_t x_batch_stride,
+                                               void* d_y, int64_t ldy, int64_t y_batch_stride, int num_heads, int nope_dim,
+                                               int rope_dim, int kv_lora, const void* d_q, int64_t q_row_stride, void* d_q_pe_out,
+                                               const void* d_kv, int64_t kv_row_stride, const void* d_kv_norm_w, float eps,
+                                               void* d_ckv_out, void* d_kpe_out, const int64_t* d_pos, const float* d_inv_freq,
+                                               float mscale, ktx_stream_t stream) {
+  KTX_REQUIRE(h && d_q && d_q_pe_out && d_kv && d_kv_norm_w && d_ckv_out && d_kpe_out && d_pos && d_inv_freq,
+              "ktx_linear_forward_batched_prep: null argument");
+  KTX_REQUIRE(dec_eligible(h, T), "ktx_linear_forward_batched_prep: decode-sized calls only (T <= 4)");
+  KTX_REQUIRE(rope_dim > 0 && rope_dim % 2 == 0 && rope_dim <= 512 && kv_lora % 8 == 0 && kv_lora <= 4096 && kv_row_stride % 8 == 0 &&
+              (nope_dim + rope_dim) % 2 == 0 && nope_dim % 2 == 0 && q_row_stride % 2 == 0, "ktx_linear_forward_batched_prep: bad layout");
+  MlaPrepParams pp{};
+  pp.T = T; pp.H = num_heads; pp.nope = nope_dim; pp.rope = rope_dim; pp.kvl = kv_lora;
+  pp.q = (const bf16_t*)d_q; pp.q_rs = q_row_stride; pp.q_pe = (bf16_t*)d_q_pe_out;
+  pp.kv = (const bf16_t*)d_kv; pp.kv_rs = kv_row_stride; pp.nw = (const bf16_t*)d_kv_norm_w; pp.eps = eps;
+  pp.ckv = (bf16_t*)d_ckv_out; pp.kpe = (bf16_t*)d_kpe_out; pp.pos = d_pos; pp.inv_freq = d_inv_freq; pp.mscale = mscale;
+  return linear_forward_impl(h, nullptr, T, d_x, ldx, x_batch_stride, d_y, ldy, y_batch_stride, stream, nullptr, &pp);
 }
 
 extern "C" size_t ktx_linear_weight_bytes(ktx_linear_t h) { return h ? h->w_bytes + h->sc_bytes : 0; }

@@ -36,6 +36,8 @@ struct MlaParams {
   float sm_scale;
   float* part_o;   // [total_q][Hq][nsplit][512]
   float* part_ml;  // [total_q][Hq][nsplit][2]
+  bf16_t* out1;    // nsplit == 1: the split-KV kernel normalises and stores the result itself (no partials, no merge launch)
+  float* lse1;
   // optional fused cache append for decode (one new token per request): latent rows [batch][512], [batch][64]
   const bf16_t *app_ckv, *app_kpe;
   bf16_t *ckv_w, *kpe_w;
@@ -278,6 +280,20 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   }
   MLA_TS(6);
 
+  if (p.out1) {   // one split holds the whole row: the merge kernel's arithmetic for a single partial (weight 1), in place
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+      const int h = head0 + (lane >> 4) * 4 + r;
+      const float l = __shfl(l_run[r], lane & 48), m = __shfl(m_run[r], lane & 48);
+      const float inv = l > 0.f ? 1.0f / l : 0.f;
+      bf16_t* po = p.out1 + ((size_t)qt * p.Hq + h) * MLA_DC + ds * NDT * 16;
+#pragma unroll
+      for (int i = 0; i < NDT; i++) po[i * 16 + (lane & 15)] = f32_to_bf16(o[i][r] * inv);
+      if (p.lse1 && (lane & 15) == 0 && ds == 0)
+        p.lse1[(size_t)qt * p.Hq + h] = l > 0.f ? (m + __logf(l)) * 1.44269504089f : -__builtin_inff();
+    }
+    return;
+  }
   // ---- partial results: un-normalised O plus (m, l) per head ------------------------------------------------------------
 #pragma unroll
   for (int r = 0; r < 4; r++) {
@@ -470,10 +486,13 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   p.part_o = (float*)d_workspace;
   p.part_ml = p.part_o + (size_t)total_q_tokens * Hq * nsplit * MLA_DC;
   p.dbg = g_mla_dbg;
+  const int only = ktx_debug_get(5);   // measurement knob (include/ktx_moe.h): 1 = split-KV kernel only, 2 = merge only
+  const bool direct = nsplit == 1 && only == 0;
+  p.out1 = direct ? (bf16_t*)d_out : nullptr;
+  p.lse1 = direct ? d_lse : nullptr;
   p.app_ckv = (const bf16_t*)d_new_ckv; p.app_kpe = (const bf16_t*)d_new_kpe; p.ckv_w = (bf16_t*)d_ckv; p.kpe_w = (bf16_t*)d_k_pe;
   const size_t lds = (size_t)(2 * MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
   const dim3 grid(nsplit, hblocks, total_q_tokens);
-  const int only = ktx_debug_get(5);   // measurement knob (include/ktx_moe.h): 1 = split-KV kernel only, 2 = merge only
   // algorithmic bytes: the latent rows of the context (hint) + q / out rows; the split partials are an implementation artefact
   const double kv_bytes = (double)std::max(cfg->kv_len_hint, 1) * (MLA_DC + MLA_DR) * 2.0 * batch;
   if (only == 2) {
@@ -500,7 +519,7 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
     hipLaunchKernelGGL((mla_decode_kernel<1, 4>), grid, dim3(256), lds, st, p);
   }
   KTX_HIP(hipGetLastError());
-  if (only != 1) {
+  if (only != 1 && !direct) {
     KTX_TIMED(st, (double)total_q_tokens * Hq * MLA_DC * 2.0, "mla_merge_kernel T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
     const dim3 mg(Hq, total_q_tokens, 4);
     if (p.nsplit <= 32) hipLaunchKernelGGL(mla_merge_kernel<2>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
@@ -508,6 +527,231 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
     else if (p.nsplit <= 144) hipLaunchKernelGGL(mla_merge_kernel<9>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
     else hipLaunchKernelGGL(mla_merge_kernel<16>, mg, dim3(256), 0, st, p, (bf16_t*)d_out, d_lse);
   }
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+// =====================================================================================================
+// Non-absorbed prompt attention (KDeepseekV2Attention.forward_chunck / forward_linux_flashinfer prefill branch,
+// archive/ktransformers/operators/attention.py:349-523: kv_b_proj expands the latents to per-head K_nope / V and a causal
+// flash attention runs over qk dim 192 = 128 nope + 64 rope, v dim 128).  The absorbed kernel above spends 2*(576+512) flop
+// per (query, key, head) and gives every query token its own workgroup; here it is 2*(192+128) and a workgroup owns 128
+// queries of one head.
+//   S^T = K Q^T : A = K tile from LDS (rows = keys), B = Q^T from registers; the C layout then leaves a lane with 4
+//   consecutive keys of ONE query (lane & 15), so the online softmax is per lane and P never travels through LDS:
+//   O^T += V^T P^T : A = V^T tile from LDS (rows = dims; the caller supplies V already transposed, [head][dim][key] — it is
+//   the output of a GEMM either way), B = the lane's own P values.  The k-slot -> key map of that product is
+//   slot (kc, e) -> key 16*(2*ks + e/4) + 4*kc + e%4, applied to both operands.
+// One workgroup: 4 wavefronts x 2 query tiles of 16 = 128 queries, one head; keys in tiles of 64.
+// =====================================================================================================
+#define PF_BN 64
+#define PF_KROW 200     // 192 + 8 bf16: 400 B rows (25 x 16 B)
+#define PF_VROW 72      // 64 + 8 bf16: 144 B rows (9 x 16 B)
+struct MlaPrefillParams {
+  const bf16_t *q_nope, *q_pe;   // [T][H][128] / [T][H][64] with element strides below
+  long long qn_ts, qn_hs, qp_ts, qp_hs;
+  const bf16_t* k_nope;          // [H][kv_pad][128]
+  const bf16_t* k_pe;            // [kv_len][64], token stride kpe_ts
+  long long kpe_ts;
+  const bf16_t* v_t;             // [H][128][kv_pad]
+  bf16_t* out;                   // [T][H][128]
+  int T, H, kv_len, kv_pad;
+  float sm_scale;
+};
+
+// one 64-key tile of one head in flight in registers: K_nope (64 keys x 16 pieces, contiguous), k_pe (64 keys x 8 pieces of the
+// cache rows; nothing is valid past kv_len), V^T (128 dims x 8 pieces of 8 keys).  Branch-free and by value, so it lives in
+// VGPRs (a lambda filling captured arrays under a condition was demoted to scratch memory).
+struct PfTile { uint4 k0, k1, k2, k3, r0, r1, v0, v1, v2, v3; };
+__device__ __forceinline__ uint4 pf_kpe_piece(const MlaPrefillParams& p, int j0, int idx) {
+  const int key = j0 + (idx >> 3);
+  const uint4 v = *reinterpret_cast<const uint4*>(p.k_pe + (size_t)min(key, p.kv_len - 1) * p.kpe_ts + (idx & 7) * 8);
+  const uint32_t keep = key < p.kv_len ? 0xffffffffu : 0u;
+  return make_uint4(v.x & keep, v.y & keep, v.z & keep, v.w & keep);
+}
+__device__ __forceinline__ PfTile pf_load_tile(const MlaPrefillParams& p, const bf16_t* kn, const bf16_t* vt, int tile, int tid) {
+  const int j0 = tile * PF_BN;
+  const bf16_t* kb = kn + (size_t)j0 * 128 + (size_t)tid * 8;
+  const bf16_t* vb = vt + (size_t)(tid >> 3) * p.kv_pad + j0 + (tid & 7) * 8;
+  const size_t vs = (size_t)32 * p.kv_pad;           // 256 threads = 32 dim rows per step
+  PfTile t;
+  t.k0 = *reinterpret_cast<const uint4*>(kb);
+  t.k1 = *reinterpret_cast<const uint4*>(kb + 2048);
+  t.k2 = *reinterpret_cast<const uint4*>(kb + 4096);
+  t.k3 = *reinterpret_cast<const uint4*>(kb + 6144);
+  t.r0 = pf_kpe_piece(p, j0, tid);
+  t.r1 = pf_kpe_piece(p, j0, tid + 256);
+  t.v0 = *reinterpret_cast<const uint4*>(vb);
+  t.v1 = *reinterpret_cast<const uint4*>(vb + vs);
+  t.v2 = *reinterpret_cast<const uint4*>(vb + 2 * vs);
+  t.v3 = *reinterpret_cast<const uint4*>(vb + 3 * vs);
+  return t;
+}
+__device__ __forceinline__ void pf_store_tile(const PfTile& t, bf16_t* Ks, bf16_t* Vs, int tid) {
+  bf16_t* kd = Ks + (tid >> 4) * PF_KROW + (tid & 15) * 8;       // 256 threads = 16 key rows per step
+  *reinterpret_cast<uint4*>(kd) = t.k0;
+  *reinterpret_cast<uint4*>(kd + 16 * PF_KROW) = t.k1;
+  *reinterpret_cast<uint4*>(kd + 32 * PF_KROW) = t.k2;
+  *reinterpret_cast<uint4*>(kd + 48 * PF_KROW) = t.k3;
+  bf16_t* rd = Ks + (tid >> 3) * PF_KROW + 128 + (tid & 7) * 8;  // 32 key rows per step
+  *reinterpret_cast<uint4*>(rd) = t.r0;
+  *reinterpret_cast<uint4*>(rd + 32 * PF_KROW) = t.r1;
+  bf16_t* vd = Vs + (tid >> 3) * PF_VROW + (tid & 7) * 8;
+  *reinterpret_cast<uint4*>(vd) = t.v0;
+  *reinterpret_cast<uint4*>(vd + 32 * PF_VROW) = t.v1;
+  *reinterpret_cast<uint4*>(vd + 64 * PF_VROW) = t.v2;
+  *reinterpret_cast<uint4*>(vd + 96 * PF_VROW) = t.v3;
+}
+
+__global__ __launch_bounds__(256) void mla_prefill_kernel(MlaPrefillParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);      // [64][PF_KROW]
+  bf16_t* Vs = Ks + PF_BN * PF_KROW;                 // [128][PF_VROW]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int h = blockIdx.y;
+  // heaviest query blocks first (causal: the last block sees the whole context)
+  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  const int q0 = qb * 128 + wave * 32;
+  const int qi = lane & 15, g = lane >> 4;
+  const int pos_off = p.kv_len - p.T;                // query t sits at position pos_off + t
+
+  // Q^T fragments: lane (query qi, k-chunk g)
+  v8bf qf[2][6];
+  int tq[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    tq[u] = min(q0 + u * 16 + qi, p.T - 1);
+    const bf16_t* qn = p.q_nope + (size_t)tq[u] * p.qn_ts + (size_t)h * p.qn_hs + g * 8;
+    const bf16_t* qr = p.q_pe + (size_t)tq[u] * p.qp_ts + (size_t)h * p.qp_hs + g * 8;
+#pragma unroll
+    for (int s = 0; s < 4; s++) qf[u][s] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
+#pragma unroll
+    for (int s = 0; s < 2; s++) qf[u][4 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
+  }
+  v4f o[2][8];
+#pragma unroll
+  for (int u = 0; u < 2; u++)
+#pragma unroll
+    for (int i = 0; i < 8; i++) o[u][i] = v4f{0.f, 0.f, 0.f, 0.f};
+  float m_run[2] = {-__builtin_inff(), -__builtin_inff()}, l_run[2] = {0.f, 0.f};
+
+  const int pos_max = pos_off + min(qb * 128 + 127, p.T - 1);
+  const int ntiles = min(pos_max, p.kv_len - 1) / PF_BN + 1;
+  const bf16_t* kn = p.k_nope + (size_t)h * p.kv_pad * 128;
+  const bf16_t* vt = p.v_t + (size_t)h * 128 * p.kv_pad;
+
+  // next tile in registers while the current one is consumed from LDS
+  PfTile nxt = pf_load_tile(p, kn, vt, 0, tid);
+  for (int tile = 0; tile < ntiles; tile++) {
+    __syncthreads();                                 // the previous tile's readers are done
+    pf_store_tile(nxt, Ks, Vs, tid);
+    __syncthreads();
+    nxt = pf_load_tile(p, kn, vt, min(tile + 1, ntiles - 1), tid);   // (unconditional: the last iteration re-reads its tile)
+    const int j0 = tile * PF_BN;
+    // ---- S^T = K Q^T: st[u][kt][r] = S[query qi of tile u][key j0 + 16*kt + 4*g + r] -------------------------------------
+    v4f st[2][4];
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++) st[u][kt] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kt = 0; kt < 4; kt++) {
+      const bf16_t* kb = Ks + (kt * 16 + qi) * PF_KROW + g * 8;
+#pragma unroll
+      for (int s = 0; s < 6; s++) {
+        const v8bf a = as_v8bf(*reinterpret_cast<const uint4*>(kb + s * 32));
+        st[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[0][s], st[0][kt], 0, 0, 0);
+        st[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[1][s], st[1][kt], 0, 0, 0);
+      }
+    }
+    // ---- online softmax, per query (lane & 15; the 4 key-chunk lanes g of a query agree after the two exchanges) ---------
+    uint4 pb[2][2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) {
+      const int lim = min(pos_off + tq[u], p.kv_len - 1);       // last visible key of this lane's query
+      float mx = -__builtin_inff();
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int key = j0 + kt * 16 + g * 4 + r;
+          st[u][kt][r] = key <= lim ? st[u][kt][r] * p.sm_scale : -__builtin_inff();
+          mx = fmaxf(mx, st[u][kt][r]);
+        }
+      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      const float m_new = fmaxf(m_run[u], mx);                  // finite from tile 0 on: key 0 is visible to every query
+      const float alpha = __expf(m_run[u] - m_new);
+      float sum = 0.f;
+      float pv[4][4];
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          pv[kt][r] = __expf(st[u][kt][r] - m_new);
+          sum += pv[kt][r];
+        }
+      sum += __shfl_xor(sum, 16, 64);
+      sum += __shfl_xor(sum, 32, 64);
+      l_run[u] = l_run[u] * alpha + sum;
+      m_run[u] = m_new;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) o[u][i][r] *= alpha;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++)
+        pb[u][ks] = make_uint4(ktx_pk_bf16(pv[2 * ks][0], pv[2 * ks][1]), ktx_pk_bf16(pv[2 * ks][2], pv[2 * ks][3]),
+                               ktx_pk_bf16(pv[2 * ks + 1][0], pv[2 * ks + 1][1]), ktx_pk_bf16(pv[2 * ks + 1][2], pv[2 * ks + 1][3]));
+    }
+    // ---- O^T += V^T P^T: o[u][i][r] = O[query qi][dim 16*i + 4*g + r] ----------------------------------------------------
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const bf16_t* vb = Vs + (i * 16 + qi) * PF_VROW + g * 4;
+#pragma unroll
+      for (int ks = 0; ks < 2; ks++) {
+        const uint2 lo = *reinterpret_cast<const uint2*>(vb + ks * 32), hi = *reinterpret_cast<const uint2*>(vb + ks * 32 + 16);
+        const v8bf a = as_v8bf(make_uint4(lo.x, lo.y, hi.x, hi.y));
+        o[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_v8bf(pb[0][ks]), o[0][i], 0, 0, 0);
+        o[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_v8bf(pb[1][ks]), o[1][i], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int u = 0; u < 2; u++) {
+    const int t = q0 + u * 16 + qi;
+    if (t < p.T) {
+      const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
+      bf16_t* op = p.out + ((size_t)t * p.H + h) * 128 + g * 4;
+#pragma unroll
+      for (int i = 0; i < 8; i++)
+        *reinterpret_cast<uint2*>(op + i * 16) = make_uint2(ktx_pk_bf16(o[u][i][0] * inv, o[u][i][1] * inv),
+                                                            ktx_pk_bf16(o[u][i][2] * inv, o[u][i][3] * inv));
+    }
+  }
+}
+
+extern "C" int ktx_mla_prefill(int T, int num_heads, int kv_len, int kv_pad, float sm_scale, const void* d_q_nope,
+                               int64_t qn_token_stride, int64_t qn_head_stride, const void* d_q_pe, int64_t qp_token_stride,
+                               int64_t qp_head_stride, const void* d_k_nope, const void* d_k_pe, int64_t kpe_token_stride,
+                               const void* d_v_t, void* d_out, void* stream) {
+  KTX_REQUIRE(d_q_nope && d_q_pe && d_k_nope && d_k_pe && d_v_t && d_out, "ktx_mla_prefill: null pointer");
+  KTX_REQUIRE(T > 0 && num_heads > 0 && kv_len >= T, "ktx_mla_prefill: need 0 < T <= kv_len (the new tokens are the last T keys)");
+  KTX_REQUIRE(kv_pad >= kv_len && kv_pad % PF_BN == 0, "ktx_mla_prefill: kv_pad must be a multiple of 64 covering kv_len");
+  KTX_REQUIRE(qn_token_stride % 8 == 0 && qn_head_stride % 8 == 0 && qp_token_stride % 8 == 0 && qp_head_stride % 8 == 0 &&
+              kpe_token_stride % 8 == 0, "ktx_mla_prefill: strides must keep 16-byte alignment");
+  MlaPrefillParams p;
+  p.q_nope = (const bf16_t*)d_q_nope; p.q_pe = (const bf16_t*)d_q_pe;
+  p.qn_ts = qn_token_stride; p.qn_hs = qn_head_stride; p.qp_ts = qp_token_stride; p.qp_hs = qp_head_stride;
+  p.k_nope = (const bf16_t*)d_k_nope; p.k_pe = (const bf16_t*)d_k_pe; p.kpe_ts = kpe_token_stride;
+  p.v_t = (const bf16_t*)d_v_t; p.out = (bf16_t*)d_out;
+  p.T = T; p.H = num_heads; p.kv_len = kv_len; p.kv_pad = kv_pad; p.sm_scale = sm_scale;
+  const size_t lds = (size_t)(PF_BN * PF_KROW + 128 * PF_VROW) * sizeof(bf16_t);
+  hipStream_t st = (hipStream_t)stream;
+  // per (query, key, head): 2*(192 + 128) flop over the causal half
+  KTX_TIMED(st, 0.0, "mla_prefill_kernel T=%d Hq=%d kv=%d", T, num_heads, kv_len);
+  hipLaunchKernelGGL(mla_prefill_kernel, dim3((T + 127) / 128, num_heads), dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

@@ -1957,6 +1957,255 @@ __global__ __launch_bounds__(256) void moe_actquant_kgroup_kernel(const bf16_t* 
   quant_row_kgroup_block(a + (size_t)row * K, K, a_q + (size_t)row * K, a_d + (size_t)row * (K / 32));
 }
 
+// =====================================================================================================
+// Decode fast path of the RAWINT4 experts (qlen*k <= KTX_DEC_MAX_PAIRS): the two-launch structure of the other formats with
+// the arithmetic of moe_rawint4_gemm_kernel above for ONE token: lane (L, j) needs only token 0's entry of each 4x4x4 block
+// product, which is a plain 4-element int8 dot (v_dot4c_i32_i8) — same integers, a quarter of the registers.  Before this path a decode token went bucket -> x-quant -> gate/up -> requant -> down -> combine: six
+// launches with a one-step prefetch; here the per-32-group activation quantisation (BufferASmallKGroupImpl::from_mat,
+// amx_buffers.hpp:431-495) happens in the consuming workgroup and the RAW tiles stream through a D-step register ring.
+// =====================================================================================================
+struct RawDecParams {
+  const int32_t* d_bsz;
+  int qlen, k, E, expert_begin, H, I;
+  const int64_t* ids;
+  const uint8_t* mask;
+  const bf16_t* x;
+  const float* weights;
+  const uint8_t *gate_w, *up_w, *down_w;
+  const bf16_t *gate_s, *up_s, *down_s;
+  size_t gu_stride, dn_stride;     // bytes of RAW tiles per expert matrix
+  size_t gu_sstride, dn_sstride;   // bf16 scales per expert matrix
+  bf16_t* a_buf;                   // [qlen*k][I]
+  void* y;
+  int incremental, partial_f32;
+};
+
+struct RawSlot {   // one 512-K step of a 16-row strip: 4 row groups of nibbles + their bf16 group scales
+  uint4 w[4], s[4];
+};
+__device__ __forceinline__ RawSlot raw_load_slot(const uint8_t* wb, const bf16_t* sb, int NS, int st) {
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  RawSlot r;
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wb + ((size_t)rg * NS + st) * 1024));
+    r.w[rg] = make_uint4(v.x, v.y, v.z, v.w);
+    r.s[rg] = *reinterpret_cast<const uint4*>(sb + ((size_t)rg * NS + st) * 64);
+  }
+  return r;
+}
+// acc[rg] += the step's 8 blocks of 64 k for the lane's (AVX lane L, weight row j); xa = LDS int8 row + 4L, as1 = LDS group
+// scales + hsel.  Same expression order as compute_step of moe_rawint4_gemm_kernel (token 0 of its 4).
+__device__ __forceinline__ void raw_dec_step(const RawSlot& sl, const int8_t* xa, const float* as1, int st, float (&acc)[4]) {
+#pragma unroll
+  for (int kb8 = 0; kb8 < 8; kb8++) {
+    const int kb = st * 8 + kb8;
+    const int a_op = *reinterpret_cast<const int*>(xa + 64 * kb);
+    const float as = as1[2 * kb];
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const uint32_t P = kb8 < 2 ? sl.w[rg].x : kb8 < 4 ? sl.w[rg].y : kb8 < 6 ? sl.w[rg].z : sl.w[rg].w;
+      const int b_op = (kb8 & 1) ? (int)(P & 0xF0F0F0F0u) : (int)((P << 4) & 0xF0F0F0F0u);
+      const uint32_t S = kb8 < 2 ? sl.s[rg].x : kb8 < 4 ? sl.s[rg].y : kb8 < 6 ? sl.s[rg].z : sl.s[rg].w;
+      const float bs = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
+      const int d0 = __builtin_amdgcn_sdot4(a_op, b_op, 0, false);   // token 0's entry of the 4x4x4 block product, as one v_dot4
+      acc[rg] = fmaf(as * bs, (float)d0, acc[rg]);
+    }
+  }
+}
+// _mm512_reduce_add_ps' tree over the 16 AVX lanes (lane bits 5,4,3,2), then /16 (amx_kernels.hpp:3385-3450)
+__device__ __forceinline__ float raw_reduce16(float v) {
+  v = v + __shfl_xor(v, 32, 64);
+  v = v + __shfl_xor(v, 16, 64);
+  v = v + __shfl_xor(v, 8, 64);
+  v = v + __shfl_xor(v, 4, 64);
+  return v / 16.0f;
+}
+// 8 bf16 of a row held by this lane (4 adjacent lanes = one 32-group) -> int8 + the group's scale, as quant_row_kgroup_block
+__device__ __forceinline__ uint2 raw_quant_piece(const uint4& v, float& d) {
+  float amax = amax8(v, 0.0f);
+  amax = fmaxf(amax, __shfl_xor(amax, 1, 64));
+  amax = fmaxf(amax, __shfl_xor(amax, 2, 64));
+  d = amax / 127.0f;
+  const float id = d ? 1.0f / d : 0.0f;
+  return quant8(v, id);
+}
+
+// one workgroup per ((t,j) pair, NW strips of I): x[t] quantised per 32-group into LDS, gate and up strips of expert
+// ids[t][j] through the ring (NS % D == 0: branch-free), SiLU*up epilogue -> a_buf[pair]
+template <int D, int NW>
+__global__ __launch_bounds__(NW * 64) void moe_dec_raw_gateup_kernel(RawDecParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [H] int8 | [H/32] fp32
+  int8_t* xq = reinterpret_cast<int8_t*>(smem);
+  float* xd = reinterpret_cast<float*>(smem + p.H);
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int pair = blockIdx.y, t = pair / p.k;
+  if (t >= T) return;
+  const long long idl = p.ids[pair] - p.expert_begin;
+  if (idl < 0 || idl >= p.E || (p.mask && p.mask[idl])) return;
+  const int e = (int)idl;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip = blockIdx.x * NW + wave;
+  const bool strip_ok = strip * 16 < p.I;
+  const int strip_c = strip_ok ? strip : 0;
+  const int NS = p.H / 512;
+  const int L = lane >> 2, j = lane & 3, hsel = L >> 3;
+  // activations first (vmcnt retires in order), then the ring
+  const bf16_t* xr = p.x + (size_t)t * p.H;
+  uint4 xv[4];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid * 8 + i * NW * 512;
+    xv[i] = make_uint4(0, 0, 0, 0);
+    if (c < p.H) xv[i] = *reinterpret_cast<const uint4*>(xr + c);
+  }
+  const uint8_t* wg = p.gate_w + (size_t)e * p.gu_stride + (size_t)(strip_c * 4) * NS * 1024 + lane * 16;
+  const uint8_t* wu = p.up_w + (size_t)e * p.gu_stride + (size_t)(strip_c * 4) * NS * 1024 + lane * 16;
+  const bf16_t* sg = p.gate_s + (size_t)e * p.gu_sstride + (size_t)(strip_c * 4) * NS * 64 + (j * 2 + hsel) * 8;
+  const bf16_t* su = p.up_s + (size_t)e * p.gu_sstride + (size_t)(strip_c * 4) * NS * 64 + (j * 2 + hsel) * 8;
+  RawSlot ring[D][2];
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    ring[d][0] = raw_load_slot(wg, sg, NS, d);
+    ring[d][1] = raw_load_slot(wu, su, NS, d);
+  }
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const int c = tid * 8 + i * NW * 512;
+    float d;
+    const uint2 q = raw_quant_piece(xv[i], d);   // every lane takes part in the shuffles; rows past H hold zeros
+    if (c < p.H) {
+      *reinterpret_cast<uint2*>(xq + c) = q;
+      if ((tid & 3) == 0) xd[c >> 5] = d;
+    }
+  }
+  __syncthreads();
+  if (!strip_ok) return;
+  float accg[4] = {0.f, 0.f, 0.f, 0.f}, accu[4] = {0.f, 0.f, 0.f, 0.f};
+  const int8_t* xa = xq + 4 * L;
+  const float* as1 = xd + hsel;
+  const int G = NS / D;
+  for (int g = 0; g < G - 1; g++) {
+#pragma unroll
+    for (int d = 0; d < D; d++) {
+      const int st = g * D + d;
+      raw_dec_step(ring[d][0], xa, as1, st, accg);
+      raw_dec_step(ring[d][1], xa, as1, st, accu);
+      ring[d][0] = raw_load_slot(wg, sg, NS, st + D);
+      ring[d][1] = raw_load_slot(wu, su, NS, st + D);
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; d++) {
+    const int st = (G - 1) * D + d;
+    raw_dec_step(ring[d][0], xa, as1, st, accg);
+    raw_dec_step(ring[d][1], xa, as1, st, accu);
+  }
+#pragma unroll
+  for (int rg = 0; rg < 4; rg++) {
+    const float gv = raw_reduce16(accg[rg]), uv = raw_reduce16(accu[rg]);
+    if (L == 0) {
+      const bf16_t gq = f32_to_bf16(gv), uq = f32_to_bf16(uv);
+      p.a_buf[(size_t)pair * p.I + strip * 16 + rg * 4 + j] = f32_to_bf16(act_fn(bf16_to_f32(gq), bf16_to_f32(uq)));
+    }
+  }
+}
+
+// one workgroup per (token, 16-row strip of H), wave j = slot j: the activated row of pair (t,j) re-quantised per 32-group
+// into the wave's own LDS row, the down strip of its expert streamed, then the slot-ordered weighted combine (a12) and the
+// merge step (a4) exactly as moe_combine_kernel does them
+template <int D>
+__global__ __launch_bounds__(512) void moe_dec_raw_down_kernel(RawDecParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  // [k][I] int8 | [k][I/32] fp32 | [k][16] fp32 down outputs | [k] valid flags | [k] routing weights
+  int8_t* aq_all = reinterpret_cast<int8_t*>(smem);
+  float* ad_all = reinterpret_cast<float*>(smem + (size_t)p.k * p.I);
+  float* s_dn = ad_all + (size_t)p.k * (p.I / 32);
+  int* s_valid = reinterpret_cast<int*>(s_dn + p.k * 16);
+  float* s_wt = reinterpret_cast<float*>(s_valid + p.k);
+  int T = p.qlen;
+  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int slot = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int pair = t * p.k + slot, strip = blockIdx.x;
+  const long long idl = p.ids[pair] - p.expert_begin;
+  const bool valid = !(idl < 0 || idl >= p.E || (p.mask && p.mask[idl]));
+  const int e = valid ? (int)idl : 0;
+  const int NS = p.I / 512;
+  const int L = lane >> 2, j = lane & 3, hsel = L >> 3;
+  if (valid) {
+    const bf16_t* ar = p.a_buf + (size_t)pair * p.I;
+    int8_t* aq = aq_all + (size_t)slot * p.I;
+    float* ad = ad_all + (size_t)slot * (p.I / 32);
+    uint4 av[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = lane * 8 + i * 512;
+      av[i] = make_uint4(0, 0, 0, 0);
+      if (c < p.I) av[i] = *reinterpret_cast<const uint4*>(ar + c);
+    }
+    const uint8_t* wd = p.down_w + (size_t)e * p.dn_stride + (size_t)(strip * 4) * NS * 1024 + lane * 16;
+    const bf16_t* sd = p.down_s + (size_t)e * p.dn_sstride + (size_t)(strip * 4) * NS * 64 + (j * 2 + hsel) * 8;
+    RawSlot ring[D];
+#pragma unroll
+    for (int d = 0; d < D; d++) ring[d] = raw_load_slot(wd, sd, NS, d);
+    const float wt = p.weights[pair];
+#pragma unroll
+    for (int i = 0; i < 8; i++) {
+      const int c = lane * 8 + i * 512;
+      float d;
+      const uint2 q = raw_quant_piece(av[i], d);
+      if (c < p.I) {
+        *reinterpret_cast<uint2*>(aq + c) = q;
+        if ((lane & 3) == 0) ad[c >> 5] = d;
+      }
+    }
+    if (lane == 0) { s_valid[slot] = 1; s_wt[slot] = wt; }
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back its own LDS row: order only
+    __builtin_amdgcn_wave_barrier();
+    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+    const int8_t* xa = aq + 4 * L;
+    const float* as1 = ad + hsel;
+    const int G = NS / D;
+    for (int g = 0; g < G - 1; g++) {
+#pragma unroll
+      for (int d = 0; d < D; d++) {
+        const int st = g * D + d;
+        raw_dec_step(ring[d], xa, as1, st, acc);
+        ring[d] = raw_load_slot(wd, sd, NS, st + D);
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < D; d++) raw_dec_step(ring[d], xa, as1, (G - 1) * D + d, acc);
+#pragma unroll
+    for (int rg = 0; rg < 4; rg++) {
+      const float v = raw_reduce16(acc[rg]);
+      if (L == 0) s_dn[slot * 16 + rg * 4 + j] = bf16_to_f32(f32_to_bf16(v));
+    }
+  } else if (lane == 0) {
+    s_valid[slot] = 0;
+    s_wt[slot] = 0.0f;
+  }
+  __syncthreads();
+  if (tid < 16) {  // a12: weighted combine in slot order, then a4
+    float acc = 0.0f;
+    for (int jj = 0; jj < p.k; jj++)
+      if (s_valid[jj]) acc = fmaf(s_dn[jj * 16 + tid], s_wt[jj], acc);
+    const size_t o = (size_t)t * p.H + strip * 16 + tid;
+    if (p.partial_f32) {
+      reinterpret_cast<float*>(p.y)[o] = acc;
+    } else {
+      bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + o;
+      if (p.incremental) acc = acc + bf16_to_f32(*yp);
+      *yp = f32_to_bf16(acc);
+    }
+  }
+}
+
 // raw row-major nibbles [N][K/2] (byte = ((q1+8)<<4)|(q0+8), even k low) -> RAW tiles; one thread per packed dword
 __global__ void pack_rawint4_kernel(const uint8_t* __restrict__ src, int N, int K, uint32_t* __restrict__ out) {
   const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -2801,6 +3050,42 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / 4;
+  const size_t nsc_gu = (size_t)I * (H / 32), nsc_dn = (size_t)H * (I / 32);
+
+  // ---- decode fast path: two launches (see moe_dec_raw_gateup_kernel) -----------------------------------------------------
+  const size_t lds_rdn = (size_t)k * (I + I / 32 * 4 + 16 * 4 + 8);
+  if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && H <= 8192 && I <= 4096 && lds_rdn <= 160 * 1024 && !g_force_generic) {
+    RawDecParams dp;
+    dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
+    dp.ids = d_expert_ids; dp.mask = h->mask; dp.x = (const bf16_t*)d_input; dp.weights = d_weights;
+    dp.gate_w = h->gate_w; dp.up_w = h->up_w; dp.down_w = h->down_w;
+    dp.gate_s = (const bf16_t*)h->gate_s; dp.up_s = (const bf16_t*)h->up_s; dp.down_s = (const bf16_t*)h->down_s;
+    dp.gu_stride = h->gu_stride; dp.dn_stride = h->dn_stride; dp.gu_sstride = nsc_gu; dp.dn_sstride = nsc_dn;
+    dp.a_buf = ws->a_buf; dp.y = d_output;
+    dp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+    const dim3 g1((I / 16 + 3) / 4, npairs), g2(H / 16, qlen);
+    const size_t lds_gu = (size_t)H + (size_t)H / 32 * 4;
+    const int ns1 = H / 512, ns2 = I / 512;
+    const int only = g_dbg[2];
+    const double wbytes = 0.5 + 2.0 / 32;   // nibbles + one bf16 scale per 32
+    if (only != 2) {
+      KTX_TIMED(st, npairs * (2.0 * I * H * wbytes + I * 2.0) + qlen * H * 2.0, "moe_dec_raw_gateup_kernel T=%d k=%d H=%d I=%d",
+                qlen, k, H, I);
+      if (ns1 % 2 == 0) hipLaunchKernelGGL((moe_dec_raw_gateup_kernel<2, 4>), g1, dim3(256), lds_gu, st, dp);
+      else hipLaunchKernelGGL((moe_dec_raw_gateup_kernel<1, 4>), g1, dim3(256), lds_gu, st, dp);
+    }
+    KTX_HIP(hipGetLastError());
+    if (only != 1) {
+      KTX_TIMED(st, npairs * ((double)H * I * wbytes + I * 2.0) + qlen * H * 2.0, "moe_dec_raw_down_kernel T=%d k=%d H=%d I=%d",
+                qlen, k, H, I);
+      if (ns2 % 4 == 0) hipLaunchKernelGGL((moe_dec_raw_down_kernel<4>), g2, dim3(64 * k), lds_rdn, st, dp);
+      else if (ns2 % 2 == 0) hipLaunchKernelGGL((moe_dec_raw_down_kernel<2>), g2, dim3(64 * k), lds_rdn, st, dp);
+      else hipLaunchKernelGGL((moe_dec_raw_down_kernel<1>), g2, dim3(64 * k), lds_rdn, st, dp);
+    }
+    KTX_HIP(hipGetLastError());
+    return 0;
+  }
+
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
   pp.rows_per_tile = 4; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
@@ -2813,7 +3098,6 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
                        ws->counters, d_bsz, qlen, 1);
   }
   KTX_HIP(hipGetLastError());
-  const size_t nsc_gu = (size_t)I * (H / 32), nsc_dn = (size_t)H * (I / 32);
   RawGemmParams g1;
   g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = (const bf16_t*)h->gate_s; g1.s1 = (const bf16_t*)h->up_s;
   g1.expert_stride = h->gu_stride; g1.scale_stride = nsc_gu; g1.N = I; g1.K = H; g1.act_q = ws->x_q; g1.act_d = ws->x_d;
@@ -2893,6 +3177,58 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   const int mt = std::min(4, pick_mt(qlen, k, E));
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
+
+  // ---- decode fast path: two launches (ktx_moe_gguf.inc, moe_dec_gguf_gateup_kernel) --------------------------------------
+  {
+    const int tg = h->gg_type[0], td = h->gg_type[2];
+    const int nkb1 = H / 256, nkb2 = I / 256;
+    const size_t lds_gu = (size_t)H + (size_t)nkb1 * ((tg == GG_Q6K ? 16 : 8) + 1) * 4 + 8 + (tg == GG_IQ1S ? 2048 * 8 : 0);
+    const size_t lds_dn = (size_t)k * I + (size_t)k * nkb2 * ((td == GG_Q6K ? 16 : 8) + 1) * 4 + (size_t)k * (16 + 2) * 4 + 8 +
+                          (td == GG_IQ1S ? 2048 * 8 : 0);
+    if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && lds_gu <= 64 * 1024 && lds_dn <= 64 * 1024 && !g_force_generic) {
+      GgDecParams dp;
+      dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
+      dp.ids = d_expert_ids; dp.mask = h->mask; dp.x = (const bf16_t*)d_input; dp.weights = d_weights;
+      dp.gate_w = h->gate_w; dp.up_w = h->up_w; dp.down_w = h->down_w;
+      dp.gate_stride = h->gg_stride[0]; dp.up_stride = h->gg_stride[1]; dp.down_stride = h->gg_stride[2];
+      dp.a_buf = reinterpret_cast<float*>(ws->a_buf); dp.y = d_output;
+      dp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
+      const dim3 g1((I / 16 + 3) / 4, npairs), g2(H / 16, qlen);
+      int d1 = nkb1 % 4 == 0 ? 4 : nkb1 % 2 == 0 ? 2 : 1;
+      const int d2 = nkb2 % 4 == 0 ? 4 : nkb2 % 2 == 0 ? 2 : 1;
+      if (tg == GG_Q6K && d1 == 4) d1 = 2;   // a 4-deep ring of gate AND up Q6_K tiles (3 planes each) does not fit the registers
+      const int only = g_dbg[2];
+      auto tname = [](int t) { return t == GG_Q4K ? "Q4_K" : t == GG_Q6K ? "Q6_K" : "IQ1_S"; };
+#define KTX_GG_GU(WT)                                                                                                \
+      do {                                                                                                           \
+        if (d1 == 4) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 4, 4>), g1, dim3(256), lds_gu, st, dp);      \
+        else if (d1 == 2) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4>), g1, dim3(256), lds_gu, st, dp); \
+        else hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 1, 4>), g1, dim3(256), lds_gu, st, dp);              \
+      } while (0)
+#define KTX_GG_DN(WT)                                                                                                \
+      do {                                                                                                           \
+        if (d2 == 4) hipLaunchKernelGGL((moe_dec_gguf_down_kernel<WT, 4>), g2, dim3(64 * k), lds_dn, st, dp);        \
+        else if (d2 == 2) hipLaunchKernelGGL((moe_dec_gguf_down_kernel<WT, 2>), g2, dim3(64 * k), lds_dn, st, dp);   \
+        else hipLaunchKernelGGL((moe_dec_gguf_down_kernel<WT, 1>), g2, dim3(64 * k), lds_dn, st, dp);                \
+      } while (0)
+      if (only != 2) {
+        KTX_TIMED(st, (double)npairs * (h->gg_stride[0] + h->gg_stride[1] + I * 4.0) + qlen * H * 2.0,
+                  "moe_dec_gguf_gateup_kernel<%s> T=%d k=%d H=%d I=%d", tname(tg), qlen, k, H, I);
+        if (tg == GG_Q4K) KTX_GG_GU(GG_Q4K); else if (tg == GG_Q6K) KTX_GG_GU(GG_Q6K); else KTX_GG_GU(GG_IQ1S);
+      }
+      KTX_HIP(hipGetLastError());
+      if (only != 1) {
+        KTX_TIMED(st, (double)npairs * (h->gg_stride[2] + I * 4.0) + qlen * H * 2.0,
+                  "moe_dec_gguf_down_kernel<%s> T=%d k=%d H=%d I=%d", tname(td), qlen, k, H, I);
+        if (td == GG_Q4K) KTX_GG_DN(GG_Q4K); else if (td == GG_Q6K) KTX_GG_DN(GG_Q6K); else KTX_GG_DN(GG_IQ1S);
+      }
+      KTX_HIP(hipGetLastError());
+#undef KTX_GG_GU
+#undef KTX_GG_DN
+      return 0;
+    }
+  }
+
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
   pp.rows_per_tile = 16 * mt; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;

@@ -12,12 +12,15 @@ rule file may itself have replaced by KTransformersLinear / RMSNorm / YarnRotary
     attn · W_UV^T                  batched bf16 linear
     o_proj                         KLinear*
 
-The reference switches to a non-absorbed flash-attention path for prompts unless `absorb_for_prefill` is set
-(attention.py:393,470-523); here the absorbed path serves every q_len (same math, the latent never leaves its 576-wide
-form) — `absorb_for_prefill` is accepted and ignored."""
+Like the reference (attention.py:393,470-523), prompt chunks (>= 64 tokens at consecutive positions, single-request cache)
+take a NON-absorbed path unless `absorb_for_prefill` is set: kv_b_proj expands the cached latents to per-head K_nope / V^T
+(two batched library GEMMs) and ktx_mla_prefill runs a causal attention over qk 192 / v 128; short chunks, paged server
+caches and decode use the absorbed kernel."""
 from __future__ import annotations
 
 from typing import Optional, Tuple
+
+import os
 
 import torch
 from torch import nn
@@ -30,6 +33,10 @@ from ktransformers_amd.operators.RoPE import yarn_get_mscale
 # call (prefill chunk), never with max_position_embeddings: a per-layer wrapper sized by the context length would need
 # ~43 GB per layer at DeepSeek-V3's 163840 positions.  The decode wrapper is never re-allocated (captured graphs hold
 # its workspace pointer); the prompt wrapper grows on demand (prompts are not graph-captured).
+_EXPANDED_MIN_Q = 64          # prompt chunks at least this long take the non-absorbed kernel
+_EXPANDED_MAX_KV = 65536      # K_nope + V^T of the context: 2 * heads * 128 * 2 B = 64 KiB per cached token at 128 heads
+
+
 def _NO_IDENTITY() -> bool:      # A/B switch for timing experiments (scripts/ab_decode.py)
     import os
     return os.environ.get("KTX_MLA_NO_IDENTITY") == "1"
@@ -187,12 +194,34 @@ class KDeepseekV2Attention(BaseInjectedModule):
         inv_freq, mscale = self._rope_params(dev)
         pos = position_ids.reshape(-1).to(torch.int64)
         kln = self.kv_a_layernorm
-        q_pe, ckv_new, kpe_new = mla_prep(q, kv, kln.weight.to(torch.bfloat16), kln.variance_epsilon, pos, inv_freq, mscale,
-                                          H, nope, rope, lora)
-
         qabs, oabs = self.get_absorbed()
-        q3 = q.unflatten(1, (H, nope + rope))                              # strided view when q is a slice of the merged GEMV
-        q_nope = qabs.forward_batched(q3[:, :, :nope])                     # [T, H, lora]
+        capacity = past_key_value.max_pages * past_key_value.page_size
+        expanded = None      # (first, last) position when this prompt chunk takes the non-absorbed kernel
+        if self._expanded_prefill_ok(q_len, past_key_value):
+            span = self._prompt_span(position_ids, pos, past_key_value)
+            if span[1] - span[0] + 1 == q_len and span[1] < min(capacity, _EXPANDED_MAX_KV):
+                expanded = span
+        if expanded is not None:
+            # prompt chunk at consecutive positions: expand the context's latents through kv_b_proj and run the causal
+            # attention over qk 192 / v 128 (attention.py:58-164 forward_chunck) — 3.4x fewer flop than the absorbed form,
+            # and no absorb products at all
+            q_pe, ckv_new, kpe_new = mla_prep(q, kv, kln.weight.to(torch.bfloat16), kln.variance_epsilon, pos, inv_freq, mscale,
+                                              H, nope, rope, lora)
+            cp = cache_position if cache_position is not None else pos
+            past_key_value.update(ckv_new, kpe_new, self.layer_idx, {"cache_position": cp})
+            out = self._expanded_prefill(q, q_pe, past_key_value.key_cache[self.layer_idx], expanded[1] + 1, q_len)
+            return self._project_out(out, residual, bsz, q_len), None, past_key_value
+        if q_len <= 4 and q.stride(-1) == 1 and kv.stride(-1) == 1 and qabs.decode_eligible(q_len) \
+                and not os.environ.get("KTX_MLA_SEPARATE_PREP"):     # (dev A/B switch, scripts/ab_decode.py)
+            # decode: latent RMSNorm + RoPE ride in the launch of the q-absorb products (independent work, one boundary less)
+            from ktransformers_amd._native import absorb_and_prep
+            q_nope, q_pe, ckv_new, kpe_new = absorb_and_prep(qabs, q, kv, kln.weight.to(torch.bfloat16), kln.variance_epsilon, pos,
+                                                             inv_freq, mscale, H, nope, rope, lora)
+        else:
+            q_pe, ckv_new, kpe_new = mla_prep(q, kv, kln.weight.to(torch.bfloat16), kln.variance_epsilon, pos, inv_freq, mscale,
+                                              H, nope, rope, lora)
+            q3 = q.unflatten(1, (H, nope + rope))                          # strided view when q is a slice of the merged GEMV
+            q_nope = qabs.forward_batched(q3[:, :, :nope])                 # [T, H, lora]
 
         Hp = (H + 15) // 16 * 16          # the MLA kernel tiles heads by 16 (every shipped model: 16 / 64 / 128 heads)
         if Hp != H:
@@ -201,7 +230,6 @@ class KDeepseekV2Attention(BaseInjectedModule):
         cache = past_key_value.key_cache[self.layer_idx]                   # [pages, page, 1, lora + rope]
         ckv_pages = cache[:, :, 0, :lora]
         kpe_pages = cache[:, :, 0, lora:]
-        capacity = past_key_value.max_pages * past_key_value.page_size
         kv_indptr, kv_indices = _cache_page_arrays(past_key_value, self.layer_idx, dev)
         object.__setattr__(self, "mla_wrapper", _decode_wrapper(dev) if q_len == 1 else _prefill_wrapper(dev, q_len))
         if q_len == 1:
@@ -237,14 +265,49 @@ class KDeepseekV2Attention(BaseInjectedModule):
                                   identity_pages=bool(getattr(past_key_value, "identity_page_table", False)) and not _NO_IDENTITY())
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
-        out = out.reshape(q_len, H * self.v_head_dim)
+        return self._project_out(out.reshape(q_len, H * self.v_head_dim), residual, bsz, q_len), None, past_key_value
+
+    def _project_out(self, out, residual, bsz, q_len):
         if residual is not None and hasattr(self.o_proj, "generate_linear"):
             out = self.o_proj(out, add1=residual.reshape(q_len, -1))        # hidden = residual + attn (o_proj epilogue)
         else:
             out = self.o_proj(out)
             if residual is not None:
                 out = residual.reshape(q_len, -1) + out
-        return out.reshape(bsz, q_len, -1), None, past_key_value
+        return out.reshape(bsz, q_len, -1)
+
+    # ---- non-absorbed prompt attention ------------------------------------------------------------------------------------
+    def _expanded_prefill_ok(self, q_len, cache) -> bool:
+        return (q_len >= _EXPANDED_MIN_Q and self.qk_nope_head_dim == 128 and self.v_head_dim == 128 and self.qk_rope_head_dim == 64
+                and bool(getattr(cache, "identity_page_table", False)) and not self.absorb_for_prefill
+                and not os.environ.get("KTX_MLA_ABSORBED_PREFILL"))
+
+    @staticmethod
+    def _prompt_span(position_ids, pos, cache):
+        """(first, last) position of the chunk on the host: one device read per forward pass (every layer sees the same
+        position tensor), prompt processing is not graph-captured."""
+        key = (id(position_ids), position_ids._version)
+        memo = getattr(cache, "_span_memo", None)
+        if memo is not None and memo[0] == key and memo[1] is position_ids:
+            return memo[2]
+        first, last = (int(v) for v in torch.stack((pos[0], pos[-1])).tolist())
+        cache._span_memo = (key, position_ids, (first, last))
+        return first, last
+
+    def _expanded_prefill(self, q, q_pe, cache, kv_len, q_len):
+        from ktransformers_amd._native import mla_prefill
+
+        H, nope, rope, lora = self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim, self.kv_lora_rank
+        rows = cache.view(-1, lora + rope)                                  # the single-request cache is in token order
+        kv_pad = (kv_len + 63) // 64 * 64
+        lat = rows.new_zeros((kv_pad, lora))
+        lat[:kv_len] = rows[:kv_len, :lora]                                 # zero rows past the context: exact-zero K / V there
+        # kv_b_proj as two batched library GEMMs (plain bf16 GEMMs -> hipBLASLt): K_nope [H, kv, 128] and V^T [H, 128, kv]
+        k_nope = torch.matmul(lat.unsqueeze(0), self.q_absorb.transpose(1, 2))
+        v_t = torch.matmul(self.out_absorb, lat.t().unsqueeze(0))
+        q3 = q.unflatten(1, (H, nope + rope))
+        attn = mla_prefill(q3[:, :, :nope], q_pe, k_nope.contiguous(), rows[:, lora:], v_t.contiguous(), kv_len, self.softmax_scale)
+        return attn.reshape(q_len, H * self.v_head_dim)
 
 
 KDeepseekV3Attention = KDeepseekV2Attention

@@ -29,6 +29,7 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "mla: page table load": ({}, {"KTX_MLA_NO_IDENTITY": "1"}),
     "mla: 4x2 shape, 128 splits": ({6: 4, 7: 128}, {}),
     "lin: LDS-DMA ring": ({9: 2}, {}),
+    "mla: separate prep launch": ({}, {"KTX_MLA_SEPARATE_PREP": "1"}),
 }
 res = {k: [] for k in CONFIGS}
 for r in range(args.rounds):

@@ -11,7 +11,7 @@ from attn_helpers import ToyAttention, load_golden, make_cfg  # noqa: E402
 from oracle.attention_ref import mla_attention_ref  # noqa: E402
 
 
-def build(cfg, w, linear_op=None):
+def build(cfg, w, linear_op=None, absorb_for_prefill=True):
     from ktransformers_amd.models.custom_cache import StaticCache
     from ktransformers_amd.operators.attention import KDeepseekV2Attention
     from ktransformers_amd.operators.linear import KTransformersLinear
@@ -31,7 +31,7 @@ def build(cfg, w, linear_op=None):
                 lin = KTransformersLinear(f"attn.{name}", loader, cfg, getattr(orig, name), dev, linear_op, dev, linear_op)
                 lin.load(mode=InferenceState.GENERATE)
                 setattr(orig, name, lin)
-    attn = KDeepseekV2Attention("attn", loader, cfg, orig, dev, dev, absorb_for_prefill=True)
+    attn = KDeepseekV2Attention("attn", loader, cfg, orig, dev, dev, absorb_for_prefill=absorb_for_prefill)
     cache = StaticCache(cfg, 1, 4096, dev, torch.bfloat16)
     return attn, cache
 
@@ -74,6 +74,42 @@ def test_prefill_and_decode_match_reference(name, linear_op):
     assert rel(dec, oracle_out) < 1.5e-2
     rows2 = cache.key_cache[0].reshape(-1, 576)[:T].float().cpu()
     rows_close(rows2, oracle_rows.float())
+
+
+def test_non_absorbed_prompt_path_matches_reference_and_absorbed():
+    """The 70-token golden prompt through the expanded (kv_b_proj + causal qk-192 attention) path, which is what the reference's
+    eager module computes: same bounds as the absorbed path, and the two paths agree with each other to bf16 noise."""
+    cfg, w, x, y_bf16, y_f32 = load_golden("v3")
+    T = x.shape[0]
+    assert T >= 64
+    oracle_out, oracle_rows = mla_attention_ref(cfg, w, x, torch.arange(T), torch.zeros(0, 576, dtype=torch.bfloat16))
+    pos = torch.arange(T, device="cuda")
+    outs = {}
+    for absorbed in (True, False):
+        attn, cache = build(cfg, w, None, absorb_for_prefill=absorbed)
+        out, _, _ = attn(x.cuda()[None], position_ids=pos[None], past_key_value=cache, cache_position=pos)
+        outs[absorbed] = out[0]
+        assert rel(out[0], y_f32) < 2e-2
+        assert rel(out[0], oracle_out) < 1.5e-2
+        rows_close(cache.key_cache[0].reshape(-1, 576)[:T].float().cpu(), oracle_rows.float())
+    assert rel(outs[False], outs[True].float().cpu()) < 1.5e-2
+
+
+def test_non_absorbed_chunked_prompt_against_the_oracle():
+    """Two prompt chunks of 100 tokens: the second attends over the first chunk's cached latents too (kv_len 200 > q_len 100),
+    and a decode step afterwards reads the rows both chunks wrote."""
+    cfg, w, _, _, _ = load_golden("v3")
+    torch.manual_seed(3)
+    x = (torch.randn(201, cfg.hidden_size) * 0.5).to(torch.bfloat16)
+    attn, cache = build(cfg, w, None, absorb_for_prefill=False)
+    hist = torch.zeros(0, 576, dtype=torch.bfloat16)
+    for a, b in ((0, 100), (100, 200), (200, 201)):
+        want, rows = mla_attention_ref(cfg, w, x[a:b], torch.arange(a, b), hist)
+        hist = torch.cat([hist, rows], 0)
+        pos = torch.arange(a, b, device="cuda")
+        got, _, _ = attn(x[a:b].cuda()[None], position_ids=pos[None], past_key_value=cache, cache_position=pos)
+        assert rel(got[0], want) < 1.5e-2, (a, b, rel(got[0], want))
+    rows_close(cache.key_cache[0].reshape(-1, 576)[:201].float().cpu(), hist.float())
 
 
 def test_marlin_linears_track_the_quantised_oracle():

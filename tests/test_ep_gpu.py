@@ -39,3 +39,53 @@ def test_prefill_and_decode_wrappers(group):
     yd = ep.forward(x[:4], ids[:4], w[:4]).float()
     r4 = ref[:4].float()
     assert torch.all((yd - r4).abs() <= r4.abs() * 2.0 ** -7 + 1e-5 * r4.abs().max())
+
+
+def test_whole_model_decode_graph_with_rccl_collectives(group):
+    """bench.py's N > 1 step on a one-rank RCCL group: the YAML-injected model with its routed experts behind all-gather ->
+    fp32 partial -> reduce-scatter, the whole greedy token step — collectives included — captured in ONE HIP graph.
+    (a) the capture succeeds, (b) replays give the tokens of the same step run eagerly, (c) the first step's logits agree
+    with the single-GPU model's to the fp32-reorder tolerance of the decode combine."""
+    import bench
+    from ktransformers_amd import parallel
+    dev = torch.device("cuda", 0)
+    wl = bench.WORKLOADS["v2lite-int4"]
+
+    def runner(ep, graph):
+        parallel.enable_expert_parallel(enabled=ep)
+        torch.manual_seed(0)                      # the synthetic KV cache; the weights are seeded by tensor name
+        return bench.ModelDecodeRunner(wl, 3, dev, 64, 32, seed=0, use_graph=graph)
+
+    def first_logits(mr):
+        with torch.no_grad():
+            return mr.model(mr.cur.clone(), mr.pos.clone(), mr.cache, mr.pos[0].clone())[0, -1].float()
+
+    try:
+        single = runner(False, False)
+        want = first_logits(single)
+        single.close()
+        ep_eager = runner(True, False)
+        assert all(l.mlp.experts.generate_experts._ep is not None for l in ep_eager.model.model.layers if hasattr(l.mlp, "experts"))
+        got = first_logits(ep_eager)
+        assert (got - want).abs().max() <= 2e-2 * want.abs().max(), float((got - want).abs().max() / want.abs().max())
+        def restart(mr):                          # both runners decode from the same state
+            mr.set_position(64)
+            mr.cur.fill_(1)
+
+        restart(ep_eager)
+        toks_eager = []
+        for _ in range(6):
+            ep_eager.step()
+            toks_eager.append(int(ep_eager.cur.item()))
+        ep_eager.close()
+        ep_graph = runner(True, True)
+        assert ep_graph.graph_ok, ep_graph.graph_error
+        restart(ep_graph)
+        toks_graph = []
+        for _ in range(6):
+            ep_graph.step()
+            toks_graph.append(int(ep_graph.cur.item()))
+        ep_graph.close()
+        assert toks_graph == toks_eager, (toks_graph, toks_eager)
+    finally:
+        parallel.enable_expert_parallel(enabled=False)

@@ -34,12 +34,29 @@ def random_iq1s(E, N, K, rng):
     return b.reshape(E, N, -1)
 
 
+def random_kquant(t, E, N, K, rng):
+    """Random but valid Q4_K / Q6_K blocks (every byte pattern is a legal block; the fp16 super-scales are kept small) for
+    shapes where quantising real matrices in numpy would take minutes."""
+    if t == IQ1:
+        return random_iq1s(E, N, K, rng)
+    nb = K // 256
+    if t == Q4:        # fp16 d | fp16 dmin | scales[12] | qs[128]
+        b = rng.integers(0, 256, (E, N, nb, 144), dtype=np.uint8)
+        dm = (rng.random((E, N, nb, 2)).astype(np.float16) * np.float16(2e-4) + np.float16(1e-4))
+        b[..., 0:4] = dm.view(np.uint8).reshape(E, N, nb, 4)
+    else:              # ql[128] | qh[64] | int8 scales[16] | fp16 d
+        b = rng.integers(0, 256, (E, N, nb, 210), dtype=np.uint8)
+        d = (rng.random((E, N, nb)).astype(np.float16) * np.float16(2e-5) + np.float16(1e-5))
+        b[..., 208:210] = d.view(np.uint8).reshape(E, N, nb, 2)
+    return b.reshape(E, N, -1)
+
+
 def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None, random_blocks=False):
     from ktransformers_amd import _native as n
     o = GgufOracle()
     if random_blocks:
         r0 = np.random.default_rng(seed)
-        gate, up, down = random_iq1s(E, I, H, r0), random_iq1s(E, I, H, r0), random_iq1s(E, H, I, r0)
+        gate, up, down = random_kquant(types[0], E, I, H, r0), random_kquant(types[1], E, I, H, r0), random_kquant(types[2], E, H, I, r0)
     else:
         gate, up, down = make(E, H, I, types, seed)
     rng = np.random.default_rng(seed + 1)
@@ -59,6 +76,14 @@ def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None, random_b
     assert (np.abs(y - ref) <= tol).all(), f"max diff {np.abs(y - ref).max()} (ref max {np.abs(ref).max()})"
     same = float((y == ref).mean())
     assert same >= 0.99, same
+    if T * k <= 64:     # the two-launch decode kernels ran above: the grouped path must give the same bits (one device expf)
+        n.force_generic_path(True)
+        try:
+            yg = h.forward(torch.from_numpy(x.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(ids).cuda(),
+                           torch.from_numpy(w).cuda()).float().cpu().numpy()
+        finally:
+            n.force_generic_path(False)
+        assert np.array_equal(y, yg), f"decode and grouped paths differ in {int((y != yg).sum())} of {y.size} outputs"
     return h
 
 
@@ -76,6 +101,13 @@ def test_invalid_ids_and_ragged_tiles():
 def test_mixtral_like_shape(T):
     """q4_k_m mix at a Mixtral-like aspect (H % 256 == 0, I % 256 == 0), prefill tile sizes MT = 1 / 4."""
     run_case(8, 2, 1024, 3584, T, (Q4, Q4, Q6), seed=9)
+
+
+@pytest.mark.parametrize("T", [1, 4])
+def test_mixtral_8x7b_real_dims(T):
+    """BASELINE.json configs[0] (Mixtral-8x7B q4_k_m, kt-kernel/bench/bench_moe.py:166-170): 8 experts, top-2, hidden 4096,
+    intermediate 14336, Q4_K gate/up + Q6_K down, decode batches."""
+    run_case(8, 2, 4096, 14336, T, (Q4, Q4, Q6), seed=21 + T, random_blocks=True)
 
 
 def test_iq1s_v3_expert_shape():

@@ -136,3 +136,30 @@ def test_decode_at_128k_context():
     w.plan(None, None, None, torch.tensor([n], dtype=torch.int32, device=DEV), None, Hq, 512, 64, page, sm, max_kv_len=n)
     out = w.run(qn.to(DEV), qp.to(DEV), ckv, k_pe)
     torch.testing.assert_close(out[0].float().cpu(), ref.to(torch.bfloat16).float(), rtol=5e-3, atol=5e-3)
+
+
+# ---- non-absorbed prompt attention (ktx_mla_prefill) ----------------------------------------------------------------------
+@pytest.mark.parametrize("H,T,kv_len", [(4, 130, 130), (3, 70, 201), (16, 128, 128), (2, 257, 1000), (128, 64, 64)])
+def test_prefill_expanded_against_fp32_attention(H, T, kv_len):
+    """Causal softmax(q k^T) v over qk 192 (128 nope + 64 shared rope) / v 128 in fp32 on the same bf16 operands; the queries are
+    the last T keys; the padded key rows are zero as the operator makes them."""
+    from ktransformers_amd._native import mla_prefill
+    g = torch.Generator().manual_seed(H * 1000 + T + kv_len)
+    kv_pad = (kv_len + 63) // 64 * 64
+    q = torch.randn((T, H, 192), generator=g).to(torch.bfloat16).to(DEV)
+    k_nope = torch.zeros((H, kv_pad, 128), dtype=torch.bfloat16, device=DEV)
+    k_nope[:, :kv_len] = torch.randn((H, kv_len, 128), generator=g).to(torch.bfloat16).to(DEV)
+    cache = torch.randn((kv_len + 5, 576), generator=g).to(torch.bfloat16).to(DEV)      # k_pe lives in the latent cache rows
+    cache[kv_len:] = float("nan")                                                        # rows past the context are never used
+    v = torch.zeros((H, kv_pad, 128), dtype=torch.bfloat16, device=DEV)
+    v[:, :kv_len] = torch.randn((H, kv_len, 128), generator=g).to(torch.bfloat16).to(DEV)
+    sm_scale = 192 ** -0.5
+    q_pe = q[:, :, 128:].contiguous()
+    out = mla_prefill(q[:, :, :128], q_pe, k_nope, cache[:, 512:], v.transpose(1, 2).contiguous(), kv_len, sm_scale)
+    torch.cuda.synchronize()
+    k = torch.cat([k_nope[:, :kv_len].float(), cache[:kv_len, 512:].float()[None].expand(H, -1, -1)], dim=-1)    # [H, kv, 192]
+    s = torch.einsum("thd,hkd->htk", q.float(), k) * sm_scale
+    pos = torch.arange(T, device=DEV)[:, None] + (kv_len - T)
+    s = s.masked_fill(torch.arange(kv_len, device=DEV)[None, :] > pos, float("-inf"))
+    ref = torch.einsum("htk,hkd->thd", torch.softmax(s, dim=-1), v[:, :kv_len].float())
+    torch.testing.assert_close(out.float(), ref.to(torch.bfloat16).float(), rtol=2.0 ** -7, atol=5e-3)

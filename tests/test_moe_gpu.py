@@ -400,6 +400,7 @@ def test_fp_formats_against_reference_golden(dev, fname, fmt, case):
                                    (8, 2, 512, 1024, 40), (4, 2, 512, 512, 300)])
 def test_rawint4_bit_exact(oracle, dev, shape):
     from helpers import rawint4_quantize
+    from ktransformers_amd import _native
     from ktransformers_amd._native import MoEHandle
     E, k, H, I, T = shape
     c = make_case(8, E, k, H, I, T, invalid_ids=T >= 5)
@@ -409,11 +410,14 @@ def test_rawint4_bit_exact(oracle, dev, shape):
     h = MoEHandle(E, k, H, I, max_len=max(T, 8), method="RAWINT4", device=0, group_size=32)
     try:
         h.load_rawint4(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch_bf16(x[1], dev) for x in q])
-        got = run(h, c, dev)
-        assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ"
         want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
-        assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
+        for generic in (False, True):     # T*k <= 64: the two-launch decode kernels, then the grouped path on the same input
+            _native.force_generic_path(generic)
+            got = run(h, c, dev)
+            assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ (generic={generic})"
+            assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
     finally:
+        _native.force_generic_path(False)
         h.close()
 
 
@@ -421,6 +425,7 @@ def test_rawint4_bit_exact(oracle, dev, shape):
 def test_rawint4_against_reference_golden(dev, case):
     """Bit-exact against outputs of the reference's OWN Kimi-K2 class (TP_MOE<AMX_K2_MOE_TP<GemmKernel224Int4SmallKGroup>>,
     k2-moe.hpp:124-191) on weights quantised by the reference test's own rawint4_quantize (tests/golden/make_golden.py)."""
+    from ktransformers_amd import _native
     from ktransformers_amd._native import MoEHandle
     g = np.load(GOLDEN)
     E, k, H, I = int(g["k2_E"]), int(g["k2_k"]), int(g["k2_H"]), int(g["k2_I"])
@@ -430,8 +435,11 @@ def test_rawint4_against_reference_golden(dev, case):
         h.load_rawint4(*[torch.from_numpy(g[f"k2_{n}_p"]).to(dev) for n in ("gate", "up", "down")],
                        *[torch_bf16(g[f"k2_{n}_s"], dev) for n in ("gate", "up", "down")])
         want = g[f"k2_{case}_y"]
-        got = run(h, c, dev)
-        assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ"
-        assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), g[f"k2_{case}_yinc"])
+        for generic in (False, True):
+            _native.force_generic_path(generic)
+            got = run(h, c, dev)
+            assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ (generic={generic})"
+            assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), g[f"k2_{case}_yinc"])
     finally:
+        _native.force_generic_path(False)
         h.close()
