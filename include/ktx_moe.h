@@ -140,11 +140,15 @@ int ktx_debug_force_generic(int on);
  * decode gate/up kernel (0 = auto), idx 1 = ablation bits (bit0: skip the weight stream; results are then meaningless),
  * idx 2 = run only one decode kernel (1 gate/up, 2 down; bench.py's per-kernel timing), idx 4 = prompt (64-row tile) GEMM
  * implementation: 0 auto (streaming kernels for hidden*intermediate >= 4M), 1 chunk-pipelined only, 2 streaming only,
- * 3 the register-tile kernels (256-row tiles; bit-exact in the tests, not yet timed, hence not selected by default),
+ * 3 the register-tile kernels (256-row tiles; bit-exact in the tests; timed in round 2 with scripts/stream_ab.py: faster
+ * only under uniform routing at V2-Lite shapes, slower under skew and at V3 shapes, hence not selected by default),
  * idx 5 = run only one kernel of ktx_mla_decode* (1 the split-KV kernel, 2 the merge; per-kernel timing), idx 6 / 7 = force
  * the MLA workgroup shape (1, 2, 4 head blocks) / the KV split count, idx 8 = force the strips-per-workgroup split of the
  * decode GEMV (tuning sweeps under scripts/), idx 9 = 2 selects the LDS-DMA ring variant of the W4 decode GEMV (measured
- * slower than the default register ring; kept for tuning). */
+ * slower than the default register ring; kept for tuning), idx 10 = 1 turns the k-slices of the AMXINT4 decode gate/up kernel
+ * off, idx 11 = 1 selects the first (>= 384 workgroups) split rule of the decode GEMV (both A/B switches of
+ * scripts/ab_decode.py), idx 12 = strips per wavefront of the prompt-sized W4 GEMM (1 = the one-strip kernel, 2 / 4 forced;
+ * 0 auto). */
 int ktx_debug_set(int idx, int val);
 int ktx_debug_get(int idx);
 /* Per-launch timing of every kernel of the library (bench.py's per-kernel table; ktx_prof.hip).  mode 1: each launch is

@@ -650,6 +650,181 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(LinParams p) {
 }
 
 // =====================================================================================================
+// Prompt-sized W4 GEMM: the general kernel above with NSW strips per wavefront.  With one strip per wavefront every MFMA
+// re-reads its 1 KiB activation fragment from LDS (64 KiB per workgroup k-step against 16 MFMAs per wavefront: LDS-bound at
+// twice the MFMA time, 228 TFLOP/s on the DeepSeek-V3 shapes); here a fragment read feeds NSW MFMAs, and the per-group
+// dequantisation epilogue  acc = fma(s, fma(-136, sum_x, tmp), acc)  runs as packed fp32 FMAs (two tokens per instruction,
+// the same two roundings per element).  Workgroup tile: (4 * NSW * 16) features x (16 * MT) tokens.
+// =====================================================================================================
+typedef float v2f __attribute__((ext_vector_type(2)));
+
+template <int G, int MT, int NSW>
+__global__ __launch_bounds__(256) void lin_gemm_w4n_kernel(LinParams p) {
+  using F = Fmt<F_W4, G>;
+  lin_select_batch(p, blockIdx.z);
+  constexpr int SPC = 2;
+  constexpr int TOK = MT * 16;
+  constexpr int C16 = 16;
+  constexpr int CS = TOK * 16 + 16;
+  constexpr int XBUF = SPC * C16 * CS;
+  constexpr int NAUX = SPC * F::GPK;
+  constexpr int ABUF = NAUX * TOK * 4;
+  constexpr int UPT = MT * SPC;
+
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  uint8_t* xs = smem;                                              // [2][XBUF]
+  float* auxs = reinterpret_cast<float*>(smem + 2 * XBUF);         // [2][NAUX][TOK]
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int strip0 = (blockIdx.x * 4 + wave) * NSW;
+  const int row0 = blockIdx.y * TOK;
+  const int NKS = p.NKS, NC = (NKS + SPC - 1) / SPC;
+  int bsz = p.T;
+  if (p.d_bsz) bsz = min(max(*p.d_bsz, 0), p.T);
+  if (row0 >= bsz) return;
+
+  // a strip past the end streams the last strip again and stores nothing (keeps the loop free of per-strip branches)
+  const uint8_t* wp[NSW];
+  const bf16_t* sp[NSW];
+#pragma unroll
+  for (int sw = 0; sw < NSW; sw++) {
+    const int strip = min(strip0 + sw, p.nstrips - 1);
+    wp[sw] = p.w + (size_t)strip * NKS * F::TILE + lane * 16;
+    sp[sw] = reinterpret_cast<const bf16_t*>(p.sc) + ((size_t)strip * NKS * 16 + (lane & 15)) * F::GPK;
+  }
+
+  v4f acc[NSW][MT];
+#pragma unroll
+  for (int sw = 0; sw < NSW; sw++)
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[sw][t] = v4f{0.f, 0.f, 0.f, 0.f};
+  uint4 wA[NSW][SPC], wB[NSW][SPC];
+  uint2 sA[NSW][SPC], sB[NSW][SPC];
+  uint4 breg[UPT];
+
+  auto load_w = [&](uint4(&dst)[NSW][SPC], uint2(&sdst)[NSW][SPC], int c) {
+#pragma unroll
+    for (int s = 0; s < SPC; s++) {
+      const int ks = min(c * SPC + s, NKS - 1);
+#pragma unroll
+      for (int sw = 0; sw < NSW; sw++) {
+        dst[sw][s] = *reinterpret_cast<const uint4*>(wp[sw] + (size_t)ks * F::TILE);
+        sdst[sw][s] = load_w4_scales<F::GPK>(sp[sw] + (size_t)ks * 16 * F::GPK);
+      }
+    }
+  };
+  auto load_b = [&](int c) {
+#pragma unroll
+    for (int it = 0; it < UPT; it++) {
+      const int u = it * 4 + wave;
+      const int tok = (u / SPC) * 4 + (lane >> 4), s = u % SPC;
+      const int k = ((c * SPC + s) * 16 + (lane & 15)) * 8;
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (row0 + tok < bsz && k < p.Kx) v = *reinterpret_cast<const uint4*>(p.x + (size_t)(row0 + tok) * p.ldx + k);
+      breg[it] = v;
+    }
+  };
+  auto store_b = [&](int buf) {
+    uint8_t* xb = xs + buf * XBUF;
+    float* ab = auxs + buf * (ABUF / 4);
+#pragma unroll
+    for (int it = 0; it < UPT; it++) {
+      const int u = it * 4 + wave;
+      const int tok = (u / SPC) * 4 + (lane >> 4), s = u % SPC, piece = lane & 15;
+      *reinterpret_cast<uint4*>(xb + (s * 16 + piece) * CS + tok * 16) = breg[it];
+      float sm = sum8_bf16(breg[it]);
+#pragma unroll
+      for (int o = 1; o < G / 8; o <<= 1) sm += __shfl_xor(sm, o, 64);
+      if ((piece & (G / 8 - 1)) == 0) ab[(s * F::GPK + piece / (G / 8)) * TOK + tok] = sm;
+    }
+  };
+  auto compute = [&](uint4(&w)[NSW][SPC], uint2(&sc)[NSW][SPC], int c, int buf) {
+    const int kc = lane >> 4;
+    const uint8_t* xb = xs + buf * XBUF + (lane & 15) * 16 + kc * CS;
+    const float* ab = auxs + buf * (ABUF / 4) + kc * 4;
+#pragma unroll
+    for (int s = 0; s < SPC; s++) {
+      if (c * SPC + s < NKS) {
+        uint4 frag[NSW][4];
+#pragma unroll
+        for (int sw = 0; sw < NSW; sw++) {
+          const uint32_t P[4] = {w[sw][s].x, w[sw][s].y, w[sw][s].z, w[sw][s].w};
+#pragma unroll
+          for (int j = 0; j < 4; j++) frag[sw][j] = w4_frag(P[j]);
+        }
+#pragma unroll
+        for (int t = 0; t < MT; t++) {
+#pragma unroll
+          for (int gi = 0; gi < F::GPK; gi++) {
+            v4f tmp[NSW];
+#pragma unroll
+            for (int sw = 0; sw < NSW; sw++) tmp[sw] = v4f{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int jj = 0; jj < F::JPG; jj++) {
+              const int j = gi * F::JPG + jj;
+              const lv8bf xa = as_v8bf(*reinterpret_cast<const uint4*>(xb + s * C16 * CS + t * 256 + j * 4 * CS));
+#pragma unroll
+              for (int sw = 0; sw < NSW; sw++)
+                tmp[sw] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa, as_v8bf(frag[sw][j]), tmp[sw], 0, 0, 0);
+            }
+            const float4 sx = *reinterpret_cast<const float4*>(ab + (s * F::GPK + gi) * TOK + t * 16);
+            const v2f sx01 = {sx.x, sx.y}, sx23 = {sx.z, sx.w}, m136 = {-136.f, -136.f};
+#pragma unroll
+            for (int sw = 0; sw < NSW; sw++) {
+              const float sv = w4_scale(sc[sw][s], gi);
+              const v2f s2 = {sv, sv};
+              const v2f t01 = __builtin_elementwise_fma(m136, sx01, v2f{tmp[sw][0], tmp[sw][1]});
+              const v2f t23 = __builtin_elementwise_fma(m136, sx23, v2f{tmp[sw][2], tmp[sw][3]});
+              const v2f a01 = __builtin_elementwise_fma(s2, t01, v2f{acc[sw][t][0], acc[sw][t][1]});
+              const v2f a23 = __builtin_elementwise_fma(s2, t23, v2f{acc[sw][t][2], acc[sw][t][3]});
+              acc[sw][t] = v4f{a01[0], a01[1], a23[0], a23[1]};
+            }
+          }
+        }
+      }
+    }
+  };
+
+  load_w(wA, sA, 0);
+  load_b(0);
+  store_b(0);
+  __syncthreads();
+  for (int c = 0; c < NC; c += 2) {
+    if (c + 1 < NC) { load_b(c + 1); load_w(wB, sB, c + 1); }
+    compute(wA, sA, c, 0);
+    if (c + 1 < NC) store_b(1);
+    __syncthreads();
+    if (c + 1 < NC) {
+      if (c + 2 < NC) { load_b(c + 2); load_w(wA, sA, c + 2); }
+      compute(wB, sB, c + 1, 1);
+      if (c + 2 < NC) store_b(0);
+      __syncthreads();
+    }
+  }
+
+#pragma unroll
+  for (int sw = 0; sw < NSW; sw++) {
+    const int strip = strip0 + sw;
+    if (strip >= p.nstrips) continue;
+    const int n = strip * 16 + (lane & 15);
+    if (n >= p.N && !p.glu) continue;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = row0 + t * 16 + (lane >> 4) * 4 + r;
+        if (p.glu) {
+          const float u = __shfl(acc[sw][t][r], (lane & 48) | ((lane + 8) & 15), 64);   // the up row sits 8 lanes to the right
+          if (row < bsz && (lane & 15) < 8) p.y[(size_t)row * p.ldy + strip * 8 + (lane & 15)] = lin_glu(acc[sw][t][r], u);
+        } else if (row < bsz) {
+          p.y[(size_t)row * p.ldy + n] = lin_addends(lin_out(acc[sw][t][r], p.bias, n), p, row, n);
+        }
+      }
+  }
+}
+
+// =====================================================================================================
 // Load-time kernels: one wavefront per W tile; lane l = kc*16 + n owns feature strip*16+n.
 // =====================================================================================================
 __device__ __forceinline__ uint32_t pack8_w4(const int (&q)[8]) {
@@ -911,9 +1086,42 @@ bool g_lin_force_gemm = false;
 
 bool dec_fits(const ktx_linear_s* h, int T);
 
+// prompt-sized W4: NSW strips per wavefront (lin_gemm_w4n_kernel)
+template <int G, int NSW>
+int launch_gemm_w4n(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
+  constexpr int MT = 4, TOK = MT * 16, CS = TOK * 16 + 16;
+  using F = Fmt<F_W4, G>;
+  const size_t smem = 2 * (size_t)(2 * 16 * CS) + 2 * (size_t)(2 * F::GPK * TOK * 4);
+  const dim3 grid((h->nstrips + 4 * NSW - 1) / (4 * NSW), (p.T + TOK - 1) / TOK, h->batch);
+  auto kern = lin_gemm_w4n_kernel<G, MT, NSW>;
+  KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
+            "lin_gemm_w4n_kernel<MT%d,NSW%d> T=%d %d->%d%s", MT, NSW, p.T, p.Kx, p.N,
+            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
+  static bool attr_set = false;
+  if (!attr_set) {
+    KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int FMT, int G>
 int forward_fmt(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
   if (dec_fits(h, p.T)) return launch_dec<FMT, G>(h, p, st);
+  if constexpr (FMT == F_W4) {
+    // enough (feature block, token tile) workgroups to fill the chip twice over -> two strips per wavefront.  Measured at
+    // T = 2048 on the DeepSeek-V3 shapes (scripts/lin_prompt_sweep.py): 350-445 TFLOP/s against 245-300 with one strip; four
+    // strips need > 256 registers (one wavefront per SIMD) and fall back to 140-290.
+    // (knob 12, scripts / tests: 1 = always the one-strip kernel, 2 / 4 = force that many strips per wavefront)
+    const long tiles = (long)((p.T + 63) / 64) * h->batch;
+    const int force = ktx_debug_get(12);
+    if (p.T > 32 && force != 1) {
+      if (force == 4) return launch_gemm_w4n<G, 4>(h, p, st);
+      if (force == 2 || (force == 0 && tiles * ((h->nstrips + 7) / 8) >= 512)) return launch_gemm_w4n<G, 2>(h, p, st);
+    }
+  }
   if (p.T <= 16) return launch_gemm<FMT, G, 1>(h, p, st);
   if (p.T <= 32) return launch_gemm<FMT, G, 2>(h, p, st);
   return launch_gemm<FMT, G, 4>(h, p, st);

@@ -187,3 +187,36 @@ def test_fused_norm_glu_and_addends(T, fmt):
     wide = torch.zeros(T, I + 64, dtype=torch.bfloat16, device="cuda")
     wide[:, :I] = ref
     assert torch.equal(hd.forward(wide[:, :I]), y)
+
+
+@pytest.mark.parametrize("K,N,G", [(2048, 576, 64), (7168, 1536, 64), (1536, 200, 64), (2048, 576, 128), (2048, 576, 32)])
+@pytest.mark.parametrize("T", [33, 130, 257])
+def test_w4_prompt_kernel_with_several_strips_per_wavefront(K, N, G, T):
+    """lin_gemm_w4n_kernel (prompt-sized W4, 2 / 4 strips per wavefront, packed-fp32 dequantisation epilogue) performs the
+    one-strip kernel's operations element for element: bit-identical outputs, with bias, addends and the GLU epilogue,
+    ragged feature counts (N % 64 != 0) and ragged token tiles."""
+    n = native()
+    torch.manual_seed(K + N + T + G)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16).cuda()
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16).cuda()
+    bias = (torch.randn(N) / 10).to(torch.bfloat16).cuda()
+    a1 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    h = n.LinearHandle(K, N, "W4", G, 512)
+    h.load_bf16(w, bias)
+    hg = None
+    if N % 16 == 0:
+        hg = n.LinearHandle(K, N, "W4", G, 512)
+        hg.load_bf16(w)
+    outs = {}
+    try:
+        for knob in (1, 2, 4):
+            n.lib.ktx_debug_set(12, knob)
+            outs[knob] = (h.forward(x), h.forward(x, add1=a1), hg.forward(x, glu=True) if hg is not None else None)
+    finally:
+        n.lib.ktx_debug_set(12, 0)
+    q, s = quantize_weights_ref(w.cpu().T.contiguous(), G)
+    close(outs[1][0], linear_w4_ref(x.cpu(), q, s, G, bias.cpu()))
+    for knob in (2, 4):
+        for a, b in zip(outs[1], outs[knob]):
+            if a is not None:
+                assert torch.equal(a, b), f"strips/wavefront = {knob}: {int((a != b).sum())} of {a.numel()} outputs differ"
