@@ -71,35 +71,60 @@ __device__ __forceinline__ v8bf load_v_frag(const bf16_t* base) {
   return c.v;
 }
 
-// Workgroup = HBW head blocks (16 heads each) x DSPLIT slices of the 512 output dims: wave (hbw, ds) computes the full
-// S = Q K^T of its head block (redundantly across ds: 36 cheap MFMAs) but only 512/DSPLIT dims of O += P V, which divides
-// the fp32 accumulator registers — the 128-VGPR O tile of the undivided form left one wave per SIMD running a serial
-// chain of LDS reads and MFMAs (~7 us per 32-token tile).
+// One LDS-DMA wave-instruction: lane l's 16 bytes at gsrc_lane land at LDS byte address lds_addr + 16 l (M0 carries the
+// wave-uniform LDS base).  Issued through inline asm ON PURPOSE: for an LDS-DMA it knows about, the compiler drains every
+// pending DMA (s_waitcnt vmcnt(0)) in front of any LDS read it cannot prove disjoint from the destination — here the K / V
+// fragment reads of the CURRENT tile while the NEXT tile's rows are in flight to the other buffer — which serialised the
+// prefetch with the compute: 3.4 us per tile and workgroup, measured, i.e. one HBM round trip per tile.  Unseen by the
+// compiler, completion is waited for explicitly in front of the per-tile barrier; the compiler's own waits for ITS loads can
+// only wait longer than needed, never shorter (loads retire in order).
+__device__ __forceinline__ void mla_dma_row(const bf16_t* gsrc_lane, const bf16_t* lds_row) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds_row);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_addr)
+               : "memory");
+}
+
+// Workgroup = HBW head blocks (16 heads each) x DSPLIT slices: wave (hbw, ds) computes 512/DSPLIT dims of O += P V (which
+// divides the fp32 accumulator registers — the 128-VGPR O tile of the undivided form left one wave per SIMD running a
+// serial chain of LDS reads and MFMAs, ~7 us per 32-token tile) and every DSPLIT-th 32-wide k-step of S = Q K^T; the DSPLIT
+// partial score tiles of a head block meet in LDS and every wave adds them in the same order, so all of them hold the
+// same S bit for bit.  (Round 1 had every wave compute the whole S: 36 MFMAs and 36 KiB of LDS reads per wave and tile
+// instead of 10 and 10 — measured 3.5-4 us per tile and workgroup at 128 heads.)
+// KV split s owns tiles s, s + nsplit, s + 2 nsplit, ...: balanced to within one tile whatever kv_len turns out to be.
 template <int HBW, int DSPLIT>
 __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams p) {
   constexpr int NWV = HBW * DSPLIT;
   constexpr int NDT = 32 / DSPLIT;   // 16-dim output tiles per wave
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584] row-major [ckv | k_pe | pad]
-  bf16_t* Pt = Kt + 2 * MLA_TILE * MLA_KROW;                           // [NWV][16][32]
+  bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584] row-major ckv rows (+ pad)
+  bf16_t* Kp = Kt + 2 * MLA_TILE * MLA_KROW;                           // [2][32][64] k_pe rows, 16-byte pieces XOR-swizzled
+  bf16_t* Pt = Kp + 2 * MLA_TILE * MLA_DR;                             // [NWV][16][32]
+  float* Sx = reinterpret_cast<float*>(Pt + NWV * 16 * MLA_TILE);      // [NWV][8][64] partial score tiles
+  constexpr int NQ = (18 + DSPLIT - 1) / DSPLIT;                        // k-steps of S per wave: ds, ds + DSPLIT, ...
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int split = blockIdx.x, hb = blockIdx.y, qt = blockIdx.z;
   MLA_TS(0);
 
-  // ---- Q fragments first: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for 18 k-steps of 32 (16 nope + 2 rope).  Their
-  // addresses depend on nothing but the block indices, so they are in flight while the request lookup below resolves.
+  // ---- Q fragments first: A[m = head (lane&15)][k = (lane>>4)*8 .. +7] for this wave's k-steps of 32 (of 16 nope + 2
+  // rope).  Their addresses depend on nothing but the block indices, so they are in flight while the request lookup resolves.
   const int hbw = wave / DSPLIT, ds = wave % DSPLIT;
   const int head0 = (hb * HBW + hbw) * 16;
-  v8bf qf[18];
+  v8bf qf[NQ];
   {
     const int h = head0 + (lane & 15);
     const bf16_t* qn = p.q_nope + ((size_t)qt * p.Hq + h) * MLA_DC + (lane >> 4) * 8;
     const bf16_t* qr = p.q_pe + ((size_t)qt * p.Hq + h) * MLA_DR + (lane >> 4) * 8;
 #pragma unroll
-    for (int s = 0; s < 16; s++) qf[s] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
-#pragma unroll
-    for (int s = 0; s < 2; s++) qf[16 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
+    for (int j = 0; j < NQ; j++) {
+      const int s = ds + j * DSPLIT;   // wave-uniform
+      qf[j] = as_v8bf(make_uint4(0, 0, 0, 0));
+      if (s < 16) qf[j] = as_v8bf(*reinterpret_cast<const uint4*>(qn + s * 32));
+      else if (s < 18) qf[j] = as_v8bf(*reinterpret_cast<const uint4*>(qr + (s - 16) * 32));
+    }
   }
 
   // which request owns query token qt?  Every wavefront resolves it on its own with ONE round of independent loads
@@ -139,8 +164,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   MLA_TS(1);
 
   const int ntiles = (kv_end + MLA_TILE - 1) / MLA_TILE;
-  const int per = (ntiles + p.nsplit - 1) / p.nsplit;
-  const int t_begin = split * per, t_end = min(ntiles, t_begin + per);
+  const int t_begin = split, t_end = ntiles, t_step = p.nsplit;   // tiles t_begin, t_begin + t_step, ... < t_end
 
   v4f o[NDT];
 #pragma unroll
@@ -150,96 +174,94 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
   for (int r = 0; r < 4; r++) { m_run[r] = -__builtin_inff(); l_run[r] = 0.f; }
 
   if (t_begin < t_end) {
-    const bool tile_in_page = (p.page_size % MLA_TILE) == 0;
-    constexpr int KPE_PER_THREAD = (MLA_TILE * 8 + NWV * 64 - 1) / (NWV * 64);
-    uint4 kreg[KPE_PER_THREAD];
+    // The appended token (decode: one new row per request) is taken from the append buffers wherever its position is staged;
+    // the workgroup (hb 0) whose split owns its tile also writes it into the cache (StaticCache.update, custom_cache.py:189-195)
+    if (app_pos >= 0 && hb == 0 && (app_pos / MLA_TILE) % p.nsplit == split && tid < 72) {
+      const int page = p.kv_indices ? p.kv_indices[page_base + app_pos / p.page_size] : page_base + app_pos / p.page_size;
+      const size_t trow = (size_t)page * p.page_size + app_pos % p.page_size;
+      if (tid < 64) *reinterpret_cast<uint4*>(p.ckv_w + trow * p.ckv_ts + tid * 8) = *reinterpret_cast<const uint4*>(p.app_ckv + (size_t)req * MLA_DC + tid * 8);
+      else *reinterpret_cast<uint4*>(p.kpe_w + trow * p.kpe_ts + (tid - 64) * 8) = *reinterpret_cast<const uint4*>(p.app_kpe + (size_t)req * MLA_DR + (tid - 64) * 8);
+    }
 
-    // ckv rows: one 1-KiB row per wave-instruction straight into LDS (global_load_lds); rows past the end are zeroed
-    // (P is 0 there and 0 * NaN would poison the output); the appended token comes from the append buffer and the
-    // workgroup (hb 0) that owns its tile also writes it into the cache (StaticCache.update, custom_cache.py:189-195)
-    auto stage_ckv = [&](int tile, bf16_t* dst) {
+    // Staging of one 32-token tile, entirely by LDS-DMA (no VGPR destination, nothing the compiler has to wait for inside the
+    // loop).  A tile lies inside one page (page_size % 32 == 0 is required by the launcher), whose index is a scalar load.
+    // ckv: one 1-KiB row per wave-instruction into Kt[row]; k_pe: eight 128-byte rows per wave-instruction into Kp, 16-byte
+    // piece g of row r at position g ^ (r & 7) (the XOR keeps the fragment reads of 16 rows at most 2-way bank-conflicted
+    // although the rows are packed).  Rows past the end of the context re-read the last valid row: finite values that the
+    // softmax weights them with exactly 0 (their scores are masked), and nothing beyond kv_len is ever touched.
+    auto stage = [&](int tile, bf16_t* dK, bf16_t* dP) {
       const int tok0 = tile * MLA_TILE;
-      const int ntok = min(MLA_TILE, kv_end - tok0);
-      // kv_indices == NULL: the request's pages are page_base, page_base + 1, ... (the single-request cache's identity table,
-      // custom_cache.py:99-104) — no dependent page-table load in front of the latent rows
-      const int page0 = p.kv_indices ? p.kv_indices[page_base + tok0 / p.page_size] : page_base + tok0 / p.page_size;
+      const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
+      const int page0 = p.kv_indices ? p.kv_indices[pidx_] : pidx_;
+      const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
+      const int last = kv_end - 1 - tok0;   // last valid row of the tile (>= 0: the tile holds a visible token)
+#pragma unroll
       for (int r = wave; r < MLA_TILE; r += NWV) {
-        if (r < ntok) {
-          const int pos = tok0 + r;
-          const int page = tile_in_page ? page0 : (p.kv_indices ? p.kv_indices[page_base + pos / p.page_size] : page_base + pos / p.page_size);
-          const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
-          const bf16_t* src = p.ckv + trow * p.ckv_ts;
-          if (pos == app_pos) {
-            src = p.app_ckv + (size_t)req * MLA_DC;
-            if (hb == 0) *reinterpret_cast<uint4*>(p.ckv_w + trow * p.ckv_ts + lane * 8) = *reinterpret_cast<const uint4*>(src + lane * 8);
-          }
-          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + lane * 8),
-                                           (__attribute__((address_space(3))) void*)(dst + r * MLA_KROW), 16, 0, 0);
-        } else {
-          *reinterpret_cast<uint4*>(dst + r * MLA_KROW + lane * 8) = make_uint4(0, 0, 0, 0);
-        }
+        const int rr = min(r, last);
+        const bf16_t* src = p.ckv + (row0 + rr) * p.ckv_ts;
+        if (tok0 + rr == app_pos) src = p.app_ckv + (size_t)req * MLA_DC;
+        mla_dma_row(src + lane * 8, dK + r * MLA_KROW);
       }
-    };
-    auto load_kpe = [&](int tile) {   // k_pe: 32 rows x 8 pieces of 16 B through registers
-      const int tok0 = tile * MLA_TILE;
-      const int ntok = min(MLA_TILE, kv_end - tok0);
-      const int page0 = p.kv_indices ? p.kv_indices[page_base + tok0 / p.page_size] : page_base + tok0 / p.page_size;
-#pragma unroll
-      for (int i = 0; i < KPE_PER_THREAD; i++) {
-        const int u = tid + i * NWV * 64, r = u >> 3, piece = u & 7;
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (u < MLA_TILE * 8 && r < ntok) {
-          const int pos = tok0 + r;
-          const int page = tile_in_page ? page0 : (p.kv_indices ? p.kv_indices[page_base + pos / p.page_size] : page_base + pos / p.page_size);
-          const size_t trow = (size_t)page * p.page_size + pos % p.page_size;
-          if (pos == app_pos) {
-            v = *reinterpret_cast<const uint4*>(p.app_kpe + (size_t)req * MLA_DR + piece * 8);
-            if (hb == 0) *reinterpret_cast<uint4*>(p.kpe_w + trow * p.kpe_ts + piece * 8) = v;
-          } else {
-            v = *reinterpret_cast<const uint4*>(p.k_pe + trow * p.kpe_ts + piece * 8);
-          }
-        }
-        kreg[i] = v;
-      }
-    };
-    auto store_kpe = [&](bf16_t* dst) {
-#pragma unroll
-      for (int i = 0; i < KPE_PER_THREAD; i++) {
-        const int u = tid + i * NWV * 64;
-        if (u < MLA_TILE * 8) *reinterpret_cast<uint4*>(dst + (u >> 3) * MLA_KROW + MLA_DC + (u & 7) * 8) = kreg[i];
+      if (wave < 4) {
+        const int r = wave * 8 + (lane >> 3), rr = min(r, last);
+        const int g = (lane & 7) ^ (lane >> 3);
+        const bf16_t* src = p.k_pe + (row0 + rr) * p.kpe_ts;
+        if (tok0 + rr == app_pos) src = p.app_kpe + (size_t)req * MLA_DR;
+        mla_dma_row(src + g * 8, dP + wave * 8 * MLA_DR);
       }
     };
 
-    // first tile in flight while the Q fragments arrive
-    stage_ckv(t_begin, Kt);
-    load_kpe(t_begin);
-    store_kpe(Kt);
+    stage(t_begin, Kt, Kp);
     MLA_TS(2);
     bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
 
-    for (int tile = t_begin; tile < t_end; tile++) {
-      const int cur = (tile - t_begin) & 1;
+    int cur = 0;
+    for (int tile = t_begin; tile < t_end; tile += t_step, cur ^= 1) {
       bf16_t* Kc = Kt + cur * MLA_TILE * MLA_KROW;
       bf16_t* Kn = Kt + (cur ^ 1) * MLA_TILE * MLA_KROW;
+      const bf16_t* Pc = Kp + cur * MLA_TILE * MLA_DR;
       const int tok0 = tile * MLA_TILE;
       const int ntok = min(MLA_TILE, kv_end - tok0);
-      // One barrier per tile: it drains this tile's LDS-DMA (the compiler emits vmcnt(0) ahead of it), publishes the k_pe
-      // stores, and proves every wave is done reading the other buffer, which the next tile's DMA may now overwrite.
+      // One barrier per tile: behind the explicit wait for this wave's LDS-DMA rows of this tile it publishes them and
+      // proves every wave is done reading the other buffer, which the next tile's DMA may now overwrite.
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tile == t_begin) MLA_TS(3);
-      const bool more = tile + 1 < t_end;
-      if (more) { stage_ckv(tile + 1, Kn); load_kpe(tile + 1); }
+      if (tile + t_step < t_end) stage(tile + t_step, Kn, Kp + (cur ^ 1) * MLA_TILE * MLA_DR);
 
-      // ---- S = Q K^T for 2 x 16 tokens -----------------------------------------------------------------------------
+      // ---- S = Q K^T for 2 x 16 tokens: this wave's k-steps -------------------------------------------------------------
       v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
       const bf16_t* kb0 = Kc + (lane & 15) * MLA_KROW + (lane >> 4) * 8;
       const bf16_t* kb1 = kb0 + 16 * MLA_KROW;
 #pragma unroll
-      for (int s = 0; s < 18; s++) {
-        const v8bf b0 = as_v8bf(*reinterpret_cast<const uint4*>(kb0 + s * 32));
-        const v8bf b1 = as_v8bf(*reinterpret_cast<const uint4*>(kb1 + s * 32));
-        s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b0, s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[s], b1, s1, 0, 0, 0);
+      for (int j = 0; j < NQ; j++) {
+        const int s = ds + j * DSPLIT;
+        if (s < 16) {   // wave-uniform
+          const v8bf b0 = as_v8bf(*reinterpret_cast<const uint4*>(kb0 + s * 32));
+          const v8bf b1 = as_v8bf(*reinterpret_cast<const uint4*>(kb1 + s * 32));
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b0, s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b1, s1, 0, 0, 0);
+        } else if (s < 18) {   // rope k-step: piece (s-16)*4 + (lane>>4) of row (lane&15) (+16), un-swizzled
+          const int row = lane & 15, q = (s - 16) * 4 + (lane >> 4);
+          const bf16_t* pr = Pc + row * MLA_DR + ((q ^ (row & 7)) * 8);
+          const v8bf b0 = as_v8bf(*reinterpret_cast<const uint4*>(pr));
+          const v8bf b1 = as_v8bf(*reinterpret_cast<const uint4*>(pr + 16 * MLA_DR));
+          s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b0, s0, 0, 0, 0);
+          s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b1, s1, 0, 0, 0);
+        }
+      }
+      if constexpr (DSPLIT > 1) {   // the head block's partial score tiles meet in LDS; fixed order -> identical S in every wave
+        float* sx = Sx + wave * 512 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { sx[r * 64] = s0[r]; sx[(4 + r) * 64] = s1[r]; }
+        __syncthreads();
+        const float* sr = Sx + hbw * DSPLIT * 512 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; r++) { s0[r] = sr[r * 64]; s1[r] = sr[(4 + r) * 64]; }
+#pragma unroll
+        for (int d = 1; d < DSPLIT; d++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) { s0[r] += sr[d * 512 + r * 64]; s1[r] += sr[d * 512 + (4 + r) * 64]; }
       }
       if (tile == t_begin) MLA_TS(4);
       // lane holds S[head = (lane>>4)*4 + r][token = tok0 + (lane&15) (+16)]
@@ -256,10 +278,11 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         alpha[r] = __expf(m_run[r] - m_new);
         l_run[r] = l_run[r] * alpha[r] + sum;
         m_run[r] = m_new;
-        // P to LDS in [head][token] order for the A-operand re-read
+        // P to LDS in [head][token] order for the A-operand re-read (one v_cvt_pk_bf16_f32 for the pair)
         const int hrow = (lane >> 4) * 4 + r;
-        Pw[hrow * MLA_TILE + (lane & 15)] = f32_to_bf16(pa);
-        Pw[hrow * MLA_TILE + 16 + (lane & 15)] = f32_to_bf16(pb);
+        const uint32_t pk = ktx_pk_bf16(pa, pb);
+        Pw[hrow * MLA_TILE + (lane & 15)] = (bf16_t)(pk & 0xffffu);
+        Pw[hrow * MLA_TILE + 16 + (lane & 15)] = (bf16_t)(pk >> 16);
       }
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
       __builtin_amdgcn_wave_barrier();
@@ -274,7 +297,6 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         const v8bf b = load_v_frag(vb + i * 16);
         o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
       }
-      if (more) store_kpe(Kn);
       if (tile == t_begin) MLA_TS(5);
     }
   }
@@ -445,6 +467,7 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   KTX_REQUIRE(cfg->head_dim_ckv == MLA_DC && cfg->head_dim_kpe == MLA_DR, "ktx_mla_decode: only kv_lora_rank 512 + rope 64");
   KTX_REQUIRE(cfg->num_heads > 0 && cfg->num_heads % 16 == 0, "ktx_mla_decode: num_heads must be a multiple of 16");
   KTX_REQUIRE(batch > 0 && total_q_tokens > 0 && cfg->page_size > 0, "ktx_mla_decode: bad sizes");
+  KTX_REQUIRE(cfg->page_size % MLA_TILE == 0, "ktx_mla_decode: page_size must be a multiple of 32 (the reference's caches use 64 and 256)");
   KTX_REQUIRE(ckv_token_stride % 8 == 0 && kpe_token_stride % 8 == 0, "ktx_mla_decode: token strides must be multiples of 8 elements");
   hipStream_t st = (hipStream_t)stream;
   const int Hq = cfg->num_heads;
@@ -491,7 +514,7 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   p.out1 = direct ? (bf16_t*)d_out : nullptr;
   p.lse1 = direct ? d_lse : nullptr;
   p.app_ckv = (const bf16_t*)d_new_ckv; p.app_kpe = (const bf16_t*)d_new_kpe; p.ckv_w = (bf16_t*)d_ckv; p.kpe_w = (bf16_t*)d_k_pe;
-  const size_t lds = (size_t)(2 * MLA_TILE * MLA_KROW + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + 16;
+  const size_t lds = (size_t)(2 * MLA_TILE * MLA_KROW + 2 * MLA_TILE * MLA_DR + nwv * 16 * MLA_TILE) * sizeof(bf16_t) + (size_t)nwv * 512 * sizeof(float) + 16;
   const dim3 grid(nsplit, hblocks, total_q_tokens);
   // algorithmic bytes: the latent rows of the context (hint) + q / out rows; the split partials are an implementation artefact
   const double kv_bytes = (double)std::max(cfg->kv_len_hint, 1) * (MLA_DC + MLA_DR) * 2.0 * batch;

@@ -22,15 +22,16 @@ torch.cuda.set_device(dev)
 wl = bench.WORKLOADS[args.workload]
 mr = bench.ModelDecodeRunner(wl, args.layers or wl["layers"], dev, args.ctx, 4096)
 
+ONLY = os.environ.get("KTX_AB_ONLY")   # comma-separated substrings of configuration names
 CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "default": ({}, {}),
-    "lin: first split rule": ({11: 1}, {}),
-    "moe gate/up: no k-slices": ({10: 1}, {}),
-    "mla: page table load": ({}, {"KTX_MLA_NO_IDENTITY": "1"}),
+    "mla: 32 splits": ({7: 32}, {}),
+    "mla: 48 splits": ({7: 48}, {}),
     "mla: 4x2 shape, 128 splits": ({6: 4, 7: 128}, {}),
-    "lin: LDS-DMA ring": ({9: 2}, {}),
     "mla: separate prep launch": ({}, {"KTX_MLA_SEPARATE_PREP": "1"}),
 }
+if ONLY:
+    CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}
 res = {k: [] for k in CONFIGS}
 for r in range(args.rounds):
     for name, (knobs, env) in CONFIGS.items():
