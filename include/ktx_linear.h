@@ -23,6 +23,7 @@
 #define KTX_LINEAR_H
 #include <stddef.h>
 #include <stdint.h>
+#include "ktx_gate.h"
 
 #ifdef __cplusplus
 extern "C" {
@@ -94,6 +95,18 @@ typedef struct ktx_linear_fusion {
 int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
                              const ktx_linear_fusion* fusion, ktx_stream_t stream);
 int ktx_linear_decode_eligible(ktx_linear_t h, int T);
+
+/* ktx_linear_forward_fused with the MoE router riding in the same launch (decode steps, T <= 4).  For the MoE block of a
+ * decoder layer (KDeepseekV3MoE.forward, archive/ktransformers/operators/experts.py:974-1012: router, routed experts and the
+ * shared experts all read the same post-attention hidden row): `h` is the shared experts' merged gate|up linear, `fusion`
+ * carries the post_attention_layernorm (norm_weight must be set) and `glu`; the router arguments are those of
+ * ktx_gate_forward_norm (include/ktx_gate.h) on the same d_x with the same norm.  Results are those of the two separate
+ * calls — router workgroups and GEMV workgroups are independent and share one grid.  Shapes without a combined kernel
+ * (other formats / group sizes, odd k-slices, T > 4, strided x) run the two launches instead; the call never fails for that. */
+int ktx_linear_forward_fused_gate(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
+                                  const ktx_linear_fusion* fusion, const struct ktx_gate_config* gate_cfg, const void* d_gate_w,
+                                  const float* d_gate_bias, float* d_logits, int32_t* d_counters, int64_t* d_topk_idx,
+                                  float* d_topk_weight, void* d_xn_out, ktx_stream_t stream);
 
 /* Batched form for the per-head absorb products of MLA (torch.matmul(q_nope, q_absorb) / matmul(attn, out_absorb.mT),
  * archive/ktransformers/operators/attention.py:414-418,465-468): batch b uses weight matrix b ([batch][N][K] at load)

@@ -102,6 +102,8 @@ def _load() -> C.CDLL:
     lib.ktx_linear_forward_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
                                              C.c_void_p]
     lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
+    lib.ktx_linear_forward_fused_gate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
+                                                  C.POINTER(_GateConfig)] + [C.c_void_p] * 8
     lib.ktx_linear_weight_bytes.argtypes = [C.c_void_p]
     lib.ktx_linear_weight_bytes.restype = C.c_size_t
     lib.ktx_linear_debug_get_w4.argtypes = [C.c_void_p] * 3
@@ -631,6 +633,38 @@ class GateHandle:
         check(lib.ktx_gate_select(C.byref(self.cfg), bsz_ptr, T, logits.data_ptr(), b.data_ptr() if b is not None else None,
                                   idx.data_ptr(), w.data_ptr(), st))
         return idx, w
+
+
+def gate_with_linear(gate: "GateHandle", lin: "LinearHandle", x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None,
+                     norm: tuple, glu: bool = True, bsz_tensor: torch.Tensor | None = None):
+    """Decode step of a MoE block: the router (GateHandle.forward with norm=) and the shared experts' merged gate|up GEMV
+    (LinearHandle.forward with norm=, glu=) on the same un-normalised row block x bf16 [T, H], in ONE launch where a combined
+    kernel exists (ktx_linear_forward_fused_gate; otherwise the library issues the two launches itself).
+    Returns (topk_idx int64 [T,k], topk_weight fp32 [T,k], xn bf16 [T,H], y bf16 [T, N/2 if glu else N])."""
+    T, dev = x.shape[0], x.device
+    if x.dtype != torch.bfloat16 or x.dim() != 2 or x.shape[1] != gate.H or lin.K != gate.H or not x.is_contiguous():
+        raise KtxError("gate_with_linear: x must be contiguous bf16 [T, hidden] and both operators must read hidden-sized rows")
+    if weight.dtype != torch.bfloat16 or T > GateHandle.LOGITS_HIP_MAX_T:
+        raise KtxError("gate_with_linear: bf16 router weights and a decode-sized batch only")
+    nw, eps = norm
+    n_out = lin.N // 2 if glu else lin.N
+    logits = torch.empty((T, gate.E), dtype=torch.float32, device=dev)
+    idx = torch.empty((T, gate.k), dtype=torch.int64, device=dev)
+    wt = torch.empty((T, gate.k), dtype=torch.float32, device=dev)
+    xn = torch.empty((T, gate.H), dtype=torch.bfloat16, device=dev)
+    y = torch.empty((T, n_out), dtype=torch.bfloat16, device=dev) if bsz_tensor is None else \
+        torch.zeros((T, n_out), dtype=torch.bfloat16, device=dev)
+    cnt = gate._counters.get(dev)
+    if cnt is None:
+        cnt = gate._counters[dev] = torch.zeros(GateHandle.LOGITS_HIP_MAX_T, dtype=torch.int32, device=dev)
+    wc = weight.contiguous()
+    b = bias.to(device=dev, dtype=torch.float32).contiguous() if bias is not None else None
+    fu = _LinearFusion(nw.data_ptr(), float(eps), None, 0, None, 0, 0, 0, 1 if glu else 0)
+    check(lib.ktx_linear_forward_fused_gate(lin._h, bsz_tensor.data_ptr() if bsz_tensor is not None else None, T, x.data_ptr(),
+                                            y.data_ptr(), C.byref(fu), C.byref(gate.cfg), wc.data_ptr(),
+                                            b.data_ptr() if b is not None else None, logits.data_ptr(), cnt.data_ptr(),
+                                            idx.data_ptr(), wt.data_ptr(), xn.data_ptr(), _stream_ptr(dev)))
+    return idx, wt, xn, y
 
 
 class MLAWrapper:

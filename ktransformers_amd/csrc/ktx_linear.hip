@@ -29,10 +29,12 @@
 #include <mutex>
 #include <vector>
 
+#include "../../include/ktx_gate.h"
 #include "../../include/ktx_linear.h"
 
 typedef __bf16 lv8bf __attribute__((ext_vector_type(8)));
 #include "ktx_prep.inc"
+#include "ktx_gate_dev.inc"   // the router's device code: it can ride in the decode GEMV's launch (lin_dec_gate_kernel)
 
 extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
 
@@ -271,18 +273,18 @@ __device__ __forceinline__ void lin_vmcnt_rt(int n) {
   }
 }
 
+// (bx, by) = the workgroup's place in the grid of products — a device function so that another kernel's launch can carry it
 template <int FMT, int G, int D, int MODE>
-__global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
+__device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const int by, const int nbx, uint8_t* smem) {
   constexpr bool EXACT = MODE != M_GUARD;
   static_assert(MODE != M_DMA || FMT == F_W4, "the LDS-DMA ring is built for the W4 format");
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if (p.prep_on && blockIdx.y == 0) {   // the prep row, dispatched FIRST so it overlaps the products: workgroup x handles tokens x, x + gridDim.x, ...
+  if (p.prep_on && by == 0) {   // the prep row, dispatched FIRST so it overlaps the products: workgroup x handles tokens x, x + nbx, ...
     float* s_cs = reinterpret_cast<float*>(smem);   // (static LDS here would push the kernel past the 160 KB attribute)
-    for (int t = blockIdx.x; t < p.prep.T; t += gridDim.x) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
+    for (int t = bx; t < p.prep.T; t += nbx) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
     return;
   }
   using F = Fmt<FMT, G>;
-  lin_select_batch(p, blockIdx.y - (p.prep_on ? 1 : 0));
+  lin_select_batch(p, by - (p.prep_on ? 1 : 0));
   const int NKS = p.NKS, TP = p.TP;
   const int ncol16 = FMT == F_FP8 ? NKS * 8 : NKS * 16;   // 16-byte LDS columns per token
   const int cs = TP * 16;
@@ -293,7 +295,7 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int sw = wave % p.SW, sl = wave / p.SW;
-  const int strip_raw = blockIdx.x * p.SW + sw;
+  const int strip_raw = bx * p.SW + sw;
   const bool strip_ok = strip_raw < p.nstrips;
   const int strip = strip_ok ? strip_raw : p.nstrips - 1;   // a surplus wave streams a valid strip and stores nothing
   const int ks0 = sl * p.SPS, ks1 = EXACT ? ks0 + p.SPS : (strip_ok ? min(ks0 + p.SPS, NKS) : ks0);
@@ -488,8 +490,8 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   __syncthreads();
   if (tid < p.SW * 64) {
     const int swo = tid >> 6, r = (tid >> 4) & 3, f = tid & 15;
-    const int n = (blockIdx.x * p.SW + swo) * 16 + f;
-    if (r < bsz && n < p.N && blockIdx.x * p.SW + swo < p.nstrips) {
+    const int n = (bx * p.SW + swo) * 16 + f;
+    if (r < bsz && n < p.N && bx * p.SW + swo < p.nstrips) {
       const int nsl = 8 / p.SW;
       float v = 0.f;
       for (int s = 0; s < nsl; s++) v += red[((s * p.SW + swo) * 4 + r) * 16 + f];
@@ -497,13 +499,35 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
         if (f < 8) {
           float u = 0.f;
           for (int s = 0; s < nsl; s++) u += red[((s * p.SW + swo) * 4 + r) * 16 + f + 8];
-          p.y[(size_t)r * p.ldy + (blockIdx.x * p.SW + swo) * 8 + f] = lin_glu(v, u);
+          p.y[(size_t)r * p.ldy + (bx * p.SW + swo) * 8 + f] = lin_glu(v, u);
         }
       } else {
         p.y[(size_t)r * p.ldy + n] = lin_addends(lin_out(v, p.bias, n), p, r, n);
       }
     }
   }
+}
+
+template <int FMT, int G, int D, int MODE>
+__global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  lin_dec_body<FMT, G, D, MODE>(p, blockIdx.x, blockIdx.y, gridDim.x, smem);
+}
+
+// The MoE router riding in the launch of the shared experts' gate|up GEMV (ktx_linear_forward_fused_gate): both read the same
+// post-attention hidden row and neither needs the other's result (KDeepseekV3MoE.forward, operators/experts.py:974-1012 runs
+// the shared experts beside the routed ones), the router is a latency chain on E/8 workgroups and the GEMV a weight stream on
+// the rest of the chip.  Row blockIdx.y == 0 (dispatched first: the longer chain) = router workgroups, 8 experts each, of
+// token blockIdx.x / gate_nwg; rows 1.. = the GEMV's grid.  Same device code as the stand-alone kernels.
+template <int G, int D, int EPL, int NJ>
+__global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs ga, int gate_nwg) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (blockIdx.y == 0) {
+    const int t = blockIdx.x / gate_nwg;
+    if (t < ga.qlen) gate_fused_body<EPL, NJ, 8>(ga, blockIdx.x - t * gate_nwg, gate_nwg, t, smem);
+    return;
+  }
+  lin_dec_body<F_W4, G, D, M_EXACT>(p, blockIdx.x, blockIdx.y - 1, gridDim.x, smem);
 }
 
 // =====================================================================================================
@@ -963,8 +987,10 @@ int set_bias(ktx_linear_s* h, const void* d_bias) {
   return 0;
 }
 
+constexpr int KTX_LIN_NOT_FUSED = -2;   // launch_dec with a router to carry: this shape has no combined kernel, nothing was launched
+
 template <int FMT, int G>
-int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
+int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs* gate = nullptr) {
   using F = Fmt<FMT, G>;
   const int NKS = h->NKS;
   p.TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
@@ -982,9 +1008,10 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
   const double x_bytes = (double)NKS * 128 * 2 * p.TP + 30.0 * 1024;
   int SW = 1;
   double best = 1e30;
+  const int extra_wg = gate ? (gate->c.n_routed_experts + 7) / 8 * p.T : 0;   // router workgroups riding in this launch occupy CUs too
   for (int c = 1; c <= 8; c <<= 1) {
     if (NKS < 8 / c) continue;   // at least one k-step per slice
-    const int nwg = (h->nstrips + c - 1) / c * h->batch;
+    const int nwg = (h->nstrips + c - 1) / c * h->batch + extra_wg;
     const double cost = (double)((nwg + ncu - 1) / ncu) * (c * strip_bytes + x_bytes);
     if (cost < best) { best = cost; SW = c; }
   }
@@ -1018,6 +1045,42 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st) {
         if (d <= p.SPS && smem + 8 * (d * 1024 + scl_bytes) <= 156 * 1024) { dma_depth = d; break; }
       if (dma_depth) smem += 8 * (dma_depth * 1024 + scl_bytes);
     }
+  }
+  if (gate) {   // the router rides in this launch (lin_dec_gate_kernel) — W4 g64, whole k-slices, router grid inside one row
+    if constexpr (FMT == F_W4 && G == 64) {
+      const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
+      const int nwg = (E + 7) / 8, epl = (E + 63) / 64;
+      const int d = p.SPS % 8 == 0 ? 8 : p.SPS % 7 == 0 ? 7 : p.SPS % 4 == 0 ? 4 : p.SPS % 2 == 0 ? 2 : 0;
+      if (p.prep_on || h->batch != 1 || nsl * p.SPS != NKS || dma_depth || d == 0 || (int)grid.x < nwg * p.T || H != p.Kx ||
+          H > 8192 || epl > 6 || ktx_debug_get(13) == 1)
+        return KTX_LIN_NOT_FUSED;
+      const size_t smem_g = std::max(smem, (size_t)H * 2);
+      const dim3 grid_g(grid.x, grid.y + 1);
+      KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0 + (double)E * H * 2.0,
+                "lin_dec_gate_kernel<W4> %d->%d + router E=%d", p.Kx, p.N, E);
+      auto go_g = [&](auto kern) -> int {
+        static bool attr_set = false;   // one flag per kernel instantiation
+        if (!attr_set) {
+          KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
+          attr_set = true;
+        }
+        hipLaunchKernelGGL(kern, grid_g, dim3(512), smem_g, st, p, *gate, nwg);
+        KTX_HIP(hipGetLastError());
+        return 0;
+      };
+#define KTX_GATE_D(EPLV, NJV)                                             \
+      switch (d) {                                                        \
+        case 8: return go_g(lin_dec_gate_kernel<G, 8, EPLV, NJV>);        \
+        case 7: return go_g(lin_dec_gate_kernel<G, 7, EPLV, NJV>);        \
+        case 4: return go_g(lin_dec_gate_kernel<G, 4, EPLV, NJV>);        \
+        default: return go_g(lin_dec_gate_kernel<G, 2, EPLV, NJV>);       \
+      }
+      if (epl <= 1 && H <= 2048) { KTX_GATE_D(1, 4) }
+      else if (epl <= 4) { KTX_GATE_D(4, 16) }
+      else { KTX_GATE_D(6, 16) }
+#undef KTX_GATE_D
+    }
+    return KTX_LIN_NOT_FUSED;
   }
   auto go = [&](auto kern) -> int {
     static bool attr_set = false;   // one flag per kernel instantiation
@@ -1108,8 +1171,9 @@ int launch_gemm_w4n(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
 }
 
 template <int FMT, int G>
-int forward_fmt(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
-  if (dec_fits(h, p.T)) return launch_dec<FMT, G>(h, p, st);
+int forward_fmt(const ktx_linear_s* h, const LinParams& p, hipStream_t st, const GateArgs* gate = nullptr) {
+  if (dec_fits(h, p.T)) return launch_dec<FMT, G>(h, p, st, gate);
+  if (gate) return KTX_LIN_NOT_FUSED;
   if constexpr (FMT == F_W4) {
     // enough (feature block, token tile) workgroups to fill the chip twice over -> two strips per wavefront.  Measured at
     // T = 2048 on the DeepSeek-V3 shapes (scripts/lin_prompt_sweep.py): 350-445 TFLOP/s against 245-300 with one strip; four
@@ -1256,7 +1320,7 @@ bool dec_fits(const ktx_linear_s* h, int T) {
 
 static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, long ldx, long xbs, void* d_y,
                                long ldy, long ybs, ktx_stream_t stream, const ktx_linear_fusion* fu = nullptr,
-                               const MlaPrepParams* prep = nullptr) {
+                               const MlaPrepParams* prep = nullptr, const GateArgs* gate = nullptr) {
   KTX_REQUIRE(h && d_x && d_y, "ktx_linear_forward: null argument");
   KTX_REQUIRE(h->loaded, "ktx_linear_forward: weights not loaded");
   KTX_REQUIRE(T >= 0 && T <= h->cfg.max_len, "ktx_linear_forward: T exceeds max_len");
@@ -1282,13 +1346,13 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   }
   hipStream_t st = (hipStream_t)stream;
   switch (h->cfg.format) {
-    case KTX_LIN_BF16: return forward_fmt<F_BF16, 128>(h, p, st);
-    case KTX_LIN_FP8: return forward_fmt<F_FP8, 128>(h, p, st);
+    case KTX_LIN_BF16: return forward_fmt<F_BF16, 128>(h, p, st, gate);
+    case KTX_LIN_FP8: return forward_fmt<F_FP8, 128>(h, p, st, gate);
     default:
       switch (h->cfg.group_size) {
-        case 32: return forward_fmt<F_W4, 32>(h, p, st);
-        case 64: return forward_fmt<F_W4, 64>(h, p, st);
-        default: return forward_fmt<F_W4, 128>(h, p, st);
+        case 32: return forward_fmt<F_W4, 32>(h, p, st, gate);
+        case 64: return forward_fmt<F_W4, 64>(h, p, st, gate);
+        default: return forward_fmt<F_W4, 128>(h, p, st, gate);
       }
   }
 }
@@ -1308,6 +1372,35 @@ extern "C" int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, in
 }
 
 extern "C" int ktx_linear_decode_eligible(ktx_linear_t h, int T) { return h && dec_eligible(h, T) ? 1 : 0; }
+
+extern "C" int ktx_linear_forward_fused_gate(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
+                                             const ktx_linear_fusion* fusion, const ktx_gate_config* gate_cfg,
+                                             const void* d_gate_w, const float* d_gate_bias, float* d_logits,
+                                             int32_t* d_counters, int64_t* d_topk_idx, float* d_topk_weight, void* d_xn_out,
+                                             ktx_stream_t stream) {
+  KTX_REQUIRE(h && fusion && fusion->norm_weight && gate_cfg && d_gate_w && d_logits && d_counters && d_topk_idx &&
+              d_topk_weight && d_xn_out, "ktx_linear_forward_fused_gate: null argument");
+  const int E = gate_cfg->n_routed_experts;
+  KTX_REQUIRE(gate_cfg->hidden_size == h->cfg.in_features, "ktx_linear_forward_fused_gate: the router and the linear read the same row");
+  KTX_REQUIRE(E > 0 && E <= KTX_GATE_MAX_E && gate_cfg->top_k > 0 && gate_cfg->top_k <= 64 && gate_cfg->top_k <= E &&
+              gate_cfg->n_group >= 1 && gate_cfg->n_group <= 64 && E % gate_cfg->n_group == 0 && gate_cfg->topk_group >= 1 &&
+              gate_cfg->topk_group <= gate_cfg->n_group, "ktx_linear_forward_fused_gate: bad router configuration");
+  const long ldx = fusion->x_ld ? (long)fusion->x_ld : (long)h->cfg.in_features;
+  const long ldy = fusion->y_ld ? (long)fusion->y_ld : (long)(fusion->glu ? h->cfg.out_features / 2 : h->cfg.out_features);
+  if (ldx == h->cfg.in_features && T > 0 && T <= 4) {   // (the router reads dense rows)
+    GateArgs ga;
+    ga.c = *gate_cfg; ga.d_bsz = d_bsz; ga.qlen = T; ga.x = (const bf16_t*)d_x; ga.w = (const bf16_t*)d_gate_w; ga.bias = d_gate_bias;
+    ga.logits = d_logits; ga.counters = d_counters; ga.topk_idx = d_topk_idx; ga.topk_w = d_topk_weight;
+    ga.norm_w = (const bf16_t*)fusion->norm_weight; ga.norm_eps = fusion->norm_eps; ga.xn_out = (bf16_t*)d_xn_out;
+    const int rc = linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion, nullptr, &ga);
+    if (rc != KTX_LIN_NOT_FUSED) return rc;
+  }
+  // no combined kernel for this shape: the two launches it would have replaced
+  if (int rc = ktx_gate_forward_norm(gate_cfg, d_bsz, T, d_x, fusion->norm_weight, fusion->norm_eps, d_xn_out, d_gate_w, d_gate_bias,
+                                     d_logits, d_counters, d_topk_idx, d_topk_weight, stream))
+    return rc;
+  return linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion);
+}
 
 extern "C" int ktx_linear_forward_batched(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, int64_t ldx,
                                           int64_t x_batch_stride, void* d_y, int64_t ldy, int64_t y_batch_stride,

@@ -281,9 +281,11 @@ class _KMoEBlock(BaseInjectedModule):
         hidden_states is the un-normalised residual stream and the norm runs inside the router launch."""
         return self._forward(hidden_states, residual, pre_norm)
 
-    def _finish(self, y, identity, residual, orig_shape):
+    def _finish(self, y, identity, residual, orig_shape, shared_act=None):
         shared = getattr(self.config, "n_shared_experts", None) is not None
         se = self.shared_experts if shared else None
+        if shared_act is not None:                                         # gate|up of the shared experts already done (rode with the router)
+            return se.down(shared_act, orig_shape, add1=y.view(*orig_shape), add2=residual).view(*orig_shape)
         # (running the shared experts' first GEMV on a side stream, forked from and joined to the captured stream so it
         # overlaps the routed launches like the reference overlaps its CPU experts, was measured: 325 vs 465 tok/s —
         # a cross-stream join inside the HIP graph costs more than the launch it hides.)
@@ -297,7 +299,14 @@ class _KMoEBlock(BaseInjectedModule):
     def _forward(self, hidden_states, residual=None, pre_norm=None):
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
-        if pre_norm is not None and hasattr(self.gate, "_handle"):
+        shared_act = None
+        side = self._router_side_linear(hidden_states, pre_norm)
+        if side is not None:
+            # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)
+            topk_idx, topk_weight, xn, shared_act = self.gate.forward_with_linear(
+                hidden_states, (pre_norm.weight, pre_norm.variance_epsilon), side)
+            hidden_states = xn.view(*orig_shape)
+        elif pre_norm is not None and hasattr(self.gate, "_handle"):
             topk_idx, topk_weight, xn = self.gate(hidden_states, norm=(pre_norm.weight, pre_norm.variance_epsilon))
             hidden_states = xn.view(*orig_shape)
         else:
@@ -313,10 +322,28 @@ class _KMoEBlock(BaseInjectedModule):
                 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
             gen.submit_for_one_decode(hidden_states[0], topk_idx[0], topk_weight[0])
             y = gen.sync_for_one_decode().unsqueeze(0)
-            return self._finish(y, identity, residual, orig_shape)
+            return self._finish(y, identity, residual, orig_shape, shared_act)
 
         y = self.moe_kexperts(hidden_states, topk_idx, topk_weight).view(*orig_shape).to(device=hidden_states.device)
-        return self._finish(y, identity, residual, orig_shape)
+        return self._finish(y, identity, residual, orig_shape, shared_act)
+
+    def _router_side_linear(self, hidden_states, pre_norm):
+        """The LinearHandle of the shared experts' merged gate|up operator when this call can use the combined launch: a decode
+        step (<= 4 rows) with the layer's post-attention norm handed in, a HIP router and merged bf16-activation shared experts."""
+        if pre_norm is None or not hasattr(self.gate, "forward_with_linear") or os.environ.get("KTX_MOE_SEPARATE_ROUTER"):
+            return None
+        if getattr(self.config, "n_shared_experts", None) is None or hidden_states.numel() // hidden_states.shape[-1] > 4:
+            return None
+        if hidden_states.dtype != torch.bfloat16 or not hidden_states.is_cuda:
+            return None
+        w = getattr(getattr(self.gate, "orig_module", None), "weight", None)
+        if w is None or w.dtype != torch.bfloat16:
+            return None
+        gu = getattr(self.shared_experts, "_gate_up", None)
+        h = getattr(gu, "_h", None)
+        if h is None or getattr(h, "fmt", None) != "W4" or not hasattr(self.shared_experts, "down"):
+            return None
+        return h
 
 
 class KDeepseekV2MoE(_KMoEBlock):

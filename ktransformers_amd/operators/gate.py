@@ -38,6 +38,16 @@ class KMoEGate(BaseInjectedModule):
         bias = getattr(self.orig_module, "e_score_correction_bias", None)
         return self._handle().forward(x.to(torch.bfloat16).contiguous(), w, bias, norm=norm)
 
+    def forward_with_linear(self, hidden_states, norm, linear_handle, glu: bool = True):
+        """Decode step: forward(hidden_states, norm=norm) AND linear_handle.forward(hidden_states, norm=norm, glu=glu) — the
+        shared experts' merged gate|up GEMV, independent work on the same row — in one launch
+        (ktx_linear_forward_fused_gate).  Returns (topk_idx, topk_weight, xn, y_linear)."""
+        from ktransformers_amd._native import gate_with_linear
+
+        x = hidden_states.reshape(-1, hidden_states.shape[-1]).to(torch.bfloat16).contiguous()
+        bias = getattr(self.orig_module, "e_score_correction_bias", None)
+        return gate_with_linear(self._handle(), linear_handle, x, self.orig_module.weight, bias, norm, glu=glu)
+
     def load(self, w: dict | None = None, device: str | None = None):
         if device is None:
             device = self.device

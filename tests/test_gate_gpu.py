@@ -102,3 +102,47 @@ def test_router_matches_reference_module_golden(name):
             assert set(idx[t].tolist()) == set(ridx[t].tolist()), f"token {t}: routed expert set differs"
             ref = dict(zip(ridx[t].tolist(), rwt[t].tolist()))
             np.testing.assert_allclose(wt[t], np.array([ref[e] for e in idx[t].tolist()], np.float32), rtol=2e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize("name,I_shared", [("deepseek_v3", 2048), ("deepseek_v2_lite", 2816), ("kimi_k2", 2048), ("deepseek_v2", 3072)])
+@pytest.mark.parametrize("T", [1, 3])
+def test_router_riding_in_the_shared_gate_up_launch(name, I_shared, T):
+    """ktx_linear_forward_fused_gate (decode step of a MoE block: router + the shared experts' merged gate|up GEMV on the same
+    un-normalised row, one launch) against the two separate calls.  With the combined kernel switched off (knob 13) the
+    library issues exactly those two launches: bit-identical.  The combined kernel runs the same device code with 8 router
+    wavefronts per workgroup and possibly another k-slice split of the GEMV, i.e. other fp32 summation orders: the
+    normalised row within one bf16 ulp, identical expert sets, weights and GEMV outputs within rounding noise."""
+    from ktransformers_amd import _native as n
+    cfg = dict(CONFIGS[name])
+    E, H = cfg.pop("E"), cfg.pop("H")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(11 + T)
+    x = torch.randn((T, H), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((E, H), generator=g) * H ** -0.5).to(torch.bfloat16).to(dev)
+    nw = (1 + 0.1 * torch.randn((H,), generator=g)).to(torch.bfloat16).to(dev)
+    bias = (torch.randn((E,), generator=g) * 0.1).to(dev) if cfg["topk_method"] == "noaux_tc" else None
+    wl = (torch.randn((2 * I_shared, H), generator=g) / 10).to(torch.bfloat16).to(dev)
+    gh = n.GateHandle(E, H, cfg["top_k"], cfg["n_group"], cfg["topk_group"], cfg["scoring_func"], cfg["topk_method"],
+                      cfg["norm_topk_prob"], cfg["routed_scaling_factor"])
+    lin = n.LinearHandle(H, 2 * I_shared, "W4", 64, 64, dev)
+    lin.load_bf16(wl)
+    idx0, wt0, xn0 = gh.forward(x, w, bias, norm=(nw, 1e-6))
+    y0 = lin.forward(x, norm=(nw, 1e-6), glu=True)
+    try:
+        n.lib.ktx_debug_set(13, 1)
+        idx1, wt1, xn1, y1 = n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6))
+    finally:
+        n.lib.ktx_debug_set(13, 0)
+    assert torch.equal(idx0, idx1) and torch.equal(wt0, wt1) and torch.equal(xn0, xn1) and torch.equal(y0, y1)
+    for rep in range(3):                                  # replays: the arrival counters must be left at zero
+        idx2, wt2, xn2, y2 = n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6))
+        torch.cuda.synchronize()
+        ulp = (xn2.float() - xn0.float()).abs() <= xn0.float().abs() * 2.0 ** -7 + 1e-30
+        assert bool(ulp.all()), "normalised row differs by more than one bf16 ulp"
+        for t in range(T):
+            assert set(idx2[t].tolist()) == set(idx0[t].tolist()), f"token {t}: routed expert set differs"
+            ref = dict(zip(idx0[t].tolist(), wt0[t].tolist()))
+            for e, v in zip(idx2[t].tolist(), wt2[t].tolist()):
+                assert abs(v - ref[e]) <= 2e-3 * abs(ref[e]) + 1e-9, (t, e, v, ref[e])
+        err = (y2.float() - y0.float()).abs().max().item()
+        assert err <= 2e-2 * y0.float().abs().max().item(), err
