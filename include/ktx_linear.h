@@ -30,10 +30,11 @@ extern "C" {
 #endif
 
 typedef struct ktx_linear_s* ktx_linear_t;
-#ifndef KTX_MOE_H
+#ifndef KTX_STREAM_T_DEFINED
+#define KTX_STREAM_T_DEFINED
 typedef void* ktx_stream_t; /* hipStream_t */
-const char* ktx_last_error(void);
 #endif
+const char* ktx_last_error(void);
 
 enum ktx_linear_format {
   KTX_LIN_BF16 = 0, /* dense bf16 weights (KLinearTorch) */

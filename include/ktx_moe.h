@@ -26,12 +26,16 @@
 #include <stddef.h>
 #include <stdint.h>
 
+#include "ktx_linear.h"
 #ifdef __cplusplus
 extern "C" {
 #endif
 
 typedef struct ktx_moe_s* ktx_moe_t;
+#ifndef KTX_STREAM_T_DEFINED
+#define KTX_STREAM_T_DEFINED
 typedef void* ktx_stream_t; /* hipStream_t */
+#endif
 
 /* weight/arithmetic formats = the reference's `method` names (kt-kernel/python/experts.py:316-360) */
 enum ktx_moe_format {
@@ -122,6 +126,19 @@ enum { KTX_FWD_INCREMENTAL = 1, KTX_FWD_PARTIAL_F32 = 2 };
 int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                        const float* d_weights, const void* d_input, void* d_output, int flags, ktx_stream_t stream);
 
+/* Decode step of a whole MoE block's tail (KDeepseekV3MoE.forward + the decoder layer's residual add,
+ * archive/ktransformers/operators/experts.py:974-1012, models/modeling_deepseek_v3.py:1225):
+ *     y[t] = residual[t] + ( sum_j w[t][j] * Expert_{ids[t][j]}(x[t])  +  side_linear(side_x[t]) )
+ * with the reference's bf16 tensor arithmetic: the routed sum rounded to bf16 as ktx_moe_forward gives it, the side linear's
+ * output rounded to bf16 as ktx_linear_forward gives it, then two bf16 adds.  side_linear: a ktx_linear_t with
+ * out_features == hidden_size — the shared experts' down_proj; side_x: bf16 [qlen][in_features], i.e.
+ * act_fn(gate(x)) * up(x) of the shared experts; d_residual: bf16 [qlen][hidden] or NULL.  For the AMXINT4 / AMXINT8 decode
+ * path and a W4 g64 side linear the down kernel computes the side strip itself (no launch of its own); every other case runs
+ * ktx_moe_forward and ktx_linear_forward_fused (adds in its epilogue) — same result contract, the call never fails for that. */
+int ktx_moe_forward_side(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                         const float* d_weights, const void* d_input, void* d_output, ktx_linear_t side_linear,
+                         const void* d_side_x, const void* d_residual, ktx_stream_t stream);
+
 /* Introspection for tests / bench: bytes of packed expert weights resident in HBM; debug taps (device pointers to
  * the last forward's intermediates in sorted-row order, plus the row of each (t,j) pair). */
 size_t ktx_moe_weight_bytes(ktx_moe_t h);
@@ -148,7 +165,8 @@ int ktx_debug_force_generic(int on);
  * slower than the default register ring; kept for tuning), idx 10 = 1 turns the k-slices of the AMXINT4 decode gate/up kernel
  * off, idx 11 = 1 selects the first (>= 384 workgroups) split rule of the decode GEMV (both A/B switches of
  * scripts/ab_decode.py), idx 12 = strips per wavefront of the prompt-sized W4 GEMM (1 = the one-strip kernel, 2 / 4 forced;
- * 0 auto), idx 13 = 1 makes ktx_linear_forward_fused_gate issue its two launches instead of the combined kernel (A/B, tests). */
+ * 0 auto), idx 13 = 1 makes ktx_linear_forward_fused_gate issue its two launches instead of the combined kernel (A/B, tests),
+ * idx 14 = 1 makes ktx_moe_forward_side run the side linear as a launch of its own (A/B, tests). */
 int ktx_debug_set(int idx, int val);
 int ktx_debug_get(int idx);
 /* Per-launch timing of every kernel of the library (bench.py's per-kernel table; ktx_prof.hip).  mode 1: each launch is

@@ -68,6 +68,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_moe_forward_ex.argtypes = lib.ktx_moe_forward.argtypes
+    lib.ktx_moe_forward_side.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8
     lib.ktx_moe_weight_bytes.argtypes = [C.c_void_p]
     lib.ktx_moe_weight_bytes.restype = C.c_size_t
     lib.ktx_moe_debug_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -348,6 +349,41 @@ class MoEHandle:
             bsz_ptr = bsz_tensor.data_ptr()
         check(lib.ktx_moe_forward(self._h, bsz_ptr, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
                                   out.data_ptr(), 1 if incremental else 0, _stream_ptr(self.device)))
+        return out
+
+    def forward_side(self, x: torch.Tensor, expert_ids: torch.Tensor, weights: torch.Tensor, side: "LinearHandle",
+                     side_x: torch.Tensor, residual: torch.Tensor | None = None, out: torch.Tensor | None = None,
+                     bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
+        """Tail of a MoE block in one call (ktx_moe_forward_side): residual + (routed experts(x) + side(side_x)) with the
+        reference's bf16 tensor adds.  side: the shared experts' down_proj handle (N == hidden), side_x bf16 [T, side.K]."""
+        T, k = expert_ids.shape
+        if x.dtype != torch.bfloat16 or x.shape != (T, self.H) or not x.is_contiguous():
+            raise KtxError(f"forward_side: x must be contiguous bf16 [{T},{self.H}]")
+        if expert_ids.dtype != torch.int64 or not expert_ids.is_contiguous():
+            raise KtxError("forward_side: expert_ids must be contiguous int64 [T,k]")
+        if weights.dtype != torch.float32 or weights.shape != (T, k) or not weights.is_contiguous():
+            raise KtxError("forward_side: weights must be contiguous fp32 [T,k]")
+        if side.N != self.H or side.batch != 1 or side.device != self.device:
+            raise KtxError("forward_side: the side linear must map to hidden_size on the experts' device")
+        if side_x.dtype != torch.bfloat16 or side_x.shape != (T, side.K) or not side_x.is_contiguous():
+            raise KtxError(f"forward_side: side_x must be contiguous bf16 [{T},{side.K}]")
+        if residual is not None and (residual.dtype != torch.bfloat16 or residual.shape != (T, self.H) or not residual.is_contiguous()):
+            raise KtxError(f"forward_side: residual must be contiguous bf16 [{T},{self.H}]")
+        if out is None:
+            out = torch.empty_like(x)
+        elif out.dtype != torch.bfloat16 or out.shape != x.shape or not out.is_contiguous():
+            raise KtxError("forward_side: out must be contiguous bf16 [T,H]")
+        for t in (x, expert_ids, weights, out, side_x) + ((residual,) if residual is not None else ()):
+            if t.device != self.device:
+                raise KtxError(f"forward_side: tensor on {t.device}, handle on {self.device}")
+        bsz_ptr = None
+        if bsz_tensor is not None:
+            if bsz_tensor.dtype != torch.int32 or bsz_tensor.device != self.device:
+                raise KtxError("forward_side: bsz_tensor must be int32 on the handle's device")
+            bsz_ptr = bsz_tensor.data_ptr()
+        check(lib.ktx_moe_forward_side(self._h, bsz_ptr, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
+                                       out.data_ptr(), side._h, side_x.data_ptr(),
+                                       residual.data_ptr() if residual is not None else None, _stream_ptr(self.device)))
         return out
 
     def forward_partial(self, x: torch.Tensor, expert_ids: torch.Tensor, weights: torch.Tensor,

@@ -1,0 +1,19 @@
+// ktx_internal.h — library-internal (C++ linkage, not part of the C ABI) hand-offs between the translation units of
+// libktx_hip.so.
+#ifndef KTX_INTERNAL_H
+#define KTX_INTERNAL_H
+#include <stdint.h>
+
+#include "../../include/ktx_linear.h"
+
+// what another kernel needs to read a dense linear's tiled weights in place (ktx_linear.hip owns the handle)
+struct KtxLinearRaw {
+  const uint8_t* w;    // W tiles [strip][NKS][tile]
+  const void* sc;      // W4: bf16 [strip][NKS][16][128/G]
+  const void* bias;    // bf16 [N] or nullptr
+  int in_features, out_features, NKS, nstrips, format, group_size, batch, device;
+  bool loaded;
+};
+int ktx_linear_raw(ktx_linear_t h, KtxLinearRaw* out);
+
+#endif

@@ -31,6 +31,7 @@
 
 #include "../../include/ktx_gate.h"
 #include "../../include/ktx_linear.h"
+#include "ktx_internal.h"
 
 typedef __bf16 lv8bf __attribute__((ext_vector_type(8)));
 #include "ktx_prep.inc"
@@ -39,6 +40,8 @@ typedef __bf16 lv8bf __attribute__((ext_vector_type(8)));
 extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
 
 namespace {
+
+#include "ktx_w4_step.inc"
 
 constexpr int F_BF16 = KTX_LIN_BF16, F_W4 = KTX_LIN_W4, F_FP8 = KTX_LIN_FP8;
 
@@ -50,19 +53,6 @@ __device__ __forceinline__ lv8bf as_v8bf(const uint4& u) {
 __device__ __forceinline__ long lo64(const uint4& u) { return (long)(((uint64_t)u.y << 32) | u.x); }
 __device__ __forceinline__ long hi64(const uint4& u) { return (long)(((uint64_t)u.w << 32) | u.z); }
 
-// 8 nibbles -> 8 bf16 (128 + q)
-__device__ __forceinline__ uint4 w4_frag(uint32_t P) {
-  return make_uint4((P & 0x000F000Fu) | 0x43004300u, ((P >> 4) & 0x000F000Fu) | 0x43004300u,
-                    ((P >> 8) & 0x000F000Fu) | 0x43004300u, ((P >> 12) & 0x000F000Fu) | 0x43004300u);
-}
-
-__device__ __forceinline__ float sum8_bf16(const uint4& v) {
-  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
-  float s = 0.f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) s += __uint_as_float(d[i] << 16) + __uint_as_float(d[i] & 0xffff0000u);
-  return s;
-}
 __device__ __forceinline__ float amax8_bf16(const uint4& v) {
   const uint32_t d[4] = {v.x, v.y, v.z, v.w};
   float s = 0.f;
@@ -132,17 +122,6 @@ struct Fmt {
   static constexpr int JPG = 4 / GPK;                     // MFMAs per group
 };
 
-template <int GPK>
-__device__ __forceinline__ uint2 load_w4_scales(const bf16_t* p) {
-  if constexpr (GPK == 1) return make_uint2(*p, 0);
-  else if constexpr (GPK == 2) return make_uint2(*reinterpret_cast<const uint32_t*>(p), 0);
-  else return *reinterpret_cast<const uint2*>(p);
-}
-__device__ __forceinline__ float w4_scale(const uint2& s, int gi) {
-  const uint32_t d = gi < 2 ? s.x : s.y;
-  return __uint_as_float((gi & 1) ? (d & 0xffff0000u) : (d << 16));
-}
-
 // one k-step of one strip for one 16-token tile: xb = LDS address of this lane's first activation piece of the step,
 // cs = LDS column stride, aux = this step's group sums (W4) / activation scales (FP8) for the lane's four tokens.
 template <int FMT, int G>
@@ -150,23 +129,7 @@ __device__ __forceinline__ void lin_step(const uint4 (&w)[Fmt<FMT, G>::NQ], cons
                                          const float* aux, int aux_stride, v4f& acc) {
   using F = Fmt<FMT, G>;
   if constexpr (FMT == F_W4) {
-    const uint32_t P[4] = {w[0].x, w[0].y, w[0].z, w[0].w};
-#pragma unroll
-    for (int gi = 0; gi < F::GPK; gi++) {
-      v4f tmp = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-      for (int jj = 0; jj < F::JPG; jj++) {
-        const int j = gi * F::JPG + jj;
-        const uint4 xa = *reinterpret_cast<const uint4*>(xb + j * 4 * cs);
-        tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_v8bf(xa), as_v8bf(w4_frag(P[j])), tmp, 0, 0, 0);
-      }
-      const float4 sx = *reinterpret_cast<const float4*>(aux + gi * aux_stride);
-      const float s = w4_scale(sc, gi);
-      acc[0] = fmaf(s, fmaf(-136.f, sx.x, tmp[0]), acc[0]);
-      acc[1] = fmaf(s, fmaf(-136.f, sx.y, tmp[1]), acc[1]);
-      acc[2] = fmaf(s, fmaf(-136.f, sx.z, tmp[2]), acc[2]);
-      acc[3] = fmaf(s, fmaf(-136.f, sx.w, tmp[3]), acc[3]);
-    }
+    w4_kstep<G>(w[0], sc, xb, cs, aux, aux_stride, acc);
   } else if constexpr (FMT == F_FP8) {
     const uint4 xa0 = *reinterpret_cast<const uint4*>(xb), xa1 = *reinterpret_cast<const uint4*>(xb + cs);
     v4f tmp = {0.f, 0.f, 0.f, 0.f};
@@ -1192,6 +1155,15 @@ int forward_fmt(const ktx_linear_s* h, const LinParams& p, hipStream_t st, const
 }
 
 }  // namespace
+
+int ktx_linear_raw(ktx_linear_t h, KtxLinearRaw* out) {   // ktx_internal.h
+  KTX_REQUIRE(h && out, "ktx_linear_raw: null argument");
+  out->w = h->d_w; out->sc = h->d_sc; out->bias = h->d_bias;
+  out->in_features = h->cfg.in_features; out->out_features = h->cfg.out_features; out->NKS = h->NKS; out->nstrips = h->nstrips;
+  out->format = h->cfg.format; out->group_size = h->cfg.group_size; out->batch = h->batch; out->device = h->cfg.device;
+  out->loaded = h->loaded;
+  return 0;
+}
 
 extern "C" int ktx_linear_debug_force_gemm(int on) {
   g_lin_force_gemm = on != 0;

@@ -36,6 +36,7 @@
 
 #include "../../include/ktx_moe.h"
 #include "ktx_common.h"
+#include "ktx_internal.h"
 
 // =====================================================================================================
 // error slot
@@ -54,29 +55,9 @@ extern "C" const char* ktx_last_error(void) { return ktx_err_slot().c_str(); }
 // device helpers
 // =====================================================================================================
 
-// amx::exp_avx512 (operators/amx/la/amx.hpp:22-45), op for op in fp32 (file is compiled with -ffp-contract=off).
-__device__ __forceinline__ float exp_poly(float x) {
-  const float log2e = 1.44269504089f;
-  float y = x * log2e;
-  float ipf = rintf(y);
-  float frac = y - ipf;
-  float p = fmaf(0.0013333558f, frac, 0.0096181291f);
-  p = fmaf(p, frac, 0.0555041087f);
-  p = fmaf(p, frac, 0.2402265069f);
-  p = fmaf(p, frac, 0.6931471805f);
-  p = fmaf(p, frac, 0.9999999995f);
-  float two_pow_i = ldexpf(1.0f, (int)ipf);
-  return two_pow_i * p;
-}
-
-// amx::act_fn with swiglu_limit == swiglu_alpha == 0 (operators/amx/la/amx.hpp:47-76).
-__device__ __forceinline__ float act_fn(float g, float u) {
-  float neg = 0.0f - g;
-  neg = (neg <= 88.0f) ? neg : 88.0f;
-  float e = exp_poly(neg);
-  float denom = 1.0f + e;
-  float act = g / denom;
-  return act * u;
+#include "ktx_moe_dec.inc"
+namespace ktxw4 {
+#include "ktx_w4_step.inc"
 }
 
 struct Tile {
@@ -277,35 +258,6 @@ struct GemmParams {
   const int32_t* counters;
   bf16_t* out;  // [sorted rows][N]
 };
-
-template <int WBITS>
-struct WFrag {
-  uint4 v[WBITS == 4 ? 1 : 2];
-};
-
-template <int WBITS>
-__device__ __forceinline__ WFrag<WBITS> load_wfrag(const uint8_t* __restrict__ tile_base, int lane) {
-  WFrag<WBITS> f;
-  if constexpr (WBITS == 4) {
-    f.v[0] = *reinterpret_cast<const uint4*>(tile_base + lane * 16);
-  } else {
-    f.v[0] = *reinterpret_cast<const uint4*>(tile_base + lane * 16);
-    f.v[1] = *reinterpret_cast<const uint4*>(tile_base + 1024 + lane * 16);
-  }
-  return f;
-}
-
-template <int WBITS>
-__device__ __forceinline__ void unpack_wfrag(const WFrag<WBITS>& f, v4i& a0, v4i& a1) {
-  if constexpr (WBITS == 4) {
-    const uint32_t m = 0xF0F0F0F0u;
-    a0 = v4i{(int)((f.v[0].x << 4) & m), (int)(f.v[0].x & m), (int)((f.v[0].y << 4) & m), (int)(f.v[0].y & m)};
-    a1 = v4i{(int)((f.v[0].z << 4) & m), (int)(f.v[0].z & m), (int)((f.v[0].w << 4) & m), (int)(f.v[0].w & m)};
-  } else {
-    a0 = v4i{(int)f.v[0].x, (int)f.v[0].y, (int)f.v[0].z, (int)f.v[0].w};
-    a1 = v4i{(int)f.v[1].x, (int)f.v[1].y, (int)f.v[1].z, (int)f.v[1].w};
-  }
-}
 
 template <int WBITS, int MT, int SPC, bool GATE_UP>
 __global__ __launch_bounds__(256) void moe_gemm_kernel(GemmParams p) {
@@ -831,217 +783,10 @@ __global__ __launch_bounds__(512) void moe_gemm_rt_kernel(GemmParams p) {
 //                           and the merge/incremental/bf16 step (a4) happen in-workgroup through LDS.
 // Every column of the 16-wide MFMA B operand carries the same token, so no lane masking is needed.
 // =====================================================================================================
-#define KTX_DEC_MAX_PAIRS 64
-
-struct DecParams {
-  const int32_t* d_bsz;
-  int qlen, k, E, expert_begin, H, I;
-  const int64_t* ids;
-  const uint8_t* mask;
-  const bf16_t* x;
-  const float* weights;
-  const uint8_t *gate_w, *up_w, *down_w;
-  const float *gate_s, *up_s, *down_s;
-  size_t gu_stride, dn_stride;
-  bf16_t* a_buf;  // [qlen*k][I]
-  void* y;        // bf16 [qlen][H] or float when partial_f32
-  int incremental, partial_f32;
-  int ablate;  // dev knob: bit0 = skip the weight stream (timing experiments only)
-};
-
-template <int WBITS>
-__device__ __forceinline__ WFrag<WBITS> load_wfrag_nt(const uint8_t* __restrict__ tile_base, int lane) {
-  WFrag<WBITS> f;
-  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-  const u4v a = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(tile_base + lane * 16));
-  f.v[0] = make_uint4(a.x, a.y, a.z, a.w);
-  if constexpr (WBITS == 8) {
-    const u4v b = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(tile_base + 1024 + lane * 16));
-    f.v[1] = make_uint4(b.x, b.y, b.z, b.w);
-  }
-  return f;
-}
-
-// quantise 8 bf16 (one uint4) with inverse scale id -> 8 int8 packed in a uint2
-__device__ __forceinline__ uint2 quant8(const uint4& v, float id) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-  uint32_t o[2] = {0, 0};
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    const int a = quant_rne_sat8(bf16_to_f32((bf16_t)(w[q] & 0xffffu)) * id);
-    const int b = quant_rne_sat8(bf16_to_f32((bf16_t)(w[q] >> 16)) * id);
-    o[q >> 1] |= ((uint32_t)(a & 0xff) | ((uint32_t)(b & 0xff) << 8)) << ((q & 1) * 16);
-  }
-  return make_uint2(o[0], o[1]);
-}
-__device__ __forceinline__ float amax8(const uint4& v, float m) {
-  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-  for (int q = 0; q < 4; q++) {
-    m = fmaxf(m, fabsf(bf16_to_f32((bf16_t)(w[q] & 0xffffu))));
-    m = fmaxf(m, fabsf(bf16_to_f32((bf16_t)(w[q] >> 16))));
-  }
-  return m;
-}
-
-// One k-step of the decode kernels: unpack one (gate, up) fragment pair and issue the four MFMAs.
-template <int WBITS>
-__device__ __forceinline__ void dec_step2(const WFrag<WBITS>& fg, const WFrag<WBITS>& fu, const v4i& b0, const v4i& b1,
-                                          v4i& accg, v4i& accu) {
-  v4i g0, g1, u0, u1;
-  unpack_wfrag<WBITS>(fg, g0, g1);
-  unpack_wfrag<WBITS>(fu, u0, u1);
-  accg = __builtin_amdgcn_mfma_i32_16x16x64_i8(g0, b0, accg, 0, 0, 0);
-  accu = __builtin_amdgcn_mfma_i32_16x16x64_i8(u0, b0, accu, 0, 0, 0);
-  accg = __builtin_amdgcn_mfma_i32_16x16x64_i8(g1, b1, accg, 0, 0, 0);
-  accu = __builtin_amdgcn_mfma_i32_16x16x64_i8(u1, b1, accu, 0, 0, 0);
-}
-
-// D = ring depth (k-steps in flight per wave).  EXACT: NKS is a multiple of D, so the hot loop is branch-free
-// straight-line code (the guarded variant costs ~2x in the loop: every predicate becomes an exec-mask branch that
-// fences the scheduler, exposing LDS and MFMA latency with one wave per SIMD).
-// KS = k-slices per strip: the workgroup is NW strips x KS slices of K, wave (strip, slice) streams NKS/KS k-steps and the
-// slices' int32 partial sums meet in LDS (exact: integer adds).  Twice the waves per CU means twice the KiB in flight on a
-// CU whose single workgroup otherwise has four waves waiting on one burst each.
 template <int WBITS, int D, int NW, bool EXACT, int KS = 1>
 __global__ __launch_bounds__(NW * KS * 64) void moe_dec_gateup_kernel(DecParams p) {
-  constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
-  constexpr int NWV = NW * KS;
-  static_assert(KS == 1 || EXACT, "k-slices are built for the branch-free variant");
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  uint8_t* xq = smem;                                              // [H + 128]
-  float* s_red = reinterpret_cast<float*>(smem + p.H + 128);       // [NWV]
-  int* s_part = reinterpret_cast<int*>(s_red + NWV);               // KS > 1: [NW][KS-1][8][64] int32 partial sums
-  int T = p.qlen;
-  if (p.d_bsz) T = min(max(*p.d_bsz, 0), p.qlen);
-  const int pair = blockIdx.y, t = pair / p.k;
-  if (t >= T) return;
-  const long long idl = p.ids[pair] - p.expert_begin;
-  if (idl < 0 || idl >= p.E || (p.mask && p.mask[idl])) return;
-  const int e = (int)idl;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform => scalar branches
-  const int sw = wave % NW, slice = wave / NW;
-  const int strip = blockIdx.x * NW + sw;
-  const bool strip_ok = strip * 16 < p.I;
-  const int NKS_ALL = p.H / 128;
-  const int NKS = NKS_ALL / KS;          // k-steps of this wave's slice
-
-  // ---- a6 part 1: this token's activations (issued first: vmcnt retires in order, and x is needed first) ----------
-  const bf16_t* xr = p.x + (size_t)t * p.H;
-  uint4 xv[4];
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int j = tid * 8 + i * NWV * 512;
-    xv[i] = make_uint4(0, 0, 0, 0);
-    if (j < p.H) xv[i] = *reinterpret_cast<const uint4*>(xr + j);
-  }
-  // ---- weight ring: D k-steps of (gate, up) in flight --------------------------------------------------------------
-  const int strip_c = strip_ok ? strip : 0;
-  const uint8_t* wg = p.gate_w + (size_t)e * p.gu_stride + ((size_t)strip_c * NKS_ALL + (size_t)slice * NKS) * TILE_BYTES;
-  const uint8_t* wu = p.up_w + (size_t)e * p.gu_stride + ((size_t)strip_c * NKS_ALL + (size_t)slice * NKS) * TILE_BYTES;
-  WFrag<WBITS> ring[D][2];
-#pragma unroll
-  for (int d = 0; d < D; d++) {
-    if (EXACT || d < NKS) {
-      ring[d][0] = load_wfrag_nt<WBITS>(wg + (size_t)d * TILE_BYTES, lane);
-      ring[d][1] = load_wfrag_nt<WBITS>(wu + (size_t)d * TILE_BYTES, lane);
-    }
-  }
-  const int n0 = strip_c * 16 + (lane >> 4) * 4;
-  const float4 sg = *reinterpret_cast<const float4*>(p.gate_s + (size_t)e * p.I + n0);
-  const float4 su = *reinterpret_cast<const float4*>(p.up_s + (size_t)e * p.I + n0);
-
-  // ---- a6 part 2: per-row int8 quantisation into LDS (amx_buffers.hpp:47-98) ---------------------------------------
-  float amax = 0.0f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) amax = amax8(xv[i], amax);
-  amax = wave_max(amax);
-  if constexpr (NWV > 1) {
-    if (lane == 0) s_red[wave] = amax;
-    __syncthreads();
-    amax = s_red[0];
-#pragma unroll
-    for (int w = 1; w < NWV; w++) amax = fmaxf(amax, s_red[w]);
-  }
-  const float xd = amax / 127.0f;
-  const float xid = xd ? 1.0f / xd : 0.0f;
-#pragma unroll
-  for (int i = 0; i < 4; i++) {
-    const int j = tid * 8 + i * NWV * 512;
-    if (j < p.H) *reinterpret_cast<uint2*>(xq + j) = quant8(xv[i], xid);
-  }
-  __syncthreads();
-  if (KS == 1 && !strip_ok) return;   // (with k-slices every wave stays for the barrier below)
-
-  v4i accg = {0, 0, 0, 0}, accu = {0, 0, 0, 0};
-  const uint8_t* bb = xq + (lane >> 4) * 32 + (size_t)slice * NKS * 128;
-  if constexpr (EXACT) {
-    const int G = NKS / D;
-    for (int g = 0; g < G - 1; g++) {
-      const uint8_t* bg = bb + g * D * 128;
-      const uint8_t* wgn = wg + (size_t)(g + 1) * D * TILE_BYTES;
-      const uint8_t* wun = wu + (size_t)(g + 1) * D * TILE_BYTES;
-#pragma unroll
-      for (int d = 0; d < D; d++) {
-        const v4i b0 = *reinterpret_cast<const v4i*>(bg + d * 128);
-        const v4i b1 = *reinterpret_cast<const v4i*>(bg + d * 128 + 16);
-        dec_step2<WBITS>(ring[d][0], ring[d][1], b0, b1, accg, accu);
-        ring[d][0] = load_wfrag_nt<WBITS>(wgn + (size_t)d * TILE_BYTES, lane);
-        ring[d][1] = load_wfrag_nt<WBITS>(wun + (size_t)d * TILE_BYTES, lane);
-      }
-    }
-    const uint8_t* bg = bb + (G - 1) * D * 128;
-#pragma unroll
-    for (int d = 0; d < D; d++) {
-      const v4i b0 = *reinterpret_cast<const v4i*>(bg + d * 128);
-      const v4i b1 = *reinterpret_cast<const v4i*>(bg + d * 128 + 16);
-      dec_step2<WBITS>(ring[d][0], ring[d][1], b0, b1, accg, accu);
-    }
-  } else {
-    for (int s0 = 0; s0 < NKS; s0 += D) {
-#pragma unroll
-      for (int d = 0; d < D; d++) {
-        const int ks = s0 + d;
-        if (ks < NKS) {
-          const v4i b0 = *reinterpret_cast<const v4i*>(bb + ks * 128);
-          const v4i b1 = *reinterpret_cast<const v4i*>(bb + ks * 128 + 16);
-          dec_step2<WBITS>(ring[d][0], ring[d][1], b0, b1, accg, accu);
-          if (ks + D < NKS) {
-            ring[d][0] = load_wfrag_nt<WBITS>(wg + (size_t)(ks + D) * TILE_BYTES, lane);
-            ring[d][1] = load_wfrag_nt<WBITS>(wu + (size_t)(ks + D) * TILE_BYTES, lane);
-          }
-        }
-      }
-    }
-  }
-  if constexpr (KS > 1) {   // the slices' exact int32 partial sums meet in LDS; slice 0 finishes the strip
-    if (slice > 0) {
-      int* dst = s_part + ((sw * (KS - 1) + slice - 1) * 8) * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < 4; r++) { dst[r * 64] = accg[r]; dst[(4 + r) * 64] = accu[r]; }
-    }
-    __syncthreads();
-    if (slice > 0 || !strip_ok) return;
-#pragma unroll
-    for (int sl = 1; sl < KS; sl++) {
-      const int* src = s_part + ((sw * (KS - 1) + sl - 1) * 8) * 64 + lane;
-#pragma unroll
-      for (int r = 0; r < 4; r++) { accg[r] += src[r * 64]; accu[r] += src[(4 + r) * 64]; }
-    }
-  }
-  if ((lane & 15) == 0) {  // all 16 columns are the same token: column 0 stores
-    const float sgv[4] = {sg.x, sg.y, sg.z, sg.w}, suv[4] = {su.x, su.y, su.z, su.w};
-    bf16_t o[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) {
-      const bf16_t g = f32_to_bf16((xd * sgv[r]) * (float)accg[r]);
-      const bf16_t u = f32_to_bf16((xd * suv[r]) * (float)accu[r]);
-      o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
-    }
-    *reinterpret_cast<uint2*>(p.a_buf + (size_t)pair * p.I + n0) =
-        make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
-  }
+  moe_dec_gateup_body<WBITS, D, NW, EXACT, KS>(p, blockIdx.x, blockIdx.y, smem);
 }
 
 template <int WBITS>
@@ -1052,11 +797,19 @@ __device__ __forceinline__ void dec_step1(const WFrag<WBITS>& f, const v4i& b0, 
   acc1 = __builtin_amdgcn_mfma_i32_16x16x64_i8(a1, b1, acc1, 0, 0, 0);  // are summed (exactly, int32) at the end
 }
 
-template <int WBITS, int D, bool EXACT>
-__global__ __launch_bounds__(512) void moe_dec_down_kernel(DecParams p) {
+// SIDE_G > 0: the workgroup also computes its 16 outputs of a W4 (group SIDE_G) dense linear on side_x — the shared experts'
+// down_proj, which the reference runs beside the routed experts (operators/experts.py:974-1012) — and the block's closing
+// adds ride in the epilogue.  The side strip's k-steps are dealt out to the k wavefronts (ceil(side_nks / k) each, at most
+// SIDE_MAX), their loads issued up front with the routed weight ring; the fp32 partial sums meet in LDS in wavefront order,
+// i.e. the k-slice structure of lin_dec_kernel (ktx_linear.hip) with the same k-step arithmetic (ktx_w4_step.inc).
+// (with the side strip the kernel is held to 128 registers — two workgroups per CU like the plain kernel, which the whole
+// grid of H/16 workgroups needs to be resident at once)
+template <int WBITS, int D, bool EXACT, int SIDE_G = 0, int SIDE_MAX = 2>
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 ? 4 : 1))) void moe_dec_down_kernel(DecParams p) {
   constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // [k][I + 128] int8 activations | [k][16] fp32 down outputs | [k] valid flags | [k] routing weights
+  // | SIDE: [k][16] fp32 side partials | side activations [side_nks * 256 B] | group sums [side_nks * GPK][4] fp32
   const int IP = p.I + 128;
   uint8_t* aq_all = smem;
   float* s_dn = reinterpret_cast<float*>(smem + (size_t)p.k * IP);
@@ -1069,6 +822,40 @@ __global__ __launch_bounds__(512) void moe_dec_down_kernel(DecParams p) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave j = routing slot j
   const int pair = t * p.k + j, strip = blockIdx.x;
+  // ---- side linear, part 1: this wave's weight tiles and scales in flight first; the activation row staged by everyone --------
+  constexpr int SGPK = SIDE_G > 0 ? 128 / SIDE_G : 1;
+  float* s_side = s_wt + p.k;                                                      // [k][16]
+  uint8_t* side_xs = smem + (((size_t)(reinterpret_cast<uint8_t*>(s_side + p.k * 16) - smem) + 15) & ~(size_t)15);
+  float* side_aux = reinterpret_cast<float*>(side_xs + (size_t)p.side_nks * 256);
+  uint4 sw[SIDE_G > 0 ? SIDE_MAX : 1];
+  uint2 ssc[SIDE_G > 0 ? SIDE_MAX : 1];
+  const int spw = SIDE_G > 0 ? (p.side_nks + p.k - 1) / p.k : 0;
+  if constexpr (SIDE_G > 0) {
+    const uint8_t* wp = p.side_w + (size_t)strip * p.side_nks * 1024 + lane * 16;
+    const bf16_t* sp = p.side_sc + ((size_t)strip * p.side_nks * 16 + (lane & 15)) * SGPK;
+#pragma unroll
+    for (int i = 0; i < SIDE_MAX; i++) {
+      const int ks = j * spw + i;
+      if (i < spw && ks < p.side_nks) {
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + (size_t)ks * 1024));
+        sw[i] = make_uint4(v.x, v.y, v.z, v.w);
+        ssc[i] = ktxw4::load_w4_scales<SGPK>(sp + (size_t)ks * 16 * SGPK);
+      }
+    }
+    const int npiece = p.side_nks * 16;   // 8-element pieces of the row (a multiple of 16: whole 16-lane groups take part)
+    for (int idx = tid; idx < npiece; idx += 64 * p.k) {
+      const uint4 v = *reinterpret_cast<const uint4*>(p.side_x + (size_t)t * p.side_nks * 128 + idx * 8);
+      *reinterpret_cast<uint4*>(side_xs + idx * 16) = v;
+      float sm = ktxw4::sum8_bf16(v);
+#pragma unroll
+      for (int o = 1; o < SIDE_G / 8; o <<= 1) sm += __shfl_xor(sm, o, 64);
+      if ((idx & (SIDE_G / 8 - 1)) == 0) {
+        float* ax = side_aux + (idx / (SIDE_G / 8)) * 4;
+        ax[0] = sm; ax[1] = sm; ax[2] = sm; ax[3] = sm;
+      }
+    }
+  }
   const long long idl = p.ids[pair] - p.expert_begin;
   const bool valid = !(idl < 0 || idl >= p.E || (p.mask && p.mask[idl]));
   const int e = valid ? (int)idl : 0;
@@ -1156,6 +943,18 @@ __global__ __launch_bounds__(512) void moe_dec_down_kernel(DecParams p) {
     s_valid[j] = 0;
     s_wt[j] = 0.0f;
   }
+  if constexpr (SIDE_G > 0) {   // ---- side linear, part 2: this wave's k-steps (token slot 0 of the MFMA tile = this token)
+    __syncthreads();            // the staged row and its group sums
+    v4f sacc = {0.f, 0.f, 0.f, 0.f};
+    const uint8_t* xb0 = side_xs + (lane >> 4) * 16;
+#pragma unroll
+    for (int i = 0; i < SIDE_MAX; i++) {
+      const int ks = j * spw + i;
+      if (i < spw && ks < p.side_nks)
+        ktxw4::w4_kstep<SIDE_G>(sw[i], ssc[i], xb0 + (size_t)ks * 256, 16, side_aux + ks * SGPK * 4, 4, sacc);
+    }
+    if (lane < 16) s_side[j * 16 + lane] = sacc[0];
+  }
   __syncthreads();
   if (tid < 16) {  // a12: weighted combine in slot order, then a4
     float acc = 0.0f;
@@ -1167,7 +966,17 @@ __global__ __launch_bounds__(512) void moe_dec_down_kernel(DecParams p) {
     } else {
       bf16_t* yp = reinterpret_cast<bf16_t*>(p.y) + o;
       if (p.incremental) acc = acc + bf16_to_f32(*yp);
-      *yp = f32_to_bf16(acc);
+      bf16_t ob = f32_to_bf16(acc);
+      if constexpr (SIDE_G > 0) {
+        // the k-slices of the side strip in wavefront order; then the adds of the block with torch's bf16 tensor arithmetic as
+        // lin_addends does them (ktx_linear.hip): shared + routed (experts.py:1004-1006), then residual + mlp (modeling_deepseek_v3.py:1225)
+        float sv = 0.f;
+        for (int jj = 0; jj < p.k; jj++) sv += s_side[jj * 16 + tid];
+        const bf16_t sb = f32_to_bf16(sv);
+        ob = f32_to_bf16(bf16_to_f32(ob) + bf16_to_f32(sb));
+        if (p.side_add2) ob = f32_to_bf16(bf16_to_f32(p.side_add2[o]) + bf16_to_f32(ob));
+      }
+      *yp = ob;
     }
   }
 }
@@ -2754,9 +2563,46 @@ extern "C" int ktx_moe_forward(ktx_moe_t h, const int32_t* d_bsz, int qlen, int 
                             incremental ? KTX_FWD_INCREMENTAL : 0, stream);
 }
 
+struct DecSide {   // ktx_moe_forward_side: the dense linear the down kernel carries, and the residual rows
+  KtxLinearRaw lin;
+  const void* x;
+  const void* add2;
+};
+constexpr int KTX_MOE_NOT_FUSED = -2;   // moe_forward_impl with a side linear: this shape has no combined kernel, nothing was launched
+
+static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                            const float* d_weights, const void* d_input, void* d_output, int flags, ktx_stream_t stream,
+                            const DecSide* side);
+
 extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                                   const float* d_weights, const void* d_input, void* d_output, int flags,
                                   ktx_stream_t stream) {
+  return moe_forward_impl(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, stream, nullptr);
+}
+
+extern "C" int ktx_moe_forward_side(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                                    const float* d_weights, const void* d_input, void* d_output, ktx_linear_t side_linear,
+                                    const void* d_side_x, const void* d_residual, ktx_stream_t stream) {
+  KTX_REQUIRE(h && side_linear && d_side_x, "ktx_moe_forward_side: null argument");
+  DecSide sd;
+  if (int rc = ktx_linear_raw(side_linear, &sd.lin)) return rc;
+  KTX_REQUIRE(sd.lin.loaded, "ktx_moe_forward_side: the side linear has no weights loaded");
+  KTX_REQUIRE(sd.lin.out_features == h->cfg.hidden_size && sd.lin.batch == 1 && sd.lin.device == h->cfg.device,
+              "ktx_moe_forward_side: the side linear must produce hidden_size outputs on the experts' device");
+  sd.x = d_side_x; sd.add2 = d_residual;
+  const int rc = moe_forward_impl(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, 0, stream, &sd);
+  if (rc != KTX_MOE_NOT_FUSED) return rc;
+  // no combined kernel for this shape / format: the launches it would have replaced (in-place add: every output element is
+  // read and written by the same thread of the linear's epilogue)
+  if (int rc2 = moe_forward_impl(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, 0, stream, nullptr)) return rc2;
+  ktx_linear_fusion fu{};
+  fu.add1 = d_output; fu.add2 = d_residual;
+  return ktx_linear_forward_fused(side_linear, d_bsz, qlen, d_side_x, d_output, &fu, stream);
+}
+
+static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
+                            const float* d_weights, const void* d_input, void* d_output, int flags, ktx_stream_t stream,
+                            const DecSide* side) {
   const int incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
   KTX_REQUIRE(h, "ktx_moe_forward: null handle");
   KTX_REQUIRE(!((flags & KTX_FWD_PARTIAL_F32) && incremental), "ktx_moe_forward_ex: PARTIAL_F32 excludes INCREMENTAL");
@@ -2777,6 +2623,15 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     dp.gu_stride = h->gu_stride; dp.dn_stride = h->dn_stride; dp.a_buf = ws->a_buf; dp.y = d_output;
     dp.incremental = incremental; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
     dp.ablate = 0;
+    dp.side_w = nullptr; dp.side_sc = nullptr; dp.side_x = nullptr; dp.side_add2 = nullptr; dp.side_nks = 0;
+    if (side) {   // W4 g64 without bias, whole 128-input k-steps, at most SIDE_MAX of them per wavefront
+      if (side->lin.format != KTX_LIN_W4 || side->lin.group_size != 64 || side->lin.bias || side->lin.in_features % 128 != 0 ||
+          side->lin.NKS > 4 * k || g_dbg[14] == 1 ||
+          (h->wbits == 8 && (I / 128) % 8 != 0 && (I / 128) % 11 == 0))   // (that instantiation would spill at 128 registers)
+        return KTX_MOE_NOT_FUSED;
+      dp.side_w = side->lin.w; dp.side_sc = (const bf16_t*)side->lin.sc; dp.side_x = (const bf16_t*)side->x;
+      dp.side_add2 = (const bf16_t*)side->add2; dp.side_nks = side->lin.NKS;
+    }
     // waves per workgroup of the gate/up kernel: with few (pair, strip) work items use small workgroups so every CU
     // gets work; the x-row register cache needs H <= NW*2048.
     const int strips = I / 16;
@@ -2791,7 +2646,8 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     // Kimi-K2: 32 strip groups x 8 pairs = 256 workgroups): knob 10 = 1 turns the split off for A/B timing
     const bool ksplit = h->wbits == 4 && nw == 4 && (H / 128) % 28 == 0 && g1.x * g1.y <= 512 && g_dbg[10] != 1;
     const size_t lds1 = (size_t)H + 128 + 16 + (ksplit ? 8 * sizeof(float) + (size_t)4 * 8 * 64 * sizeof(int) : 4 * sizeof(float));
-    const size_t lds2 = (size_t)k * (I + 128) + (size_t)k * 16 * sizeof(float) + (size_t)k * 2 * sizeof(int);
+    const size_t lds2 = (size_t)k * (I + 128) + (size_t)k * 16 * sizeof(float) + (size_t)k * 2 * sizeof(int) +
+                        (side ? (size_t)k * 16 * sizeof(float) + 16 + (size_t)dp.side_nks * (256 + 2 * 4 * sizeof(float)) : 0);
     KTX_REQUIRE(lds2 <= 160 * 1024, "ktx_moe_forward: k*I too large for the decode path");
     const int nks1 = H / 128, nks2 = I / 128;
     const int only = g_dbg[2];
@@ -2801,13 +2657,19 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
       else if (nw == 2) hipLaunchKernelGGL((moe_dec_gateup_kernel<WB, DD, 2, EX>), g1, dim3(128), lds1, st, dp);    \
       else hipLaunchKernelGGL((moe_dec_gateup_kernel<WB, DD, 4, EX>), g1, dim3(256), lds1, st, dp);                 \
     } while (0)
-#define KTX_LAUNCH_DN(WB, DD, EX)                                                                                   \
+#define KTX_LAUNCH_DN1(WB, DD, EX, SG, SM)                                                                          \
     do {                                                                                                            \
       static std::once_flag once; static hipError_t err = hipSuccess;                                               \
-      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_down_kernel<WB, DD, EX>), \
+      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_down_kernel<WB, DD, EX, SG, SM>), \
                                                            hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
       KTX_HIP(err);                                                                                                 \
-      hipLaunchKernelGGL((moe_dec_down_kernel<WB, DD, EX>), g2, dim3(64 * k), lds2, st, dp);                        \
+      hipLaunchKernelGGL((moe_dec_down_kernel<WB, DD, EX, SG, SM>), g2, dim3(64 * k), lds2, st, dp);                \
+    } while (0)
+#define KTX_LAUNCH_DN(WB, DD, EX)                                                                                   \
+    do {                                                                                                            \
+      if (side && (dp.side_nks + k - 1) / k <= 2) KTX_LAUNCH_DN1(WB, DD, EX, 64, 2);                                \
+      else if (side) KTX_LAUNCH_DN1(WB, DD, EX, 64, 4);                                                             \
+      else KTX_LAUNCH_DN1(WB, DD, EX, 0, 2);                                                                        \
     } while (0)
     const double wb = h->wbits / 8.0;
     if (only != 2) {
@@ -2829,8 +2691,10 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     KTX_HIP(hipGetLastError());
     if (only != 1) {
       ProfScope ps(3, st, false);
-      KTX_TIMED(st, qlen * k * ((double)H * I * wb + H * 4.0 + I * 2.0) + qlen * H * 2.0,
-                "moe_dec_down_kernel<W%d> T=%d k=%d H=%d I=%d", h->wbits, qlen, k, H, I);
+      KTX_TIMED(st, qlen * k * ((double)H * I * wb + H * 4.0 + I * 2.0) + qlen * H * 2.0 +
+                        (side ? (double)H * dp.side_nks * 128 * 0.5625 + qlen * (dp.side_nks * 256.0 + H * 2.0) : 0.0),
+                "moe_dec_down_kernel<W%d> T=%d k=%d H=%d I=%d%s", h->wbits, qlen, k, H, I,
+                side ? ktx_fmt(" + side W4 %d->%d", dp.side_nks * 128, H).c_str() : "");
       if (h->wbits == 4) {
         if (nks2 % 16 == 0) KTX_LAUNCH_DN(4, 16, true);
         else if (nks2 % 14 == 0) KTX_LAUNCH_DN(4, 14, true);
@@ -2845,6 +2709,7 @@ extern "C" int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, i
     KTX_HIP(hipGetLastError());
     return 0;
   }
+  if (side) return KTX_MOE_NOT_FUSED;   // only the AMXINT4 / AMXINT8 decode kernels carry a side linear
   if (h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_BF16)
     return forward_fp(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   if (h->cfg.format == KTX_FMT_RAWINT4)

@@ -162,7 +162,9 @@ class KExpertsHIP(KExpertsBase):
             self.handle.close()
             self.handle = None
 
-    def forward(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0):
+    def forward(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0, side=None):
+        """side = (LinearHandle, side_x [T, K], residual [T, H] | None): an extension of the reference signature — the call
+        returns residual + (experts(x) + side_linear(side_x)), the tail of the whole MoE block (MoEHandle.forward_side)."""
         if self.handle is None:
             raise RuntimeError("KExpertsHIP.forward before load()")
         dev = self.handle.device
@@ -171,6 +173,13 @@ class KExpertsHIP(KExpertsBase):
         w = weights.to(device=dev, dtype=torch.float32).contiguous()
         if x.dim() == 1:
             x, ids, w = x.unsqueeze(0), ids.unsqueeze(0), w.unsqueeze(0)
+        if side is not None:
+            if self._ep is not None:
+                raise RuntimeError("KExpertsHIP.forward(side=...) is a single-GPU path")
+            lin, sx, res = side
+            out = self.handle.forward_side(x, ids, w, lin, sx.reshape(x.shape[0], -1).contiguous(),
+                                           None if res is None else res.reshape(x.shape[0], -1).contiguous(), bsz_tensor=bsz_tensor)
+            return out.to(device=self.out_device if str(self.out_device) != "cuda" else dev)
         if self._ep is not None:
             # decode-sized batches: all-gather + local partial + reduce-scatter; prompts: all-to-all-v dispatch / return
             out = self._ep.forward(x, ids, w) if x.shape[0] <= 16 else self._ep.forward_prefill(x, ids, w)
@@ -180,9 +189,9 @@ class KExpertsHIP(KExpertsBase):
 
     # reference fast path (experts.py:293-318): enqueue on the capturing stream, result later.  On the GPU both halves
     # are stream-ordered launches, so submit runs the forward and sync returns its output buffer.
-    def submit_for_one_decode(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0):
+    def submit_for_one_decode(self, input_tensor, expert_ids, weights, bsz_tensor=None, cuda_graph_idx=0, side=None):
         self._decode_out = self.forward(input_tensor.view(1, -1), expert_ids.view(1, -1), weights.view(1, -1),
-                                        bsz_tensor=bsz_tensor)
+                                        bsz_tensor=bsz_tensor, side=side)
 
     def sync_for_one_decode(self, cuda_graph_idx=0):
         out, self._decode_out = self._decode_out, None
@@ -320,12 +329,35 @@ class _KMoEBlock(BaseInjectedModule):
         gen = getattr(self.experts, "generate_experts", None)
         if (sequence_length == 1 and gen is not None and hasattr(gen, "submit_for_one_decode")
                 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
-            gen.submit_for_one_decode(hidden_states[0], topk_idx[0], topk_weight[0])
+            tail = self._tail_side(shared_act, residual, gen)
+            gen.submit_for_one_decode(hidden_states[0], topk_idx[0], topk_weight[0], **({"side": tail} if tail else {}))
             y = gen.sync_for_one_decode().unsqueeze(0)
-            return self._finish(y, identity, residual, orig_shape, shared_act)
+            return y.view(*orig_shape) if tail else self._finish(y, identity, residual, orig_shape, shared_act)
 
+        ex = self.experts
+        op = getattr(ex, "generate_experts", None) if getattr(ex, "mode", None) == InferenceState.GENERATE else \
+            getattr(ex, "prefill_experts", None)
+        tail = self._tail_side(shared_act, residual, op)
+        if tail:
+            return op.forward(hidden_states, topk_idx, topk_weight, side=tail).view(*orig_shape).to(device=hidden_states.device)
         y = self.moe_kexperts(hidden_states, topk_idx, topk_weight).view(*orig_shape).to(device=hidden_states.device)
         return self._finish(y, identity, residual, orig_shape, shared_act)
+
+    def _tail_side(self, shared_act, residual, experts_op):
+        """(down_proj handle, shared_act, residual) when the routed experts' call can carry the shared experts' down projection and
+        the block's closing adds (KExpertsHIP.forward(side=...)): decode steps whose shared gate|up half already ran beside the
+        router, a single-GPU HBM experts operator, a W4 down_proj onto hidden_size."""
+        if shared_act is None or not isinstance(experts_op, KExpertsHIP) or experts_op._ep is not None \
+                or os.environ.get("KTX_MOE_SEPARATE_SHARED_DOWN"):
+            return None
+        down = getattr(getattr(self.shared_experts, "orig_module", None), "down_proj", None)
+        lin = getattr(down, "generate_linear", None) if getattr(down, "mode", None) == InferenceState.GENERATE else \
+            getattr(down, "prefill_linear", None)
+        h = getattr(lin, "_h", None)
+        if h is None or getattr(h, "fmt", None) != "W4" or h.N != self.config.hidden_size or getattr(lin, "has_bias", False):
+            return None
+        res = None if residual is None else residual.reshape(-1, residual.shape[-1])
+        return (h, shared_act, res)
 
     def _router_side_linear(self, hidden_states, pre_norm):
         """The LinearHandle of the shared experts' merged gate|up operator when this call can use the combined launch: a decode

@@ -30,6 +30,7 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "mla: 4x2 shape, 128 splits": ({6: 4, 7: 128}, {}),
     "mla: separate prep launch": ({}, {"KTX_MLA_SEPARATE_PREP": "1"}),
     "moe: router in its own launch": ({}, {"KTX_MOE_SEPARATE_ROUTER": "1"}),
+    "moe: shared down in its own launch": ({}, {"KTX_MOE_SEPARATE_SHARED_DOWN": "1"}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}

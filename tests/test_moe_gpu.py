@@ -443,3 +443,48 @@ def test_rawint4_against_reference_golden(dev, case):
     finally:
         _native.force_generic_path(False)
         h.close()
+
+
+@pytest.mark.parametrize("method", ["AMXINT4", "AMXINT8"])
+@pytest.mark.parametrize("shape", [
+    (16, 8, 7168, 2048, 2048, 1),   # DeepSeek-V3 / Kimi-K2 layer shape: shared intermediate 2048 -> 2 side k-steps per wavefront
+    (16, 8, 7168, 2048, 2048, 3),
+    (8, 6, 2048, 1408, 2816, 1),    # DeepSeek-V2-Lite: two shared experts (2816 = 22 k-steps over 6 wavefronts, ragged)
+    (8, 6, 2048, 1408, 2816, 4),
+    (8, 2, 512, 256, 384, 5),       # invalid routing ids beside the side strip
+])
+def test_forward_side_equals_the_separate_launches(dev, method, shape):
+    """ktx_moe_forward_side (tail of a MoE block: routed experts + the shared experts' W4 down_proj + the two closing bf16 adds)
+    against ktx_moe_forward followed by ktx_linear_forward_fused(add1 = routed, add2 = residual).  With the combined kernel
+    switched off (knob 14) the library runs exactly those launches: bit-identical.  The combined kernel deals the side strip's
+    k-steps out to the routed wavefronts (k-slices of other lengths than the stand-alone GEMV's, the same k-step arithmetic):
+    the routed part stays bit-exact, the sum agrees within the fp32 re-association of the side GEMV (<= 1 bf16 ulp of the
+    largest operand per element)."""
+    from ktransformers_amd import _native as n
+    E, k, H, I, Ks, T = shape
+    c = make_case(3, E, k, H, I, T, invalid_ids=T >= 5)
+    h = make_handle(method, c, E, k, H, I, 8, dev)
+    g = torch.Generator().manual_seed(E + H + T)
+    wd = (torch.randn((H, Ks), generator=g) / 16).to(torch.bfloat16).to(dev)
+    sx = (torch.randn((T, Ks), generator=g) / 4).to(torch.bfloat16).to(dev)
+    res = torch.randn((T, H), generator=g).to(torch.bfloat16).to(dev)
+    lin = n.LinearHandle(Ks, H, "W4", 64, 8, dev)
+    lin.load_bf16(wd)
+    x, ids, w = torch_bf16(c["x"], dev), torch.from_numpy(c["ids"]).to(dev), torch.from_numpy(c["w"]).to(dev)
+    routed = h.forward(x, ids, w)
+    want = lin.forward(sx, add1=routed, add2=res)
+    want_nores = lin.forward(sx, add1=routed)
+    try:
+        n.lib.ktx_debug_set(14, 1)
+        assert torch.equal(h.forward_side(x, ids, w, lin, sx, res), want)
+        assert torch.equal(h.forward_side(x, ids, w, lin, sx, None), want_nores)
+    finally:
+        n.lib.ktx_debug_set(14, 0)
+    side_only = lin.forward(sx).float()
+    for r, ref in ((res, want), (None, want_nores)):
+        got = h.forward_side(x, ids, w, lin, sx, r)
+        torch.cuda.synchronize()
+        scale = torch.maximum(torch.maximum(routed.float().abs(), side_only.abs()), ref.float().abs())
+        bad = (got.float() - ref.float()).abs() > scale * 2.0 ** -7 + 1e-30
+        assert not bool(bad.any()), f"{int(bad.sum())} of {bad.numel()} outputs differ by more than one bf16 ulp of the operands"
+        assert float((got != ref).float().mean()) < 0.2, "re-association noise should touch a minority of the outputs"
