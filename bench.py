@@ -205,8 +205,11 @@ class GreedyFeedbackStep(torch.nn.Module):
         self.model = model
 
     def forward(self, cur_token, position_ids, past_key_values, cache_position):
-        logits = self.model(cur_token, position_ids, past_key_values, cache_position)
-        nxt = logits[0, -1].argmax(dim=-1).view(1, 1)
+        if hasattr(self.model, "greedy_next_token") and not os.environ.get("KTX_TORCH_ARGMAX"):
+            nxt = self.model.greedy_next_token(cur_token, position_ids, past_key_values, cache_position).view(1, 1)
+        else:
+            logits = self.model(cur_token, position_ids, past_key_values, cache_position)
+            nxt = logits[0, -1].argmax(dim=-1).view(1, 1)
         cur_token.copy_(nxt)
         position_ids.add_(1)
         cache_position.add_(1)

@@ -22,12 +22,11 @@
 extern "C" {
 #endif
 
-#ifndef KTX_MOE_H
-#ifndef KTX_LINEAR_H
+#ifndef KTX_STREAM_T_DEFINED
+#define KTX_STREAM_T_DEFINED
 typedef void* ktx_stream_t; /* hipStream_t */
+#endif
 const char* ktx_last_error(void);
-#endif
-#endif
 
 /* y[t] = w * (x[t] * rsqrt(mean(x[t]^2) + eps)) for t < min(T, *d_bsz) (d_bsz may be NULL).  native_rounding = 1
  * reproduces forward_native's two roundings (bf16(w * bf16(x*r))); 0 rounds once like flashinfer's rmsnorm.
@@ -54,6 +53,14 @@ int ktx_mla_prep(int T, int num_heads, int nope_dim, int rope_dim, int kv_lora, 
                  void* d_q_pe_out, const void* d_kv, int64_t kv_row_stride, const void* d_kv_norm_w, float eps,
                  void* d_ckv_out, void* d_kpe_out, const int64_t* d_pos, const float* d_inv_freq, float mscale,
                  ktx_stream_t stream);
+
+/* Greedy sampling (decode_one_tokens with do_sample = False: torch.argmax over the last position's logits,
+ * archive/ktransformers/util/utils.py:483-494): out[r] = index of the first maximum of row r of x, bf16 [rows][n] with row
+ * stride ldx (elements; every row 16-byte aligned).  Taken on the lm_head's bf16 output directly — the fp32 copy the reference makes first
+ * (logits.float()) is exact and monotonic, so the index is the same.  One launch; d_workspace: ktx_argmax_workspace_bytes(rows)
+ * bytes, zero-initialised once by the caller (the kernel leaves its arrival counters at zero).  NaN logits never win. */
+size_t ktx_argmax_workspace_bytes(int rows);
+int ktx_argmax_bf16(const void* d_x, int64_t ldx, int rows, int n, int64_t* d_out, void* d_workspace, ktx_stream_t stream);
 
 #ifdef __cplusplus
 }

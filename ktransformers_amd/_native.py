@@ -113,6 +113,9 @@ def _load() -> C.CDLL:
                                 C.c_void_p, C.c_void_p]
     lib.ktx_fused_add_rmsnorm.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_void_p]
     lib.ktx_silu_mul.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    lib.ktx_argmax_workspace_bytes.argtypes = [C.c_int]
+    lib.ktx_argmax_workspace_bytes.restype = C.c_size_t
+    lib.ktx_argmax_bf16.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_mla_prep.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
     lib.ktx_profile_enable.argtypes = [C.c_int]
@@ -855,6 +858,31 @@ def silu_mul(gate_up: torch.Tensor, bsz_tensor: torch.Tensor | None = None) -> t
     check(lib.ktx_silu_mul(g2.data_ptr(), g2.stride(0), out.data_ptr(), g2.shape[0], inter,
                            bsz_tensor.data_ptr() if bsz_tensor is not None else None, _stream_ptr(g2.device)))
     return out.reshape(*gate_up.shape[:-1], inter)
+
+
+_ARGMAX_WS: dict = {}
+
+
+def argmax_bf16(logits: torch.Tensor) -> torch.Tensor:
+    """Greedy sampling in one launch: logits bf16 [..., n] (unit inner stride) -> int64 [...] index of each row's first maximum
+    (ktx_argmax_bf16).  The workspace (arrival counters, zeroed once) is kept per device and row count."""
+    _bf16_rows(logits, "argmax_bf16")
+    x = logits.reshape(-1, logits.shape[-1])
+    rows, n = x.shape
+    if x.stride(1) != 1 or (rows > 1 and x.stride(0) % 8 != 0) or x.data_ptr() % 16 != 0:
+        if rows > 1 and n % 8 != 0:                       # pad the rows to 16-byte boundaries
+            xp = torch.full((rows, (n + 7) // 8 * 8), float("-inf"), dtype=torch.bfloat16, device=x.device)
+            xp[:, :n] = x
+            x = xp
+        else:
+            x = x.contiguous()
+    key = (x.device, rows)
+    ws = _ARGMAX_WS.get(key)
+    if ws is None:
+        ws = _ARGMAX_WS[key] = torch.zeros(int(lib.ktx_argmax_workspace_bytes(rows)), dtype=torch.uint8, device=x.device)
+    out = torch.empty((rows,), dtype=torch.int64, device=x.device)
+    check(lib.ktx_argmax_bf16(x.data_ptr(), x.stride(0), rows, n, out.data_ptr(), ws.data_ptr(), _stream_ptr(x.device)))
+    return out.reshape(logits.shape[:-1])
 
 
 def mla_prep(q: torch.Tensor | None, kv: torch.Tensor | None, kv_norm_weight: torch.Tensor | None, eps: float,

@@ -162,6 +162,64 @@ __global__ __launch_bounds__(256) void mla_prep_kernel(PrepParams p) {
               half, pos, p.inv_freq, p.mscale);
 }
 
+
+// ---- greedy sampling: argmax over a row of bf16 logits (first maximum wins, like torch.argmax on the device) -----------------
+// One launch: every workgroup scans a contiguous chunk and hands its (value, index) to the last arriver (arrival ticket,
+// payload through write-through sc1 stores / sc1 loads — the fence-free hand-off of the router, ktx_gate_dev.inc), which
+// reduces the partials and writes the int64 index.  NaNs never win a comparison.
+constexpr int ARGMAX_WGS = 64;
+__device__ __forceinline__ void argmax_pick(float& bv, int& bi, float v, int i) {
+  if (v > bv || (v == bv && i < bi)) { bv = v; bi = i; }
+}
+__global__ __launch_bounds__(256) void argmax_bf16_kernel(const bf16_t* __restrict__ x, long ld, int n, float* __restrict__ pval,
+                                                          int* __restrict__ pidx, int* __restrict__ counters,
+                                                          int64_t* __restrict__ out) {
+  __shared__ float s_v[4];
+  __shared__ int s_i[4];
+  __shared__ int s_last;
+  const int row = blockIdx.y, wg = blockIdx.x, nwg = gridDim.x, tid = threadIdx.x, lane = tid & 63;
+  const bf16_t* xr = x + (size_t)row * ld;
+  const int npiece = n >> 3, per = (npiece + nwg - 1) / nwg;   // whole 16-byte pieces; the last n % 8 elements one by one
+  const int p0 = wg * per, p1 = min(npiece, p0 + per);
+  float bv = -__builtin_inff();
+  int bi = 0x7fffffff;
+  for (int p = p0 + tid; p < p1; p += 256) {
+    const uint4 v = *reinterpret_cast<const uint4*>(xr + (size_t)p * 8);
+    const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      argmax_pick(bv, bi, __uint_as_float(d[q] << 16), p * 8 + 2 * q);
+      argmax_pick(bv, bi, __uint_as_float(d[q] & 0xffff0000u), p * 8 + 2 * q + 1);
+    }
+  }
+  if (wg == nwg - 1 && tid < (n & 7)) argmax_pick(bv, bi, bf16_to_f32(xr[npiece * 8 + tid]), npiece * 8 + tid);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) argmax_pick(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
+  if (lane == 0) { s_v[tid >> 6] = bv; s_i[tid >> 6] = bi; }
+  __syncthreads();
+  if (tid == 0) {
+    for (int w = 1; w < 4; w++) argmax_pick(bv, bi, s_v[w], s_i[w]);
+    __hip_atomic_store(&pval[row * ARGMAX_WGS + wg], bv, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(&pidx[row * ARGMAX_WGS + wg], bi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const int ticket = __hip_atomic_fetch_add(&counters[row], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int last = ticket == nwg - 1;
+    if (last) __hip_atomic_store(&counters[row], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ready for the next launch
+    s_last = last;
+  }
+  __syncthreads();
+  if (!s_last || tid >= 64) return;
+  bv = -__builtin_inff();
+  bi = 0x7fffffff;
+  if (lane < nwg) {
+    bv = __hip_atomic_load(&pval[row * ARGMAX_WGS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    bi = __hip_atomic_load(&pidx[row * ARGMAX_WGS + lane], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) argmax_pick(bv, bi, __shfl_xor(bv, o, 64), __shfl_xor(bi, o, 64));
+  if (lane == 0) out[row] = bi == 0x7fffffff ? 0 : bi;
+}
+
 }  // namespace
 
 extern "C" int ktx_rmsnorm(const void* d_x, int64_t ldx, const void* d_w, void* d_y, int64_t ldy, int T, int dim, float eps,
@@ -201,6 +259,25 @@ extern "C" int ktx_silu_mul(const void* d_gu, int64_t ldg, void* d_y, int T, int
   KTX_TIMED((hipStream_t)stream, (double)T * inter * 6.0, "silu_mul_kernel T=%d I=%d", T, inter);
   hipLaunchKernelGGL(silu_mul_kernel, dim3((inter / 8 + 255) / 256, T), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)d_gu, (long)ldg, (bf16_t*)d_y, T, inter, d_bsz);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" size_t ktx_argmax_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * (2 * ARGMAX_WGS + 1) * 4; }
+
+extern "C" int ktx_argmax_bf16(const void* d_x, int64_t ldx, int rows, int n, int64_t* d_out, void* d_workspace,
+                               ktx_stream_t stream) {
+  KTX_REQUIRE(d_x && d_out && d_workspace, "ktx_argmax_bf16: null argument");
+  KTX_REQUIRE(n > 0 && ldx >= n && (rows == 1 || ldx % 8 == 0) && ((uintptr_t)d_x & 15) == 0,
+              "ktx_argmax_bf16: rows must start on 16-byte boundaries (ldx % 8 == 0, ldx >= n)");
+  if (rows <= 0) return 0;
+  float* pval = (float*)d_workspace;
+  int* pidx = (int*)(pval + (size_t)rows * ARGMAX_WGS);
+  int* counters = pidx + (size_t)rows * ARGMAX_WGS;
+  const int nwg = std::min(ARGMAX_WGS, std::max(1, (n / 8 + 255) / 256));
+  KTX_TIMED((hipStream_t)stream, (double)rows * n * 2.0, "argmax_bf16_kernel T=%d n=%d", rows, n);
+  hipLaunchKernelGGL(argmax_bf16_kernel, dim3(nwg, rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)d_x, (long)ldx, n,
+                     pval, pidx, counters, d_out);
   KTX_HIP(hipGetLastError());
   return 0;
 }

@@ -199,6 +199,18 @@ class DeepseekForCausalLM(nn.Module):
             h = h[:, -1:, :]
         return self.lm_head(h).float()
 
+    def greedy_next_token(self, input_ids=None, position_ids=None, past_key_values=None, cache_position=None):
+        """forward(...)[:, -1].argmax(-1) — decode_one_tokens with do_sample = False (archive/ktransformers/util/utils.py:483-494)
+        — with the argmax taken on the lm_head's bf16 output by one HIP launch (ktx_argmax_bf16): the fp32 copy of the logits that
+        forward() returns is exact and monotonic, so the token is the same.  Returns int64 [batch]."""
+        from ktransformers_amd._native import argmax_bf16
+
+        h = self.model(input_ids, position_ids, past_key_values, cache_position)[:, -1, :]
+        logits = self.lm_head(h)
+        if logits.dtype != torch.bfloat16 or not logits.is_cuda:
+            return logits.float().argmax(dim=-1)
+        return argmax_bf16(logits)
+
 
 # the reference's rule files match on these class paths
 DeepseekV2RMSNorm = DeepseekV3RMSNorm = DeepseekRMSNorm

@@ -75,6 +75,12 @@ def test_prompt_logits_and_greedy_tokens_match_reference(model_and_gold):
             p = torch.tensor([[t]], device="cuda")
             outs.append(model(ids[:, t:t + 1], p, cache, p[0])[0, 0].cpu())
     dec = torch.stack(outs)
+    # greedy_next_token (lm_head -> one-launch argmax on the bf16 logits) picks forward()'s argmax
+    cache.reset()
+    with torch.no_grad():
+        for t in range(T):
+            p = torch.tensor([[t]], device="cuda")
+            assert int(model.greedy_next_token(ids[:, t:t + 1], p, cache, p[0])[0]) == int(dec[t].argmax())
     assert float((dec - ref).norm() / ref.norm()) < 2e-2
     assert float((dec - logits).norm() / logits.norm()) < 1.5e-2
     assert torch.equal(dec.argmax(-1)[clear], ref.argmax(-1)[clear])

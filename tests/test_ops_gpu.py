@@ -72,3 +72,24 @@ def test_silu_mul():
     y = n.silu_mul(gu.cuda())
     ref = torch.nn.functional.silu(gu[:, :1408]) * gu[:, 1408:]
     ulp_close(y, ref)
+
+
+@pytest.mark.parametrize("rows,n", [(1, 129280), (1, 102400), (3, 4096), (1, 100), (2, 24)])
+def test_argmax_bf16_first_maximum(rows, n):
+    """ktx_argmax_bf16 (greedy sampling in one launch) == torch.argmax on the fp32 copy of the logits, ties included (the first
+    maximum wins), replay-safe (the arrival counters return to zero)."""
+    torch.manual_seed(rows * 1000 + n)
+    x = torch.randn((rows, n), device="cuda").to(torch.bfloat16)
+    for rep in range(3):
+        got = n_native().argmax_bf16(x)
+        assert torch.equal(got, x.float().argmax(dim=-1)), rep
+    t = torch.zeros((rows, n), device="cuda", dtype=torch.bfloat16)          # many exact ties: the lowest index among the maxima
+    for r in range(rows):
+        t[r, torch.tensor([n - 1, n // 2, min(n - 1, 7 + r)], device="cuda")] = 3.0
+    assert torch.equal(n_native().argmax_bf16(t), t.float().argmax(dim=-1))
+    assert n_native().argmax_bf16(x[0]).shape == ()
+
+
+def n_native():
+    from ktransformers_amd import _native
+    return _native
