@@ -131,6 +131,22 @@ size_t ktx_linear_weight_bytes(ktx_linear_t h);
 /* tests only: read back the quantiser's result in the layout of ktx_linear_load_w4 (HOST pointers). */
 int ktx_linear_debug_get_w4(ktx_linear_t h, uint8_t* q, uint16_t* s);
 
+/* q_b_proj(q_a_layernorm(q_a)) -> [ q-absorb products of the heads' q_nope | RoPE of the heads' q_pe ], plus the kv half of
+ * ktx_mla_prep, in ONE launch for a decode step (T <= 4): everything between the merged q_a|kv_a projection and the MLA kernel
+ * (archive/ktransformers/operators/attention.py:360-418: q_b_proj, q_a_layernorm, torch.matmul(q_nope, q_absorb), rotary).
+ * One workgroup per head streams the head's q_b rows (W4) and its W_UK block (BF16 batched handle) — both requested up front —
+ * so the two GEMVs share one memory round trip instead of being two dependent launches.  Arithmetic and roundings are those
+ * of ktx_linear_forward_fused(q_b, norm) / ktx_linear_forward_batched(q_absorb) / ktx_mla_prep.  d_kv may be NULL (no kv half).
+ * Ask ktx_linear_qb_absorb_eligible first: the combined kernel exists for W4 g64 q_b with q_lora_rank 1536, nope 128,
+ * rope <= 64, kv_lora 512 (DeepSeek-V3 / R1, Kimi-K2, DeepSeek-V2); everything else keeps the separate calls. */
+int ktx_linear_qb_absorb_eligible(ktx_linear_t q_b, ktx_linear_t q_absorb, int T, int num_heads, int nope_dim, int rope_dim,
+                                  int kv_lora);
+int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_absorb, int T, const void* d_q_a, int64_t q_a_row_stride,
+                                 const void* d_q_a_norm_w, float q_a_norm_eps, int num_heads, int nope_dim, int rope_dim,
+                                 int kv_lora, void* d_q_nope_out, void* d_q_pe_out, const void* d_kv, int64_t kv_row_stride,
+                                 const void* d_kv_norm_w, float kv_norm_eps, void* d_ckv_out, void* d_kpe_out,
+                                 const int64_t* d_pos, const float* d_inv_freq, float mscale, ktx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

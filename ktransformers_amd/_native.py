@@ -103,6 +103,10 @@ def _load() -> C.CDLL:
     lib.ktx_linear_forward_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
                                              C.c_void_p]
     lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
+    lib.ktx_linear_qb_absorb_eligible.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
+    lib.ktx_linear_forward_qb_absorb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_float] + \
+        [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
+                         C.c_void_p, C.c_float, C.c_void_p]
     lib.ktx_linear_forward_fused_gate.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
                                                   C.POINTER(_GateConfig)] + [C.c_void_p] * 8
     lib.ktx_linear_weight_bytes.argtypes = [C.c_void_p]
@@ -594,6 +598,38 @@ def absorb_and_prep(qabs: "LinearHandle", q: torch.Tensor, kv: torch.Tensor, kv_
                                               q.data_ptr(), q.stride(0), q_pe.data_ptr(), kv.data_ptr(), kv.stride(0),
                                               kv_norm_weight.data_ptr(), float(eps), ckv.data_ptr(), kpe.data_ptr(),
                                               positions.data_ptr(), inv_freq.data_ptr(), float(mscale), _stream_ptr(dev)))
+    return q_nope, q_pe, ckv, kpe
+
+
+def qb_absorb_eligible(q_b: "LinearHandle", qabs: "LinearHandle", T: int, num_heads: int, nope_dim: int, rope_dim: int,
+                       kv_lora: int) -> bool:
+    return bool(lib.ktx_linear_qb_absorb_eligible(q_b._h, qabs._h, int(T), num_heads, nope_dim, rope_dim, kv_lora))
+
+
+def qb_absorb_and_prep(q_b: "LinearHandle", qabs: "LinearHandle", q_a: torch.Tensor, q_a_norm: tuple, kv: torch.Tensor,
+                       kv_norm_weight: torch.Tensor, eps: float, positions: torch.Tensor, inv_freq: torch.Tensor, mscale: float,
+                       num_heads: int, nope_dim: int, rope_dim: int, kv_lora: int):
+    """Decode step (T <= 4), one launch (ktx_linear_forward_qb_absorb): q_b_proj(q_a_layernorm(q_a)) per head, the q-absorb
+    products of its nope part, RoPE of its rope part, and the kv half of mla_prep.  q_a: bf16 [T, q_lora] (unit inner stride,
+    any 16-byte aligned row stride), kv: bf16 [T, kv_lora + rope].  Returns (q_nope [T,H,lora], q_pe [T,H,rope], ckv, k_pe)."""
+    T, dev = positions.numel(), positions.device
+    _bf16_rows(q_a, "qb_absorb_and_prep q_a")
+    _bf16_rows(kv, "qb_absorb_and_prep kv")
+    q_a = q_a.reshape(T, -1)
+    kv = kv.reshape(T, -1)
+    if q_a.stride(1) != 1 or kv.stride(1) != 1 or q_a.shape[1] != q_b.K:
+        raise KtxError("qb_absorb_and_prep: q_a must be [T, q_lora] with unit inner stride")
+    if positions.dtype != torch.int64 or inv_freq.dtype != torch.float32:
+        raise KtxError("qb_absorb_and_prep: positions must be int64 and inv_freq fp32")
+    nw, neps = q_a_norm
+    q_nope = torch.empty((T, num_heads, kv_lora), dtype=torch.bfloat16, device=dev)
+    q_pe = torch.empty((T, num_heads, rope_dim), dtype=torch.bfloat16, device=dev)
+    ckv = torch.empty((T, kv_lora), dtype=torch.bfloat16, device=dev)
+    kpe = torch.empty((T, rope_dim), dtype=torch.bfloat16, device=dev)
+    check(lib.ktx_linear_forward_qb_absorb(q_b._h, qabs._h, T, q_a.data_ptr(), q_a.stride(0), nw.data_ptr(), float(neps), num_heads,
+                                           nope_dim, rope_dim, kv_lora, q_nope.data_ptr(), q_pe.data_ptr(), kv.data_ptr(),
+                                           kv.stride(0), kv_norm_weight.data_ptr(), float(eps), ckv.data_ptr(), kpe.data_ptr(),
+                                           positions.data_ptr(), inv_freq.data_ptr(), float(mscale), _stream_ptr(dev)))
     return q_nope, q_pe, ckv, kpe
 
 

@@ -494,6 +494,202 @@ __global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs
 }
 
 // =====================================================================================================
+// q_b_proj + q-absorb of an MLA decode step in ONE launch (ktx_linear_forward_qb_absorb): one workgroup per head.
+//   phase 1: the head's (nope + rope) rows of q_b_proj(q_a_layernorm(q_a))   — W4, the arithmetic of lin_dec_kernel with the
+//            fused RMSNorm: strips x two k-halves dealt to the 8 wavefronts, halves summed in order;
+//   RoPE of the head's q_pe (mla_prep's arithmetic, ktx_prep.inc) -> q_pe_out;
+//   phase 2: q_nope_abs[h] = W_UK[h]^T q_nope[h]                              — BF16 batched linear, one 128-wide k-step.
+// Both weight streams (~300 KB per head) are requested before anything else: they depend on nothing but the head index, so
+// the two GEMVs that used to be two dependent launches share one memory round trip.  Block 0 (prep_on): the kv half of
+// mla_prep (latent RMSNorm + k_pe RoPE) for every token, as in lin_dec_kernel's prep row.
+// =====================================================================================================
+struct QbAbsorbParams {
+  const uint8_t* w1; const bf16_t* sc1; int NKS1, SPH;          // q_b: strips per head = (nope + rope) / 16
+  const uint8_t* w2; size_t wbs2;                                // absorb: [head][lora/16 strips][4 KiB]
+  const bf16_t* x; long ldx; int Kx;                             // q_a rows
+  const bf16_t* norm_w; float eps;
+  int T, H, nope, rope, lora;
+  bf16_t *q_nope, *q_pe;                                          // [T][H][lora], [T][H][rope]
+  const int64_t* pos; const float* inv_freq; float mscale;
+  int prep_on; MlaPrepParams prep;
+};
+
+template <int G, int NK2>   // NK2 = k-steps per k-half of q_b (q_lora / 256)
+__global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
+  using F1 = Fmt<F_W4, G>;
+  constexpr int TP = 4, CS = TP * 16, UPW = 3, S2W = 4;   // units (strip, k-half) per wave; absorb strips per wave
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (p.prep_on && blockIdx.x == 0) {
+    float* s_cs = reinterpret_cast<float*>(smem);
+    for (int t = 0; t < p.prep.T; t++) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
+    return;
+  }
+  const int h = blockIdx.x - (p.prep_on ? 1 : 0);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int NKS1 = 2 * NK2, npiece = NKS1 * 16, QW = p.nope + p.rope;
+  uint8_t* xs = smem;                                                              // [npiece][TP][16 B]
+  float* aux = reinterpret_cast<float*>(xs + (size_t)npiece * CS);                 // [NKS1 * GPK][4]
+  float* nred = aux + NKS1 * F1::GPK * 4;                                          // [8][4]
+  float* red1 = nred + 32;                                                         // [SPH][2][4][16]
+  float* s_cs = red1 + p.SPH * 2 * 4 * 16;                                         // [TP][rope]
+  bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + TP * p.rope);                      // [TP][QW]
+  uint8_t* xs2 = reinterpret_cast<uint8_t*>(qh + TP * QW);                         // [nope / 8][TP][16 B]
+
+  // ---- every weight byte this workgroup will need, requested now ------------------------------------------------------
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  uint4 w1r[UPW][NK2];
+  uint2 s1r[UPW][NK2];
+#pragma unroll
+  for (int i = 0; i < UPW; i++) {
+    const int u = wave * UPW + i, sih = min(u >> 1, p.SPH - 1), kh = u & 1;   // a surplus unit re-reads the last strip, stores nothing
+    const size_t strip = (size_t)h * p.SPH + sih;
+    const uint8_t* wp = p.w1 + (strip * NKS1 + (size_t)kh * NK2) * 1024 + lane * 16;
+    const bf16_t* sp = p.sc1 + ((strip * NKS1 + (size_t)kh * NK2) * 16 + (lane & 15)) * F1::GPK;
+#pragma unroll
+    for (int s_ = 0; s_ < NK2; s_++) {
+      const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + (size_t)s_ * 1024));
+      w1r[i][s_] = make_uint4(v.x, v.y, v.z, v.w);
+      s1r[i][s_] = load_w4_scales<F1::GPK>(sp + (size_t)s_ * 16 * F1::GPK);
+    }
+  }
+  uint4 w2r[S2W][4];
+#pragma unroll
+  for (int i = 0; i < S2W; i++) {
+    const uint8_t* wp = p.w2 + (size_t)h * p.wbs2 + (size_t)(wave * S2W + i) * 4096 + lane * 16;
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+      const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + q * 1024));
+      w2r[i][q] = make_uint4(v.x, v.y, v.z, v.w);
+    }
+  }
+
+  // ---- the q_a rows: RMSNorm (q_a_layernorm) and staging exactly as lin_dec_kernel does them ---------------------------
+  const int ntot = TP * npiece;
+  constexpr int XPRE = 2;   // ntot <= 1024 (q_lora <= 2048)
+  uint4 xpre[XPRE];
+#pragma unroll
+  for (int i = 0; i < XPRE; i++) {
+    const int idx = tid + i * 512;
+    xpre[i] = make_uint4(0, 0, 0, 0);
+    if (idx < ntot) {
+      const int tok = idx / npiece, col = idx - tok * npiece;
+      if (tok < p.T && col * 8 < p.Kx) xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
+    }
+  }
+  if (tid < TP * (p.rope >> 1)) {   // cos / sin of the tokens' positions (mla_prep's table)
+    const int tok = tid / (p.rope >> 1), i = tid - tok * (p.rope >> 1);
+    if (tok < p.T) {
+      const float fr = (float)p.pos[tok] * p.inv_freq[i];
+      s_cs[tok * p.rope + i] = prep_rbf(cosf(fr) * p.mscale);
+      s_cs[tok * p.rope + (p.rope >> 1) + i] = prep_rbf(sinf(fr) * p.mscale);
+    }
+  }
+  float ss[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < XPRE; i++) {
+    const int tok = (tid + i * 512) / npiece;
+    const uint32_t d[4] = {xpre[i].x, xpre[i].y, xpre[i].z, xpre[i].w};
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const float a = __uint_as_float(d[j] << 16), b = __uint_as_float(d[j] & 0xffff0000u);
+      q += a * a + b * b;
+    }
+#pragma unroll
+    for (int t4 = 0; t4 < 4; t4++) ss[t4] += tok == t4 ? q : 0.f;
+  }
+#pragma unroll
+  for (int t4 = 0; t4 < 4; t4++) {
+    const float w = wave_sum(ss[t4]);
+    if (lane == 0) nred[wave * 4 + t4] = w;
+  }
+  __syncthreads();
+  float rnorm[4];
+#pragma unroll
+  for (int t4 = 0; t4 < 4; t4++) {
+    float tot = 0.f;
+    for (int w = 0; w < 8; w++) tot += nred[w * 4 + t4];
+    rnorm[t4] = 1.0f / sqrtf(tot / (float)p.Kx + p.eps);
+  }
+#pragma unroll
+  for (int i = 0; i < XPRE; i++) {
+    const int idx = tid + i * 512;
+    if (idx < ntot) {   // (ntot is a multiple of 16: whole 16-lane groups take part in the shuffles)
+      const int tok = idx / npiece, col = idx - tok * npiece;
+      uint4 v = xpre[i];
+      if (tok < p.T && col * 8 < p.Kx)
+        v = lin_norm8(v, tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3], p.norm_w + col * 8);
+      *reinterpret_cast<uint4*>(xs + col * CS + tok * 16) = v;
+      float sm = sum8_bf16(v);
+#pragma unroll
+      for (int o = 1; o < G / 8; o <<= 1) sm += __shfl_xor(sm, o, 64);
+      if ((col & (G / 8 - 1)) == 0) aux[(col / (G / 8)) * 4 + tok] = sm;
+    }
+  }
+  __syncthreads();
+
+  // ---- phase 1: q_b rows of this head ------------------------------------------------------------------------------------
+  const int kc = lane >> 4, tokp = (lane & 15) & (TP - 1);
+  {
+    const uint8_t* xb0 = xs + tokp * 16 + kc * CS;
+#pragma unroll
+    for (int i = 0; i < UPW; i++) {
+      const int u = wave * UPW + i, sih = u >> 1, kh = u & 1;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int s_ = 0; s_ < NK2; s_++) {
+        const int ks = kh * NK2 + s_;
+        w4_kstep<G>(w1r[i][s_], s1r[i][s_], xb0 + (size_t)ks * 16 * CS, CS, aux + ks * F1::GPK * 4, 4, acc);
+      }
+      if (lane < 16 && sih < p.SPH) {
+#pragma unroll
+        for (int r = 0; r < 4; r++) red1[((sih * 2 + kh) * 4 + r) * 16 + lane] = acc[r];
+      }
+    }
+  }
+  __syncthreads();
+  for (int idx = tid; idx < TP * QW; idx += 512) {   // the k-halves in order, one bf16 rounding (lin_dec_kernel's epilogue)
+    const int r = idx / QW, n = idx - r * QW, sih = n >> 4, f = n & 15;
+    float v = 0.f;
+    v += red1[((sih * 2 + 0) * 4 + r) * 16 + f];
+    v += red1[((sih * 2 + 1) * 4 + r) * 16 + f];
+    qh[r * QW + n] = f32_to_bf16(v);
+  }
+  __syncthreads();
+  // ---- RoPE of q_pe (global), staging of q_nope for the absorb product (LDS) ------------------------------------------------
+  {
+    const int half = p.rope >> 1;
+    for (int idx = tid; idx < p.T * half; idx += 512) {
+      const int tok = idx / half, i = idx - tok * half;
+      prep_rope_pair(qh + tok * QW + p.nope, p.q_pe + ((size_t)tok * p.H + h) * p.rope, i, half, s_cs[tok * p.rope + i],
+                     s_cs[tok * p.rope + half + i]);
+    }
+    const int np2 = p.nope >> 3;
+    for (int idx = tid; idx < TP * np2; idx += 512) {
+      const int tok = idx / np2, col = idx - tok * np2;
+      *reinterpret_cast<uint4*>(xs2 + col * CS + tok * 16) = *reinterpret_cast<const uint4*>(qh + tok * QW + col * 8);
+    }
+  }
+  __syncthreads();
+  // ---- phase 2: the absorb product, one k-step of 128 -----------------------------------------------------------------------
+  {
+    const uint8_t* xb0 = xs2 + tokp * 16 + kc * 4 * CS;
+#pragma unroll
+    for (int i = 0; i < S2W; i++) {
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+      lin_step<F_BF16, 128>(w2r[i], make_uint2(0, 0), xb0, CS, nullptr, 4, acc);
+      if (lane < 16) {
+        const int n = (wave * S2W + i) * 16 + lane;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+          if (r < p.T) p.q_nope[((size_t)r * p.H + h) * p.lora + n] = f32_to_bf16(0.f + acc[r]);
+      }
+    }
+  }
+}
+
+// =====================================================================================================
 // General kernel: token tiles of 16*MT rows (grid.y) x groups of 4 strips (grid.x, one per wavefront); weights are
 // prefetched one 256-k chunk ahead in registers, activations double-buffered in LDS as [column][token][16 B]
 // (column stride padded by 16 B so the staging stores of 16 lanes = 16 columns hit 16 different banks).
@@ -1397,6 +1593,62 @@ extern "C" int ktx_linear_forward_batched_prep(ktx_linear_t h, int T, const void
   pp.kv = (const bf16_t*)d_kv; pp.kv_rs = kv_row_stride; pp.nw = (const bf16_t*)d_kv_norm_w; pp.eps = eps;
   pp.ckv = (bf16_t*)d_ckv_out; pp.kpe = (bf16_t*)d_kpe_out; pp.pos = d_pos; pp.inv_freq = d_inv_freq; pp.mscale = mscale;
   return linear_forward_impl(h, nullptr, T, d_x, ldx, x_batch_stride, d_y, ldy, y_batch_stride, stream, nullptr, &pp);
+}
+
+static bool qb_absorb_ok(const ktx_linear_s* qb, const ktx_linear_s* ab, int T, int H, int nope, int rope, int lora) {
+  return qb && ab && qb->loaded && ab->loaded && T >= 1 && T <= 4 && !g_lin_force_gemm && ktx_debug_get(15) != 1 &&
+         qb->cfg.format == KTX_LIN_W4 && qb->cfg.group_size == 64 && qb->batch == 1 && !qb->d_bias &&
+         qb->cfg.in_features == 1536 &&                                     // NK2 = 6 is the instantiated k-half
+         qb->cfg.out_features == H * (nope + rope) && nope % 16 == 0 && rope % 16 == 0 && (nope + rope) / 16 <= 12 &&
+         rope % 2 == 0 && rope <= 64 && 4 * (rope / 2) <= 512 &&
+         ab->cfg.format == KTX_LIN_BF16 && ab->batch == H && !ab->d_bias && ab->cfg.in_features == nope && nope == 128 &&
+         ab->cfg.out_features == lora && lora == 512 && ab->cfg.device == qb->cfg.device;
+}
+
+extern "C" int ktx_linear_qb_absorb_eligible(ktx_linear_t q_b, ktx_linear_t q_absorb, int T, int num_heads, int nope_dim,
+                                             int rope_dim, int kv_lora) {
+  return qb_absorb_ok(q_b, q_absorb, T, num_heads, nope_dim, rope_dim, kv_lora) ? 1 : 0;
+}
+
+extern "C" int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_absorb, int T, const void* d_q_a, int64_t q_a_row_stride,
+                                            const void* d_q_a_norm_w, float q_a_norm_eps, int num_heads, int nope_dim, int rope_dim,
+                                            int kv_lora, void* d_q_nope_out, void* d_q_pe_out, const void* d_kv,
+                                            int64_t kv_row_stride, const void* d_kv_norm_w, float kv_norm_eps, void* d_ckv_out,
+                                            void* d_kpe_out, const int64_t* d_pos, const float* d_inv_freq, float mscale,
+                                            ktx_stream_t stream) {
+  KTX_REQUIRE(q_b && q_absorb && d_q_a && d_q_a_norm_w && d_q_nope_out && d_q_pe_out && d_pos && d_inv_freq,
+              "ktx_linear_forward_qb_absorb: null argument");
+  KTX_REQUIRE(qb_absorb_ok(q_b, q_absorb, T, num_heads, nope_dim, rope_dim, kv_lora),
+              "ktx_linear_forward_qb_absorb: no combined kernel for these operators (ask ktx_linear_qb_absorb_eligible first)");
+  KTX_REQUIRE(q_a_row_stride % 8 == 0, "ktx_linear_forward_qb_absorb: q_a rows must start on 16-byte boundaries");
+  KTX_REQUIRE(!d_kv || (d_kv_norm_w && d_ckv_out && d_kpe_out && kv_lora % 8 == 0 && kv_lora <= 4096 && kv_row_stride % 8 == 0),
+              "ktx_linear_forward_qb_absorb: the kv half needs its norm weight, both outputs and 16-byte aligned rows");
+  QbAbsorbParams p{};
+  p.w1 = q_b->d_w; p.sc1 = (const bf16_t*)q_b->d_sc; p.NKS1 = q_b->NKS; p.SPH = (nope_dim + rope_dim) / 16;
+  p.w2 = q_absorb->d_w; p.wbs2 = q_absorb->w_bytes / q_absorb->batch;
+  p.x = (const bf16_t*)d_q_a; p.ldx = (long)q_a_row_stride; p.Kx = q_b->cfg.in_features;
+  p.norm_w = (const bf16_t*)d_q_a_norm_w; p.eps = q_a_norm_eps;
+  p.T = T; p.H = num_heads; p.nope = nope_dim; p.rope = rope_dim; p.lora = kv_lora;
+  p.q_nope = (bf16_t*)d_q_nope_out; p.q_pe = (bf16_t*)d_q_pe_out;
+  p.pos = d_pos; p.inv_freq = d_inv_freq; p.mscale = mscale;
+  if (d_kv) {
+    p.prep_on = 1;
+    MlaPrepParams& pp = p.prep;
+    pp.T = T; pp.H = num_heads; pp.nope = nope_dim; pp.rope = rope_dim; pp.kvl = kv_lora;
+    pp.q = nullptr; pp.q_rs = 0; pp.q_pe = nullptr;
+    pp.kv = (const bf16_t*)d_kv; pp.kv_rs = kv_row_stride; pp.nw = (const bf16_t*)d_kv_norm_w; pp.eps = kv_norm_eps;
+    pp.ckv = (bf16_t*)d_ckv_out; pp.kpe = (bf16_t*)d_kpe_out; pp.pos = d_pos; pp.inv_freq = d_inv_freq; pp.mscale = mscale;
+  }
+  const int NKS1 = q_b->NKS, QW = nope_dim + rope_dim;
+  const size_t smem = (size_t)NKS1 * 16 * 64 + (size_t)NKS1 * 2 * 16 + 32 * 4 + (size_t)p.SPH * 2 * 4 * 16 * 4 + (size_t)4 * rope_dim * 4 +
+                      (size_t)4 * QW * 2 + (size_t)(nope_dim / 8) * 64 + 64;
+  hipStream_t st = (hipStream_t)stream;
+  KTX_TIMED(st, (double)q_b->w_bytes + (double)q_b->sc_bytes + (double)q_absorb->w_bytes +
+                    (double)T * (p.Kx + num_heads * (kv_lora + rope_dim)) * 2.0,
+            "lin_qb_absorb_kernel<W4> %d->%dx%d ->%d%s", p.Kx, num_heads, QW, kv_lora, d_kv ? " +mla_prep" : "");
+  hipLaunchKernelGGL((lin_qb_absorb_kernel<64, 6>), dim3(num_heads + p.prep_on), dim3(512), std::max(smem, (size_t)520 * 4 + 2048), st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
 }
 
 extern "C" size_t ktx_linear_weight_bytes(ktx_linear_t h) { return h ? h->w_bytes + h->sc_bytes : 0; }

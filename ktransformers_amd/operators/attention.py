@@ -27,6 +27,7 @@ from torch import nn
 
 from ktransformers_amd.operators.base_operator import BaseInjectedModule
 from ktransformers_amd.operators.RoPE import yarn_get_mscale
+from ktransformers_amd.util.utils import InferenceState
 
 # One decode wrapper and one prompt wrapper per device, shared by every attention layer (the layers of a model run
 # serially on one stream, so they can share the split-KV workspace).  The workspace scales with the QUERY tokens of one
@@ -183,18 +184,26 @@ class KDeepseekV2Attention(BaseInjectedModule):
                 x = rmsnorm(x.contiguous(), norm[0], norm[1], native_rounding=True)
             first = (self.q_proj if self.q_lora_rank is None else self.q_a_proj)(x)
             kv = self.kv_a_proj_with_mqa(x)
-        if self.q_lora_rank is None:
-            q = first
-        else:
-            ln = self.q_a_layernorm                                        # DeepseekV3RMSNorm.forward (native rounding)
-            q = self.q_b_proj(first, norm=(ln.weight, ln.variance_epsilon)) if hasattr(self.q_b_proj, "generate_linear") \
-                else self.q_b_proj(rmsnorm(first, ln.weight.to(torch.bfloat16), ln.variance_epsilon, native_rounding=True))
-            q = q.reshape(q_len, H * (nope + rope))
-
         inv_freq, mscale = self._rope_params(dev)
         pos = position_ids.reshape(-1).to(torch.int64)
         kln = self.kv_a_layernorm
         qabs, oabs = self.get_absorbed()
+        fused_q = None   # decode: q_b_proj + q-absorb + RoPE + the kv half of mla_prep in one launch (ktx_linear_forward_qb_absorb)
+        if self.q_lora_rank is None:
+            q = first
+        else:
+            ln = self.q_a_layernorm                                        # DeepseekV3RMSNorm.forward (native rounding)
+            qb_h = self._decode_qb_handle(q_len, first, kv, qabs)
+            if qb_h is not None:
+                from ktransformers_amd._native import qb_absorb_and_prep
+                q = None
+                fused_q = qb_absorb_and_prep(qb_h, qabs, first, (ln.weight.to(torch.bfloat16), ln.variance_epsilon), kv,
+                                             kln.weight.to(torch.bfloat16), kln.variance_epsilon, pos, inv_freq, mscale,
+                                             H, nope, rope, lora)
+            else:
+                q = self.q_b_proj(first, norm=(ln.weight, ln.variance_epsilon)) if hasattr(self.q_b_proj, "generate_linear") \
+                    else self.q_b_proj(rmsnorm(first, ln.weight.to(torch.bfloat16), ln.variance_epsilon, native_rounding=True))
+                q = q.reshape(q_len, H * (nope + rope))
         capacity = past_key_value.max_pages * past_key_value.page_size
         expanded = None      # (first, last) position when this prompt chunk takes the non-absorbed kernel
         if self._expanded_prefill_ok(q_len, past_key_value):
@@ -211,7 +220,9 @@ class KDeepseekV2Attention(BaseInjectedModule):
             past_key_value.update(ckv_new, kpe_new, self.layer_idx, {"cache_position": cp})
             out = self._expanded_prefill(q, q_pe, past_key_value.key_cache[self.layer_idx], expanded[1] + 1, q_len)
             return self._project_out(out, residual, bsz, q_len), None, past_key_value
-        if q_len <= 4 and q.stride(-1) == 1 and kv.stride(-1) == 1 and qabs.decode_eligible(q_len) \
+        if fused_q is not None:
+            q_nope, q_pe, ckv_new, kpe_new = fused_q
+        elif q_len <= 4 and q.stride(-1) == 1 and kv.stride(-1) == 1 and qabs.decode_eligible(q_len) \
                 and not os.environ.get("KTX_MLA_SEPARATE_PREP"):     # (dev A/B switch, scripts/ab_decode.py)
             # decode: latent RMSNorm + RoPE ride in the launch of the q-absorb products (independent work, one boundary less)
             from ktransformers_amd._native import absorb_and_prep
@@ -266,6 +277,23 @@ class KDeepseekV2Attention(BaseInjectedModule):
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
         return self._project_out(out.reshape(q_len, H * self.v_head_dim), residual, bsz, q_len), None, past_key_value
+
+    def _decode_qb_handle(self, q_len, q_a, kv, qabs):
+        """The q_b_proj LinearHandle when this call can take the combined q_b + q-absorb launch: a decode step through the
+        absorbed kernel, W4 q_b_proj, the shapes ktx_linear_qb_absorb_eligible knows."""
+        if q_len > 4 or os.environ.get("KTX_MLA_SEPARATE_QB") or q_a.stride(-1) != 1 or kv.stride(-1) != 1:
+            return None
+        if q_a.dtype != torch.bfloat16 or q_a.stride(0) % 8 != 0 or kv.stride(0) % 8 != 0:
+            return None
+        qb = self.q_b_proj
+        lin = getattr(qb, "generate_linear", None) if getattr(qb, "mode", None) == InferenceState.GENERATE else \
+            getattr(qb, "prefill_linear", None)
+        h = getattr(lin, "_h", None)
+        if h is None or getattr(h, "fmt", None) != "W4":
+            return None
+        from ktransformers_amd._native import qb_absorb_eligible
+        return h if qb_absorb_eligible(h, qabs, q_len, self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim,
+                                       self.kv_lora_rank) else None
 
     def _project_out(self, out, residual, bsz, q_len):
         if residual is not None and hasattr(self.o_proj, "generate_linear"):

@@ -220,3 +220,40 @@ def test_w4_prompt_kernel_with_several_strips_per_wavefront(K, N, G, T):
         for a, b in zip(outs[1], outs[knob]):
             if a is not None:
                 assert torch.equal(a, b), f"strips/wavefront = {knob}: {int((a != b).sum())} of {a.numel()} outputs differ"
+
+
+@pytest.mark.parametrize("H,T", [(128, 1), (64, 3), (16, 4)])
+def test_qb_absorb_and_prep_in_one_launch(H, T):
+    """ktx_linear_forward_qb_absorb (q_b_proj with q_a_layernorm, the per-head q-absorb products, RoPE of q_pe and the kv half of
+    mla_prep, one launch) against the separate calls it replaces: q_b (fused norm) -> absorb_and_prep.  RoPE, the latent norm and
+    the absorb products run the same arithmetic on the same q values; q_b's 12 k-steps are summed as two halves instead of one
+    run, so q agrees within fp32 re-association (a bf16 ulp here and there), which the comparison allows for."""
+    n = native()
+    nope, rope, lora, qlora = 128, 64, 512, 1536
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(H * 10 + T)
+    wqb = (torch.randn((H * (nope + rope), qlora), generator=g) / 20).to(torch.bfloat16).to(dev)
+    wuk = (torch.randn((H, lora, nope), generator=g) / 10).to(torch.bfloat16).to(dev)
+    qa_full = torch.randn((T, qlora + lora + rope), generator=g).to(torch.bfloat16).to(dev)      # the merged q_a | kv_a GEMV output
+    q_a, kv = qa_full[:, :qlora], qa_full[:, qlora:]
+    nw = (1 + 0.1 * torch.randn((qlora,), generator=g)).to(torch.bfloat16).to(dev)
+    knw = (1 + 0.1 * torch.randn((lora,), generator=g)).to(torch.bfloat16).to(dev)
+    pos = torch.tensor([5, 77, 4000, 123456][:T], dtype=torch.int64, device=dev)
+    inv_freq = (1.0 / (10000 ** (torch.arange(0, rope, 2).float() / rope))).to(dev)
+    qb = n.LinearHandle(qlora, H * (nope + rope), "W4", 64, 8, dev)
+    qb.load_bf16(wqb)
+    qabs = n.LinearHandle(nope, lora, "BF16", 0, 8, dev, batch=H)
+    qabs.load_bf16(wuk)
+    assert n.qb_absorb_eligible(qb, qabs, T, H, nope, rope, lora)
+    q = qb.forward(q_a, norm=(nw, 1e-6)).reshape(T, H * (nope + rope))
+    ref = n.absorb_and_prep(qabs, q, kv, knw, 1e-6, pos, inv_freq, 1.3, H, nope, rope, lora)
+    for rep in range(2):
+        got = n.qb_absorb_and_prep(qb, qabs, q_a, (nw, 1e-6), kv, knw, 1e-6, pos, inv_freq, 1.3, H, nope, rope, lora)
+        torch.cuda.synchronize()
+        assert torch.equal(got[2], ref[2]) and torch.equal(got[3], ref[3]), "kv half of mla_prep: same code, same bits"
+        for a, b, what in ((got[0], ref[0], "q_nope (absorbed)"), (got[1], ref[1], "q_pe")):
+            a, b = a.float(), b.float()
+            assert torch.isfinite(a).all()
+            rel = float((a - b).norm() / b.norm())
+            assert rel < 2e-3, (what, rel)
+            assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), what
