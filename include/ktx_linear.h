@@ -147,6 +147,15 @@ int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_absorb, int T,
                                  const void* d_kv_norm_w, float kv_norm_eps, void* d_ckv_out, void* d_kpe_out,
                                  const int64_t* d_pos, const float* d_inv_freq, float mscale, ktx_stream_t stream);
 
+/* The merge of the MLA KV splits and the per-head un-absorb products (torch.matmul(attn_output, out_absorb.mT),
+ * archive/ktransformers/operators/attention.py:465-468) of a decode step (T <= 4) in ONE launch: h = the batched BF16 W_UV
+ * handle (batch = heads, kv_lora 512 -> v_head_dim 128); d_part_o / d_part_ml / nsplit = what ktx_mla_decode_partials
+ * (include/ktx_mla.h) left in its workspace.  y[t*ldy + head*y_batch_stride + n] = W_UV[head] . merged[t][head], with the
+ * merged row rounded to bf16 exactly where ktx_mla_decode_append rounds it.  Ask ktx_linear_merge_eligible first. */
+int ktx_linear_merge_eligible(ktx_linear_t h, int T, int nsplit, int num_heads);
+int ktx_linear_forward_batched_merge(ktx_linear_t h, int T, const float* d_part_o, const float* d_part_ml, int nsplit,
+                                     int num_heads, void* d_y, int64_t ldy, int64_t y_batch_stride, ktx_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -55,6 +55,17 @@ int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_nope, const
                           const int32_t* d_bsz, int batch, int total_q_tokens, const void* d_new_ckv, const void* d_new_kpe,
                           void* d_out, float* d_lse, void* d_workspace, size_t workspace_bytes, void* stream);
 
+/* ktx_mla_decode_append without its merge launch: the split-KV kernel only.  *nsplit_out (host) receives the number of KV
+ * splits S; d_workspace then holds, for the caller's own merge (ktx_linear_forward_batched_merge folds it into the un-absorb
+ * products of a decode step):  part_o fp32 [T][Hq][S][512] — un-normalised partial outputs relative to the split's own max —
+ * followed by part_ml fp32 [T][Hq][S][2] = (m, l) per split (l == 0: the split saw no token; its part_o row is undefined).
+ *     out[t][h] = sum_s exp(m_s - m*) part_o[s] / sum_s exp(m_s - m*) l_s,   m* = max over splits with l_s > 0 */
+int ktx_mla_decode_partials(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv, void* d_k_pe,
+                            int64_t ckv_token_stride, int64_t kpe_token_stride, const int32_t* d_qo_indptr,
+                            const int32_t* d_kv_indptr, const int32_t* d_kv_indices, const int32_t* d_kv_len_arr,
+                            const int32_t* d_bsz, int batch, int total_q_tokens, const void* d_new_ckv, const void* d_new_kpe,
+                            void* d_workspace, size_t workspace_bytes, int* nsplit_out, void* stream);
+
 /* cache.update(): scatter T new latent rows [ckv(512) | k_pe(64)] to cache[page_idx[t]][page_offset[t]]
  * (custom_cache.py:189-195 / :433-441).  kv_cache bf16 [pages][page_size][token_stride].  num_pages > 0: rows whose
  * page_idx / page_offset fall outside [0, num_pages) x [0, page_size) are dropped instead of written (the reference's

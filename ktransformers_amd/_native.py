@@ -103,6 +103,11 @@ def _load() -> C.CDLL:
     lib.ktx_linear_forward_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
                                              C.c_void_p]
     lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
+    lib.ktx_mla_decode_partials.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
+        C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]
+    lib.ktx_linear_merge_eligible.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
+    lib.ktx_linear_forward_batched_merge.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p,
+                                                     C.c_int64, C.c_int64, C.c_void_p]
     lib.ktx_linear_qb_absorb_eligible.argtypes = [C.c_void_p, C.c_void_p] + [C.c_int] * 5
     lib.ktx_linear_forward_qb_absorb.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_float] + \
         [C.c_int] * 4 + [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p,
@@ -574,6 +579,20 @@ class LinearHandle:
         return out
 
 
+def merge_and_unabsorb(oabs: "LinearHandle", partials: tuple, T: int, num_heads: int, out: torch.Tensor | None = None) -> torch.Tensor:
+    """Decode step: merge of the MLA KV splits + the per-head un-absorb products in one launch
+    (ktx_linear_forward_batched_merge).  partials = MLAWrapper.run_partials(...) = (workspace, nsplit).
+    Returns bf16 [T, heads, v_head_dim]."""
+    ws, nsplit = partials
+    if out is None:
+        out = torch.empty((T, num_heads, oabs.N), dtype=torch.bfloat16, device=ws.device)
+    part_o = ws.data_ptr()
+    part_ml = part_o + T * num_heads * nsplit * oabs.K * 4
+    check(lib.ktx_linear_forward_batched_merge(oabs._h, T, part_o, part_ml, nsplit, num_heads, out.data_ptr(), out.stride(0),
+                                               out.stride(1), _stream_ptr(ws.device)))
+    return out
+
+
 def absorb_and_prep(qabs: "LinearHandle", q: torch.Tensor, kv: torch.Tensor, kv_norm_weight: torch.Tensor, eps: float,
                     positions: torch.Tensor, inv_freq: torch.Tensor, mscale: float, num_heads: int, nope_dim: int, rope_dim: int,
                     kv_lora: int):
@@ -784,7 +803,7 @@ class MLAWrapper:
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self.need_plan = False
 
-    def run(self, q_nope, q_pe, ckv, k_pe, return_lse: bool = False, new_ckv=None, new_kpe=None):
+    def run(self, q_nope, q_pe, ckv, k_pe, return_lse: bool = False, new_ckv=None, new_kpe=None, partials: bool = False):
         """new_ckv [batch,512] / new_kpe [batch,64]: fuse StaticCache.update of the current decode token into the launch
         (the kernel reads position kv_len-1 from these buffers and stores it into the cache pages)."""
         if self.cfg is None:
@@ -807,6 +826,17 @@ class MLAWrapper:
             raise KtxError("MLAWrapper.run: pass both new_ckv and new_kpe or neither")
         if new_ckv is not None and (new_ckv.dtype != torch.bfloat16 or not new_ckv.is_contiguous() or not new_kpe.is_contiguous()):
             raise KtxError("MLAWrapper.run: new_ckv/new_kpe must be contiguous bf16")
+        if partials:
+            ns = C.c_int(0)
+            check(lib.ktx_mla_decode_partials(C.byref(self.cfg), q_nope.data_ptr(), q_pe.data_ptr(), ckv.data_ptr(), k_pe.data_ptr(),
+                                              ckv_ts, kpe_ts, self.qo_indptr.data_ptr(), self.kv_indptr.data_ptr(),
+                                              self.kv_indices.data_ptr() if self.kv_indices is not None else None,
+                                              self.kv_len_arr.data_ptr(),
+                                              self.bsz_tensor.data_ptr() if self.bsz_tensor is not None else None, batch, T,
+                                              new_ckv.data_ptr() if new_ckv is not None else None,
+                                              new_kpe.data_ptr() if new_kpe is not None else None, self.workspace.data_ptr(),
+                                              self.workspace.numel(), C.byref(ns), _stream_ptr(q_nope.device)))
+            return self.workspace, int(ns.value)
         check(lib.ktx_mla_decode_append(C.byref(self.cfg), q_nope.data_ptr(), q_pe.data_ptr(), ckv.data_ptr(), k_pe.data_ptr(),
                                         ckv_ts, kpe_ts, self.qo_indptr.data_ptr(), self.kv_indptr.data_ptr(),
                                         self.kv_indices.data_ptr() if self.kv_indices is not None else None, self.kv_len_arr.data_ptr(),
@@ -816,6 +846,12 @@ class MLAWrapper:
                                         out.data_ptr(), lse.data_ptr() if lse is not None else None, self.workspace.data_ptr(),
                                         self.workspace.numel(), _stream_ptr(q_nope.device)))
         return (out, lse) if return_lse else out
+
+    def run_partials(self, q_nope, q_pe, ckv, k_pe, new_ckv=None, new_kpe=None):
+        """run() without its merge launch (ktx_mla_decode_partials): returns (workspace, nsplit) for merge_and_unabsorb, which
+        folds the merge into the un-absorb products of a decode step.  The workspace is this wrapper's: consume it before the
+        next run on the same wrapper (the layers of a model run serially on one stream)."""
+        return self.run(q_nope, q_pe, ckv, k_pe, new_ckv=new_ckv, new_kpe=new_kpe, partials=True)
 
 
 def mla_cache_append(kv_cache: torch.Tensor, ckv_new: torch.Tensor, kpe_new: torch.Tensor, page_idx: torch.Tensor,

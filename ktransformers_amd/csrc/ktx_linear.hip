@@ -690,6 +690,132 @@ __global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
 }
 
 // =====================================================================================================
+// Merge of the MLA KV splits + the un-absorb product of a decode step in ONE launch (ktx_linear_forward_batched_merge): one
+// workgroup per head.  The head's W_UV block (128 KB of BF16 tiles) is requested first — it depends on nothing — then the
+// split partials (ktx_mla_decode_partials' layout) are merged exactly as mla_merge_kernel defines it (weights exp(m_s - m*),
+// dead splits selected away, one bf16 rounding of the normalised row), the row is staged as the GEMV's activation, and the
+// 4 k-steps of lin_dec_kernel's BF16 path produce the head's v_head_dim outputs.  8 split lanes x 64 dim groups of 8.
+// =====================================================================================================
+struct MergeUnabsorbParams {
+  const uint8_t* w; size_t wbs;            // [head][N/16 strips][NKS][4 KiB]
+  const float *part_o, *part_ml;           // [T][H][S][K], [T][H][S][2]
+  int T, H, S, K, N, NKS;                  // K = kv_lora (512), N = v_head_dim (128)
+  bf16_t* y; long ldy, ybs;                // y[t*ldy + h*ybs + n]
+};
+
+__global__ __launch_bounds__(512) void lin_merge_unabsorb_kernel(MergeUnabsorbParams p) {
+  constexpr int TP = 4, CS = TP * 16;
+  __shared__ float s_w[256];
+  __shared__ float s_red[16];
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  float* s_acc = reinterpret_cast<float*>(smem);                         // [8][K]
+  uint8_t* xs = smem + (size_t)8 * p.K * 4;                              // [K / 8][TP][16 B]
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  // ---- the head's weight tiles: wave = strip (N = 128 -> 8 strips), 4 k-steps x 4 planes
+  uint4 wr[4][4];
+  {
+    const uint8_t* wp = p.w + (size_t)h * p.wbs + (size_t)wave * p.NKS * 4096 + lane * 16;
+#pragma unroll
+    for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+      for (int q = 0; q < 4; q++) {
+        const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + (size_t)ks * 4096 + q * 1024));
+        wr[ks][q] = make_uint4(v.x, v.y, v.z, v.w);
+      }
+  }
+  const int sl = wave, dg = lane;   // split lane, dim group (8 dims)
+  for (int t = 0; t < TP; t++) {
+    if (t < p.T) {
+      const size_t base = ((size_t)t * p.H + h) * p.S;
+      // every load of the merge up front: the (m, l) pairs and the first rows of partials
+      const float2 ml = tid < p.S ? *reinterpret_cast<const float2*>(p.part_ml + (base + tid) * 2) : make_float2(0.f, 0.f);
+      const float* po = p.part_o + base * p.K + dg * 8;
+      // the first eight rows of this split lane (all of them up to 64 splits) are requested before the statistics resolve: the
+      // rows do not depend on them, only their weights do
+      float4 fa[8], fb[8];
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int sidx = min(sl + 8 * u, p.S - 1);
+        fa[u] = *reinterpret_cast<const float4*>(po + (size_t)sidx * p.K);
+        fb[u] = *reinterpret_cast<const float4*>(po + (size_t)sidx * p.K + 4);
+      }
+      float mstar = ml.y > 0.f ? ml.x : -__builtin_inff();
+      mstar = wave_max(mstar);
+      if (lane == 0) s_red[wave] = mstar;
+      __syncthreads();
+      mstar = s_red[0];
+#pragma unroll
+      for (int w = 1; w < 8; w++) mstar = fmaxf(mstar, s_red[w]);
+      const float wgt = ml.y > 0.f ? __expf(ml.x - mstar) : 0.f;
+      if (tid < p.S) s_w[tid] = wgt;
+      float lsum = wave_sum(ml.y * wgt);
+      if (lane == 0) s_red[8 + wave] = lsum;
+      __syncthreads();
+      lsum = 0.f;
+#pragma unroll
+      for (int w = 0; w < 8; w++) lsum += s_red[8 + w];
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int sidx = sl + 8 * u;
+        const float w = sidx < p.S ? s_w[sidx] : 0.f;
+        if (w > 0.f) {   // a dead split's row may be stale memory: selected away, not multiplied by 0
+          acc[0] += fa[u].x * w; acc[1] += fa[u].y * w; acc[2] += fa[u].z * w; acc[3] += fa[u].w * w;
+          acc[4] += fb[u].x * w; acc[5] += fb[u].y * w; acc[6] += fb[u].z * w; acc[7] += fb[u].w * w;
+        }
+      }
+      for (int s0 = sl + 64; s0 < p.S; s0 += 32) {   // more than 64 splits: four more rows of this split lane at a time
+        float4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int sidx = min(s0 + 8 * u, p.S - 1);
+          va[u] = *reinterpret_cast<const float4*>(po + (size_t)sidx * p.K);
+          vb[u] = *reinterpret_cast<const float4*>(po + (size_t)sidx * p.K + 4);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int sidx = s0 + 8 * u;
+          const float w = sidx < p.S ? s_w[sidx] : 0.f;
+          if (w > 0.f) {
+            acc[0] += va[u].x * w; acc[1] += va[u].y * w; acc[2] += va[u].z * w; acc[3] += va[u].w * w;
+            acc[4] += vb[u].x * w; acc[5] += vb[u].y * w; acc[6] += vb[u].z * w; acc[7] += vb[u].w * w;
+          }
+        }
+      }
+      if (dg * 8 < p.K) {
+#pragma unroll
+        for (int q = 0; q < 8; q++) s_acc[sl * p.K + dg * 8 + q] = acc[q];
+      }
+      __syncthreads();
+      const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+      for (int d = tid; d < p.K; d += 512) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v += s_acc[i * p.K + d];
+        reinterpret_cast<bf16_t*>(xs + (d >> 3) * CS + t * 16)[d & 7] = f32_to_bf16(v * inv);
+      }
+    } else {
+      for (int d = tid; d < p.K; d += 512) reinterpret_cast<bf16_t*>(xs + (d >> 3) * CS + t * 16)[d & 7] = 0;
+    }
+    __syncthreads();
+  }
+  // ---- the un-absorb GEMV: wave = strip, the k-steps in order (lin_dec_kernel's BF16 arithmetic with one k-slice)
+  const int kc = lane >> 4, tokp = (lane & 15) & (TP - 1);
+  const uint8_t* xb0 = xs + tokp * 16 + kc * 4 * CS;
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int ks = 0; ks < 4; ks++) lin_step<F_BF16, 128>(wr[ks], make_uint2(0, 0), xb0 + (size_t)ks * 16 * CS, CS, nullptr, 4, acc);
+  if (lane < 16) {
+    const int n = wave * 16 + lane;
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (r < p.T && n < p.N) p.y[(size_t)r * p.ldy + (size_t)h * p.ybs + n] = f32_to_bf16(0.f + acc[r]);
+  }
+}
+
+// =====================================================================================================
 // General kernel: token tiles of 16*MT rows (grid.y) x groups of 4 strips (grid.x, one per wavefront); weights are
 // prefetched one 256-k chunk ahead in registers, activations double-buffered in LDS as [column][token][16 B]
 // (column stride padded by 16 B so the staging stores of 16 lanes = 16 columns hit 16 different banks).
@@ -1647,6 +1773,36 @@ extern "C" int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_abs
                     (double)T * (p.Kx + num_heads * (kv_lora + rope_dim)) * 2.0,
             "lin_qb_absorb_kernel<W4> %d->%dx%d ->%d%s", p.Kx, num_heads, QW, kv_lora, d_kv ? " +mla_prep" : "");
   hipLaunchKernelGGL((lin_qb_absorb_kernel<64, 6>), dim3(num_heads + p.prep_on), dim3(512), std::max(smem, (size_t)520 * 4 + 2048), st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+static bool merge_unabsorb_ok(const ktx_linear_s* h, int T, int nsplit, int num_heads) {
+  return h && h->loaded && T >= 1 && T <= 4 && nsplit >= 1 && nsplit <= 256 && !g_lin_force_gemm && h->cfg.format == KTX_LIN_BF16 &&
+         h->batch == num_heads && !h->d_bias && h->cfg.in_features == 512 && h->cfg.out_features == 128 &&
+         num_heads >= 64;   // one workgroup per head: with few heads the separate, wider launches are faster
+}
+
+extern "C" int ktx_linear_merge_eligible(ktx_linear_t h, int T, int nsplit, int num_heads) {
+  return merge_unabsorb_ok(h, T, nsplit, num_heads) ? 1 : 0;
+}
+
+extern "C" int ktx_linear_forward_batched_merge(ktx_linear_t h, int T, const float* d_part_o, const float* d_part_ml, int nsplit,
+                                                int num_heads, void* d_y, int64_t ldy, int64_t y_batch_stride,
+                                                ktx_stream_t stream) {
+  KTX_REQUIRE(h && d_part_o && d_part_ml && d_y, "ktx_linear_forward_batched_merge: null argument");
+  KTX_REQUIRE(merge_unabsorb_ok(h, T, nsplit, num_heads),
+              "ktx_linear_forward_batched_merge: no combined kernel for this operator (ask ktx_linear_merge_eligible first)");
+  MergeUnabsorbParams p{};
+  p.w = h->d_w; p.wbs = h->w_bytes / h->batch;
+  p.part_o = d_part_o; p.part_ml = d_part_ml;
+  p.T = T; p.H = num_heads; p.S = nsplit; p.K = h->cfg.in_features; p.N = h->cfg.out_features; p.NKS = h->NKS;
+  p.y = (bf16_t*)d_y; p.ldy = (long)ldy; p.ybs = (long)y_batch_stride;
+  const size_t smem = (size_t)8 * p.K * 4 + (size_t)(p.K / 8) * 64;
+  hipStream_t st = (hipStream_t)stream;
+  KTX_TIMED(st, (double)h->w_bytes + (double)T * num_heads * (p.K + p.N) * 2.0,
+            "lin_merge_unabsorb_kernel<BF16> %d->%d x%d nsplit=%d", p.K, p.N, num_heads, nsplit);
+  hipLaunchKernelGGL(lin_merge_unabsorb_kernel, dim3(num_heads), dim3(512), smem, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

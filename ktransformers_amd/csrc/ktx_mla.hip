@@ -455,14 +455,45 @@ extern "C" int ktx_mla_decode(const ktx_mla_config* cfg, const void* d_q_nope, c
                                total_q_tokens, nullptr, nullptr, d_out, d_lse, d_workspace, workspace_bytes, stream);
 }
 
+static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
+                           void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
+                           const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
+                           const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
+                           const void* d_new_ckv, const void* d_new_kpe, void* d_out, float* d_lse,
+                           void* d_workspace, size_t workspace_bytes, void* stream, int* partials_nsplit);
+
 extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
                                      void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
                                      const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
                                      const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
                                      const void* d_new_ckv, const void* d_new_kpe, void* d_out, float* d_lse,
                                      void* d_workspace, size_t workspace_bytes, void* stream) {
+  KTX_REQUIRE(d_out, "ktx_mla_decode: null pointer");
+  return mla_decode_impl(cfg, d_q_nope, d_q_pe, d_ckv, d_k_pe, ckv_token_stride, kpe_token_stride, d_qo_indptr, d_kv_indptr,
+                         d_kv_indices, d_kv_len_arr, d_bsz, batch, total_q_tokens, d_new_ckv, d_new_kpe, d_out, d_lse, d_workspace,
+                         workspace_bytes, stream, nullptr);
+}
+
+extern "C" int ktx_mla_decode_partials(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
+                                       void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
+                                       const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
+                                       const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
+                                       const void* d_new_ckv, const void* d_new_kpe, void* d_workspace, size_t workspace_bytes,
+                                       int* nsplit_out, void* stream) {
+  KTX_REQUIRE(nsplit_out, "ktx_mla_decode_partials: null nsplit_out");
+  return mla_decode_impl(cfg, d_q_nope, d_q_pe, d_ckv, d_k_pe, ckv_token_stride, kpe_token_stride, d_qo_indptr, d_kv_indptr,
+                         d_kv_indices, d_kv_len_arr, d_bsz, batch, total_q_tokens, d_new_ckv, d_new_kpe, nullptr, nullptr, d_workspace,
+                         workspace_bytes, stream, nsplit_out);
+}
+
+static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
+                           void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
+                           const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
+                           const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
+                           const void* d_new_ckv, const void* d_new_kpe, void* d_out, float* d_lse,
+                           void* d_workspace, size_t workspace_bytes, void* stream, int* partials_nsplit) {
   KTX_REQUIRE((d_new_ckv == nullptr) == (d_new_kpe == nullptr), "ktx_mla_decode_append: give both new_ckv and new_kpe or neither");
-  KTX_REQUIRE(cfg && d_q_nope && d_q_pe && d_ckv && d_k_pe && d_out && d_workspace, "ktx_mla_decode: null pointer");
+  KTX_REQUIRE(cfg && d_q_nope && d_q_pe && d_ckv && d_k_pe && d_workspace, "ktx_mla_decode: null pointer");
   KTX_REQUIRE(d_qo_indptr && d_kv_indptr && d_kv_len_arr, "ktx_mla_decode: null index array");
   KTX_REQUIRE(cfg->head_dim_ckv == MLA_DC && cfg->head_dim_kpe == MLA_DR, "ktx_mla_decode: only kv_lora_rank 512 + rope 64");
   KTX_REQUIRE(cfg->num_heads > 0 && cfg->num_heads % 16 == 0, "ktx_mla_decode: num_heads must be a multiple of 16");
@@ -509,7 +540,8 @@ extern "C" int ktx_mla_decode_append(const ktx_mla_config* cfg, const void* d_q_
   p.part_o = (float*)d_workspace;
   p.part_ml = p.part_o + (size_t)total_q_tokens * Hq * nsplit * MLA_DC;
   p.dbg = g_mla_dbg;
-  const int only = ktx_debug_get(5);   // measurement knob (include/ktx_moe.h): 1 = split-KV kernel only, 2 = merge only
+  int only = ktx_debug_get(5);   // measurement knob (include/ktx_moe.h): 1 = split-KV kernel only, 2 = merge only
+  if (partials_nsplit) { only = 1; *partials_nsplit = nsplit; }   // the caller merges the partials itself (ktx_linear_forward_batched_merge)
   const bool direct = nsplit == 1 && only == 0;
   p.out1 = direct ? (bf16_t*)d_out : nullptr;
   p.lse1 = direct ? d_lse : nullptr;

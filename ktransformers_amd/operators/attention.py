@@ -77,6 +77,11 @@ def _cache_page_arrays(cache, layer_idx: int, dev: torch.device):
     return memo[key], cache.page_table_list[layer_idx][0]
 
 
+def _native_mod():
+    from ktransformers_amd import _native
+    return _native
+
+
 class KDeepseekV2Attention(BaseInjectedModule):
     SUPPORTS_FUSION = True     # forward(..., pre_norm=, residual=)
 
@@ -263,6 +268,15 @@ class KDeepseekV2Attention(BaseInjectedModule):
             self.mla_wrapper.plan(None, kv_indptr, kv_indices, kv_len, None, Hp, lora, rope, past_key_value.page_size,
                                   self.softmax_scale, torch.bfloat16, torch.bfloat16, max_kv_len=hint,
                                   identity_pages=bool(getattr(past_key_value, "identity_page_table", False)) and not _NO_IDENTITY())
+            fuse_merge = (Hp == H and not os.environ.get("KTX_MLA_SEPARATE_MERGE")
+                          and bool(_native_mod().lib.ktx_linear_merge_eligible(oabs._h, q_len, 1, H)))
+            if fuse_merge:
+                # the merge of the KV splits rides in the launch of the un-absorb products (one workgroup per head)
+                parts = self.mla_wrapper.run_partials(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
+                past_key_value.note_appended(self.layer_idx, 1)
+                object.__setattr__(self, "_decode_plan", kv_len)
+                out = _native_mod().merge_and_unabsorb(oabs, parts, q_len, H)
+                return self._project_out(out.reshape(q_len, H * self.v_head_dim), residual, bsz, q_len), None, past_key_value
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages, new_ckv=ckv_new, new_kpe=kpe_new)
             past_key_value.note_appended(self.layer_idx, 1)
             object.__setattr__(self, "_decode_plan", kv_len)

@@ -33,6 +33,7 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "moe: shared down in its own launch": ({}, {"KTX_MOE_SEPARATE_SHARED_DOWN": "1"}),
     "sampling: torch argmax on fp32 logits": ({}, {"KTX_TORCH_ARGMAX": "1"}),
     "mla: q_b and q-absorb as two launches": ({}, {"KTX_MLA_SEPARATE_QB": "1"}),
+    "mla: merge and un-absorb as two launches": ({}, {"KTX_MLA_SEPARATE_MERGE": "1"}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}

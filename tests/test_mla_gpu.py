@@ -163,3 +163,36 @@ def test_prefill_expanded_against_fp32_attention(H, T, kv_len):
     s = s.masked_fill(torch.arange(kv_len, device=DEV)[None, :] > pos, float("-inf"))
     ref = torch.einsum("htk,hkd->thd", torch.softmax(s, dim=-1), v[:, :kv_len].float())
     torch.testing.assert_close(out.float(), ref.to(torch.bfloat16).float(), rtol=2.0 ** -7, atol=5e-3)
+
+
+@pytest.mark.parametrize("Hq,kv_len,T", [(128, 4023, 1), (64, 700, 1), (128, 33, 1), (64, 5000, 3)])
+def test_merge_riding_the_unabsorb_launch(Hq, kv_len, T):
+    """ktx_mla_decode_partials + ktx_linear_forward_batched_merge (the KV-split merge inside the launch of the per-head un-absorb
+    products) against run() followed by forward_batched: the merged row is rounded to bf16 at the same point; only the fp32
+    order of the split sum differs (8 split lanes instead of 16)."""
+    from ktransformers_amd import _native as n
+    g = torch.Generator().manual_seed(Hq + kv_len)
+    page = 64
+    pages = (kv_len + page - 1) // page
+    kv = torch.randn((pages, page, 576), generator=g).to(torch.bfloat16).to(DEV)
+    qn = torch.randn((T, Hq, 512), generator=g).to(torch.bfloat16).to(DEV)
+    qp = torch.randn((T, Hq, 64), generator=g).to(torch.bfloat16).to(DEV)
+    wuv = (torch.randn((Hq, 128, 512), generator=g) / 16).to(torch.bfloat16).to(DEV)
+    oabs = n.LinearHandle(512, 128, "BF16", 0, 8, DEV, batch=Hq)
+    oabs.load_bf16(wuv)
+    w = n.MLAWrapper(1, pages, device=DEV, max_q_tokens=T)
+    ckv, k_pe = torch.split(kv, [512, 64], dim=-1)
+    qo = torch.tensor([0, T], dtype=torch.int32, device=DEV)
+    w.plan(qo, None, None, torch.tensor([kv_len], dtype=torch.int32, device=DEV), None, Hq, 512, 64, page, 192 ** -0.5,
+           max_kv_len=kv_len)
+    attn = w.run(qn, qp, ckv, k_pe)
+    ref = oabs.forward_batched(attn)
+    assert n.lib.ktx_linear_merge_eligible(oabs._h, T, 1, Hq)
+    for rep in range(2):
+        parts = w.run_partials(qn, qp, ckv, k_pe)
+        got = n.merge_and_unabsorb(oabs, parts, T, Hq)
+        torch.cuda.synchronize()
+        a, b = got.float(), ref.float()
+        assert torch.isfinite(a).all()
+        assert float((a - b).norm() / b.norm()) < 2e-3
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
