@@ -85,6 +85,7 @@ struct PrepParams {
   int32_t* src_of_row;   // [qlen*k]  sorted row -> token index
   Tile* tiles;
   int32_t* counters;  // [0] = num_tiles, [1] = num_rows
+  int bm_words;       // set by launch_moe_prep: 32-token words per expert in one window of the scatter's bitmaps
 };
 
 __device__ __forceinline__ void quant_row_block(const bf16_t* __restrict__ src, int K, int8_t* __restrict__ dst,
@@ -140,13 +141,32 @@ __global__ __launch_bounds__(1024) void moe_prep_kernel(PrepParams p) {
     return;
   }
 
-  // ---- block 0: histogram -> offsets -> scatter -> tile list ---------------------------------------------
+  // ---- block 0: histogram -> offsets -> STABLE scatter -> tile list -------------------------------------
+  // Rows of an expert are laid out in (token, slot) order — the reference's m_local_pos_ (moe_base.hpp:208-227): the row of a
+  // pair depends on the routing table only, never on arrival order.  Two implementations of the rank "how many earlier pairs
+  // chose the same expert":
+  //  * per-expert token bitmaps (the common case: a token names an expert at most once).  A window of 32 * bm_words tokens at a
+  //    time: every pair sets its token's bit in its expert's bitmap (an OR: order-free), one thread per expert turns the words
+  //    into exclusive popcount prefixes, and a pair's rank is prefix[word] + popcount(bits below its token) — O(1) per pair;
+  //  * a wavefront-ballot counting sort for routing tables in which a token names one expert twice (detected by the OR): a wave
+  //    finds the lanes holding the same expert with one ballot per distinct expert (match-any loop), the rank inside the wave
+  //    is a popcount of the lower lanes, the 16 waves of a 1024-pair chunk are chained through a per-(wave, expert) count
+  //    window in LDS, chunks through a running count.
+  extern __shared__ int s_dyn[];
+  __shared__ int s_dup;
   const int E = p.E, npairs = T * p.k;
+  const int lane = tid & 63, wave = tid >> 6;
   for (int e = tid; e < E; e += blockDim.x) { s_cnt[e] = 0; s_cur[e] = 0; }
+  if (tid == 0) s_dup = 0;
   __syncthreads();
-  for (int i = tid; i < npairs; i += blockDim.x) {
-    long long id = p.ids[i] - p.expert_begin;
-    if (id >= 0 && id < E && !(p.mask && p.mask[id])) atomicAdd(&s_cnt[(int)id], 1);
+  auto expert_of = [&](int i) -> int {
+    if (i >= npairs) return -1;
+    const long long id = p.ids[i] - p.expert_begin;
+    return (id >= 0 && id < E && !(p.mask && p.mask[id])) ? (int)id : -1;
+  };
+  for (int i = tid; i < npairs; i += blockDim.x) {   // per-expert totals (an integer sum: the order of the adds does not matter)
+    const int e = expert_of(i);
+    if (e >= 0) atomicAdd(&s_cnt[e], 1);
   }
   __syncthreads();
   if (tid < 64) {  // wave 0: exclusive scans of counts and of tile counts
@@ -173,14 +193,85 @@ __global__ __launch_bounds__(1024) void moe_prep_kernel(PrepParams p) {
     if (tid == 63) { p.counters[0] = tinc; p.counters[1] = inc; }
   }
   __syncthreads();
-  for (int i = tid; i < npairs; i += blockDim.x) {
-    long long id = p.ids[i] - p.expert_begin;
-    int r = -1;
-    if (id >= 0 && id < E && !(p.mask && p.mask[id])) {
-      r = s_off[(int)id] + atomicAdd(&s_cur[(int)id], 1);
-      p.src_of_row[r] = i / p.k;
+  {   // ---- bitmap scatter, window by window
+    const int nw = p.bm_words, WT = nw * 32;
+    unsigned* bm = reinterpret_cast<unsigned*>(s_dyn);   // [E][nw]
+    int* pc = s_dyn + E * nw;                             // [E][nw + 1]: exclusive popcount prefixes, window total last
+    for (int t0 = 0; t0 < T && !s_dup; t0 += WT) {
+      const int i0 = t0 * p.k, i1 = min(T, t0 + WT) * p.k;
+      for (int i = tid; i < E * nw; i += blockDim.x) bm[i] = 0u;
+      __syncthreads();
+      for (int i = i0 + tid; i < i1; i += blockDim.x) {
+        const int e = expert_of(i);
+        if (e >= 0) {
+          const int t = i / p.k - t0;
+          const unsigned bit = 1u << (t & 31);
+          if (atomicOr(&bm[e * nw + (t >> 5)], bit) & bit) s_dup = 1;   // the token names this expert twice
+        }
+      }
+      __syncthreads();
+      if (s_dup) break;
+      for (int e = wave; e < E; e += 16) {   // one wave per expert: lane = bitmap word (nw <= 64), shuffle prefix sum
+        const int c = lane < nw ? __popc(bm[e * nw + lane]) : 0;
+        int inc = c;
+#pragma unroll
+        for (int o = 1; o < 64; o <<= 1) {
+          const int a = __shfl_up(inc, o, 64);
+          if (lane >= o) inc += a;
+        }
+        if (lane < nw) pc[e * (nw + 1) + lane] = inc - c;
+        if (lane == 63) pc[e * (nw + 1) + nw] = inc;
+      }
+      __syncthreads();
+      for (int i = i0 + tid; i < i1; i += blockDim.x) {
+        const int e = expert_of(i);
+        int r = -1;
+        if (e >= 0) {
+          const int t = i / p.k - t0, w = t >> 5;
+          r = s_off[e] + s_cur[e] + pc[e * (nw + 1) + w] + __popc(bm[e * nw + w] & ((1u << (t & 31)) - 1u));
+          p.src_of_row[r] = i / p.k;
+        }
+        p.row_of_pair[i] = r;
+      }
+      __syncthreads();
+      for (int e = tid; e < E; e += blockDim.x) s_cur[e] += pc[e * (nw + 1) + nw];
+      __syncthreads();
     }
-    p.row_of_pair[i] = r;
+  }
+  if (s_dup) {   // ---- ballot counting sort over ALL pairs (rows already written by the bitmap windows are rewritten identically)
+    int* s_wcnt = s_dyn;   // [16 waves][E]: zero outside the current chunk's window
+    for (int e = tid; e < E; e += blockDim.x) s_cur[e] = 0;
+    for (int i = tid; i < 16 * E; i += blockDim.x) s_wcnt[i] = 0;
+    __syncthreads();
+    for (int base = 0; base < npairs; base += 1024) {
+      const int i = base + tid;
+      const int e = expert_of(i);
+      int rank = 0;
+      unsigned long long rem = __ballot(e >= 0);
+      while (rem) {   // wave-uniform loop: one round per distinct expert among the wave's 64 pairs
+        const int lead = __builtin_amdgcn_readfirstlane(__ffsll((long long)rem) - 1);
+        const int e0 = __builtin_amdgcn_readlane(e, lead);
+        const unsigned long long m = __ballot(e == e0);
+        if (e == e0) rank = __popcll(m & ((1ull << lane) - 1ull));
+        if (lane == lead) s_wcnt[wave * E + e0] = __popcll(m);
+        rem &= ~m;
+      }
+      __syncthreads();
+      int r = -1;
+      if (e >= 0) {
+        int pre = 0;
+        for (int w = 0; w < wave; w++) pre += s_wcnt[w * E + e];
+        r = s_off[e] + s_cur[e] + pre + rank;
+        p.src_of_row[r] = i / p.k;
+      }
+      if (i < npairs) p.row_of_pair[i] = r;
+      __syncthreads();
+      if (e >= 0 && rank == 0) {   // one lane per (wave, expert): advance the running count, close the window
+        atomicAdd(&s_cur[e], s_wcnt[wave * E + e]);
+        s_wcnt[wave * E + e] = 0;
+      }
+      __syncthreads();
+    }
   }
   for (int e = tid; e < E; e += blockDim.x) {
     const int c = s_cnt[e];
@@ -190,6 +281,22 @@ __global__ __launch_bounds__(1024) void moe_prep_kernel(PrepParams p) {
       p.tiles[s_toff[e] + i] = t;
     }
   }
+}
+
+// launch: the scatter's bitmaps / count window live in dynamic LDS (beyond 48 KB the attribute is needed)
+static hipError_t launch_moe_prep(const PrepParams& pp, int nblocks, hipStream_t st) {
+  static std::once_flag once;
+  static hipError_t attr_err = hipSuccess;
+  std::call_once(once, [&] {
+    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  });
+  if (attr_err != hipSuccess) return attr_err;
+  PrepParams p2 = pp;
+  const int E = std::max(pp.E, 1);
+  p2.bm_words = std::max(1, std::min(64, (64 * 1024) / (8 * E)));   // ~64 KB of bitmaps + prefixes per window
+  const size_t smem = std::max((size_t)16 * E * sizeof(int), (size_t)E * (2 * p2.bm_words + 1) * sizeof(int));
+  hipLaunchKernelGGL(moe_prep_kernel, dim3(nblocks), dim3(1024), smem, st, p2);
+  return hipGetLastError();
 }
 
 // =====================================================================================================
@@ -848,10 +955,11 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 
       const uint4 v = *reinterpret_cast<const uint4*>(p.side_x + (size_t)t * p.side_nks * 128 + idx * 8);
       *reinterpret_cast<uint4*>(side_xs + idx * 16) = v;
       float sm = ktxw4::sum8_bf16(v);
+      constexpr int PPG = SIDE_G > 0 ? SIDE_G / 8 : 1;   // 8-element pieces per scale group
 #pragma unroll
-      for (int o = 1; o < SIDE_G / 8; o <<= 1) sm += __shfl_xor(sm, o, 64);
-      if ((idx & (SIDE_G / 8 - 1)) == 0) {
-        float* ax = side_aux + (idx / (SIDE_G / 8)) * 4;
+      for (int o = 1; o < PPG; o <<= 1) sm += __shfl_xor(sm, o, 64);
+      if ((idx & (PPG - 1)) == 0) {
+        float* ax = side_aux + (idx / PPG) * 4;
         ax[0] = sm; ax[1] = sm; ax[2] = sm; ax[3] = sm;
       }
     }
@@ -2732,7 +2840,7 @@ static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, 
   pp.tiles = ws->tiles; pp.counters = ws->counters;
   {
     ProfScope ps(0, st);
-    hipLaunchKernelGGL(moe_prep_kernel, dim3(qlen + 1), dim3(1024), 0, st, pp);
+    KTX_HIP(launch_moe_prep(pp, qlen + 1, st));
   }
   KTX_HIP(hipGetLastError());
 
@@ -2860,7 +2968,7 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
   pp.tiles = ws->tiles; pp.counters = ws->counters;
   {
     ProfScope ps(0, st);
-    hipLaunchKernelGGL(moe_prep_kernel, dim3(1), dim3(1024), 0, st, pp);  // block 0 only: bucketing, no quantisation
+    KTX_HIP(launch_moe_prep(pp, 1, st));  // block 0 only: bucketing, no quantisation
   }
   KTX_HIP(hipGetLastError());
 
@@ -2958,7 +3066,7 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
   pp.tiles = ws->tiles; pp.counters = ws->counters;
   {
     ProfScope ps(0, st);
-    hipLaunchKernelGGL(moe_prep_kernel, dim3(1), dim3(1024), 0, st, pp);
+    KTX_HIP(launch_moe_prep(pp, 1, st));
     hipLaunchKernelGGL(moe_actquant_kgroup_kernel, dim3(qlen), dim3(256), 0, st, (const bf16_t*)d_input, H, ws->x_q, ws->x_d,
                        ws->counters, d_bsz, qlen, 1);
   }
@@ -3101,7 +3209,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   pp.tiles = ws->tiles; pp.counters = ws->counters;
   {
     ProfScope ps(0, st);
-    hipLaunchKernelGGL(moe_prep_kernel, dim3(1), dim3(1024), 0, st, pp);
+    KTX_HIP(launch_moe_prep(pp, 1, st));
     hipLaunchKernelGGL(q8k_quant_kernel<false>, dim3(qlen), dim3(256), 0, st, d_input, H, ws->x_q, ws->x_d, ws->x_bs, d_bsz, 1, qlen);
   }
   KTX_HIP(hipGetLastError());

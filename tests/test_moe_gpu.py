@@ -488,3 +488,39 @@ def test_forward_side_equals_the_separate_launches(dev, method, shape):
         bad = (got.float() - ref.float()).abs() > scale * 2.0 ** -7 + 1e-30
         assert not bool(bad.any()), f"{int(bad.sum())} of {bad.numel()} outputs differ by more than one bf16 ulp of the operands"
         assert float((got != ref).float().mean()) < 0.2, "re-association noise should touch a minority of the outputs"
+
+
+@pytest.mark.parametrize("dup", [False, True])
+@pytest.mark.parametrize("shape", [(64, 6, 256, 128, 700), (256, 8, 256, 128, 2048), (8, 2, 256, 256, 1500), (16, 4, 256, 128, 100)])
+def test_bucketing_is_the_reference_stable_order(oracle, dev, shape, dup):
+    """a5: the (token, slot) -> sorted-row map of the grouped path is the reference's m_local_pos_ (token-major arrival rank
+    inside each expert, experts in ascending order; moe_base.hpp:208-227) — the wavefront-ballot counting sort of
+    moe_prep_kernel is deterministic, so the map can be compared entry by entry with the oracle's bucketing, twice."""
+    import ctypes as C
+    from ktransformers_amd import _native as n
+    E, k, H, I, T = shape
+    c = make_case(7, E, k, H, I, T, invalid_ids=True)
+    if dup:   # a token that names one expert twice: the bitmap scatter hands over to the ballot counting sort
+        c["ids"][T // 2, 1] = c["ids"][T // 2, 0]
+        c["ids"][T - 2, k - 1] = c["ids"][T - 2, 0]
+    h = make_handle("AMXINT4", c, E, k, H, I, T, dev)
+    num, pos, _ = oracle.bucket(E, c["ids"])
+    off = np.concatenate([[0], np.cumsum(num)[:-1]]).astype(np.int64)
+    ids = c["ids"].astype(np.int64)
+    ok = (ids >= 0) & (ids < E)
+    want = np.where(ok, off[np.clip(ids, 0, E - 1)] + pos, -1).astype(np.int32)
+    for rep in range(2):
+        run(h, c, dev)
+        rp = C.c_void_p()
+        n.check(n.lib.ktx_moe_debug_ptrs(h._h, None, None, C.byref(rp)))
+        torch.cuda.synchronize()
+        got = torch.empty(T * k, dtype=torch.int32, device=dev)
+        assert _memcpy_d2d(got.data_ptr(), rp.value, T * k * 4) == 0
+        assert np.array_equal(got.cpu().numpy().reshape(T, k), want), rep
+
+
+def _memcpy_d2d(dst, src, nbytes):
+    import ctypes as C
+    hip = C.CDLL("libamdhip64.so")
+    hip.hipMemcpy.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t, C.c_int]
+    return hip.hipMemcpy(dst, src, nbytes, 3)
