@@ -147,6 +147,12 @@ int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_absorb, int T,
                                  const void* d_kv_norm_w, float kv_norm_eps, void* d_ckv_out, void* d_kpe_out,
                                  const int64_t* d_pos, const float* d_inv_freq, float mscale, ktx_stream_t stream);
 
+/* W4 handle -> row-major bf16 weights [out_features][ld_out] with Marlin's in-register rounding w = bf16((q - 8) * s) — what
+ * gptq_marlin_gemm multiplies bf16 activations with (custom_marlin/gptq_marlin).  For prompt-sized calls (hundreds of tokens)
+ * the operator de-quantises into a scratch buffer with this call and runs a plain library GEMM on it (F.linear -> hipBLASLt):
+ * the weight bytes are expanded once per call instead of once per 64-token tile, and the arithmetic is the reference's. */
+int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_out, ktx_stream_t stream);
+
 /* The merge of the MLA KV splits and the per-head un-absorb products (torch.matmul(attn_output, out_absorb.mT),
  * archive/ktransformers/operators/attention.py:465-468) of a decode step (T <= 4) in ONE launch: h = the batched BF16 W_UV
  * handle (batch = heads, kv_lora 512 -> v_head_dim 128); d_part_o / d_part_ml / nsplit = what ktx_mla_decode_partials

@@ -103,6 +103,7 @@ def _load() -> C.CDLL:
     lib.ktx_linear_forward_fused.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.POINTER(_LinearFusion),
                                              C.c_void_p]
     lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
+    lib.ktx_linear_dequant_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ktx_mla_decode_partials.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]
     lib.ktx_linear_merge_eligible.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -477,7 +478,39 @@ class LinearHandle:
         return t.contiguous()
 
     def _bias(self, bias):
-        return None if bias is None else self._chk(bias, torch.bfloat16, (self.N,), "bias")
+        self._bias_t = None if bias is None else self._chk(bias, torch.bfloat16, (self.N,), "bias")
+        return self._bias_t
+
+    # ---- prompt-sized W4 calls: de-quantise once (Marlin's rounding), then a plain library GEMM ------------------------------
+    PROMPT_MIN_T = 512          # below this the hand-written W4 GEMM (no scratch pass) is faster
+    _DEQ_SCRATCH: dict = {}
+
+    def dequant_bf16(self, out: torch.Tensor | None = None) -> torch.Tensor:
+        """bf16 [N, K] = bf16((q - 8) * s), the weights gptq_marlin_gemm multiplies with (ktx_linear_dequant_bf16)."""
+        if self.fmt != "W4" or self.batch != 1:
+            raise KtxError("dequant_bf16: W4 handles only")
+        if out is None:
+            out = torch.empty((self.N, self.K), dtype=torch.bfloat16, device=self.device)
+        check(lib.ktx_linear_dequant_bf16(self._h, out.data_ptr(), out.stride(0), _stream_ptr(self.device)))
+        return out
+
+    def _prompt_forward(self, x2: torch.Tensor, out, add1, add2, glu: bool) -> torch.Tensor:
+        need = self.N * self.K
+        buf = LinearHandle._DEQ_SCRATCH.get(self.device)
+        if buf is None or buf.numel() < need:
+            buf = LinearHandle._DEQ_SCRATCH[self.device] = torch.empty(need, dtype=torch.bfloat16, device=self.device)
+        w = self.dequant_bf16(buf[:need].view(self.N, self.K))
+        y = torch.nn.functional.linear(x2, w, getattr(self, "_bias_t", None))
+        if glu:   # rows are interleaved per 16-row strip as [8 gate | 8 up]
+            T = y.shape[0]
+            y = silu_mul(y.view(T, self.N // 16, 2, 8).permute(0, 2, 1, 3).reshape(T, self.N))
+        for a in (add1, add2):   # the epilogue adds of the decoder layer, torch's bf16 tensor arithmetic
+            if a is not None:
+                y = a.reshape(y.shape) + y
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
 
     def load_bf16(self, weight: torch.Tensor, bias: torch.Tensor | None = None) -> None:
         """weight: bf16 [out, in] (nn.Linear layout). W4 handles quantise with quantize_weights' arithmetic."""
@@ -533,6 +566,11 @@ class LinearHandle:
             strided = False
         T = x2.shape[0]
         n_out = self.N // 2 if glu else self.N
+        if (self.fmt == "W4" and self.batch == 1 and T >= self.PROMPT_MIN_T and bsz_tensor is None
+                and not os.environ.get("KTX_W4_PROMPT_KERNEL") and not torch.cuda.is_current_stream_capturing()):
+            if norm is not None:
+                x2 = rmsnorm(x2.contiguous(), norm[0], norm[1], native_rounding=True)
+            return self._prompt_forward(x2, out, add1, add2, glu).reshape(*x.shape[:-1], n_out)
         if out is None:
             out = torch.empty((T, n_out), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
                 torch.zeros((T, n_out), dtype=torch.bfloat16, device=self.device)

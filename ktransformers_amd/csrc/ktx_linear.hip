@@ -1200,6 +1200,36 @@ __global__ __launch_bounds__(64) void lin_quant_w4_kernel(const bf16_t* __restri
   }
 }
 
+// W tiles -> row-major bf16 [N][Kx] with Marlin's in-register rounding  w = bf16((q - 8) * s)  (gptq_marlin's dequant + scale for
+// bf16 activations multiplies the de-quantised nibble by the group scale in bf16, custom_marlin/gptq_marlin/gptq_marlin.cu;
+// the golden fixtures and oracle/linear_ref.py(round_weights=True) state the same rule).  One wavefront per tile: lane
+// (kc, n) holds feature n's 8-element runs j*32 + kc*8 of the k-step and writes four 16-byte pieces of its row.  Prompt-sized
+// calls then run a plain library GEMM on the result (ktx_linear_dequant_bf16).
+template <int G>
+__global__ __launch_bounds__(64) void lin_dequant_w4_kernel(const uint4* __restrict__ tiles, const bf16_t* __restrict__ scales,
+                                                            int N, int Kx, int NKS, bf16_t* __restrict__ out, long ldo) {
+  constexpr int GPK = 128 / G;
+  const int tile = blockIdx.x, strip = tile / NKS, ks = tile % NKS;
+  const int lane = threadIdx.x, n = strip * 16 + (lane & 15), kc = lane >> 4;
+  if (n >= N) return;
+  const uint4 t = tiles[(size_t)tile * 64 + lane];
+  const uint32_t P[4] = {t.x, t.y, t.z, t.w};
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const int k0 = ks * 128 + j * 32 + kc * 8;
+    if (k0 >= Kx) continue;
+    const float sc = bf16_to_f32(scales[((size_t)tile * 16 + (lane & 15)) * GPK + (j * 32) / G]);
+    uint32_t o[4];
+#pragma unroll
+    for (int pi = 0; pi < 4; pi++) {   // element 2p in nibble p, element 2p+1 in nibble p+4 (the tile layout of this file)
+      const float lo = (float)((int)((P[j] >> (4 * pi)) & 15u) - 8) * sc;
+      const float hi = (float)((int)((P[j] >> (4 * (pi + 4))) & 15u) - 8) * sc;
+      o[pi] = ktx_pk_bf16(lo, hi);
+    }
+    *reinterpret_cast<uint4*>(out + (size_t)n * ldo + k0) = make_uint4(o[0], o[1], o[2], o[3]);
+  }
+}
+
 // pre-quantised: q uint8 [Kx][N], s bf16 [Kx/G][N]
 template <int G>
 __global__ __launch_bounds__(64) void lin_pack_w4_kernel(const uint8_t* __restrict__ q, const bf16_t* __restrict__ s, int N,
@@ -1803,6 +1833,22 @@ extern "C" int ktx_linear_forward_batched_merge(ktx_linear_t h, int T, const flo
   KTX_TIMED(st, (double)h->w_bytes + (double)T * num_heads * (p.K + p.N) * 2.0,
             "lin_merge_unabsorb_kernel<BF16> %d->%d x%d nsplit=%d", p.K, p.N, num_heads, nsplit);
   hipLaunchKernelGGL(lin_merge_unabsorb_kernel, dim3(num_heads), dim3(512), smem, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+extern "C" int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_out, ktx_stream_t stream) {
+  KTX_REQUIRE(h && d_out, "ktx_linear_dequant_bf16: null argument");
+  KTX_REQUIRE(h->loaded && h->cfg.format == KTX_LIN_W4 && h->batch == 1, "ktx_linear_dequant_bf16: needs a loaded, unbatched W4 handle");
+  KTX_REQUIRE(ld_out >= h->cfg.in_features && ld_out % 8 == 0, "ktx_linear_dequant_bf16: rows must start on 16-byte boundaries");
+  hipStream_t st = (hipStream_t)stream;
+  const int N = h->cfg.out_features, Kx = h->cfg.in_features, ntiles = h->nstrips * h->NKS;
+  KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)N * Kx * 2.0, "lin_dequant_w4_kernel %d->%d", Kx, N);
+  switch (h->cfg.group_size) {
+    case 32: hipLaunchKernelGGL(lin_dequant_w4_kernel<32>, dim3(ntiles), dim3(64), 0, st, (const uint4*)h->d_w, (const bf16_t*)h->d_sc, N, Kx, h->NKS, (bf16_t*)d_out, (long)ld_out); break;
+    case 64: hipLaunchKernelGGL(lin_dequant_w4_kernel<64>, dim3(ntiles), dim3(64), 0, st, (const uint4*)h->d_w, (const bf16_t*)h->d_sc, N, Kx, h->NKS, (bf16_t*)d_out, (long)ld_out); break;
+    default: hipLaunchKernelGGL(lin_dequant_w4_kernel<128>, dim3(ntiles), dim3(64), 0, st, (const uint4*)h->d_w, (const bf16_t*)h->d_sc, N, Kx, h->NKS, (bf16_t*)d_out, (long)ld_out); break;
+  }
   KTX_HIP(hipGetLastError());
   return 0;
 }

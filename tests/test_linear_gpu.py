@@ -257,3 +257,47 @@ def test_qb_absorb_and_prep_in_one_launch(H, T):
             rel = float((a - b).norm() / b.norm())
             assert rel < 2e-3, (what, rel)
             assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max()), what
+
+
+@pytest.mark.parametrize("K,N,G", [(2048, 576, 64), (7168, 1536, 64), (1536, 208, 128)])
+def test_prompt_sized_w4_dequantises_once_and_runs_a_library_gemm(K, N, G):
+    """T >= LinearHandle.PROMPT_MIN_T: the W4 weights are expanded once with Marlin's in-register rounding bf16((q - 8) * s)
+    (ktx_linear_dequant_bf16: bit-identical to the torch expression on the reference quantiser's q and s) and a plain library
+    GEMM runs on them — against fp64 math on the same rounded weights, against the hand-written W4 GEMM, and with the GLU /
+    addend epilogues of the decoder layer."""
+    import os
+    n = native()
+    torch.manual_seed(K + N)
+    T = n.LinearHandle.PROMPT_MIN_T + 40
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16).cuda()
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16).cuda()
+    a1 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    a2 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    h = n.LinearHandle(K, N, "W4", G, 1024)
+    h.load_bf16(w)
+    q, s = quantize_weights_ref(w.cpu().T.contiguous(), G)
+    wdq = ((q.float() - 8.0) * s.float().repeat_interleave(G, dim=0)).T.contiguous().to(torch.bfloat16)      # [N, K]
+    assert torch.equal(h.dequant_bf16().cpu(), wdq)
+    y = h.forward(x)
+    close(y, linear_w4_ref(x.cpu(), q, s, G, None, round_weights=True), rel=2e-3 ** 1)
+    os.environ["KTX_W4_PROMPT_KERNEL"] = "1"
+    try:
+        y_k = h.forward(x)
+        y_k_add = h.forward(x, add1=a1, add2=a2)
+    finally:
+        os.environ.pop("KTX_W4_PROMPT_KERNEL")
+    assert float((y.float() - y_k.float()).norm() / y_k.float().norm()) < 3e-3      # exact-integer weights vs bf16-rounded ones
+    y_add = h.forward(x, add1=a1, add2=a2)
+    assert float((y_add.float() - y_k_add.float()).norm() / y_k_add.float().norm()) < 3e-3
+    assert torch.equal(y_add, a2 + (a1 + y))
+    if N % 16 == 0:
+        hg = n.LinearHandle(K, N, "W4", G, 1024)
+        hg.load_bf16(w)
+        got = hg.forward(x, glu=True)
+        os.environ["KTX_W4_PROMPT_KERNEL"] = "1"
+        try:
+            ref = hg.forward(x, glu=True)
+        finally:
+            os.environ.pop("KTX_W4_PROMPT_KERNEL")
+        assert got.shape == ref.shape == (T, N // 2)
+        assert float((got.float() - ref.float()).norm() / ref.float().norm()) < 5e-3
