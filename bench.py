@@ -329,7 +329,8 @@ def timed(fn, steps, warmup, dev, dist_on):
 # ---------------------------------------------------------------------------------------------------------------------
 # per-kernel timing: every library launch of REAL decode steps, bracketed by HIP events on the launch stream
 # ---------------------------------------------------------------------------------------------------------------------
-KTX_KERNEL_NAMES = ("lin_dec_kernel", "lin_dec_gate_kernel", "lin_qb_absorb_kernel", "lin_gemm_kernel", "lin_gemm_w4n_kernel",
+KTX_KERNEL_NAMES = ("lin_dec_kernel", "lin_dec_gate_kernel", "lin_qb_absorb_kernel", "lin_merge_unabsorb_kernel",
+                    "lin_dequant_w4_kernel", "lin_gemm_kernel", "lin_gemm_w4n_kernel",
                     "gate_fused_kernel", "gate_logits_kernel", "gate_select_kernel", "moe_dec_gateup_kernel", "moe_dec_down_kernel",
                     "mla_decode_kernel", "mla_merge_kernel", "mla_prep_kernel", "rmsnorm_kernel", "silu_mul_kernel",
                     "argmax_bf16_kernel")

@@ -505,7 +505,10 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
   // workgroup shape (head blocks x dim slices): decode-sized calls of many-headed models take 2x4 (32 heads share one staged
   // KV tile, 128 output dims per wave), prompts of those models 4x2, everything else 1x4
   const bool decode_sized = total_q_tokens <= 16;
-  int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized) ? 2 : (Hq % 64 == 0) ? 4 : 1;
+  // long contexts (many tiles per split): 64 heads per workgroup share each staged tile and twice the splits pay off — measured
+  // at 128 heads / 128K tokens (scripts/mla_sweep.py --ctx 131072): 4x2 with 128 splits 103 us, 2x4 with 64 splits 157 us
+  const bool long_ctx = decode_sized && cfg->kv_len_hint >= 8192 && Hq % 64 == 0;
+  int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized && !long_ctx) ? 2 : (Hq % 64 == 0) ? 4 : 1;
   {   // tuning knobs (scripts/mla_sweep.py): 6 = force the workgroup shape, 7 = force the split count
     const int fs = ktx_debug_get(6);
     if ((fs == 1) || (fs == 2 && Hq % 32 == 0) || (fs == 4 && Hq % 64 == 0)) shape = fs;
@@ -520,7 +523,8 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
   // capped where the partials reach ~16 MB and at about one workgroup per CU
   int nsplit = std::max(1, 2048 / std::max(1, hblocks * total_q_tokens));
   const size_t per_split_bytes = (size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float);
-  nsplit = std::min<int>(nsplit, std::max<size_t>(16, ((size_t)16 << 20) / per_split_bytes));
+  nsplit = std::min<int>(nsplit, std::max<size_t>(16, ((size_t)(long_ctx ? 34 : 16) << 20) / per_split_bytes));
+  if (long_ctx) nsplit = std::min(nsplit, 128);
   if (shape == 2) nsplit = std::min(nsplit, std::max(16, 256 / std::max(1, hblocks * total_q_tokens)));
   if (ktx_debug_get(7) > 0) nsplit = ktx_debug_get(7);
   if (cfg->kv_len_hint > 0) nsplit = std::min(nsplit, std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE));
