@@ -929,7 +929,7 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 
   const int tid = threadIdx.x, lane = tid & 63;
   const int j = __builtin_amdgcn_readfirstlane(tid >> 6);  // wave j = routing slot j
   const int pair = t * p.k + j, strip = blockIdx.x;
-  // ---- side linear, part 1: this wave's weight tiles and scales in flight first; the activation row staged by everyone --------
+  // ---- side linear, part 1: this wave's weight tiles and scales in flight first, then its slice of the activation row ------
   constexpr int SGPK = SIDE_G > 0 ? 128 / SIDE_G : 1;
   float* s_side = s_wt + p.k;                                                      // [k][16]
   uint8_t* side_xs = smem + (((size_t)(reinterpret_cast<uint8_t*>(s_side + p.k * 16) - smem) + 15) & ~(size_t)15);
@@ -950,17 +950,24 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 
         ssc[i] = ktxw4::load_w4_scales<SGPK>(sp + (size_t)ks * 16 * SGPK);
       }
     }
-    const int npiece = p.side_nks * 16;   // 8-element pieces of the row (a multiple of 16: whole 16-lane groups take part)
-    for (int idx = tid; idx < npiece; idx += 64 * p.k) {
-      const uint4 v = *reinterpret_cast<const uint4*>(p.side_x + (size_t)t * p.side_nks * 128 + idx * 8);
-      *reinterpret_cast<uint4*>(side_xs + idx * 16) = v;
+    // the wave stages exactly the k-steps it will multiply (16 pieces of 8 each: lane = (k-step i, piece)), so the staging
+    // needs no workgroup barrier — only the wave reads these LDS bytes back
+    {
+      const int i = lane >> 4, ks = j * spw + i;
+      const bool mine = i < spw && ks < p.side_nks;
+      const int idx = ks * 16 + (lane & 15);
+      uint4 v = make_uint4(0, 0, 0, 0);
+      if (mine) v = *reinterpret_cast<const uint4*>(p.side_x + (size_t)t * p.side_nks * 128 + idx * 8);
       float sm = ktxw4::sum8_bf16(v);
-      constexpr int PPG = SIDE_G > 0 ? SIDE_G / 8 : 1;   // 8-element pieces per scale group
+      constexpr int PPG = SIDE_G > 0 ? SIDE_G / 8 : 1;   // 8-element pieces per scale group (<= 16: inside the 16-lane run)
 #pragma unroll
       for (int o = 1; o < PPG; o <<= 1) sm += __shfl_xor(sm, o, 64);
-      if ((idx & (PPG - 1)) == 0) {
-        float* ax = side_aux + (idx / PPG) * 4;
-        ax[0] = sm; ax[1] = sm; ax[2] = sm; ax[3] = sm;
+      if (mine) {
+        *reinterpret_cast<uint4*>(side_xs + idx * 16) = v;
+        if ((idx & (PPG - 1)) == 0) {
+          float* ax = side_aux + (idx / PPG) * 4;
+          ax[0] = sm; ax[1] = sm; ax[2] = sm; ax[3] = sm;
+        }
       }
     }
   }
@@ -1052,7 +1059,8 @@ __global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 
     s_wt[j] = 0.0f;
   }
   if constexpr (SIDE_G > 0) {   // ---- side linear, part 2: this wave's k-steps (token slot 0 of the MFMA tile = this token)
-    __syncthreads();            // the staged row and its group sums
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");   // the wave reads back its own staged pieces: order only
+    __builtin_amdgcn_wave_barrier();
     v4f sacc = {0.f, 0.f, 0.f, 0.f};
     const uint8_t* xb0 = side_xs + (lane >> 4) * 16;
 #pragma unroll
