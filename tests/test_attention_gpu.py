@@ -184,3 +184,55 @@ def test_cache_bounds_raise_instead_of_writing_out_of_range():
     cache.past_tokens[0] = 64
     with pytest.raises(IndexError):                                # decode step past the last page
         attn(xg[None, :1], position_ids=pos[None, 64:65], past_key_value=cache, cache_position=pos[64:65])
+
+
+def test_decode_combined_launches_at_v3_head_dims():
+    """The decode step of the operator at DeepSeek-V3's attention dimensions (128 heads, q_lora 1536, W4 projections) takes the
+    combined launches — q_b_proj + q-absorb + RoPE + latent norm (ktx_linear_forward_qb_absorb) and KV-split merge + un-absorb
+    (ktx_linear_forward_batched_merge): same outputs as the separate launches up to fp32 re-association, identical cache rows."""
+    import os
+    from attn_helpers import make_cfg
+    from ktransformers_amd import _native
+    cfg = make_cfg(2048, 128, 1536)
+    g = torch.Generator().manual_seed(3)
+    H, qh = 128, 192
+
+    def rnd(n, k, s):
+        return (torch.randn((n, k), generator=g) * s).to(torch.bfloat16)
+    w = {"q_a_proj": rnd(1536, 2048, 2048 ** -0.5), "q_b_proj": rnd(H * qh, 1536, 1536 ** -0.5),
+         "kv_a_proj_with_mqa": rnd(576, 2048, 2048 ** -0.5), "kv_b_proj": rnd(H * 256, 512, 512 ** -0.5),
+         "o_proj": rnd(2048, H * 128, (H * 128) ** -0.5),
+         "q_a_layernorm": (1 + 0.1 * torch.randn(1536, generator=g)).to(torch.bfloat16),
+         "kv_a_layernorm": (1 + 0.1 * torch.randn(512, generator=g)).to(torch.bfloat16)}
+    x = torch.randn((44, 2048), generator=g).to(torch.bfloat16).cuda()
+    pos = torch.arange(44, device="cuda")
+    outs, rows = {}, {}
+    for mode in ("combined", "separate"):
+        for k in ("KTX_MLA_SEPARATE_QB", "KTX_MLA_SEPARATE_MERGE"):
+            os.environ.pop(k, None)
+            if mode == "separate":
+                os.environ[k] = "1"
+        try:
+            attn, cache = build(cfg, w, "KLinearMarlin")
+            attn(x[None, :40], position_ids=pos[None, :40], past_key_value=cache, cache_position=pos[:40])
+            dec = []
+            _native.timing_enable(2)        # labels only: which kernels did the decode steps launch?
+            _native.timing_collect()
+            for t in range(40, 44):
+                o, _, _ = attn(x[None, t:t + 1], position_ids=pos[None, t:t + 1], past_key_value=cache, cache_position=pos[t:t + 1])
+                dec.append(o[0])
+            torch.cuda.synchronize()
+            labels = [lab for lab, _, _ in _native.timing_collect()]
+            _native.timing_enable(0)
+            combined = sum("lin_qb_absorb_kernel" in lab for lab in labels), sum("lin_merge_unabsorb_kernel" in lab for lab in labels)
+            assert combined == ((4, 4) if mode == "combined" else (0, 0)), (mode, labels[:12])
+            # launches per decode step of the operator (q_a and kv_a are not merged in this build): 6 combined, more separate
+            assert (len(labels) == 6 * 4) if mode == "combined" else (len(labels) >= 8 * 4), (mode, len(labels), labels[:12])
+            outs[mode] = torch.cat(dec, 0).float().cpu()
+            rows[mode] = cache.key_cache[0].reshape(-1, 576)[:44].clone().cpu()
+        finally:
+            for k in ("KTX_MLA_SEPARATE_QB", "KTX_MLA_SEPARATE_MERGE"):
+                os.environ.pop(k, None)
+    assert torch.isfinite(outs["combined"]).all() and outs["combined"].abs().max() > 0
+    assert torch.equal(rows["combined"], rows["separate"]), "latent rows: same code in both launches"
+    assert rel(outs["combined"].cuda(), outs["separate"]) < 5e-3
