@@ -527,7 +527,14 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
   if (long_ctx) nsplit = std::min(nsplit, 128);
   if (shape == 2) nsplit = std::min(nsplit, std::max(16, 256 / std::max(1, hblocks * total_q_tokens)));
   if (ktx_debug_get(7) > 0) nsplit = ktx_debug_get(7);
-  if (cfg->kv_len_hint > 0) nsplit = std::min(nsplit, std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE));
+  if (cfg->kv_len_hint > 0) {
+    // no more splits than tiles — and no more than the deepest split needs: with T tiles dealt round-robin the launch takes
+    // ceil(T / nsplit) tiles' time, so the smallest split count with that depth writes the fewest partials for the merge to read
+    const int tiles = std::max(1, (cfg->kv_len_hint + MLA_TILE - 1) / MLA_TILE);
+    nsplit = std::min(nsplit, tiles);
+    const int depth = (tiles + nsplit - 1) / nsplit;
+    if (ktx_debug_get(7) <= 0) nsplit = (tiles + depth - 1) / depth;
+  }
   // <= 256 splits: the merge kernel keeps splits/16 partial rows per thread in registers (NS = 16 is its largest, spill-free
   // instantiation); longer contexts simply put more 32-token tiles into each split
   nsplit = std::min(nsplit, std::min(256, std::max(1, cfg->max_splits)));

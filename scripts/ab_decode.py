@@ -27,6 +27,7 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "default": ({}, {}),
     "mla: 32 splits": ({7: 32}, {}),
     "mla: 48 splits": ({7: 48}, {}),
+    "mla: 63 splits": ({7: 63}, {}),
     "mla: 4x2 shape, 128 splits": ({6: 4, 7: 128}, {}),
     "mla: separate prep launch": ({}, {"KTX_MLA_SEPARATE_PREP": "1"}),
     "moe: router in its own launch": ({}, {"KTX_MOE_SEPARATE_ROUTER": "1"}),
