@@ -45,6 +45,7 @@ enum ktx_moe_format {
   KTX_FMT_FP8 = 3,     /* DeepSeek e4m3 + 128x128 block scale_inv, bf16 activations       (amx/fp8-moe.hpp) */
   KTX_FMT_BF16 = 4,    /* bf16 weights                                                    (amx/bf16-moe.hpp) */
   KTX_FMT_GGUF = 5,    /* GGUF k-/i-quant blocks (Q4_K / Q6_K / IQ1_S) x Q8_K activations — the llamafile backend (operators/llamafile/moe.hpp) */
+  KTX_FMT_FP8_PERCHANNEL = 6, /* e4m3 + one fp32 scale per output row (GLM-4.7-FP8 style), bf16 activations (amx/fp8-perchannel-moe.hpp) */
 };
 
 enum ktx_moe_matrix { KTX_MAT_GATE = 0, KTX_MAT_UP = 1, KTX_MAT_DOWN = 2 };
@@ -84,6 +85,13 @@ int ktx_moe_load_quantized(ktx_moe_t h, int expert, int which, const int8_t* q, 
  * handles ktx_moe_load_bf16 stores the weights as they are (re-tiled).  Synchronous. */
 int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, const float* d_gate_scale,
                      const float* d_up_scale, const float* d_down_scale);
+
+/* FP8_PERCHANNEL experts: e4m3 bytes as for ktx_moe_load_fp8 and ONE fp32 scale per output row — gate/up scales
+ * [expert_num][I], down scales [expert_num][H], DEVICE pointers (load_weights of AMX_FP8_PERCHANNEL_MOE_TP,
+ * operators/amx/fp8-perchannel-moe.hpp:508-555).  Arithmetic: fp32 sum of the bf16 products over the whole K, then
+ * `* scale[n]`, then the bf16 rounding (float_mat_vec_perchannel, amx/la/amx_raw_kernels.hpp:630-840).  Synchronous. */
+int ktx_moe_load_fp8_perchannel(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down,
+                                const float* d_gate_scale, const float* d_up_scale, const float* d_down_scale);
 
 /* RAWINT4 (Kimi-K2 native / compressed-tensors int4): packed nibbles gate/up [expert_num][I][H/2], down
  * [expert_num][H][I/2] (byte = ((q1+8)<<4)|(q0+8), even k in the low nibble) and bf16 scales [expert_num][N][K/32],

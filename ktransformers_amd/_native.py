@@ -14,7 +14,7 @@ import torch
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "lib", "libktx_hip.so")
 
-FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4, "GGUF": 5}
+FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4, "GGUF": 5, "FP8_PERCHANNEL": 6}
 GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 14, 19
 GGML_BLOCK_BYTES = {12: 144, 14: 210, 19: 50}
 MAT_GATE, MAT_UP, MAT_DOWN = 0, 1, 2
@@ -61,6 +61,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_load_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_moe_load_quantized.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
     lib.ktx_moe_load_fp8.argtypes = [C.c_void_p] * 7
+    lib.ktx_moe_load_fp8_perchannel.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_load_rawint4.argtypes = [C.c_void_p] * 7
     lib.ktx_moe_load_gguf.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
     lib.ktx_moe_combine.argtypes = [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
@@ -287,6 +288,24 @@ class MoEHandle:
         torch.cuda.synchronize(self.device)
         check(lib.ktx_moe_load_fp8(self._h, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ss[0].data_ptr(),
                                    ss[1].data_ptr(), ss[2].data_ptr()))
+
+    def load_fp8_perchannel(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_scale: torch.Tensor,
+                            up_scale: torch.Tensor, down_scale: torch.Tensor) -> None:
+        """FP8_PERCHANNEL experts: uint8/float8_e4m3fn [E,I,H]/[E,I,H]/[E,H,I] + one fp32 scale per output row:
+        gate/up [E,I], down [E,H]."""
+        ws = []
+        for t, shape in ((gate, (self.E, self.I, self.H)), (up, (self.E, self.I, self.H)), (down, (self.E, self.H, self.I))):
+            if t.element_size() != 1 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
+                raise KtxError(f"load_fp8_perchannel: expected contiguous 1-byte {shape} on {self.device}")
+            ws.append(t)
+        ss = []
+        for t, n in ((gate_scale, self.I), (up_scale, self.I), (down_scale, self.H)):
+            if t.dtype != torch.float32 or tuple(t.shape) != (self.E, n) or not t.is_contiguous() or t.device != self.device:
+                raise KtxError("load_fp8_perchannel: scales must be contiguous fp32 [E, N] on the handle's device")
+            ss.append(t)
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_moe_load_fp8_perchannel(self._h, ws[0].data_ptr(), ws[1].data_ptr(), ws[2].data_ptr(), ss[0].data_ptr(),
+                                              ss[1].data_ptr(), ss[2].data_ptr()))
 
     def load_rawint4(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_scale: torch.Tensor,
                      up_scale: torch.Tensor, down_scale: torch.Tensor) -> None:

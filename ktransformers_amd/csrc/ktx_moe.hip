@@ -1260,6 +1260,7 @@ __device__ __forceinline__ uint2 fp8x4_to_bf16x4(uint32_t v) {
 struct FpGemmParams {
   const uint8_t *w0, *w1;     // tiled weights (gate | down, up)
   const float *s0, *s1;       // FP8: scale_inv [E][N/128][K/128]; BF16: nullptr
+  const float *r0, *r1;       // FP8_PERCHANNEL: scale per output row [E][N] (the block scales are then all 1), else nullptr
   size_t expert_stride;       // bytes per expert matrix
   size_t scale_stride;        // floats per expert
   int N, K;
@@ -1432,9 +1433,13 @@ __global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
       bf16_t o[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const bf16_t g = f32_to_bf16(acc[0][t][r]);
+        // FP8_PERCHANNEL: the whole-K sum times the row's scale (apply_scale_perchannel, amx_raw_kernels.hpp:686-700); x * 1.0f
+        // is exact, so the other formats are untouched
+        const float rs0 = p.r0 ? p.r0[(size_t)tile.expert * p.N + n0 + r] : 1.0f;
+        const bf16_t g = f32_to_bf16(acc[0][t][r] * rs0);
         if constexpr (GATE_UP) {
-          const bf16_t u = f32_to_bf16(acc[1][t][r]);
+          const float rs1 = p.r1 ? p.r1[(size_t)tile.expert * p.N + n0 + r] : 1.0f;
+          const bf16_t u = f32_to_bf16(acc[1][t][r] * rs1);
           o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
         } else {
           o[r] = g;
@@ -1464,6 +1469,7 @@ struct DecFpParams {
   const float* weights;
   const uint8_t *gate_w, *up_w, *down_w;
   const float *gate_s, *up_s, *down_s;   // FP8: scale_inv [E][N/128][K/128]
+  const float *gate_r, *up_r, *down_r;   // FP8_PERCHANNEL: scale per output row [E][N] (block scales all 1), else nullptr
   size_t gu_stride, dn_stride;           // bytes per expert matrix
   bf16_t* a_buf;                         // [qlen*k][I]
   void* y;
@@ -1585,7 +1591,9 @@ __global__ __launch_bounds__(NW * 64) void moe_dec_fp_gateup_kernel(DecFpParams 
     bf16_t o[4];
 #pragma unroll
     for (int r = 0; r < 4; r++) {
-      const bf16_t gq = f32_to_bf16(accg[r]), uq = f32_to_bf16(accu[r]);
+      // FP8_PERCHANNEL: whole-K sum times the row's scale (x * 1.0f is exact: the other formats are untouched)
+      const float rg = p.gate_r ? p.gate_r[(size_t)e * p.I + n0 + r] : 1.0f, ru = p.up_r ? p.up_r[(size_t)e * p.I + n0 + r] : 1.0f;
+      const bf16_t gq = f32_to_bf16(accg[r] * rg), uq = f32_to_bf16(accu[r] * ru);
       o[r] = f32_to_bf16(act_fn(bf16_to_f32(gq), bf16_to_f32(uq)));
     }
     *reinterpret_cast<uint2*>(p.a_buf + (size_t)pair * p.I + n0) =
@@ -1655,7 +1663,10 @@ __global__ __launch_bounds__(512) void moe_dec_fp_down_kernel(DecFpParams p) {
     if ((lane & 15) == 0) {
       const int r0 = (lane >> 4) * 4;
 #pragma unroll
-      for (int r = 0; r < 4; r++) s_dn[j * 16 + r0 + r] = bf16_to_f32(f32_to_bf16(acc[r]));
+      for (int r = 0; r < 4; r++) {
+        const float rd = p.down_r ? p.down_r[(size_t)e * p.H + strip * 16 + r0 + r] : 1.0f;   // FP8_PERCHANNEL row scale
+        s_dn[j * 16 + r0 + r] = bf16_to_f32(f32_to_bf16(acc[r] * rd));
+      }
     }
   } else if (lane == 0) {
     s_valid[j] = 0;
@@ -2220,6 +2231,7 @@ struct ktx_moe_s {
   size_t gu_stride, dn_stride;  // bytes per expert matrix
   uint8_t *gate_w = nullptr, *up_w = nullptr, *down_w = nullptr;
   float *gate_s = nullptr, *up_s = nullptr, *down_s = nullptr;
+  float *gate_r = nullptr, *up_r = nullptr, *down_r = nullptr;   // FP8_PERCHANNEL: fp32 scale per output row [E][N]
   uint8_t* mask = nullptr;
   std::shared_ptr<Workspace> ws_own;   // keeps the arena alive as long as this handle (and graphs captured through it)
   Workspace* ws = nullptr;
@@ -2239,7 +2251,7 @@ static int pick_mt(int qlen, int k, int E) {
 
 extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_REQUIRE(cfg && out, "ktx_moe_create: null argument");
-  KTX_REQUIRE(cfg->format >= KTX_FMT_AMXINT4 && cfg->format <= KTX_FMT_GGUF, "ktx_moe_create: unknown format");
+  KTX_REQUIRE(cfg->format >= KTX_FMT_AMXINT4 && cfg->format <= KTX_FMT_FP8_PERCHANNEL, "ktx_moe_create: unknown format");
   KTX_REQUIRE(cfg->format != KTX_FMT_GGUF || (cfg->hidden_size % 256 == 0 && cfg->intermediate_size % 256 == 0),
               "ktx_moe_create: GGUF k-quants need hidden_size and intermediate_size to be multiples of 256 (QK_K)");
   KTX_REQUIRE(cfg->format != KTX_FMT_RAWINT4 || cfg->group_size == 32,
@@ -2277,6 +2289,11 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
   KTX_HIP(hipMalloc(&h->gate_s, gu_sbytes));
   KTX_HIP(hipMalloc(&h->up_s, gu_sbytes));
   KTX_HIP(hipMalloc(&h->down_s, dn_sbytes));
+  }
+  if (cfg->format == KTX_FMT_FP8_PERCHANNEL) {   // the block-scale arrays above are filled with 1, these carry the row scales
+    KTX_HIP(hipMalloc(&h->gate_r, E * I * sizeof(float)));
+    KTX_HIP(hipMalloc(&h->up_r, E * I * sizeof(float)));
+    KTX_HIP(hipMalloc(&h->down_r, E * H * sizeof(float)));
   }
   {
     std::lock_guard<std::mutex> lk(g_ws_mu);
@@ -2328,7 +2345,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
 extern "C" int ktx_moe_destroy(ktx_moe_t h) {
   if (!h) return 0;
   DeviceGuard _dg(h->cfg.device);
-  void* ptrs[] = {h->gate_w, h->up_w, h->down_w, h->gate_s, h->up_s, h->down_s, h->mask};
+  void* ptrs[] = {h->gate_w, h->up_w, h->down_w, h->gate_s, h->up_s, h->down_s, h->gate_r, h->up_r, h->down_r, h->mask};
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete h;
@@ -2395,7 +2412,7 @@ extern "C" int ktx_moe_load_bf16(ktx_moe_t h, const void* d_gate, const void* d_
   KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_bf16: null argument");
   KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
-  KTX_REQUIRE(h->cfg.format != KTX_FMT_FP8 && h->cfg.format != KTX_FMT_RAWINT4,
+  KTX_REQUIRE(h->cfg.format != KTX_FMT_FP8 && h->cfg.format != KTX_FMT_FP8_PERCHANNEL && h->cfg.format != KTX_FMT_RAWINT4,
               "ktx_moe_load_bf16: FP8 / RAWINT4 handles take pre-quantised weights (ktx_moe_load_fp8 / ktx_moe_load_rawint4)");
   if (h->cfg.format == KTX_FMT_BF16) {  // no quantisation: re-tile only (BufferBBF16Impl::from_mat is a re-layout too)
     const size_t pieces = (size_t)I * H * 2 / 16;
@@ -2476,6 +2493,36 @@ extern "C" int ktx_moe_load_fp8(ktx_moe_t h, const void* d_gate, const void* d_u
   KTX_HIP(hipMemcpy(h->gate_s, d_gate_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
   KTX_HIP(hipMemcpy(h->up_s, d_up_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
   KTX_HIP(hipMemcpy(h->down_s, d_down_scale, E * nsc * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipDeviceSynchronize());
+  return 0;
+}
+
+extern "C" int ktx_moe_load_fp8_perchannel(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down,
+                                           const float* d_gate_scale, const float* d_up_scale, const float* d_down_scale) {
+  KTX_REQUIRE(h && d_gate && d_up && d_down && d_gate_scale && d_up_scale && d_down_scale, "ktx_moe_load_fp8_perchannel: null argument");
+  KTX_REQUIRE(h->cfg.format == KTX_FMT_FP8_PERCHANNEL, "ktx_moe_load_fp8_perchannel: handle was not created with KTX_FMT_FP8_PERCHANNEL");
+  KTX_ON_DEVICE(h->cfg.device);
+  const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
+  const size_t pieces = (size_t)I * H / 16, nsc = (size_t)(I / 128) * (H / 128);
+  for (int e = 0; e < E; e++) {
+    const uint8_t* src[3] = {(const uint8_t*)d_gate + (size_t)e * I * H, (const uint8_t*)d_up + (size_t)e * I * H,
+                             (const uint8_t*)d_down + (size_t)e * H * I};
+    uint8_t* dst[3] = {h->gate_w + e * h->gu_stride, h->up_w + e * h->gu_stride, h->down_w + e * h->dn_stride};
+    const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
+    for (int m = 0; m < 3; m++)
+      hipLaunchKernelGGL(pack_wfp_kernel, dim3((unsigned)((pieces + 255) / 256)), dim3(256), 0, 0, src[m], Ns[m], Ks[m], 1,
+                         reinterpret_cast<uint4*>(dst[m]));
+  }
+  KTX_HIP(hipGetLastError());
+  // the FP8 kernels run with every 128x128 block scale = 1 (c = fma(group, 1, c) is a plain fp32 add of the group sums);
+  // the row scales are applied by their epilogues
+  const std::vector<float> ones((size_t)E * nsc, 1.0f);
+  KTX_HIP(hipMemcpy(h->gate_s, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+  KTX_HIP(hipMemcpy(h->up_s, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+  KTX_HIP(hipMemcpy(h->down_s, ones.data(), ones.size() * sizeof(float), hipMemcpyHostToDevice));
+  KTX_HIP(hipMemcpy(h->gate_r, d_gate_scale, (size_t)E * I * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipMemcpy(h->up_r, d_up_scale, (size_t)E * I * sizeof(float), hipMemcpyDeviceToDevice));
+  KTX_HIP(hipMemcpy(h->down_r, d_down_scale, (size_t)E * H * sizeof(float), hipMemcpyDeviceToDevice));
   KTX_HIP(hipDeviceSynchronize());
   return 0;
 }
@@ -2826,7 +2873,7 @@ static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, 
     return 0;
   }
   if (side) return KTX_MOE_NOT_FUSED;   // only the AMXINT4 / AMXINT8 decode kernels carry a side linear
-  if (h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_BF16)
+  if (h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_FP8_PERCHANNEL || h->cfg.format == KTX_FMT_BF16)
     return forward_fp(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
   if (h->cfg.format == KTX_FMT_RAWINT4)
     return forward_rawint4(h, d_bsz, qlen, k, d_expert_ids, d_weights, d_input, d_output, flags, st);
@@ -2901,7 +2948,7 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
                       const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st) {
   Workspace* ws = h->ws;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
-  const bool fp8 = h->cfg.format == KTX_FMT_FP8;
+  const bool fp8 = h->cfg.format == KTX_FMT_FP8 || h->cfg.format == KTX_FMT_FP8_PERCHANNEL;   // per-channel: block scales = 1 + row scales
   const int mt = std::min(4, pick_mt(qlen, k, E));
   const int npairs = qlen * k;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
@@ -2919,6 +2966,7 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
     dp.ids = d_expert_ids; dp.mask = h->mask; dp.x = (const bf16_t*)d_input; dp.weights = d_weights;
     dp.gate_w = h->gate_w; dp.up_w = h->up_w; dp.down_w = h->down_w;
     dp.gate_s = h->gate_s; dp.up_s = h->up_s; dp.down_s = h->down_s;
+    dp.gate_r = h->gate_r; dp.up_r = h->up_r; dp.down_r = h->down_r;
     dp.gu_stride = h->gu_stride; dp.dn_stride = h->dn_stride; dp.a_buf = ws->a_buf; dp.y = d_output;
     dp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
     const dim3 g1((I / 16 + 3) / 4, npairs), g2(H / 16, qlen);
@@ -2981,7 +3029,8 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
   KTX_HIP(hipGetLastError());
 
   FpGemmParams g1;
-  g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = h->gate_s; g1.s1 = h->up_s; g1.expert_stride = h->gu_stride;
+  g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.s0 = h->gate_s; g1.s1 = h->up_s; g1.r0 = h->gate_r; g1.r1 = h->up_r;
+  g1.expert_stride = h->gu_stride;
   g1.scale_stride = (size_t)(I / 128) * (H / 128); g1.N = I; g1.K = H; g1.act = (const bf16_t*)d_input;
   g1.row_src = ws->src_of_row; g1.tiles = ws->tiles; g1.counters = ws->counters; g1.out = ws->a_buf;
   int rc;
@@ -2991,7 +3040,8 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
   }
   if (rc) return rc;
   FpGemmParams g2;
-  g2.w0 = h->down_w; g2.w1 = nullptr; g2.s0 = h->down_s; g2.s1 = nullptr; g2.expert_stride = h->dn_stride;
+  g2.w0 = h->down_w; g2.w1 = nullptr; g2.s0 = h->down_s; g2.s1 = nullptr; g2.r0 = h->down_r; g2.r1 = nullptr;
+  g2.expert_stride = h->dn_stride;
   g2.scale_stride = (size_t)(H / 128) * (I / 128); g2.N = H; g2.K = I; g2.act = ws->a_buf; g2.row_src = nullptr;
   g2.tiles = ws->tiles; g2.counters = ws->counters; g2.out = ws->dn_buf;
   {

@@ -54,9 +54,9 @@ class AMXMoEWrapper(BaseMoEWrapper):
 
 
 class NativeMoEWrapper(BaseMoEWrapper):
-    """RAWINT4 / FP8 / BF16 straight from the model's own safetensors (utils/amx.py:549-959)."""
+    """RAWINT4 / FP8 / FP8_PERCHANNEL / BF16 straight from the model's own safetensors (utils/amx.py:549-959)."""
 
-    FORMAT = {"RAWINT4": "RAWINT4", "FP8": "FP8", "BF16": "BF16"}
+    FORMAT = {"RAWINT4": "RAWINT4", "FP8": "FP8", "FP8_PERCHANNEL": "FP8_PERCHANNEL", "BF16": "BF16"}
     _native_loader_instance = None
 
     def __init__(self, *args, **kw):
@@ -73,6 +73,8 @@ class NativeMoEWrapper(BaseMoEWrapper):
             return CompressedSafeTensorLoader(weight_path)
         if method == "FP8":
             return FP8SafeTensorLoader(weight_path)
+        if method == "FP8_PERCHANNEL":     # utils/amx.py:674-675: the same loader reading `weight_scale` (one scale per row)
+            return FP8SafeTensorLoader(weight_path, scale_suffix="weight_scale")
         if method == "BF16":
             return BF16SafeTensorLoader(weight_path)
         raise NotImplementedError(f"Unsupported method for NativeMoEWrapper: {method}")
@@ -114,9 +116,14 @@ class NativeMoEWrapper(BaseMoEWrapper):
         if self.method == "BF16":
             self.moe = self._new_handle()
             self.moe.load_bf16(stack("gate", torch.bfloat16), stack("up", torch.bfloat16), stack("down", torch.bfloat16))
+        elif self.method == "FP8_PERCHANNEL":   # utils/amx.py:774-779, 895-897: fp32 scale per output row, per_channel = True
+            self.moe = self._new_handle()
+            self.moe.load_fp8_perchannel(stack("gate").view(torch.uint8), stack("up").view(torch.uint8), stack("down").view(torch.uint8),
+                                         stack("gate_scale", torch.float32), stack("up_scale", torch.float32),
+                                         stack("down_scale", torch.float32))
         elif self.method == "FP8":
             if getattr(self.loader, "is_per_channel", lambda: False)():
-                raise NotImplementedError("per-channel FP8 scales are the FP8_PERCHANNEL method, which this build lacks")
+                raise ValueError("this checkpoint carries per-channel FP8 scales: load it with method='FP8_PERCHANNEL'")
             self.moe = self._new_handle(group_size=128)
             self.moe.load_fp8(stack("gate").view(torch.uint8), stack("up").view(torch.uint8), stack("down").view(torch.uint8),
                               stack("gate_scale", torch.float32), stack("up_scale", torch.float32), stack("down_scale", torch.float32))

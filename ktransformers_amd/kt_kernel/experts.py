@@ -17,7 +17,7 @@ SFT_METHODS = frozenset(["AMXBF16_SFT", "AMXFP8_SFT", "INT8_SFT", "AMXINT8_SFT",
                          "AMXINT4_1KGroup_SFT", "AMXBF16_SFT_SkipLoRA", "AMXINT8_SFT_SkipLoRA", "AMXINT4_SFT_SkipLoRA",
                          "AMXINT4_1_SFT_SkipLoRA", "AMXINT4_KGroup_SFT_SkipLoRA", "AMXINT4_1KGroup_SFT_SkipLoRA"])
 _BACKENDS = {"AMXINT4": AMXMoEWrapper, "AMXINT8": AMXMoEWrapper, "RAWINT4": NativeMoEWrapper, "FP8": NativeMoEWrapper,
-             "BF16": NativeMoEWrapper, "LLAMAFILE": LlamafileMoEWrapper}
+             "FP8_PERCHANNEL": NativeMoEWrapper, "BF16": NativeMoEWrapper, "LLAMAFILE": LlamafileMoEWrapper}
 SUPPORTED_METHODS = frozenset(_BACKENDS)
 
 

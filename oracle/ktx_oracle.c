@@ -23,6 +23,7 @@
 #define KTXO_FMT_AMXINT8 1
 #define KTXO_FMT_RAWINT4 2
 #define KTXO_FMT_FP8 3
+#define KTXO_FMT_FP8PC 5   /* e4m3 weights, one fp32 scale per output row (FP8_PERCHANNEL) */
 #define KTXO_FMT_BF16 4
 
 /* ------------------------------------------------------------------------------------------------ */
@@ -308,6 +309,22 @@ static void gemv_fp8(const uint16_t* a_bf16, const uint8_t* w, const float* scal
   }
 }
 
+/* float_mat_vec_perchannel (amx_raw_kernels.hpp:630-840, fp8-perchannel-moe.hpp:93-108): the e4m3 weights widened to bf16
+ * exactly, ONE fp32 chain of bf16-pair products over the whole K (GemmKernel224FP8PerChannel::avx_kernel_4), then
+ * apply_scale_perchannel: c = c * scale[n] (a plain multiply), then the bf16 rounding of the output buffer. */
+static void gemv_fp8pc(const uint16_t* a_bf16, const uint8_t* w, const float* scale, int N, int K, int even_first,
+                       uint16_t* out) {
+#pragma omp parallel for schedule(static)
+  for (int n = 0; n < N; n++) {
+    const uint8_t* row = w + (size_t)n * K;
+    float c = 0.0f;
+    for (int j = 0; j < K; j += 2)
+      c = dpbf16(c, ktxo_bf16_to_f32(a_bf16[j]), ktxo_e4m3_to_f32(row[j]), ktxo_bf16_to_f32(a_bf16[j + 1]),
+                 ktxo_e4m3_to_f32(row[j + 1]), even_first);
+    out[n] = ktxo_f32_to_bf16(c * scale[n]);
+  }
+}
+
 /* GemmKernel224BF16::avx_kernel(_4) (amx_raw_kernels.hpp:93-256): one fp32 chain over the whole K. */
 static void gemv_bf16(const uint16_t* a_bf16, const uint16_t* w, int N, int K, int even_first, uint16_t* out) {
 #pragma omp parallel for schedule(static)
@@ -325,9 +342,10 @@ static void gemv_bf16(const uint16_t* a_bf16, const uint16_t* w, int N, int K, i
  * (AMX_FP8_MOE_TP / AMX_BF16_MOE_TP: operators/amx/fp8-moe.hpp:93-108, bf16-moe.hpp; BufferABF16Impl::from_mat copies). */
 int ktxo_moe_forward_fp(const ktxo_moe* m, int T, int k, const int64_t* ids, const float* w, const uint16_t* x,
                         uint16_t* y, int incremental) {
-  if (m->fmt != KTXO_FMT_FP8 && m->fmt != KTXO_FMT_BF16) return -1;
+  if (m->fmt != KTXO_FMT_FP8 && m->fmt != KTXO_FMT_BF16 && m->fmt != KTXO_FMT_FP8PC) return -1;
   const int H = m->H, I = m->I, ef = m->dp_even_first;
-  const int fp8 = m->fmt == KTXO_FMT_FP8;
+  const int pc = m->fmt == KTXO_FMT_FP8PC;          /* per-channel scales: gate/up [E][I], down [E][H] */
+  const int fp8 = m->fmt == KTXO_FMT_FP8 || pc;
   uint16_t* g = (uint16_t*)malloc(sizeof(uint16_t) * I);
   uint16_t* u = (uint16_t*)malloc(sizeof(uint16_t) * I);
   uint16_t* dn = (uint16_t*)malloc(sizeof(uint16_t) * H);
@@ -341,7 +359,10 @@ int ktxo_moe_forward_fp(const ktxo_moe* m, int T, int k, const int64_t* ids, con
       int64_t id = ids[(size_t)t * k + j];
       if (skip_expert(m, id)) continue;
       const size_t wo = (size_t)id * I * H * esz;
-      if (fp8) {
+      if (pc) {
+        gemv_fp8pc(xt, (const uint8_t*)m->gate_q + wo, m->gate_d + id * I, I, H, ef, g);
+        gemv_fp8pc(xt, (const uint8_t*)m->up_q + wo, m->up_d + id * I, I, H, ef, u);
+      } else if (fp8) {
         gemv_fp8(xt, (const uint8_t*)m->gate_q + wo, m->gate_d + id * sgu, I, H, ef, g);
         gemv_fp8(xt, (const uint8_t*)m->up_q + wo, m->up_d + id * sgu, I, H, ef, u);
       } else {
@@ -349,7 +370,8 @@ int ktxo_moe_forward_fp(const ktxo_moe* m, int T, int k, const int64_t* ids, con
         gemv_bf16(xt, (const uint16_t*)((const uint8_t*)m->up_q + wo), I, H, ef, u);
       }
       for (int i = 0; i < I; i++) g[i] = ktxo_f32_to_bf16(ktxo_act_fn(ktxo_bf16_to_f32(g[i]), ktxo_bf16_to_f32(u[i])));
-      if (fp8) gemv_fp8(g, (const uint8_t*)m->down_q + wo, m->down_d + id * sdn, H, I, ef, dn);
+      if (pc) gemv_fp8pc(g, (const uint8_t*)m->down_q + wo, m->down_d + id * H, H, I, ef, dn);
+      else if (fp8) gemv_fp8(g, (const uint8_t*)m->down_q + wo, m->down_d + id * sdn, H, I, ef, dn);
       else gemv_bf16(g, (const uint16_t*)((const uint8_t*)m->down_q + wo), H, I, ef, dn);
       const float wt = w[(size_t)t * k + j];
       for (int e = 0; e < H; e++) acc[e] = fmaf(ktxo_bf16_to_f32(dn[e]), wt, acc[e]);

@@ -18,7 +18,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 ORACLE_SO = os.path.join(_HERE, "libktx_oracle.so")
 REF_SO = os.path.join(_HERE, "_ref", "libkt_ref.so")
 
-FMT_AMXINT4, FMT_AMXINT8, FMT_RAWINT4, FMT_FP8, FMT_BF16 = 0, 1, 2, 3, 4
+FMT_AMXINT4, FMT_AMXINT8, FMT_RAWINT4, FMT_FP8, FMT_BF16, FMT_FP8_PERCHANNEL = 0, 1, 2, 3, 4, 5
 
 
 def build(ref: bool = True) -> None:
@@ -147,7 +147,7 @@ class Oracle:
             if rc != 0:
                 raise RuntimeError("ktxo_moe_forward_rawint4 failed")
             return y
-        if moe["fmt"] in (FMT_FP8, FMT_BF16):
+        if moe["fmt"] in (FMT_FP8, FMT_BF16, FMT_FP8_PERCHANNEL):
             if trace:
                 raise NotImplementedError("traces are only kept for the integer formats")
             rc = self.lib.ktxo_moe_forward_fp(C.byref(s), C.c_int(T), C.c_int(k), _p(ids), _p(weights), _p(x_bf16), _p(y),
@@ -174,6 +174,15 @@ class Oracle:
         return dict(fmt=FMT_FP8, E=E, H=H, I=I, gate_q=c(gate_fp8, dtype=np.uint8), up_q=c(up_fp8, dtype=np.uint8),
                     down_q=c(down_fp8, dtype=np.uint8), gate_d=c(gate_s, dtype=np.float32), up_d=c(up_s, dtype=np.float32),
                     down_d=c(down_s, dtype=np.float32), mask=mask, dp_even_first=dp_even_first)
+
+    def make_moe_fp8_perchannel(self, gate_fp8, up_fp8, down_fp8, gate_s, up_s, down_s, mask=None, dp_even_first=0):
+        """e4m3 bytes gate/up [E,I,H], down [E,H,I]; fp32 scale per output row: gate/up [E,I], down [E,H] (FP8_PERCHANNEL)."""
+        E, I, H = gate_fp8.shape
+        c = np.ascontiguousarray
+        return dict(fmt=FMT_FP8_PERCHANNEL, E=E, H=H, I=I, gate_q=c(gate_fp8, dtype=np.uint8), up_q=c(up_fp8, dtype=np.uint8),
+                    down_q=c(down_fp8, dtype=np.uint8), gate_d=c(gate_s, dtype=np.float32).reshape(E, I),
+                    up_d=c(up_s, dtype=np.float32).reshape(E, I), down_d=c(down_s, dtype=np.float32).reshape(E, H), mask=mask,
+                    dp_even_first=dp_even_first)
 
     def make_moe_rawint4(self, gate_p, up_p, down_p, gate_s, up_s, down_s, mask=None, uncontracted=0):
         """packed nibbles gate/up [E,I,H/2], down [E,H,I/2] uint8; scales bf16 bits (uint16) or fp32 [E,N,K/32]."""
@@ -212,7 +221,7 @@ class Oracle:
 class Reference:
     """The reference's own kernels (oracle/_ref).  One worker pool per instance."""
 
-    KIND = {FMT_AMXINT4: 0, FMT_AMXINT8: 1, FMT_RAWINT4: 2, FMT_FP8: 3, FMT_BF16: 4}
+    KIND = {FMT_AMXINT4: 0, FMT_AMXINT8: 1, FMT_RAWINT4: 2, FMT_FP8: 3, FMT_BF16: 4, FMT_FP8_PERCHANNEL: 5}
 
     def __init__(self, threads: int = 4, subpools: int = 1):
         if not reference_available():

@@ -12,6 +12,7 @@
 //   TP_MOE<AMX_K2_MOE_TP<amx::GemmKernel224Int4SmallKGroup>>  kt-kernel/operators/amx/k2-moe.hpp
 //   TP_MOE<AMX_FP8_MOE_TP<amx::GemmKernel224FP8>>         kt-kernel/operators/amx/fp8-moe.hpp
 //   TP_MOE<AMX_BF16_MOE_TP<amx::GemmKernel224BF16>>       kt-kernel/operators/amx/bf16-moe.hpp
+//   TP_MOE<AMX_FP8_PERCHANNEL_MOE_TP<amx::GemmKernel224FP8PerChannel>>  kt-kernel/operators/amx/fp8-perchannel-moe.hpp
 //   forward() protocol                                    kt-kernel/operators/moe-tp.hpp:201-246
 //   WorkerPool(WorkerPoolConfig)                          kt-kernel/cpu_backend/worker_pool.h:132-168
 #include <cstdint>
@@ -23,6 +24,7 @@
 
 #include "operators/amx/bf16-moe.hpp"
 #include "operators/amx/fp8-moe.hpp"
+#include "operators/amx/fp8-perchannel-moe.hpp"
 #include "operators/amx/k2-moe.hpp"
 #include "operators/amx/moe.hpp"
 
@@ -30,13 +32,14 @@ namespace {
 
 thread_local std::string g_err;
 
-enum Kind { KIND_INT4 = 0, KIND_INT8 = 1, KIND_K2 = 2, KIND_FP8 = 3, KIND_BF16 = 4 };
+enum Kind { KIND_INT4 = 0, KIND_INT8 = 1, KIND_K2 = 2, KIND_FP8 = 3, KIND_BF16 = 4, KIND_FP8PC = 5 };
 
 using MoeInt4 = TP_MOE<AMX_MOE_TP<amx::GemmKernel224Int4>>;
 using MoeInt8 = TP_MOE<AMX_MOE_TP<amx::GemmKernel224Int8>>;
 using MoeK2 = TP_MOE<AMX_K2_MOE_TP<amx::GemmKernel224Int4SmallKGroup>>;
 using MoeFP8 = TP_MOE<AMX_FP8_MOE_TP<amx::GemmKernel224FP8>>;
 using MoeBF16 = TP_MOE<AMX_BF16_MOE_TP<amx::GemmKernel224BF16>>;
+using MoeFP8PC = TP_MOE<AMX_FP8_PERCHANNEL_MOE_TP<amx::GemmKernel224FP8PerChannel>>;
 
 struct Handle {
   int kind;
@@ -46,6 +49,7 @@ struct Handle {
   std::unique_ptr<MoeK2> k2;
   std::unique_ptr<MoeFP8> f8;
   std::unique_ptr<MoeBF16> bf;
+  std::unique_ptr<MoeFP8PC> pc;
 };
 
 template <class F>
@@ -99,6 +103,7 @@ void* ktref_moe_create(int kind, int expert_num, int k, int hidden, int inter, i
     c.quant_config.group_size = group_size;
     c.quant_config.zero_point = false;
     c.quant_config.bits = (kind == KIND_K2) ? 4 : 8;
+    c.quant_config.per_channel = (kind == KIND_FP8PC);
     h->cfg = c;
   });
   if (rc) {
@@ -141,6 +146,10 @@ int ktref_moe_load(void* hv, const void* gate, const void* up, const void* down,
         h->bf = std::make_unique<MoeBF16>(h->cfg);
         h->bf->load_weights();
         break;
+      case KIND_FP8PC:
+        h->pc = std::make_unique<MoeFP8PC>(h->cfg);
+        h->pc->load_weights();
+        break;
       default:
         throw std::runtime_error("bad kind");
     }
@@ -159,6 +168,7 @@ int ktref_moe_forward(void* hv, int qlen, int k, const int64_t* expert_ids, cons
       case KIND_K2: m = h->k2.get(); break;
       case KIND_FP8: m = h->f8.get(); break;
       case KIND_BF16: m = h->bf.get(); break;
+      case KIND_FP8PC: m = h->pc.get(); break;
     }
     if (!m) throw std::runtime_error("not loaded");
     m->forward(qlen, k, expert_ids, weights, input, output, incremental != 0);

@@ -62,6 +62,22 @@ def fp8_block_quant(w_f32):
     return q.reshape(E, N, K), scale.reshape(E, N // 128, K // 128).astype(np.float32)
 
 
+def fp8_perchannel_quant(w_f32):
+    """[E,N,K] fp32 -> (e4m3 bytes [E,N,K], fp32 scale [E,N]): one scale per output row, scale = row amax / 448, nearest e4m3
+    (the per-channel scheme of GLM-4.7-FP8 style checkpoints the reference's FP8_PERCHANNEL method loads,
+    kt-kernel/operators/amx/fp8-perchannel-moe.hpp:508-555)."""
+    E, N, K = w_f32.shape
+    grid = e4m3_lut()[:127].astype(np.float32)
+    amax = np.abs(w_f32).max(axis=2, keepdims=True)
+    scale = (amax / 448.0).astype(np.float32)
+    scale[scale == 0] = 1
+    v = (w_f32 / scale).astype(np.float32)
+    mid = (grid[1:] + grid[:-1]) / 2
+    idx = np.searchsorted(mid, np.abs(v)).astype(np.uint8)
+    q = idx | ((v < 0).astype(np.uint8) << 7)
+    return q, scale.reshape(E, N).astype(np.float32)
+
+
 def rawint4_quantize(w_f32, group=32):
     """[E,N,K] fp32 -> (packed uint8 [E,N,K/2] with byte = ((q1+8)<<4)|(q0+8), bf16 scale bits uint16 [E,N,K/group]),
     vectorised form of rawint4_quantize in kt-kernel/test/per_commit/test_moe_rawint4_accuracy.py:69-94

@@ -82,7 +82,12 @@ def test_deferred_experts_fold_into_the_next_layer(oracle, dev):
     assert np.array_equal(numpy_u16(outs[1]), want1)
 
 
-@pytest.mark.parametrize("method,builder,layer", [("FP8", B.fp8_block, 2), ("BF16", B.bf16_per_expert, 3), ("RAWINT4", B.compressed_int4, 5)])
+def _fp8_per_channel(folder, dims=None):
+    return B.fp8_block(folder, scale="weight_scale", per_channel=True, dims=dims)
+
+
+@pytest.mark.parametrize("method,builder,layer", [("FP8", B.fp8_block, 2), ("BF16", B.bf16_per_expert, 3), ("RAWINT4", B.compressed_int4, 5),
+                                                  ("FP8_PERCHANNEL", _fp8_per_channel, 2)])
 def test_checkpoint_formats_equal_a_directly_loaded_handle(dev, tmp_path, method, builder, layer):
     from ktransformers_amd._native import MoEHandle
     from ktransformers_amd.kt_kernel.utils import loader as L
@@ -91,7 +96,8 @@ def test_checkpoint_formats_equal_a_directly_loaded_handle(dev, tmp_path, method
     perm = [2, 0, 1]
     w = make(method, layer, E, k, H, I, path=str(tmp_path))
     w.load_weights(torch.tensor(perm))
-    src = {"FP8": L.FP8SafeTensorLoader, "BF16": L.BF16SafeTensorLoader, "RAWINT4": L.CompressedSafeTensorLoader}[method](str(tmp_path))
+    src = {"FP8": L.FP8SafeTensorLoader, "BF16": L.BF16SafeTensorLoader, "RAWINT4": L.CompressedSafeTensorLoader,
+           "FP8_PERCHANNEL": lambda p: L.FP8SafeTensorLoader(p, scale_suffix="weight_scale")}[method](str(tmp_path))
     e = src.load_experts(f"model.layers.{layer}")
     st = lambda name: torch.stack([e[name][i] for i in perm]).to(dev).contiguous()
     h = MoEHandle(E, k, H, I, max_len=64, method=method, device=dev, group_size={"FP8": 128, "RAWINT4": 32}.get(method, 0))
@@ -100,6 +106,9 @@ def test_checkpoint_formats_equal_a_directly_loaded_handle(dev, tmp_path, method
     elif method == "FP8":
         h.load_fp8(st("gate").view(torch.uint8), st("up").view(torch.uint8), st("down").view(torch.uint8), st("gate_scale"),
                    st("up_scale"), st("down_scale"))
+    elif method == "FP8_PERCHANNEL":
+        h.load_fp8_perchannel(st("gate").view(torch.uint8), st("up").view(torch.uint8), st("down").view(torch.uint8),
+                              st("gate_scale"), st("up_scale"), st("down_scale"))
     else:
         h.load_rawint4(st("gate"), st("up"), st("down"), st("gate_scale"), st("up_scale"), st("down_scale"))
     g = torch.Generator().manual_seed(1)

@@ -376,6 +376,34 @@ def test_fp_formats_against_oracle(oracle, dev, fmt, shape):
         h.close()
 
 
+@pytest.mark.parametrize("shape", [(8, 2, 512, 256, 1), (8, 2, 512, 256, 5), (8, 8, 7168, 2048, 2), (8, 2, 256, 512, 40),
+                                   (4, 2, 256, 256, 700)])
+def test_fp8_perchannel_against_oracle(oracle, dev, shape):
+    """FP8_PERCHANNEL (e4m3 weights, one fp32 scale per output row; the method the reference serves GLM-4.7-FP8 style
+    checkpoints with) against the oracle that tests/test_oracle_cpu.py pins bit for bit to the reference's own
+    AMX_FP8_PERCHANNEL_MOE_TP: decode kernels (T*k <= 64), the grouped path on the same input, invalid ids, incremental.
+    Same bound as the block-scaled format: the fp32 summation order over K is the MFMA's, not the AVX512 chain's."""
+    from helpers import fp8_perchannel_quant
+    from ktransformers_amd import _native
+    from ktransformers_amd._native import MoEHandle
+    E, k, H, I, T = shape
+    c = make_case(12, E, k, H, I, T, invalid_ids=T >= 5)
+    q = [fp8_perchannel_quant(bf16_to_f32(c[n])) for n in ("gate", "up", "down")]
+    mo = oracle.make_moe_fp8_perchannel(q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+    h = MoEHandle(E, k, H, I, max_len=max(T, 8), method="FP8_PERCHANNEL", device=0)
+    try:
+        h.load_fp8_perchannel(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch.from_numpy(x[1]).to(dev) for x in q])
+        for generic in (False, True):
+            _native.force_generic_path(generic)
+            _check_fp(run(h, c, dev), want)
+            _check_fp(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
+    finally:
+        _native.force_generic_path(False)
+        h.close()
+
+
 @pytest.mark.parametrize("fname,fmt", [("fp8", "FP8"), ("bf16", "BF16")])
 @pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
 def test_fp_formats_against_reference_golden(dev, fname, fmt, case):

@@ -6,7 +6,8 @@ import numpy as np
 import pytest
 
 from helpers import bf16_to_f32, f32_to_bf16, make_case
-from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, FMT_RAWINT4, Reference, reference_available
+from oracle.oracle import (FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, FMT_FP8_PERCHANNEL, FMT_RAWINT4, Reference,
+                           reference_available)
 
 GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "moe_amx_golden.npz")
 
@@ -57,6 +58,26 @@ def test_oracle_fp_formats_match_live_reference(oracle, shape):
     mb = ref.make_moe(FMT_BF16, c["gate"], c["up"], c["down"], k=k, max_len=64)
     assert np.array_equal(oracle.moe_forward(oracle.make_moe_bf16(c["gate"], c["up"], c["down"]), c["ids"], c["w"], c["x"]),
                           ref.moe_forward(mb, c["ids"], c["w"], c["x"]))
+
+
+@pytest.mark.skipif(not reference_available(), reason="oracle/_ref not built or host lacks AVX512-VNNI/BF16")
+@pytest.mark.parametrize("shape", [(8, 2, 512, 256, 40), (8, 2, 1024, 512, 3), (4, 2, 256, 512, 1)])
+def test_oracle_fp8_perchannel_matches_live_reference(oracle, shape):
+    """FP8_PERCHANNEL restatement (one fp32 chain over K, then * scale[n]) against the reference's own
+    TP_MOE<AMX_FP8_PERCHANNEL_MOE_TP<GemmKernel224FP8PerChannel>> (fp8-perchannel-moe.hpp), vector and matrix paths."""
+    from helpers import fp8_perchannel_quant
+    E, k, H, I, T = shape
+    c = make_case(5, E, k, H, I, T, invalid_ids=T >= 5)
+    ref = Reference(threads=4)
+    gq, gs = fp8_perchannel_quant(bf16_to_f32(c["gate"])); uq, us = fp8_perchannel_quant(bf16_to_f32(c["up"]))
+    dq, ds = fp8_perchannel_quant(bf16_to_f32(c["down"]))
+    mr = ref.make_moe_quant(FMT_FP8_PERCHANNEL, E, H, I, k, gq, uq, dq, gs, us, ds, max_len=64)
+    mo = oracle.make_moe_fp8_perchannel(gq, uq, dq, gs, us, ds)
+    yr = ref.moe_forward(mr, c["ids"], c["w"], c["x"])
+    yo = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    assert np.array_equal(yo, yr)
+    assert np.array_equal(oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=yo),
+                          ref.moe_forward(mr, c["ids"], c["w"], c["x"], y_prev=yr))
 
 
 @pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
