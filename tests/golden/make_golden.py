@@ -13,8 +13,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)
 sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 
-from helpers import bf16_to_f32, fp8_block_quant, make_case, rawint4_quantize  # noqa: E402
-from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, FMT_RAWINT4, Reference  # noqa: E402
+from helpers import bf16_to_f32, fp8_block_quant, fp8_perchannel_quant, make_case, rawint4_quantize  # noqa: E402
+from oracle.oracle import FMT_AMXINT4, FMT_AMXINT8, FMT_BF16, FMT_FP8, FMT_FP8_PERCHANNEL, FMT_RAWINT4, Reference  # noqa: E402
 
 E, k, H, I = 4, 2, 128, 128
 ref = Reference(threads=2)
@@ -46,6 +46,18 @@ for fname, moe in (("fp8", moe8), ("bf16", moeb)):
         y = ref.moe_forward(moe, c["ids"], c["w"], c["x"])
         out[f"{fname}_{name}_y"] = y
         out[f"{fname}_{name}_yinc"] = ref.moe_forward(moe, c["ids"], c["w"], c["x"], y_prev=y)
+
+# FP8_PERCHANNEL (one fp32 scale per output row): the reference's own TP_MOE<AMX_FP8_PERCHANNEL_MOE_TP<GemmKernel224FP8PerChannel>>
+# (kt-kernel/operators/amx/fp8-perchannel-moe.hpp) on the same weights, same seeded inputs
+pq = [fp8_perchannel_quant(bf16_to_f32(base[n])) for n in ("gate", "up", "down")]
+out.update(fp8pc_gate=pq[0][0], fp8pc_up=pq[1][0], fp8pc_down=pq[2][0], fp8pc_gate_s=pq[0][1], fp8pc_up_s=pq[1][1],
+           fp8pc_down_s=pq[2][1])
+moepc = ref.make_moe_quant(FMT_FP8_PERCHANNEL, E, H, I, k, pq[0][0], pq[1][0], pq[2][0], pq[0][1], pq[1][1], pq[2][1], max_len=64)
+for name, T, inv in cases:
+    c = make_case(1000 + T, E, k, H, I, T, invalid_ids=inv)
+    y = ref.moe_forward(moepc, c["ids"], c["w"], c["x"])
+    out[f"fp8pc_{name}_y"] = y
+    out[f"fp8pc_{name}_yinc"] = ref.moe_forward(moepc, c["ids"], c["w"], c["x"], y_prev=y)
 
 # RAWINT4 (Kimi-K2 native int4, group 32): the reference's own TP_MOE<AMX_K2_MOE_TP<GemmKernel224Int4SmallKGroup>>
 # (kt-kernel/operators/amx/k2-moe.hpp:124-191) on weights quantised by the reference test's own rawint4_quantize

@@ -404,7 +404,7 @@ def test_fp8_perchannel_against_oracle(oracle, dev, shape):
         h.close()
 
 
-@pytest.mark.parametrize("fname,fmt", [("fp8", "FP8"), ("bf16", "BF16")])
+@pytest.mark.parametrize("fname,fmt", [("fp8", "FP8"), ("fp8pc", "FP8_PERCHANNEL"), ("bf16", "BF16")])
 @pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
 def test_fp_formats_against_reference_golden(dev, fname, fmt, case):
     from ktransformers_amd._native import MoEHandle
@@ -416,6 +416,9 @@ def test_fp_formats_against_reference_golden(dev, fname, fmt, case):
         if fmt == "FP8":
             h.load_fp8(*[torch.from_numpy(g[f"fp8_{n}"]).to(dev) for n in ("gate", "up", "down")],
                        *[torch.from_numpy(g[f"fp8_{n}_s"]).to(dev) for n in ("gate", "up", "down")])
+        elif fmt == "FP8_PERCHANNEL":
+            h.load_fp8_perchannel(*[torch.from_numpy(g[f"fp8pc_{n}"]).to(dev) for n in ("gate", "up", "down")],
+                                  *[torch.from_numpy(g[f"fp8pc_{n}_s"]).to(dev) for n in ("gate", "up", "down")])
         else:
             h.load_bf16(torch_bf16(g["gate"], dev), torch_bf16(g["up"], dev), torch_bf16(g["down"], dev))
         _check_fp(run(h, c, dev), g[f"{fname}_{case}_y"])

@@ -29,12 +29,15 @@ def test_oracle_matches_reference_golden(oracle, golden, fname, fmt, case):
     assert np.array_equal(y2, g[f"{fname}_{case}_yinc"]), "incremental merge differs from the reference"
 
 
-@pytest.mark.parametrize("fname", ["fp8", "bf16"])
+@pytest.mark.parametrize("fname", ["fp8", "fp8pc", "bf16"])
 @pytest.mark.parametrize("case", ["t1", "t7_invalid", "t33_prefill"])
 def test_oracle_fp_formats_match_reference_golden(oracle, golden, fname, case):
     g = golden
     if fname == "fp8":
         moe = oracle.make_moe_fp8(g["fp8_gate"], g["fp8_up"], g["fp8_down"], g["fp8_gate_s"], g["fp8_up_s"], g["fp8_down_s"])
+    elif fname == "fp8pc":      # one fp32 scale per output row (the reference's AMX_FP8_PERCHANNEL_MOE_TP)
+        moe = oracle.make_moe_fp8_perchannel(g["fp8pc_gate"], g["fp8pc_up"], g["fp8pc_down"], g["fp8pc_gate_s"], g["fp8pc_up_s"],
+                                             g["fp8pc_down_s"])
     else:
         moe = oracle.make_moe_bf16(g["gate"], g["up"], g["down"])
     x, ids, w = g[f"int4_{case}_x"], g[f"int4_{case}_ids"], g[f"int4_{case}_w"]   # same seeded inputs for all formats
