@@ -129,6 +129,17 @@ def _load() -> C.CDLL:
     lib.ktx_argmax_bf16.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_mla_prep.argtypes = [C.c_int] * 5 + [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_float,
                                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_void_p]
+    lib.ktx_ep_create.argtypes = [C.c_int] * 7 + [C.POINTER(C.c_void_p)]
+    lib.ktx_ep_destroy.argtypes = [C.c_void_p]
+    lib.ktx_ep_destroy.restype = None
+    lib.ktx_ep_export.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ktx_ep_local_ptr.argtypes = [C.c_void_p, C.POINTER(C.c_void_p)]
+    lib.ktx_ep_import.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.ktx_ep_import_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
+    lib.ktx_ep_gather.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
+    lib.ktx_ep_reduce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ktx_ep_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
+    lib.ktx_ep_set_spin_seconds.argtypes = [C.c_void_p, C.c_double]
     lib.ktx_profile_enable.argtypes = [C.c_int]
     lib.ktx_debug_force_generic.argtypes = [C.c_int]
     lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
@@ -148,7 +159,7 @@ STREAM_CALLS = frozenset((
     "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
     "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_mla_prefill", "ktx_linear_forward",
     "ktx_linear_forward_batched", "ktx_linear_forward_batched_prep", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
-    "ktx_mla_prep", "ktx_argmax"))
+    "ktx_mla_prep", "ktx_argmax"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
 TRACE: list | None = None
 HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
 
@@ -435,6 +446,91 @@ class MoEHandle:
         check(lib.ktx_moe_forward_ex(self._h, None, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
                                      out.data_ptr(), 2, _stream_ptr(self.device)))
         return out
+
+
+EP_MEMORY = {"uncached": 0, "finegrained": 1, "plain": 2}
+EP_HANDLE_BYTES = 64
+
+
+class EpExchange:
+    """Expert-parallel decode exchange over direct peer writes (include/ktx_ep.h): this rank's symmetric buffer plus the
+    mapped buffers of its peers.  gather() and reduce() are the two launches of one MoE layer; every rank makes the same
+    sequence of calls with the same T.  Peers in other processes are mapped from export_handle() bytes, peers in this
+    process from local_ptr()."""
+
+    def __init__(self, world: int, rank: int, max_tokens: int, hidden: int, topk: int, device, memory: str = "uncached"):
+        self.device = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        self.world, self.rank, self.max_tokens, self.H, self.k = world, rank, max_tokens, hidden, topk
+        self._h = C.c_void_p()
+        check(lib.ktx_ep_create(self.device.index or 0, world, rank, max_tokens, hidden, topk, EP_MEMORY[memory], C.byref(self._h)))
+
+    def close(self) -> None:
+        if self._h:
+            lib.ktx_ep_destroy(self._h)
+            self._h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def export_handle(self) -> bytes:
+        buf = C.create_string_buffer(EP_HANDLE_BYTES)
+        check(lib.ktx_ep_export(self._h, buf))
+        return buf.raw
+
+    def local_ptr(self) -> int:
+        p = C.c_void_p()
+        check(lib.ktx_ep_local_ptr(self._h, C.byref(p)))
+        return int(p.value)
+
+    def import_handle(self, peer: int, handle: bytes) -> None:
+        if len(handle) != EP_HANDLE_BYTES:
+            raise KtxError(f"EpExchange.import_handle: expected {EP_HANDLE_BYTES} bytes")
+        check(lib.ktx_ep_import(self._h, peer, C.create_string_buffer(handle, EP_HANDLE_BYTES)))
+
+    def import_ptr(self, peer: int, ptr: int) -> None:
+        check(lib.ktx_ep_import_ptr(self._h, peer, C.c_void_p(ptr)))
+
+    def set_spin_seconds(self, seconds: float) -> None:
+        check(lib.ktx_ep_set_spin_seconds(self._h, float(seconds)))
+
+    def gather(self, x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor):
+        """x bf16 [T,H], ids int64 [T,k], w fp32 [T,k] -> (xg [R*T,H], idsg [R*T,k], wg [R*T,k]), rank r's rows at r*T."""
+        T = x.shape[0]
+        if x.dtype != torch.bfloat16 or x.shape != (T, self.H) or not x.is_contiguous():
+            raise KtxError(f"EpExchange.gather: x must be contiguous bf16 [T,{self.H}]")
+        if ids.dtype != torch.int64 or ids.shape != (T, self.k) or not ids.is_contiguous():
+            raise KtxError(f"EpExchange.gather: ids must be contiguous int64 [T,{self.k}]")
+        if w.dtype != torch.float32 or w.shape != (T, self.k) or not w.is_contiguous():
+            raise KtxError(f"EpExchange.gather: w must be contiguous fp32 [T,{self.k}]")
+        n = self.world * T
+        xg = torch.empty((n, self.H), dtype=torch.bfloat16, device=self.device)
+        idsg = torch.empty((n, self.k), dtype=torch.int64, device=self.device)
+        wg = torch.empty((n, self.k), dtype=torch.float32, device=self.device)
+        check(lib.ktx_ep_gather(self._h, T, x.data_ptr(), ids.data_ptr(), w.data_ptr(), xg.data_ptr(), idsg.data_ptr(),
+                                wg.data_ptr(), _stream_ptr(self.device)))
+        return xg, idsg, wg
+
+    def reduce(self, part: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
+        """part fp32 [R*T,H] -> bf16 [T,H]: the partials of this rank's tokens added in rank order, rounded once."""
+        n = part.shape[0]
+        if part.dtype != torch.float32 or part.dim() != 2 or part.shape[1] != self.H or n % self.world or not part.is_contiguous():
+            raise KtxError(f"EpExchange.reduce: part must be contiguous fp32 [{self.world}*T,{self.H}]")
+        T = n // self.world
+        if out is None:
+            out = torch.empty((T, self.H), dtype=torch.bfloat16, device=self.device)
+        elif out.dtype != torch.bfloat16 or out.shape != (T, self.H) or not out.is_contiguous():
+            raise KtxError("EpExchange.reduce: out must be contiguous bf16 [T,H]")
+        check(lib.ktx_ep_reduce(self._h, T, part.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+        return out
+
+    def status(self) -> int:
+        """0 = healthy, 1 / 2 = a gather / reduce poll gave up waiting for a peer.  Synchronises the current stream."""
+        st = C.c_int(0)
+        check(lib.ktx_ep_status(self._h, _stream_ptr(self.device), C.byref(st)))
+        return int(st.value)
 
 
 GATE_SCORING = {"sigmoid": 0, "softmax": 1}

@@ -13,6 +13,12 @@ bf16 rounding.  Sharding by EXPERT instead of by intermediate column keeps exact
 
 The fp32 summation order across ranks differs from the single-GPU slot order j=0..k-1, so EP outputs match the
 single-GPU ones to fp32 rounding (<=1 bf16 ulp), not bit-for-bit; tests state that tolerance.
+
+Decode has two transports behind the same ep_decode_forward signature:
+  collectives (default, and the only one on CPU / gloo): all_gather_into_tensor + reduce_scatter_tensor;
+  peer writes (enable_peer_exchange, GPU only; include/ktx_ep.h): two launches per layer that write tagged 8-byte
+  granules straight into the peers' buffers over xGMI and add the partials in RANK order — the fixed part order of the
+  reference's merge_results — so the result is bit-identical to sum_r partial_r evaluated left to right.
 """
 from __future__ import annotations
 
@@ -23,7 +29,7 @@ import torch.distributed as dist
 
 
 # Process-wide expert-parallel setting consulted by KExpertsHIP at load(): rule files cannot carry a process group.
-EP_STATE = {"enabled": False, "group": None}
+EP_STATE = {"enabled": False, "group": None, "exchange": None}
 
 
 def enable_expert_parallel(group=None, enabled: bool = True) -> None:
@@ -33,12 +39,68 @@ def enable_expert_parallel(group=None, enabled: bool = True) -> None:
     EP_STATE["group"] = group
 
 
+def enable_peer_exchange(hidden: int, topk: int, max_tokens: int, device, group=None, memory: str | None = None,
+                         verify: bool = True):
+    """Collective call (every rank of `group`, after init_process_group): allocate this rank's symmetric buffer, swap the
+    inter-process handles through the process group, map the peers, and — verify=True — push one known pattern through
+    both kernels on the real fabric before anything depends on it.  From then on ExpertParallelMoE.forward (decode) takes
+    the peer-write transport for T <= max_tokens.  Returns the EpExchange; raises if the transport cannot be set up or the
+    pattern does not come back (the caller decides whether to go on with the collectives — never silently)."""
+    import os
+
+    from ktransformers_amd._native import EpExchange
+    world, rank = dist.get_world_size(group), dist.get_rank(group)
+    ex = EpExchange(world, rank, max_tokens, hidden, topk, device, memory or os.environ.get("KTX_EP_MEMORY", "uncached"))
+    handles = [None] * world
+    dist.all_gather_object(handles, ex.export_handle(), group=group)
+    for r in range(world):
+        if r != rank:
+            ex.import_handle(r, handles[r])
+    dist.barrier(group)          # every buffer mapped everywhere before the first put
+    if verify:
+        verify_peer_exchange(ex)
+        dist.barrier(group)
+    EP_STATE["exchange"] = ex
+    return ex
+
+
+def verify_peer_exchange(ex, T: int = 1) -> None:
+    """One gather + reduce of rank-dependent patterns; raises unless every row and every sum arrives exactly."""
+    dev, R, H, k = ex.device, ex.world, ex.H, ex.k
+    col = torch.arange(H, device=dev, dtype=torch.float32)
+
+    def xrow(r):       # exactly representable in bf16
+        return ((col % 61) - 30 + r).to(torch.bfloat16).expand(T, H).contiguous()
+
+    ids = (torch.arange(T * k, device=dev, dtype=torch.int64).view(T, k) * 7 + ex.rank)
+    w = (torch.arange(T * k, device=dev, dtype=torch.float32).view(T, k) + 0.5 * ex.rank)
+    xg, idsg, wg = ex.gather(xrow(ex.rank), ids, w)
+    # part[row of rank r] = what THIS rank contributes to rank r's tokens: small integers, so every order of adding is exact
+    part = torch.stack([(col % 17) * (ex.rank + 1) + r for r in range(R)]).repeat_interleave(T, dim=0).contiguous()
+    out = ex.reduce(part)
+    st = ex.status()
+    if st != 0:
+        raise RuntimeError(f"peer exchange self-check: a poll gave up waiting for a peer (status {st})")
+    for r in range(R):
+        sl = slice(r * T, (r + 1) * T)
+        ok = torch.equal(xg[sl], xrow(r)) and torch.equal(idsg[sl], ids - ex.rank + r) and torch.equal(wg[sl], w + 0.5 * (r - ex.rank))
+        if not ok:
+            raise RuntimeError(f"peer exchange self-check: rank {r}'s token row arrived damaged at rank {ex.rank}")
+    want = ((col % 17) * (R * (R + 1) // 2) + R * ex.rank).to(torch.bfloat16).expand(T, H)
+    if not torch.equal(out, want):
+        raise RuntimeError(f"peer exchange self-check: reduced partials differ at rank {ex.rank}")
+
+
 def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
-                      x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, group=None) -> torch.Tensor:
+                      x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, group=None, exchange=None) -> torch.Tensor:
     """x bf16 [T,H], ids int64 [T,k], w fp32 [T,k] (this rank's tokens) -> bf16 [T,H].
 
     `local_partial(xg, idsg, wg) -> fp32 [world*T, H]` computes this rank's experts' contribution for all gathered
-    tokens (MoEHandle.forward_partial on GPU; the oracle in the gloo tests)."""
+    tokens (MoEHandle.forward_partial on GPU; the oracle in the gloo tests).  `exchange` (an EpExchange whose peers are
+    mapped) selects the peer-write transport: two launches, partials added in rank order."""
+    if exchange is not None:
+        xg, idsg, wg = exchange.gather(x.contiguous(), ids.contiguous(), w.contiguous())
+        return exchange.reduce(local_partial(xg, idsg, wg))
     world = dist.get_world_size(group)
     T, H = x.shape
     k = ids.shape[1]
@@ -120,7 +182,10 @@ class ExpertParallelMoE:
         self.group = group
 
     def forward(self, x, ids, w):
-        return ep_decode_forward(self.handle.forward_partial, x, ids, w, self.group)
+        ex = EP_STATE["exchange"]
+        if ex is not None and (x.shape[0] > ex.max_tokens or x.shape[1] != ex.H or ids.shape[1] != ex.k):
+            ex = None
+        return ep_decode_forward(self.handle.forward_partial, x, ids, w, self.group, exchange=ex)
 
     def forward_prefill(self, x, ids, w):
         """All-to-all-v dispatch / combine; bit-identical to the single-GPU forward.  The local handle must have been

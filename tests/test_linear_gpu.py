@@ -50,12 +50,13 @@ def test_w4_quantizer_bit_exact_vs_reference_golden(name, G):
 SHAPES = [(256, 64), (2048, 576), (2048, 3072), (1536, 200), (7168, 1536), (384, 48)]
 
 
-@pytest.mark.parametrize("K,N", SHAPES)
-@pytest.mark.parametrize("T", [1, 2, 3, 4, 7, 16, 33, 130])
-@pytest.mark.parametrize("G", [64, 128, 32])
+# every shape at the group size the models use (64); the other group sizes on two shapes
+W4_CASES = [(K, N, T, G) for G in (64, 128, 32) for T in (1, 2, 3, 4, 7, 16, 33, 130) for (K, N) in SHAPES
+            if G == 64 or (K, N) in ((256, 64), (2048, 576))]
+
+
+@pytest.mark.parametrize("K,N,T,G", W4_CASES)
 def test_w4_forward(K, N, T, G):
-    if G != 64 and (K, N) not in ((256, 64), (2048, 576)):
-        pytest.skip("group sweep on two shapes")
     n = native()
     torch.manual_seed(K + N + T)
     w = (torch.randn(N, K) / 10).to(torch.bfloat16)
