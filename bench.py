@@ -630,8 +630,19 @@ def main():
         dist.init_process_group("nccl", device_id=dev)
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
         assert wl["E"] % world == 0
-        from ktransformers_amd.parallel import enable_expert_parallel
+        from ktransformers_amd.parallel import enable_expert_parallel, enable_peer_exchange
         enable_expert_parallel()      # experts sharded over the ranks, attention / dense parts replicated
+        # decode exchange: direct peer writes over xGMI (two launches per MoE layer; checked on this node's fabric while it
+        # is set up), else the two collectives.  KTX_EP_TRANSPORT=collectives forces the latter for an A/B.
+        ep_transport, ep_exchange = "collectives: all-gather + reduce-scatter per MoE layer (RCCL)", None
+        if os.environ.get("KTX_EP_TRANSPORT", "peer") != "collectives":
+            try:
+                ep_exchange = enable_peer_exchange(wl["H"], wl["k"], 16, dev)
+                ep_transport = ("peer writes: tagged 8-byte granules into the peers' buffers over xGMI, two launches per MoE "
+                                "layer (ktx_ep_gather / ktx_ep_reduce), partials added in rank order")
+            except Exception as e:      # raised on every rank alike: all ranks fall back together, and the line says so
+                ep_transport += f" [peer-write transport refused: {type(e).__name__}: {e}]"[:400]
+                log(f"[bench] {ep_transport}")
 
     from ktransformers_amd import _native  # noqa: F401  (raises if the HIP library is missing: no CPU fallback)
 
@@ -675,13 +686,15 @@ def main():
                    "hidden": H, "intermediate": I, "experts": E, "top_k": k, "heads": wl["heads"], "layers": n_layers,
                    "dense_layers": n_dense, "moe_layers": n_layers - n_dense, "vocab": cfg.vocab_size, "ctx": args.ctx,
                    "batch_per_gpu": 1, "parallelism": f"ep{world}" if dist_on else "single",
-                   "rccl_ranks": world if dist_on else 0, "hip_graph": bool(mr.graph_ok), "graph_error": mr.graph_error,
+                   "rccl_ranks": world if dist_on else 0, "ep_transport": ep_transport if dist_on else None,
+                   "hip_graph": bool(mr.graph_ok), "graph_error": mr.graph_error,
                    "prewarm_steps": n_pre,
                    "step": "one greedy token through the YAML-injected model: embedding, per layer [RMSNorm, MLA attention operator "
                            "(W4-g64 q_a|kv_a, q_b, o projections, YaRN RoPE, absorb, paged MQA over the cached context, cache "
                            "append), RMSNorm, dense W4 MLP | router + top-k AMXINT4 routed experts + W4 shared expert], RMSNorm, "
                            "W4 lm_head, argmax; token and position fed back inside the HIP graph; random weights"
-                           + ("; routed experts sharded expert-parallel over %d ranks (all-gather + reduce-scatter per MoE layer), "
+                           + ("; routed experts sharded expert-parallel over %d ranks (every rank's token row gathered, local "
+                              "experts, fp32 partials reduced at the token's home rank; transport in ep_transport), "
                               "attention / dense / router replicated, one token stream per rank" % world if dist_on else "")},
         "whole_step": {"algorithmic_bytes": tot_bytes, "GBs": round(tot_bytes / (ms_per_step * 1e-3) / 1e9, 1),
                        "frac_of_hbm_peak": round(tot_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
@@ -760,11 +773,16 @@ def main():
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
 
+    if dist_on and ep_exchange is not None:
+        # a poll that gave up during the run means a rank computed on rows that never arrived: the number is void, say so
+        st = torch.tensor([ep_exchange.status()], device=dev, dtype=torch.int32)
+        dist.all_reduce(st, op=dist.ReduceOp.MAX)
+        out["config"]["ep_transport_status"] = int(st.item())
+        if int(st.item()) != 0:
+            out["value"], out["error"] = None, "peer-write exchange: a poll gave up waiting for a peer during the run"
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:
-        import torch.distributed as dist
-
         dist.destroy_process_group()
 
 

@@ -39,27 +39,56 @@ def enable_expert_parallel(group=None, enabled: bool = True) -> None:
     EP_STATE["group"] = group
 
 
+def _all_ranks_ok(ok: bool, what: str, group) -> None:
+    """Collective: raise the same error on EVERY rank if any rank failed, so that no rank goes on alone."""
+    flags = [None] * dist.get_world_size(group)
+    dist.all_gather_object(flags, None if ok is True else str(ok), group=group)
+    bad = [(r, f) for r, f in enumerate(flags) if f is not None]
+    if bad:
+        raise RuntimeError(f"peer exchange: {what} failed on rank(s) " + "; ".join(f"{r}: {f}" for r, f in bad))
+
+
 def enable_peer_exchange(hidden: int, topk: int, max_tokens: int, device, group=None, memory: str | None = None,
                          verify: bool = True):
     """Collective call (every rank of `group`, after init_process_group): allocate this rank's symmetric buffer, swap the
     inter-process handles through the process group, map the peers, and — verify=True — push one known pattern through
     both kernels on the real fabric before anything depends on it.  From then on ExpertParallelMoE.forward (decode) takes
-    the peer-write transport for T <= max_tokens.  Returns the EpExchange; raises if the transport cannot be set up or the
-    pattern does not come back (the caller decides whether to go on with the collectives — never silently)."""
+    the peer-write transport for T <= max_tokens.  Returns the EpExchange; raises ON EVERY RANK if any rank could not set
+    the transport up or did not get the pattern back (the caller decides whether to go on with the collectives — never
+    silently, and never with the ranks disagreeing about the transport)."""
     import os
 
     from ktransformers_amd._native import EpExchange
     world, rank = dist.get_world_size(group), dist.get_rank(group)
-    ex = EpExchange(world, rank, max_tokens, hidden, topk, device, memory or os.environ.get("KTX_EP_MEMORY", "uncached"))
+    ex, handle, ok = None, None, True
+    try:
+        ex = EpExchange(world, rank, max_tokens, hidden, topk, device, memory or os.environ.get("KTX_EP_MEMORY", "uncached"))
+        handle = ex.export_handle()
+    except Exception as e:
+        ok = f"{type(e).__name__}: {e}"
     handles = [None] * world
-    dist.all_gather_object(handles, ex.export_handle(), group=group)
-    for r in range(world):
-        if r != rank:
-            ex.import_handle(r, handles[r])
-    dist.barrier(group)          # every buffer mapped everywhere before the first put
-    if verify:
-        verify_peer_exchange(ex)
-        dist.barrier(group)
+    dist.all_gather_object(handles, handle, group=group)
+    if ok is True and all(h is not None for h in handles):
+        try:
+            for r in range(world):
+                if r != rank:
+                    ex.import_handle(r, handles[r])
+        except Exception as e:
+            ok = f"{type(e).__name__}: {e}"
+    elif ok is True:
+        ok = "a peer has no buffer to map"
+    try:
+        _all_ranks_ok(ok, "mapping the peers' buffers", group)      # also: every buffer mapped everywhere before the first put
+        if verify:
+            try:
+                verify_peer_exchange(ex)
+            except Exception as e:
+                ok = f"{type(e).__name__}: {e}"
+            _all_ranks_ok(ok, "the transport self-check", group)
+    except Exception:
+        if ex is not None:
+            ex.close()
+        raise
     EP_STATE["exchange"] = ex
     return ex
 

@@ -69,6 +69,38 @@ def test_expert_parallel_decode_matches_single_process(world):
         assert (got != want).mean() < 0.05
 
 
+def _peer_refused_worker(rank, world, port, q):
+    from ktransformers_amd import parallel
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        parallel.enable_peer_exchange(256, 2, 4, "cuda:0")
+        q.put((rank, "no error"))
+    except RuntimeError as e:
+        q.put((rank, str(e)))
+    assert parallel.EP_STATE["exchange"] is None
+    dist.barrier()            # the ranks are still in step with each other
+    dist.destroy_process_group()
+
+
+def test_peer_exchange_is_refused_on_every_rank_alike_where_there_is_no_gpu():
+    """enable_peer_exchange is a collective: when a rank cannot set the transport up (here: no HIP device at all) EVERY
+    rank raises the same error and the collectives stay the transport — never one rank polling for peers that fell back."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 17
+    procs = [ctx.Process(target=_peer_refused_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = dict(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert res[0] == res[1] and "failed on rank(s) 0:" in res[0] and "1:" in res[0], res
+
+
 def test_expert_range():
     from ktransformers_amd.parallel import expert_range
     assert expert_range(256, 8, 3) == (96, 32)
