@@ -256,6 +256,10 @@ class ModelDecodeRunner:
 
         dev, ctx = self.dev, self.ctx
         self.runner, self.graph_ok, self.graph_error = None, False, None
+        if torch.distributed.is_available() and torch.distributed.is_initialized():
+            # ranks finish loading seconds apart; the first warm-up step already exchanges with the peers
+            torch.cuda.synchronize(dev)
+            torch.distributed.barrier()
         self.cache.past_tokens = [ctx] * self.cfg.num_hidden_layers
         self.pos = torch.tensor([[ctx]], device=dev, dtype=torch.long)
         self.cur = torch.tensor([[1 + 17 * self.seed]], device=dev, dtype=torch.long)
@@ -638,6 +642,7 @@ def main():
         if os.environ.get("KTX_EP_TRANSPORT", "peer") != "collectives":
             try:
                 ep_exchange = enable_peer_exchange(wl["H"], wl["k"], 16, dev)
+                ep_exchange.set_spin_seconds(120)    # ranks capture their graphs at their own pace; a dead peer still ends the wait
                 ep_transport = ("peer writes: tagged 8-byte granules into the peers' buffers over xGMI, two launches per MoE "
                                 "layer (ktx_ep_gather / ktx_ep_reduce), partials added in rank order")
             except Exception as e:      # raised on every rank alike: all ranks fall back together, and the line says so

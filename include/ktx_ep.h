@@ -67,7 +67,7 @@ int ktx_ep_reduce(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stre
 
 /* 0 = healthy; otherwise the code of the first poll that gave up (1 = gather, 2 = reduce).  Synchronises `stream`. */
 int ktx_ep_status(ktx_ep_t ep, ktx_stream_t stream, int* status_out);
-/* seconds a poll waits before giving up (default 5) */
+/* seconds a poll waits before giving up (default 30) */
 int ktx_ep_set_spin_seconds(ktx_ep_t ep, double seconds);
 
 #ifdef __cplusplus

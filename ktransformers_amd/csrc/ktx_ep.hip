@@ -158,7 +158,7 @@ struct ktx_ep_s {
   size_t bytes = 0;
   uint64_t* base[KTX_EP_MAX_WORLD] = {};
   bool ipc[KTX_EP_MAX_WORLD] = {};
-  double spin_seconds = 5.0;
+  double spin_seconds = 30.0;
 };
 
 extern "C" {
