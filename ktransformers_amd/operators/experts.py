@@ -120,6 +120,23 @@ class KExpertsHIP(KExpertsBase):
             # a "llamafile" rule over a bf16 (safetensors) weight source: the reference would reject it; quantise online
             # to the int4 format instead of failing, like its AMX backends do for bf16 sources.
             self.method = "AMXINT4"
+        elif self.method == "GGUF":
+            from ktransformers_amd._native import GGML_BLOCK_BYTES
+            types = {n: int(w[f"{n}_type"]) for n in ("gate", "up", "down")}
+            if not all(t in GGML_BLOCK_BYTES for t in types.values()):
+                # a ggml type the expert kernels do not read natively (they read Q4_K, Q6_K, IQ1_S): the blocks are
+                # de-quantised on the host with the loader's (reference-pinned) codecs and served as BF16 experts — exact
+                # weights, un-quantised activations; NOT the llamafile arithmetic (Q8_K activations), and 2 bytes per weight.
+                import warnings
+
+                from ktransformers_amd.util.gguf_loader import GGML_NAMES, dequantize_expert_blocks
+                warnings.warn(f"{self.key}: GGUF expert types {[GGML_NAMES.get(t, t) for t in types.values()]} have no native "
+                              "expert kernel; de-quantising to BF16 experts", RuntimeWarning, stacklevel=2)
+                E_all = self.n_routed_experts
+                w = {"gate": dequantize_expert_blocks(w["gate"], types["gate"], E_all, inter, cfg.hidden_size),
+                     "up": dequantize_expert_blocks(w["up"], types["up"], E_all, inter, cfg.hidden_size),
+                     "down": dequantize_expert_blocks(w["down"], types["down"], E_all, cfg.hidden_size, inter)}
+                self.method = "BF16"
         h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=self.max_len,
                       method=self.method, device=dev, expert_begin=self.expert_begin,
                       global_expert_num=self.n_routed_experts, group_size=_GROUP_SIZE.get(self.method, 0))

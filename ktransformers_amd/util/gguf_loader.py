@@ -104,7 +104,80 @@ def _dequant(ggml_type: int, raw: np.ndarray) -> np.ndarray:
                       ((ql[:, :, :32] >> 4) | (((qh >> 4) & 3) << 4)) - 32, ((ql[:, :, 32:] >> 4) | (((qh >> 6) & 3) << 4)) - 32],
                      axis=2).reshape(nb, 2, 128).astype(np.float32)
         return (d * np.repeat(sc, 16, axis=2) * q).astype(np.float32).reshape(-1)
+    f16 = lambda cols: np.ascontiguousarray(cols).view(np.float16).astype(np.float32)  # noqa: E731
+    if ggml_type == 2:                                       # Q4_0: fp16 d | 16 bytes, low nibbles then high nibbles, offset 8
+        b = b.reshape(-1, 18)
+        d, qs = f16(b[:, 0:2]), b[:, 2:]
+        q = np.concatenate([qs & 0xF, qs >> 4], axis=1).astype(np.float32) - 8.0
+        return (d * q).reshape(-1)
+    if ggml_type == 6:                                       # Q5_0: fp16 d | 32 high bits | 16 bytes of nibbles, offset 16
+        b = b.reshape(-1, 22)
+        d, qs = f16(b[:, 0:2]), b[:, 6:]
+        hi = np.unpackbits(b[:, 2:6], axis=1, bitorder="little")          # bit j of the little-endian word -> value j
+        q = (np.concatenate([qs & 0xF, qs >> 4], axis=1) | (hi << 4)).astype(np.float32) - 16.0
+        return (d * q).reshape(-1)
+    if ggml_type == 10:                                      # Q2_K: 16 x (4-bit scale | 4-bit min) | 64 bytes of 2-bit q | d | dmin
+        b = b.reshape(-1, 84)
+        nb = b.shape[0]
+        sc = b[:, :16]
+        d, dmin = f16(b[:, 80:82]), f16(b[:, 82:84])
+        qs = b[:, 16:80].reshape(nb, 2, 1, 32)                               # two halves of 32 bytes, four 2-bit planes each
+        q = ((qs >> np.array([0, 2, 4, 6], np.uint8).reshape(1, 1, 4, 1)) & 3).reshape(nb, 16, 16).astype(np.float32)
+        dl = (d * (sc & 0xF).astype(np.float32)).reshape(nb, 16, 1)
+        ml = (dmin * (sc >> 4).astype(np.float32)).reshape(nb, 16, 1)
+        return (dl * q - ml).reshape(-1)
+    if ggml_type == 11:                                      # Q3_K: 32 bytes of high bits | 64 bytes of 2-bit q | 12 bytes = 16 six-bit scales | d
+        b = b.reshape(-1, 110)
+        nb = b.shape[0]
+        d = f16(b[:, 108:110]).reshape(nb, 1, 1)
+        hbit = np.unpackbits(b[:, :32].reshape(nb, 32, 1), axis=2, bitorder="little")      # [nb, l, plane]
+        hbit = hbit.transpose(0, 2, 1).reshape(nb, 2, 4, 32)                                # plane = half * 4 + shift
+        qs = b[:, 32:96].reshape(nb, 2, 1, 32)
+        q2 = (qs >> np.array([0, 2, 4, 6], np.uint8).reshape(1, 1, 4, 1)) & 3
+        q = (q2.astype(np.int16) - 4 * (1 - hbit.astype(np.int16))).reshape(nb, 16, 16).astype(np.float32)
+        lo, hi2 = b[:, 96:104], b[:, 104:108]                                               # 4-bit parts, 2-bit parts
+        s6 = np.concatenate([(lo & 0xF) | ((np.tile(hi2, 2) >> np.repeat(np.array([0, 2], np.uint8), 4)) & 3) << 4,
+                             (lo >> 4) | ((np.tile(hi2, 2) >> np.repeat(np.array([4, 6], np.uint8), 4)) & 3) << 4], axis=1)
+        dl = d * (s6.astype(np.float32) - 32.0).reshape(nb, 16, 1)
+        return (dl * q).reshape(-1)
+    if ggml_type == 13:                                      # Q5_K: d | dmin | 12 bytes of 6-bit scales / mins | 32 bytes of high bits | 128 bytes of nibbles
+        b = b.reshape(-1, 176)
+        nb = b.shape[0]
+        d, dmin = f16(b[:, 0:2]).reshape(nb, 1, 1), f16(b[:, 2:4]).reshape(nb, 1, 1)
+        s1, qs = b[:, 4:16].reshape(nb, 12, 1), b[:, 48:].reshape(nb, 4, 32)
+        fac = d * np.concatenate([s1[:, 0:4] & 63, (s1[:, 8:] & 15) | ((s1[:, 0:4] >> 6) << 4)], axis=1).astype(np.float32)
+        off = dmin * np.concatenate([s1[:, 4:8] & 63, (s1[:, 8:] >> 4) | ((s1[:, 4:8] >> 6) << 4)], axis=1).astype(np.float32)
+        hbit = np.unpackbits(b[:, 16:48].reshape(nb, 32, 1), axis=2, bitorder="little").transpose(0, 2, 1)   # [nb, plane, l]
+        q = (np.stack([qs & 0xF, qs >> 4], axis=2).reshape(nb, 8, 32) + (hbit << 4)).astype(np.float32)
+        return (fac * q - off).reshape(-1)
+    if ggml_type == 23:                                      # IQ4_XS: d | 16 bits of scale high parts | 4 bytes of low parts | 128 bytes of codebook indices
+        b = b.reshape(-1, 136)
+        nb = b.shape[0]
+        d = f16(b[:, 0:2])
+        sh = np.ascontiguousarray(b[:, 2:4]).view(np.uint16).astype(np.uint32)              # [nb, 1]
+        ib = np.arange(8, dtype=np.uint32)
+        lo = (np.repeat(b[:, 4:8], 2, axis=1).astype(np.uint32) >> (4 * (ib % 2))) & 0xF
+        ls = (lo | (((sh >> (2 * ib)) & 3) << 4)).astype(np.float32) - 32.0
+        dl = (d * ls).reshape(nb, 8, 1)
+        qs = b[:, 8:].reshape(nb, 8, 16)
+        kv = np.array([-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113], np.float32)   # the IQ4_NL codebook
+        return (dl * kv[np.concatenate([qs & 0xF, qs >> 4], axis=2)]).reshape(-1)
     raise NotImplementedError(f"ggml_type {ggml_type} ({GGML_NAMES.get(ggml_type, '?')}) is not de-quantised here")
+
+
+def dequantize_expert_blocks(raw, ggml_type: int, num_experts: int, rows: int, cols: int) -> torch.Tensor:
+    """Raw ggml blocks of one stacked expert tensor ([E, rows, cols] elements, any layout of whole blocks) -> bf16
+    [E, rows, cols], one expert at a time (the fp32 intermediate of a whole DeepSeek-sized tensor would not fit in host
+    memory).  For expert types the HIP expert kernels do not read natively."""
+    n_el, n_by = GGML_QUANT_SIZES[ggml_type]
+    flat = (raw.numpy() if isinstance(raw, torch.Tensor) else np.asarray(raw)).reshape(-1).view(np.uint8)
+    per = rows * cols // n_el * n_by
+    if cols % n_el or flat.size != num_experts * per:
+        raise ValueError(f"expert blocks: {flat.size} bytes for {num_experts} x {rows} x {cols} of ggml type {ggml_type}")
+    out = torch.empty((num_experts, rows, cols), dtype=torch.bfloat16)
+    for e in range(num_experts):
+        out[e] = torch.from_numpy(_dequant(ggml_type, flat[e * per:(e + 1) * per]).reshape(rows, cols)).to(torch.bfloat16)
+    return out
 
 
 class GGUFLoader:

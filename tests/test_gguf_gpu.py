@@ -156,3 +156,54 @@ def test_llamafile_backend_through_the_operator_and_gguf_file(tmp_path):
                    torch.from_numpy(w).cuda()).float().cpu().numpy()
     ref = bf16_to_f32(GgufOracle().moe_forward(src["gate"], src["up"], src["down"], (Q4, Q4, Q6), E, H, I, ids, w, x))
     assert (np.abs(y - ref) <= 2.0 ** -7 * np.abs(ref) + 2e-3 * np.abs(ref).max()).all()
+
+
+def test_expert_types_without_a_native_kernel_are_served_as_dequantised_bf16_experts(tmp_path):
+    """A GGUF file whose experts are Q5_K / Q8_0 (types the expert kernels do not read): the operator says so (RuntimeWarning),
+    de-quantises the blocks with the loader's reference-pinned codecs and serves BF16 experts.  Checked against fp64 math on
+    the same de-quantised weights (bf16 kernels: 2^-7 relative + a small absolute term), not against llamafile arithmetic."""
+    from helpers import write_gguf
+    from toy_model import ToyConfig
+    from ktransformers_amd.operators.experts import KTransformersExperts
+    from ktransformers_amd.util.gguf_loader import GGUFLoader, _dequant
+    from ktransformers_amd.util.utils import InferenceState
+
+    rng = np.random.default_rng(11)
+    E, H, I, k, T = 4, 256, 512, 2, 3
+
+    def blocks(n, nbytes, f16_cols):       # any bit pattern is a valid block; keep the fp16 scales small and positive
+        b = rng.integers(0, 256, (n, nbytes), dtype=np.uint8)
+        for c in f16_cols:
+            b[:, c:c + 2] = (rng.random(n).astype(np.float16) * np.float16(0.004) + np.float16(0.001)).view(np.uint8).reshape(n, 2)
+        return b
+
+    gate, up = blocks(E * I * H // 256, 176, (0, 2)), blocks(E * I * H // 256, 176, (0, 2))        # Q5_K
+    down = blocks(E * H * I // 32, 34, (0,))                                                         # Q8_0
+    write_gguf(str(tmp_path / "toy.gguf"), {"blk.1.ffn_gate_exps.weight": (13, [H, I, E], gate.tobytes()),
+                                            "blk.1.ffn_up_exps.weight": (13, [H, I, E], up.tobytes()),
+                                            "blk.1.ffn_down_exps.weight": (8, [I, H, E], down.tobytes())},
+               {"deepseek2.expert_count": E})
+    cfg = ToyConfig(hidden_size=H, moe_intermediate_size=I, intermediate_size=I, n_routed_experts=E, num_experts_per_tok=k)
+    orig = torch.nn.ModuleList([torch.nn.Identity() for _ in range(E)])
+    ex = KTransformersExperts("model.layers.1.mlp.experts", GGUFLoader(str(tmp_path)), cfg, orig, prefill_device="cuda",
+                              prefill_op="KExpertsTorch", generate_device="cpu", generate_op="KExpertsCPU", out_device="cuda",
+                              backend="llamafile", max_len=16)
+    with pytest.warns(RuntimeWarning, match="no native expert kernel"):
+        ex.load(mode=InferenceState.GENERATE)
+    assert ex.generate_experts.method == "BF16"
+    x = f32_to_bf16((rng.standard_normal((T, H)) / 4).astype(np.float32))
+    ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
+    w = rng.random((T, k)).astype(np.float32)
+    y = ex.forward(torch.from_numpy(x.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(ids).cuda(),
+                   torch.from_numpy(w).cuda()).float().cpu().numpy()
+    rb = lambda a: bf16_to_f32(f32_to_bf16(a)).astype(np.float64)      # noqa: E731  (the weights the handle holds)
+    G, U = rb(_dequant(13, gate.reshape(-1)).reshape(E, I, H)), rb(_dequant(13, up.reshape(-1)).reshape(E, I, H))
+    D = rb(_dequant(8, down.reshape(-1)).reshape(E, H, I))
+    xf = bf16_to_f32(x).astype(np.float64)
+    ref = np.zeros((T, H))
+    for t in range(T):
+        for j in range(k):
+            e = ids[t, j]
+            g, u = G[e] @ xf[t], U[e] @ xf[t]
+            ref[t] += w[t, j] * (D[e] @ (g / (1 + np.exp(-g)) * u))
+    assert (np.abs(y - ref) <= 2.0 ** -6 * np.abs(ref) + 1e-2 * np.abs(ref).max()).all()

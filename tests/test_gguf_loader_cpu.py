@@ -6,6 +6,7 @@ import json
 import os
 
 import numpy as np
+import pytest
 import torch
 
 from helpers import write_gguf
@@ -61,3 +62,17 @@ def test_reader_matches_reference_loader_and_roundtrips(tmp_path):
     assert np.array_equal(deq.numpy(), dequantize_q6_k(src["down"]).reshape(src["E"], src["H"], src["I"]))
     deq4 = ld.load_gguf_tensor("blk.1.ffn_gate_exps.weight", target_dtype=torch.float32)
     assert np.array_equal(deq4.numpy(), dequantize_q4_k(src["gate"]).reshape(src["E"], src["I"], src["H"]))
+
+
+@pytest.mark.parametrize("t", [2, 6, 8, 10, 11, 12, 13, 14, 23])
+def test_every_type_the_reference_loader_reads_dequantises_bit_for_bit(t):
+    """util/gguf_loader._dequant against the REFERENCE's own numpy dequantisers on committed random blocks
+    (tests/golden/make_gguf_golden.py; custom_gguf.py:225-572): Q4_0, Q5_0, Q8_0, Q2_K..Q6_K, IQ4_XS — same values, same
+    float32 association (d*scale, then *q, then - dmin*min)."""
+    from ktransformers_amd.util.gguf_loader import GGML_QUANT_SIZES, _dequant
+    g = np.load(os.path.join(os.path.dirname(GOLD), "gguf_blocks_golden.npz"))
+    blocks, want = {12: ("q4k_blocks", "q4k_values"), 14: ("q6k_blocks", "q6k_values")}.get(t, (f"t{t}_blocks", f"t{t}_values"))
+    blocks, want = g[blocks], g[want]
+    assert blocks.shape[1] == GGML_QUANT_SIZES[t][1] and want.shape[1] == GGML_QUANT_SIZES[t][0]
+    got = _dequant(t, blocks.reshape(-1)).reshape(want.shape)
+    assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
