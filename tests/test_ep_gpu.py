@@ -1,6 +1,7 @@
 """GPU: the expert-parallel wrappers on a single-rank RCCL group (the 8-GPU run belongs to the driver): prefill
 (all-to-all-v dispatch + ktx_moe_combine) must reproduce MoEHandle.forward bit for bit; decode (all-gather + fp32
-partial + reduce-scatter) to 1 bf16 ulp."""
+partial + reduce-scatter) to 1 bf16 ulp; the peer-write decode transport wired through the whole model (its multi-rank
+behaviour is tests/test_ep_peer_gpu.py's)."""
 import os
 
 import numpy as np
@@ -87,5 +88,23 @@ def test_whole_model_decode_graph_with_rccl_collectives(group):
             toks_graph.append(int(ep_graph.cur.item()))
         ep_graph.close()
         assert toks_graph == toks_eager, (toks_graph, toks_eager)
+        # the same step with the peer-write transport (include/ktx_ep.h) in place of the two collectives: set up through the
+        # process group (handle swap + on-fabric self-check), taken by every KExpertsHIP, captured in the graph; with one
+        # rank the reduce is a single rounding, so the tokens are those of the collective path
+        ex = parallel.enable_peer_exchange(wl["H"], wl["k"], 16, dev)
+        try:
+            ep_peer = runner(True, True)
+            assert ep_peer.graph_ok, ep_peer.graph_error
+            restart(ep_peer)
+            toks_peer = []
+            for _ in range(6):
+                ep_peer.step()
+                toks_peer.append(int(ep_peer.cur.item()))
+            ep_peer.close()
+            assert ex.status() == 0
+            assert toks_peer == toks_eager, (toks_peer, toks_eager)
+        finally:
+            parallel.EP_STATE["exchange"] = None
+            ex.close()
     finally:
         parallel.enable_expert_parallel(enabled=False)
