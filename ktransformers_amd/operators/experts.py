@@ -109,11 +109,12 @@ class KExpertsHIP(KExpertsBase):
             w = self.load_weights(device=str(dev))[self.key]
         from ktransformers_amd import parallel
         ep_on = parallel.EP_STATE["enabled"] and torch.distributed.is_available() and torch.distributed.is_initialized()
+        handle_len = self.max_len                            # (self.max_len itself is never changed: load() after unload())
         if ep_on:   # shard the experts over the ranks; routing ids stay global
             world = torch.distributed.get_world_size(parallel.EP_STATE["group"])
             rank = torch.distributed.get_rank(parallel.EP_STATE["group"])
             self.expert_begin, self.expert_count = parallel.expert_range(self.n_routed_experts, world, rank)
-            self.max_len = self.max_len * min(world, 8)      # decode gathers every rank's tokens; prefill receives rows
+            handle_len = self.max_len * min(world, 8)        # decode gathers every rank's tokens; prefill receives rows
         cfg = self.config
         inter = getattr(cfg, "moe_intermediate_size", None) or cfg.intermediate_size
         if self.method == "GGUF" and "gate_type" not in w:
@@ -137,7 +138,7 @@ class KExpertsHIP(KExpertsBase):
                      "up": dequantize_expert_blocks(w["up"], types["up"], E_all, inter, cfg.hidden_size),
                      "down": dequantize_expert_blocks(w["down"], types["down"], E_all, cfg.hidden_size, inter)}
                 self.method = "BF16"
-        h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=self.max_len,
+        h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=handle_len,
                       method=self.method, device=dev, expert_begin=self.expert_begin,
                       global_expert_num=self.n_routed_experts, group_size=_GROUP_SIZE.get(self.method, 0))
         sl = slice(self.expert_begin, self.expert_begin + self.expert_count)
@@ -198,7 +199,9 @@ class KExpertsHIP(KExpertsBase):
                                            None if res is None else res.reshape(x.shape[0], -1).contiguous(), bsz_tensor=bsz_tensor)
             return out.to(device=self.out_device if str(self.out_device) != "cuda" else dev)
         if self._ep is not None:
-            # decode-sized batches: all-gather + local partial + reduce-scatter; prompts: all-to-all-v dispatch / return
+            # decode-sized batches: all-gather + local partial + reduce-scatter; prompts: all-to-all-v dispatch / return.
+            # Contract (as for any collective): every rank calls with the same number of tokens when it is <= 16 — the
+            # choice of path and the gather's row count are taken from the local T, there is no extra collective to agree on it.
             out = self._ep.forward(x, ids, w) if x.shape[0] <= 16 else self._ep.forward_prefill(x, ids, w)
         else:
             out = self.handle.forward(x, ids, w, bsz_tensor=bsz_tensor)
