@@ -610,6 +610,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the DeepSeek-V2-Lite secondary decode number")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--force-dist", action="store_true",
+                    help="dev / test aid: take the N > 1 code path (process group, expert parallelism, exchange transport) "
+                         "even with WORLD_SIZE=1, so that path can be run on a one-GPU box")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
@@ -620,7 +623,7 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    dist_on = world > 1
+    dist_on = world > 1 or args.force_dist
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
     dev = torch.device("cuda", local_rank)
     torch.cuda.set_device(dev)

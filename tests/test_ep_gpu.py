@@ -108,3 +108,25 @@ def test_whole_model_decode_graph_with_rccl_collectives(group):
             ex.close()
     finally:
         parallel.enable_expert_parallel(enabled=False)
+
+
+def test_bench_takes_its_multi_gpu_branch_on_one_rank():
+    """`bench.py --force-dist` with WORLD_SIZE=1: the N > 1 code path of main() — RCCL process group, experts behind the EP
+    wrappers, the peer-write transport set up through the group (handle swap, self-check), the load/capture barrier, the timed
+    loop with its barriers and MAX over ranks, the transport status in the JSON line — on the one GPU this box has.
+    (Its own process: the module fixture above already owns this process's default group.)"""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--workload", "v2lite-int4",
+                        "--layers", "3", "--steps", "8", "--warmup", "2", "--no-prefill", "--no-secondary", "--no-cpu-baseline"],
+                       env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["value"] and line["value"] > 0 and line["n_gpus"] == 1 and line["scaling"] == "weak"
+    assert cfg["parallelism"] == "ep1" and cfg["rccl_ranks"] == 1 and cfg["hip_graph"] is True, cfg
+    assert cfg["ep_transport"].startswith("peer writes") and cfg["ep_transport_status"] == 0, cfg
