@@ -910,9 +910,13 @@ __device__ __forceinline__ void dec_step1(const WFrag<WBITS>& f, const v4i& b0, 
 // SIDE_MAX), their loads issued up front with the routed weight ring; the fp32 partial sums meet in LDS in wavefront order,
 // i.e. the k-slice structure of lin_dec_kernel (ktx_linear.hip) with the same k-step arithmetic (ktx_w4_step.inc).
 // (with the side strip the kernel is held to 128 registers — two workgroups per CU like the plain kernel, which the whole
-// grid of H/16 workgroups needs to be resident at once)
+// grid of H/16 workgroups needs to be resident at once; the variants whose ring + four side k-steps would spill at 128 —
+// the 16-deep W4 ring and the W8 rings with SIDE_MAX 4 — get 168 instead)
+template <int WBITS, int D, int SIDE_G, int SIDE_MAX>
+constexpr int dec_down_waves() { return SIDE_G == 0 ? 1 : ((SIDE_MAX > 2 && (D >= 16 || WBITS == 8)) || (WBITS == 8 && D == 11)) ? 3 : 4; }
 template <int WBITS, int D, bool EXACT, int SIDE_G = 0, int SIDE_MAX = 2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 ? 4 : 1))) void moe_dec_down_kernel(DecParams p) {
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(dec_down_waves<WBITS, D, SIDE_G, SIDE_MAX>())))
+void moe_dec_down_kernel(DecParams p) {
   constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   // [k][I + 128] int8 activations | [k][16] fp32 down outputs | [k] valid flags | [k] routing weights
@@ -2828,6 +2832,7 @@ static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, 
       KTX_HIP(err);                                                                                                 \
       hipLaunchKernelGGL((moe_dec_down_kernel<WB, DD, EX, SG, SM>), g2, dim3(64 * k), lds2, st, dp);                \
     } while (0)
+    // (W8 with the 11-deep ring never carries a side strip — refused above)
 #define KTX_LAUNCH_DN(WB, DD, EX)                                                                                   \
     do {                                                                                                            \
       if (side && (dp.side_nks + k - 1) / k <= 2) KTX_LAUNCH_DN1(WB, DD, EX, 64, 2);                                \
@@ -3232,8 +3237,10 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
       auto tname = [](int t) { return t == GG_Q4K ? "Q4_K" : t == GG_Q6K ? "Q6_K" : "IQ1_S"; };
 #define KTX_GG_GU(WT)                                                                                                \
       do {                                                                                                           \
-        if (d1 == 4) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 4, 4>), g1, dim3(256), lds_gu, st, dp);      \
-        else if (d1 == 2) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4>), g1, dim3(256), lds_gu, st, dp); \
+        if constexpr (WT != GG_Q6K) {   /* (never chosen for Q6_K, see d1 above: not instantiated either) */         \
+          if (d1 == 4) { hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 4, 4>), g1, dim3(256), lds_gu, st, dp); break; } \
+        }                                                                                                            \
+        if (d1 >= 2) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4>), g1, dim3(256), lds_gu, st, dp); \
         else hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 1, 4>), g1, dim3(256), lds_gu, st, dp);              \
       } while (0)
 #define KTX_GG_DN(WT)                                                                                                \
