@@ -909,13 +909,13 @@ __device__ __forceinline__ void dec_step1(const WFrag<WBITS>& f, const v4i& b0, 
 // adds ride in the epilogue.  The side strip's k-steps are dealt out to the k wavefronts (ceil(side_nks / k) each, at most
 // SIDE_MAX), their loads issued up front with the routed weight ring; the fp32 partial sums meet in LDS in wavefront order,
 // i.e. the k-slice structure of lin_dec_kernel (ktx_linear.hip) with the same k-step arithmetic (ktx_w4_step.inc).
-// (with the side strip the kernel is held to 128 registers — two workgroups per CU like the plain kernel, which the whole
-// grid of H/16 workgroups needs to be resident at once; the variants whose ring + four side k-steps would spill at 128 —
-// the 16-deep W4 ring and the W8 rings with SIDE_MAX 4 — get 168 instead)
-template <int WBITS, int D, int SIDE_G, int SIDE_MAX>
-constexpr int dec_down_waves() { return SIDE_G == 0 ? 1 : ((SIDE_MAX > 2 && (D >= 16 || WBITS == 8)) || (WBITS == 8 && D == 11)) ? 3 : 4; }
+// (with the side strip the kernel is held to 128 registers — two workgroups per CU like the plain kernel, so that the whole
+// grid of H/16 workgroups is resident at once.  The variants with four side k-steps per wavefront on the 16-deep W4 ring or
+// a W8 ring then keep 5-9 values in scratch (20-36 B per lane, -Rpass-analysis=kernel-resource-usage); giving them 168
+// registers removes the scratch but leaves ONE workgroup per CU — two rounds of workgroups for H >= 4112 — which is the
+// worse trade for a latency-bound launch, so the cap stays.  W8 with the 11-deep ring is refused at dispatch.)
 template <int WBITS, int D, bool EXACT, int SIDE_G = 0, int SIDE_MAX = 2>
-__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(dec_down_waves<WBITS, D, SIDE_G, SIDE_MAX>())))
+__global__ __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(SIDE_G > 0 ? 4 : 1)))
 void moe_dec_down_kernel(DecParams p) {
   constexpr int TILE_BYTES = (WBITS == 4) ? 1024 : 2048;
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
