@@ -268,6 +268,9 @@ int ktx_ep_gather(ktx_ep_t ep, int T, const void* d_x, const int64_t* d_ids, con
   EpDev d;
   if (int rc = ep_dev(ep, T, &d, "ktx_ep_gather")) return rc;
   KTX_REQUIRE(d_x && d_ids && d_w && d_xg && d_idsg && d_wg, "ktx_ep_gather: null pointer");
+  KTX_REQUIRE((((uintptr_t)d_x | (uintptr_t)d_xg | (uintptr_t)d_w | (uintptr_t)d_wg) & 3) == 0 &&
+                  (((uintptr_t)d_ids | (uintptr_t)d_idsg) & 7) == 0,
+              "ktx_ep_gather: rows must be 4-byte aligned (x, w) / 8-byte aligned (ids): they travel as 32-bit words");
   DevGuard dg(ep->device);
   KTX_HIP(dg.err);
   hipStream_t st = (hipStream_t)stream;
@@ -282,6 +285,7 @@ int ktx_ep_reduce(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stre
   EpDev d;
   if (int rc = ep_dev(ep, T, &d, "ktx_ep_reduce")) return rc;
   KTX_REQUIRE(d_part && d_out, "ktx_ep_reduce: null pointer");
+  KTX_REQUIRE(((uintptr_t)d_part & 3) == 0 && ((uintptr_t)d_out & 1) == 0, "ktx_ep_reduce: misaligned pointer");
   DevGuard dg(ep->device);
   KTX_HIP(dg.err);
   hipStream_t st = (hipStream_t)stream;
