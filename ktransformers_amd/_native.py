@@ -459,10 +459,15 @@ class EpExchange:
     process from local_ptr()."""
 
     def __init__(self, world: int, rank: int, max_tokens: int, hidden: int, topk: int, device, memory: str = "uncached"):
-        self.device = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        dev = torch.device(device) if not isinstance(device, int) else torch.device("cuda", device)
+        if dev.index is None:       # "cuda": the process's current device, like every torch allocation
+            dev = torch.device("cuda", torch.cuda.current_device())
+        self.device = dev
         self.world, self.rank, self.max_tokens, self.H, self.k = world, rank, max_tokens, hidden, topk
         self._h = C.c_void_p()
-        check(lib.ktx_ep_create(self.device.index or 0, world, rank, max_tokens, hidden, topk, EP_MEMORY[memory], C.byref(self._h)))
+        if memory not in EP_MEMORY:
+            raise KtxError(f"EpExchange: memory must be one of {sorted(EP_MEMORY)}, got {memory!r}")
+        check(lib.ktx_ep_create(dev.index, world, rank, max_tokens, hidden, topk, EP_MEMORY[memory], C.byref(self._h)))
 
     def close(self) -> None:
         if self._h:
