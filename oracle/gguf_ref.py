@@ -6,13 +6,15 @@ quantize_q4_k / quantize_q6_k are simple encoders written for the tests (any val
 NOT ggml's search-based quantisers).  Block layouts:
   Q4_K (type 12, 144 B / 256 w): fp16 d, fp16 dmin, 12 B packed 6-bit (scale, min) x 8, 128 B nibbles (4 x [32 low | 32 high])
   Q6_K (type 14, 210 B / 256 w): 128 B low nibbles, 64 B high 2-bit, 16 x int8 scales, fp16 d
+  Q5_K (type 13, 176 B / 256 w): Q4_K's header, then 32 B of fifth bits (bit j of byte l = sub-block j, element l), 128 B nibbles
+       (oracle side only so far: no HIP kernel reads Q5_K natively yet)
 """
 import ctypes as C
 
 import numpy as np
 
-GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 14, 19
-BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
+GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 13, 14, 19
+BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q5_K: 176, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
 
 
 def dequantize_q4_k(data: np.ndarray) -> np.ndarray:
@@ -70,6 +72,48 @@ def quantize_q4_k(w: np.ndarray) -> np.ndarray:
     out[:, 12:16] = (sc[:, 4:8] & 15) | ((m[:, 4:8] & 15) << 4)
     qq = q.reshape(nb, 4, 2, 32)
     out[:, 16:] = (qq[:, :, 0] | (qq[:, :, 1] << 4)).reshape(nb, 128)
+    return out.reshape(*lead, -1)
+
+
+def dequantize_q5_k(data: np.ndarray) -> np.ndarray:
+    """uint8 [..., nblk*176] -> float32 [..., nblk*256] (custom_gguf.py:356-410: d*scale*q - dmin*min, q in 0..31)."""
+    lead = data.shape[:-1]
+    b = np.ascontiguousarray(data, dtype=np.uint8).reshape(-1, 176)
+    nb = b.shape[0]
+    d = b[:, 0:2].copy().view(np.float16).astype(np.float32).reshape(nb, 1, 1)
+    dmin = b[:, 2:4].copy().view(np.float16).astype(np.float32).reshape(nb, 1, 1)
+    s1, qs = b[:, 4:16].reshape(nb, 12, 1), b[:, 48:].reshape(nb, 4, 32)
+    fac = d * np.concatenate([s1[:, 0:4] & 63, (s1[:, 8:] & 15) | ((s1[:, 0:4] >> 6) << 4)], axis=1).astype(np.float32)
+    off = dmin * np.concatenate([s1[:, 4:8] & 63, (s1[:, 8:] >> 4) | ((s1[:, 4:8] >> 6) << 4)], axis=1).astype(np.float32)
+    hbit = np.unpackbits(b[:, 16:48].reshape(nb, 32, 1), axis=2, bitorder="little").transpose(0, 2, 1)     # [nb, sub-block, l]
+    q = (np.stack([qs & 0xF, qs >> 4], axis=2).reshape(nb, 8, 32) + (hbit << 4)).astype(np.float32)
+    return (fac * q - off).astype(np.float32).reshape(*lead, -1)
+
+
+def quantize_q5_k(w: np.ndarray) -> np.ndarray:
+    """float32 [..., K] (K % 256 == 0) -> uint8 [..., K/256*176]; the Q4_K test encoder with 32 levels."""
+    lead = w.shape[:-1]
+    x = np.ascontiguousarray(w, dtype=np.float32).reshape(-1, 8, 32)
+    nb = x.shape[0]
+    mn = np.minimum(x.min(axis=2), 0.0)
+    mx = np.maximum(x.max(axis=2), mn + 1e-30)
+    sc_f, m_f = (mx - mn) / 31.0, -mn
+    d = (sc_f.max(axis=1) / 63.0).astype(np.float16)
+    dmin = (m_f.max(axis=1) / 63.0).astype(np.float16)
+    df, dmf = d.astype(np.float32)[:, None], dmin.astype(np.float32)[:, None]
+    sc = np.clip(np.rint(np.divide(sc_f, df, out=np.zeros_like(sc_f), where=df > 0)), 0, 63).astype(np.uint8)
+    m = np.clip(np.rint(np.divide(m_f, dmf, out=np.zeros_like(m_f), where=dmf > 0)), 0, 63).astype(np.uint8)
+    eff = (df * sc)[:, :, None]
+    q = np.clip(np.rint(np.divide(x + (dmf * m)[:, :, None], eff, out=np.zeros_like(x), where=eff > 0)), 0, 31).astype(np.uint8)
+    out = np.zeros((nb, 176), np.uint8)
+    out[:, 0:2] = d.view(np.uint8).reshape(nb, 2)
+    out[:, 2:4] = dmin.view(np.uint8).reshape(nb, 2)
+    out[:, 4:8] = (sc[:, 0:4] & 63) | ((sc[:, 4:8] >> 4) << 6)
+    out[:, 8:12] = (m[:, 0:4] & 63) | ((m[:, 4:8] >> 4) << 6)
+    out[:, 12:16] = (sc[:, 4:8] & 15) | ((m[:, 4:8] & 15) << 4)
+    out[:, 16:48] = np.packbits((q >> 4).transpose(0, 2, 1), axis=2, bitorder="little").reshape(nb, 32)   # bit j of byte l
+    qq = (q & 0xF).reshape(nb, 4, 2, 32)
+    out[:, 48:] = (qq[:, :, 0] | (qq[:, :, 1] << 4)).reshape(nb, 128)
     return out.reshape(*lead, -1)
 
 
@@ -166,8 +210,9 @@ def quantize_iq1_s(w: np.ndarray) -> np.ndarray:
     return out.reshape(*lead, -1)
 
 
-QUANT = {GGML_TYPE_Q4_K: quantize_q4_k, GGML_TYPE_Q6_K: quantize_q6_k, GGML_TYPE_IQ1_S: quantize_iq1_s}
-DEQUANT = {GGML_TYPE_Q4_K: dequantize_q4_k, GGML_TYPE_Q6_K: dequantize_q6_k, GGML_TYPE_IQ1_S: dequantize_iq1_s}
+QUANT = {GGML_TYPE_Q4_K: quantize_q4_k, GGML_TYPE_Q5_K: quantize_q5_k, GGML_TYPE_Q6_K: quantize_q6_k, GGML_TYPE_IQ1_S: quantize_iq1_s}
+DEQUANT = {GGML_TYPE_Q4_K: dequantize_q4_k, GGML_TYPE_Q5_K: dequantize_q5_k, GGML_TYPE_Q6_K: dequantize_q6_k,
+           GGML_TYPE_IQ1_S: dequantize_iq1_s}
 
 
 class _GgufMoe(C.Structure):

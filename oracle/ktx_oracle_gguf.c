@@ -31,6 +31,7 @@
 
 #define QK_K 256
 #define GGML_TYPE_Q4_K 12
+#define GGML_TYPE_Q5_K 13
 #define GGML_TYPE_Q6_K 14
 #define GGML_TYPE_IQ1_S 19
 
@@ -97,6 +98,34 @@ float ktxo_vec_dot_q4_K(const uint8_t* wrow, int K, const int8_t* q8, const floa
       const uint8_t* q = qs + (j / 2) * 32;
       int32_t dot = 0;
       for (int l = 0; l < 32; l++) dot += (int32_t)((j & 1) ? (q[l] >> 4) : (q[l] & 0xF)) * q8[j * 32 + l];
+      isum += (int32_t)s * dot;
+      msum += (int32_t)m * ((int32_t)bs[2 * j] + bs[2 * j + 1]);
+    }
+    acc = fmaf(d8[b] * d, (float)isum, acc);
+    acc = fmaf(-(d8[b] * dmin), (float)msum, acc);
+  }
+  return acc;
+}
+
+/* block_q5_K: { fp16 d, fp16 dmin, uint8 scales[12], uint8 qh[32], uint8 qs[128] } = 176 B (custom_gguf.py:356-410
+ * dequantize_q5_k): Q4_K's structure with a fifth bit per weight — sub-block j of 32 takes bit j of qh[l].  Same folding as
+ * Q4_K.  (No HIP kernel reads this type yet: the product de-quantises such experts to BF16; this
+ * restatement and its pin against the reference's iqk kernel are there for the native kernel to be checked against.) */
+float ktxo_vec_dot_q5_K(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 176, q8 += QK_K, bs += 16) {
+    uint16_t dh, mh; memcpy(&dh, wrow, 2); memcpy(&mh, wrow + 2, 2);
+    const float d = fp16_to_f32(dh), dmin = fp16_to_f32(mh);
+    const uint8_t *sc = wrow + 4, *qh = wrow + 16, *qs = wrow + 48;
+    int32_t isum = 0, msum = 0;
+    for (int j = 0; j < 8; j++) {
+      uint8_t s, m; get_scale_min_k4(j, sc, &s, &m);
+      const uint8_t* q = qs + (j / 2) * 32;
+      int32_t dot = 0;
+      for (int l = 0; l < 32; l++) {
+        const int lo = (j & 1) ? (q[l] >> 4) : (q[l] & 0xF);
+        dot += (int32_t)(lo + (((qh[l] >> j) & 1) << 4)) * q8[j * 32 + l];
+      }
       isum += (int32_t)s * dot;
       msum += (int32_t)m * ((int32_t)bs[2 * j] + bs[2 * j + 1]);
     }
@@ -187,11 +216,12 @@ void ktxo_dequant_iq1_s(const uint8_t* blocks, int nblocks, float* out) {
 const uint16_t* ktxo_iq1s_grid(void) { return iq1s_grid_packed; }
 
 static size_t row_bytes(int type, int K) {
-  return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : type == GGML_TYPE_Q6_K ? 210 : 50);
+  return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : type == GGML_TYPE_Q5_K ? 176 : type == GGML_TYPE_Q6_K ? 210 : 50);
 }
 
 static float vec_dot(int type, const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
   if (type == GGML_TYPE_IQ1_S) return ktxo_vec_dot_iq1_s(wrow, K, q8, d8, bs);
+  if (type == GGML_TYPE_Q5_K) return ktxo_vec_dot_q5_K(wrow, K, q8, d8, bs);
   return type == GGML_TYPE_Q4_K ? ktxo_vec_dot_q4_K(wrow, K, q8, d8, bs) : ktxo_vec_dot_q6_K(wrow, K, q8, d8, bs);
 }
 
@@ -207,7 +237,7 @@ int ktxo_moe_forward_gguf(const ktxo_gguf_moe* m, int T, int k, const int64_t* i
                           uint16_t* y, float* inter_out) {
   const int H = m->H, I = m->I;
   const int types[3] = {m->gate_type, m->up_type, m->down_type};
-  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q6_K && types[i] != GGML_TYPE_IQ1_S) return -1;
+  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q5_K && types[i] != GGML_TYPE_Q6_K && types[i] != GGML_TYPE_IQ1_S) return -1;
   float* xf = malloc(sizeof(float) * H);
   int8_t* xq = malloc(H); float* xd = malloc(sizeof(float) * (H / QK_K)); int16_t* xbs = malloc(2 * (H / 16));
   float* inter = malloc(sizeof(float) * I);

@@ -8,8 +8,8 @@ import numpy as np
 import pytest
 
 from helpers import bf16_to_f32
-from oracle.gguf_ref import (DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle, dequantize_iq1_s,
-                             dequantize_q4_k, dequantize_q6_k, iq1s_grid, quantize_iq1_s)
+from oracle.gguf_ref import (DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, QUANT, GgufOracle,
+                             dequantize_iq1_s, dequantize_q4_k, dequantize_q5_k, dequantize_q6_k, iq1s_grid, quantize_iq1_s)
 from oracle.oracle import f32_to_bf16
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "gguf_blocks_golden.npz")
@@ -19,15 +19,16 @@ def test_block_layouts_match_reference_dequantisers():
     g = np.load(GOLD)
     assert np.array_equal(dequantize_q4_k(g["q4k_blocks"]), g["q4k_values"])
     assert np.array_equal(dequantize_q6_k(g["q6k_blocks"]), g["q6k_values"])
+    assert np.array_equal(dequantize_q5_k(g["t13_blocks"]), g["t13_values"])
 
 
-@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q6_K])
+@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K])
 def test_test_quantisers_round_trip(t):
     rng = np.random.default_rng(t)
     w = (rng.standard_normal((6, 512)) / 10).astype(np.float32)
     wq = DEQUANT[t](QUANT[t](w))
     rel = np.linalg.norm(wq - w) / np.linalg.norm(w)
-    assert rel < (0.12 if t == GGML_TYPE_Q4_K else 0.03), rel
+    assert rel < {GGML_TYPE_Q4_K: 0.12, GGML_TYPE_Q5_K: 0.06, GGML_TYPE_Q6_K: 0.03}[t], rel
 
 
 def test_q8k_quantiser():
@@ -44,7 +45,8 @@ def test_q8k_quantiser():
 
 
 @pytest.mark.parametrize("types", [(GGML_TYPE_Q4_K, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K), (GGML_TYPE_Q6_K, GGML_TYPE_Q4_K, GGML_TYPE_Q4_K),
-                                   (GGML_TYPE_IQ1_S, GGML_TYPE_IQ1_S, GGML_TYPE_IQ1_S)])
+                                   (GGML_TYPE_IQ1_S, GGML_TYPE_IQ1_S, GGML_TYPE_IQ1_S),
+                                   (GGML_TYPE_Q5_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K)])     # the q5_k_m mix (oracle side only so far)
 def test_gguf_forward_tracks_dequantised_math(types):
     o = GgufOracle()
     E, k, H, I, T = 4, 2, 256, 512, 3

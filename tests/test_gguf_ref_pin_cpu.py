@@ -13,11 +13,11 @@ import os
 import numpy as np
 import pytest
 
-from oracle.gguf_ref import DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, QUANT, GgufOracle
+from oracle.gguf_ref import DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, QUANT, GgufOracle
 
 REF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
 GGML_TYPE_Q8_K = 15
-BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
+BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q5_K: 176, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
 VARIANTS = {"avx2": ("libiqk_ref_avx2.so", "iqk_mul_mat", "avx2"), "zen4": ("libiqk_ref_zen4.so", "iqk_mul_mat_zen4", "avx512_vnni")}
 
 
@@ -68,7 +68,7 @@ def q8k_rows(o, x):
 
 
 @pytest.mark.parametrize("variant", ["avx2", "zen4"])
-@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S])
+@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S])
 @pytest.mark.parametrize("shape", [(48, 512, 1), (40, 2048, 5), (24, 1536, 19)])
 def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
     iqk = load(variant)
@@ -85,7 +85,8 @@ def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
     if not ok:
         pytest.skip(f"the reference's {variant} build has no kernel for ggml type {t}")
 
-    vec_dot = {GGML_TYPE_Q4_K: o.lib.ktxo_vec_dot_q4_K, GGML_TYPE_Q6_K: o.lib.ktxo_vec_dot_q6_K, GGML_TYPE_IQ1_S: o.lib.ktxo_vec_dot_iq1_s}[t]
+    vec_dot = {GGML_TYPE_Q4_K: o.lib.ktxo_vec_dot_q4_K, GGML_TYPE_Q5_K: o.lib.ktxo_vec_dot_q5_K, GGML_TYPE_Q6_K: o.lib.ktxo_vec_dot_q6_K,
+               GGML_TYPE_IQ1_S: o.lib.ktxo_vec_dot_iq1_s}[t]
     vec_dot.restype = C.c_float
     mine = np.empty((T, N), np.float32)
     rb = BLOCK_BYTES[t] * (K // 256)
