@@ -30,8 +30,11 @@
 #include <string.h>
 
 #define QK_K 256
+#define GGML_TYPE_Q2_K 10
+#define GGML_TYPE_Q3_K 11
 #define GGML_TYPE_Q4_K 12
 #define GGML_TYPE_Q5_K 13
+#define GGML_TYPE_IQ4_XS 23
 #define GGML_TYPE_Q6_K 14
 #define GGML_TYPE_IQ1_S 19
 
@@ -135,6 +138,80 @@ float ktxo_vec_dot_q5_K(const uint8_t* wrow, int K, const int8_t* q8, const floa
   return acc;
 }
 
+/* The three remaining Q8_K-activation types the reference's loader knows (custom_gguf.py:225-519).  Like Q5_K: checker only,
+ * pinned against the reference's iqk kernels; the product de-quantises such experts to BF16 until native kernels exist.
+ *
+ * block_q2_K: { uint8 scales[16] (4-bit scale | 4-bit min), uint8 qs[64], fp16 d, fp16 dmin } = 84 B; 16 sub-blocks of 16;
+ * element half*128 + shift*32 + l = (qs[half*32 + l] >> 2*shift) & 3. */
+float ktxo_vec_dot_q2_K(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 84, q8 += QK_K, bs += 16) {
+    const uint8_t *sc = wrow, *qs = wrow + 16;
+    uint16_t dh, mh; memcpy(&dh, wrow + 80, 2); memcpy(&mh, wrow + 82, 2);
+    const float d = fp16_to_f32(dh), dmin = fp16_to_f32(mh);
+    int32_t isum = 0, msum = 0;
+    for (int g = 0; g < 16; g++) {
+      const int half = g / 8, shift = (g % 8) / 2, l0 = (g & 1) * 16;
+      int32_t dot = 0;
+      for (int l = 0; l < 16; l++) dot += (int32_t)((qs[half * 32 + l0 + l] >> (2 * shift)) & 3) * q8[g * 16 + l];
+      isum += (int32_t)(sc[g] & 0xF) * dot;
+      msum += (int32_t)(sc[g] >> 4) * bs[g];
+    }
+    acc = fmaf(d8[b] * d, (float)isum, acc);
+    acc = fmaf(-(d8[b] * dmin), (float)msum, acc);
+  }
+  return acc;
+}
+
+/* block_q3_K: { uint8 hmask[32], uint8 qs[64], uint8 scales[12] (16 six-bit scales, offset 32), fp16 d } = 110 B; element
+ * half*128 + shift*32 + l = ((qs[half*32 + l] >> 2*shift) & 3) - (bit (half*4 + shift) of hmask[l] ? 0 : 4). */
+float ktxo_vec_dot_q3_K(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  (void)bs;
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 110, q8 += QK_K) {
+    const uint8_t *hm = wrow, *qs = wrow + 32, *lo = wrow + 96, *hi2 = wrow + 104;
+    uint16_t dh; memcpy(&dh, wrow + 108, 2);
+    const float d = fp16_to_f32(dh);
+    int32_t isum = 0;
+    for (int g = 0; g < 16; g++) {
+      const int s6 = g < 8 ? (lo[g] & 0xF) | (((hi2[g % 4] >> (2 * (g / 4))) & 3) << 4)
+                           : (lo[g - 8] >> 4) | (((hi2[(g - 8) % 4] >> (4 + 2 * ((g - 8) / 4))) & 3) << 4);
+      const int half = g / 8, shift = (g % 8) / 2, l0 = (g & 1) * 16;
+      int32_t dot = 0;
+      for (int l = 0; l < 16; l++) {
+        const int q = (int)((qs[half * 32 + l0 + l] >> (2 * shift)) & 3) - (((hm[l0 + l] >> (half * 4 + shift)) & 1) ? 0 : 4);
+        dot += q * q8[g * 16 + l];
+      }
+      isum += (s6 - 32) * dot;
+    }
+    acc = fmaf(d8[b] * d, (float)isum, acc);
+  }
+  return acc;
+}
+
+/* block_iq4_xs: { fp16 d, uint16 scales_h, uint8 scales_l[4], uint8 qs[128] } = 136 B; 8 sub-blocks of 32 (16 low nibbles,
+ * then 16 high nibbles of 16 bytes), values from the 16-entry IQ4_NL table, 6-bit scale - 32. */
+float ktxo_vec_dot_iq4_xs(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
+  (void)bs;
+  static const int8_t kv[16] = {-127, -104, -83, -65, -49, -35, -22, -10, 1, 13, 25, 38, 53, 69, 89, 113};
+  float acc = 0.f;
+  for (int b = 0; b < K / QK_K; b++, wrow += 136, q8 += QK_K) {
+    uint16_t dh, sh; memcpy(&dh, wrow, 2); memcpy(&sh, wrow + 2, 2);
+    const float d = fp16_to_f32(dh);
+    const uint8_t *sl = wrow + 4, *qs = wrow + 8;
+    int32_t isum = 0;
+    for (int ib = 0; ib < 8; ib++) {
+      const int ls = ((sl[ib / 2] >> (4 * (ib % 2))) & 0xF) | (((sh >> (2 * ib)) & 3) << 4);
+      int32_t dot = 0;
+      for (int l = 0; l < 16; l++)
+        dot += (int32_t)kv[qs[ib * 16 + l] & 0xF] * q8[ib * 32 + l] + (int32_t)kv[qs[ib * 16 + l] >> 4] * q8[ib * 32 + 16 + l];
+      isum += (ls - 32) * dot;
+    }
+    acc = fmaf(d8[b] * d, (float)isum, acc);
+  }
+  return acc;
+}
+
 /* block_q6_K: { uint8 ql[128], uint8 qh[64], int8 scales[16], fp16 d } = 210 B (custom_gguf.py dequantize_q6_k) */
 float ktxo_vec_dot_q6_K(const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
   (void)bs;
@@ -216,12 +293,16 @@ void ktxo_dequant_iq1_s(const uint8_t* blocks, int nblocks, float* out) {
 const uint16_t* ktxo_iq1s_grid(void) { return iq1s_grid_packed; }
 
 static size_t row_bytes(int type, int K) {
-  return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : type == GGML_TYPE_Q5_K ? 176 : type == GGML_TYPE_Q6_K ? 210 : 50);
+  return (size_t)(K / QK_K) * (type == GGML_TYPE_Q4_K ? 144 : type == GGML_TYPE_Q5_K ? 176 : type == GGML_TYPE_Q6_K ? 210 :
+                               type == GGML_TYPE_Q2_K ? 84 : type == GGML_TYPE_Q3_K ? 110 : type == GGML_TYPE_IQ4_XS ? 136 : 50);
 }
 
 static float vec_dot(int type, const uint8_t* wrow, int K, const int8_t* q8, const float* d8, const int16_t* bs) {
   if (type == GGML_TYPE_IQ1_S) return ktxo_vec_dot_iq1_s(wrow, K, q8, d8, bs);
   if (type == GGML_TYPE_Q5_K) return ktxo_vec_dot_q5_K(wrow, K, q8, d8, bs);
+  if (type == GGML_TYPE_Q2_K) return ktxo_vec_dot_q2_K(wrow, K, q8, d8, bs);
+  if (type == GGML_TYPE_Q3_K) return ktxo_vec_dot_q3_K(wrow, K, q8, d8, bs);
+  if (type == GGML_TYPE_IQ4_XS) return ktxo_vec_dot_iq4_xs(wrow, K, q8, d8, bs);
   return type == GGML_TYPE_Q4_K ? ktxo_vec_dot_q4_K(wrow, K, q8, d8, bs) : ktxo_vec_dot_q6_K(wrow, K, q8, d8, bs);
 }
 
@@ -237,7 +318,8 @@ int ktxo_moe_forward_gguf(const ktxo_gguf_moe* m, int T, int k, const int64_t* i
                           uint16_t* y, float* inter_out) {
   const int H = m->H, I = m->I;
   const int types[3] = {m->gate_type, m->up_type, m->down_type};
-  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q5_K && types[i] != GGML_TYPE_Q6_K && types[i] != GGML_TYPE_IQ1_S) return -1;
+  for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q5_K && types[i] != GGML_TYPE_Q6_K && types[i] != GGML_TYPE_IQ1_S &&
+                                  types[i] != GGML_TYPE_Q2_K && types[i] != GGML_TYPE_Q3_K && types[i] != GGML_TYPE_IQ4_XS) return -1;
   float* xf = malloc(sizeof(float) * H);
   int8_t* xq = malloc(H); float* xd = malloc(sizeof(float) * (H / QK_K)); int16_t* xbs = malloc(2 * (H / 16));
   float* inter = malloc(sizeof(float) * I);

@@ -17,7 +17,20 @@ from oracle.gguf_ref import DEQUANT, GGML_TYPE_IQ1_S, GGML_TYPE_Q4_K, GGML_TYPE_
 
 REF_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "oracle", "_ref")
 GGML_TYPE_Q8_K = 15
-BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q5_K: 176, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50}
+GGML_TYPE_Q2_K, GGML_TYPE_Q3_K, GGML_TYPE_IQ4_XS = 10, 11, 23
+BLOCK_BYTES = {GGML_TYPE_Q4_K: 144, GGML_TYPE_Q5_K: 176, GGML_TYPE_Q6_K: 210, GGML_TYPE_IQ1_S: 50, GGML_TYPE_Q2_K: 84,
+               GGML_TYPE_Q3_K: 110, GGML_TYPE_IQ4_XS: 136}
+# types restated for the checker only (no HIP kernel yet): random bit patterns are valid blocks; fp16 fields kept small
+RANDOM_BITS = {GGML_TYPE_IQ1_S: (0,), GGML_TYPE_Q2_K: (80, 82), GGML_TYPE_Q3_K: (108,), GGML_TYPE_IQ4_XS: (0,)}
+
+
+def dequant(t, wb):
+    """float32 values of the blocks: the oracle's codec where it has one, else the loader's (pinned bit for bit to the
+    reference's numpy dequantisers by tests/test_gguf_loader_cpu.py)."""
+    if t in DEQUANT:
+        return DEQUANT[t](wb)
+    from ktransformers_amd.util.gguf_loader import _dequant
+    return _dequant(t, np.ascontiguousarray(wb).reshape(-1)).reshape(wb.shape[0], -1)
 VARIANTS = {"avx2": ("libiqk_ref_avx2.so", "iqk_mul_mat", "avx2"), "zen4": ("libiqk_ref_zen4.so", "iqk_mul_mat_zen4", "avx512_vnni")}
 
 
@@ -45,11 +58,12 @@ def load(variant):
 
 def random_blocks(t, N, K, rng):
     """Valid blocks of type t: Q4_K / Q6_K through the test quantisers; IQ1_S as random bit patterns with a small d."""
-    if t != GGML_TYPE_IQ1_S:
+    if t not in RANDOM_BITS:
         return QUANT[t]((rng.standard_normal((N, K)) / 10).astype(np.float32))
-    b = rng.integers(0, 256, (N, K // 256, 50), dtype=np.uint8)
-    d = rng.random((N, K // 256)).astype(np.float16) * np.float16(0.004) + np.float16(0.001)
-    b[..., 0:2] = d.view(np.uint8).reshape(N, K // 256, 2)
+    b = rng.integers(0, 256, (N, K // 256, BLOCK_BYTES[t]), dtype=np.uint8)
+    for c in RANDOM_BITS[t]:
+        d = rng.random((N, K // 256)).astype(np.float16) * np.float16(0.004) + np.float16(0.001)
+        b[..., c:c + 2] = d.view(np.uint8).reshape(N, K // 256, 2)
     return b.reshape(N, -1)
 
 
@@ -68,7 +82,8 @@ def q8k_rows(o, x):
 
 
 @pytest.mark.parametrize("variant", ["avx2", "zen4"])
-@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S])
+@pytest.mark.parametrize("t", [GGML_TYPE_Q4_K, GGML_TYPE_Q5_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S, GGML_TYPE_Q2_K, GGML_TYPE_Q3_K,
+                               GGML_TYPE_IQ4_XS])
 @pytest.mark.parametrize("shape", [(48, 512, 1), (40, 2048, 5), (24, 1536, 19)])
 def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
     iqk = load(variant)
@@ -77,6 +92,14 @@ def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
     rng = np.random.default_rng(N * 1000 + K + T + t)
     wb = np.ascontiguousarray(random_blocks(t, N, K, rng))
     x = rng.standard_normal((T, K)).astype(np.float32)
+    if t == GGML_TYPE_IQ4_XS:
+        # the reference's IQ4_XS kernel forms (value + 128) * q8 pair sums in 16 bits (maddubs), which SATURATE when a large
+        # code sits next to the block's +-127 element — on uniformly random blocks and normal activations a few outputs per
+        # hundred differ from the exact product by 10-40 % (measured here).  That is data-dependent behaviour of the CPU kernel,
+        # not the format: the pin uses activations whose pair sums stay below 2^15 (one outlier per block, its neighbour 0).
+        x = np.clip(x * 0.1, -0.25, 0.25)
+        x[:, 0::256] = np.where(rng.random((T, K // 256)) < 0.5, -1.0, 1.0).astype(np.float32)
+        x[:, 1::256] = 0
     x[0, :256] = 0  # an all-zero activation block (d = 0)
     rec, q8, d8, bs = q8k_rows(o, x)
 
@@ -86,7 +109,8 @@ def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
         pytest.skip(f"the reference's {variant} build has no kernel for ggml type {t}")
 
     vec_dot = {GGML_TYPE_Q4_K: o.lib.ktxo_vec_dot_q4_K, GGML_TYPE_Q5_K: o.lib.ktxo_vec_dot_q5_K, GGML_TYPE_Q6_K: o.lib.ktxo_vec_dot_q6_K,
-               GGML_TYPE_IQ1_S: o.lib.ktxo_vec_dot_iq1_s}[t]
+               GGML_TYPE_IQ1_S: o.lib.ktxo_vec_dot_iq1_s, GGML_TYPE_Q2_K: o.lib.ktxo_vec_dot_q2_K, GGML_TYPE_Q3_K: o.lib.ktxo_vec_dot_q3_K,
+               GGML_TYPE_IQ4_XS: o.lib.ktxo_vec_dot_iq4_xs}[t]
     vec_dot.restype = C.c_float
     mine = np.empty((T, N), np.float32)
     rb = BLOCK_BYTES[t] * (K // 256)
@@ -96,7 +120,7 @@ def test_restated_vec_dot_against_reference_iqk_kernels(variant, t, shape):
                                   C.c_void_p(d8[ti].ctypes.data), C.c_void_p(bs[ti].ctypes.data))
 
     # exact value of the quantised product and the size of its per-block terms, in float64
-    wd = DEQUANT[t](wb).astype(np.float64).reshape(N, K // 256, 256)
+    wd = dequant(t, wb).astype(np.float64).reshape(N, K // 256, 256)
     xd = (q8.astype(np.float64).reshape(T, K // 256, 256) * d8.astype(np.float64)[:, :, None])
     terms = np.einsum("nbk,tbk->tnb", wd, xd)
     exact = terms.sum(-1)
