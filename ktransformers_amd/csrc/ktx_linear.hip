@@ -103,7 +103,14 @@ struct LinParams {
   // step (latent RMSNorm + RoPE) beside the per-head absorb products — independent work, one launch instead of two
   int prep_on;
   MlaPrepParams prep;
+  unsigned long long* stamps;   // dev probe (ktx_debug_set_ptr(0, buf)): 16 wall-clock slots for this launch, else nullptr
+  // lin_sk_kernel (ktx_linear_sk.inc): groups per strip, the split of the groups over the workgroups, cross-workgroup meeting place
+  int sk_gps, sk_unit, sk_Q, sk_R;
+  unsigned long long* sk_words;   // [nstrips][64]: one word per (token, feature) of a strip shared between workgroups
 };
+// dev probe: slot 0 / 1 = first workgroup entry / last workgroup exit of the launch (all workgroups), slots 2.. = phases of
+// workgroup (0, first product row) as seen by its thread 0
+#define LIN_STAMP(i) do { if (p.stamps && stamp_wg && threadIdx.x == 0) p.stamps[i] = wall_clock64(); } while (0)
 
 // batch b of a batched linear: shift the base pointers once
 __device__ __forceinline__ void lin_select_batch(LinParams& p, int b) {
@@ -241,6 +248,9 @@ template <int FMT, int G, int D, int MODE>
 __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const int by, const int nbx, uint8_t* smem) {
   constexpr bool EXACT = MODE != M_GUARD;
   static_assert(MODE != M_DMA || FMT == F_W4, "the LDS-DMA ring is built for the W4 format");
+  const bool stamp_wg = bx == 0 && by == (p.prep_on ? 1 : 0);
+  if (p.stamps && threadIdx.x == 0) atomicMin(p.stamps, wall_clock64());
+  LIN_STAMP(2);
   if (p.prep_on && by == 0) {   // the prep row, dispatched FIRST so it overlaps the products: workgroup x handles tokens x, x + nbx, ...
     float* s_cs = reinterpret_cast<float*>(smem);   // (static LDS here would push the kernel past the 160 KB attribute)
     for (int t = bx; t < p.prep.T; t += nbx) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
@@ -384,7 +394,9 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   for (int i = 0; i < XPRE; i++)
     if (tid + i * 512 < ntot) stage_piece(tid + i * 512, xpre[i]);
   for (int idx = tid + XPRE * 512; idx < ntot; idx += 512) stage_piece(idx, piece(XPRE, idx));
+  LIN_STAMP(3);
   __syncthreads();
+  LIN_STAMP(4);
 
   // ---- stream
   v4f acc = {0.f, 0.f, 0.f, 0.f};
@@ -446,11 +458,13 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   }
 
   // ---- k-slices meet in LDS; tokens 0..3 live in lanes 0..15 (C rows 4*(lane>>4)+r)
+  LIN_STAMP(5);
   if (lane < 16) {
 #pragma unroll
     for (int r = 0; r < 4; r++) red[(wave * 4 + r) * 16 + lane] = acc[r];
   }
   __syncthreads();
+  LIN_STAMP(6);
   if (tid < p.SW * 64) {
     const int swo = tid >> 6, r = (tid >> 4) & 3, f = tid & 15;
     const int n = (bx * p.SW + swo) * 16 + f;
@@ -467,6 +481,13 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
       } else {
         p.y[(size_t)r * p.ldy + n] = lin_addends(lin_out(v, p.bias, n), p, r, n);
       }
+    }
+  }
+  if (p.stamps) {
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      if (stamp_wg) { p.stamps[7] = wall_clock64(); p.stamps[8] = ((unsigned long long)p.Kx << 32) | (unsigned)p.N; }
+      atomicMax(p.stamps + 1, wall_clock64());
     }
   }
 }
@@ -492,6 +513,8 @@ __global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs
   }
   lin_dec_body<F_W4, G, D, M_EXACT>(p, blockIdx.x, blockIdx.y - 1, gridDim.x, smem);
 }
+
+#include "ktx_linear_sk.inc"
 
 // =====================================================================================================
 // q_b_proj + q-absorb of an MLA decode step in ONE launch (ktx_linear_forward_qb_absorb): one workgroup per head.
@@ -1286,6 +1309,8 @@ struct ktx_linear_s {
   bf16_t* d_bias = nullptr;
   size_t w_bytes = 0, sc_bytes = 0;
   bool loaded = false;
+  unsigned long long* d_sk_words = nullptr;   // lin_sk_kernel: [nstrips][64] meeting words (zero between launches)
+  int sk_ncu = 0;
 };
 
 namespace {
@@ -1304,10 +1329,90 @@ int set_bias(ktx_linear_s* h, const void* d_bias) {
 
 constexpr int KTX_LIN_NOT_FUSED = -2;   // launch_dec with a router to carry: this shape has no combined kernel, nothing was launched
 
+
+// The all-CU decode GEMV (lin_sk_kernel) where it applies: W4 g64, one matrix, T <= 4, no rider in the launch.  Returns
+// KTX_LIN_NOT_FUSED when this shape is not covered (the caller then takes lin_dec_kernel).
+//
+// How the groups are dealt (cost in bytes of the busiest workgroup, ~24 KB per us and CU; a strip shared between
+// workgroups costs one atomic round trip, ~1.5 us = 36 KB):
+//   whole strips per workgroup — no meeting in global memory; the right choice whenever the strips divide evenly enough
+//       (every DeepSeek-V3 / Kimi-K2 / V2-Lite shape: within 2 % of the balanced deal) and required by the glu epilogue;
+//   single groups — balanced to +- one group whatever the shape; strips at workgroup borders meet through sk_words.
+// Ring depth D: the divisor of the k-steps that leaves the fewest tiles on the busiest wavefront.
+template <int G>
+int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st) {
+  using F = Fmt<F_W4, G>;
+  const int NKS = h->NKS;
+  if (h->batch != 1 || p.prep_on || !h->d_sk_words || NKS * 16 > SK_XMAX * 512 || ktx_debug_get(16) == 1) return KTX_LIN_NOT_FUSED;
+  const int TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
+  const int force_unit = ktx_debug_get(17);   // dev knob: 1 = deal single groups, 2 = deal whole strips
+  int best_D = 0, best_unit = 0, best_nwg = 0;
+  double best_cost = 1e30;
+  for (int D : {8, 7, 6, 4}) {
+    if (NKS % D) continue;
+    const int GPS = NKS / D;
+    for (int mode = 0; mode < 2; mode++) {   // 0: whole strips, 1: single groups
+      if (mode == 1 && (p.glu || force_unit == 2)) continue;
+      if (mode == 0 && force_unit == 1 && !p.glu) continue;
+      const int unit = mode == 0 ? GPS : 1;
+      const long items = (long)h->nstrips * GPS / unit;
+      const int nwg = (int)std::min<long>(h->sk_ncu, items);
+      const long per_wg = (items + nwg - 1) / nwg * unit;            // groups of the busiest workgroup
+      const long per_wave = (per_wg + 7) / 8 * D;                     // tiles of its busiest wavefront
+      const bool shared = mode == 1 && (items % nwg != 0 || (items / nwg) % GPS != 0);
+      const double cost = (double)per_wave * 8 * 1088 + (shared ? 36.0 * 1024 : 0.0);
+      if (cost < best_cost) { best_cost = cost; best_D = D; best_unit = unit; best_nwg = nwg; }
+    }
+  }
+  if (!best_D) return KTX_LIN_NOT_FUSED;
+  const int D = best_D, GPS = NKS / D, unit = best_unit, nwg = best_nwg;
+  const long items = (long)h->nstrips * GPS / unit;
+  const int Q = (int)(items / nwg), R = (int)(items % nwg);
+  const int max_local = ((Q + 1) * unit + GPS - 1) / GPS + 1;   // strips one workgroup can touch
+  if (max_local > SK_MAX_STRIPS || (GPS + Q * unit - 1) / (Q * unit) + 1 > SK_MAXC) return KTX_LIN_NOT_FUSED;
+  const size_t smem = (size_t)NKS * 16 * TP * 16 + (size_t)NKS * F::GPK * 16 + 128 + (size_t)max_local * 8 * 64 * 4;
+  if (smem > 160 * 1024) return KTX_LIN_NOT_FUSED;
+  p.TP = TP; p.sk_gps = GPS; p.sk_unit = unit; p.sk_Q = Q; p.sk_R = R; p.sk_words = h->d_sk_words;
+  KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0, "lin_sk_kernel<W4> %d->%d", p.Kx, p.N);
+  auto go = [&](auto kern) -> int {
+    static bool attr_set = false;   // one flag per kernel instantiation
+    if (!attr_set) {
+      KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      attr_set = true;
+    }
+    hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, st, p);
+    KTX_HIP(hipGetLastError());
+    return 0;
+  };
+  const int xr = (NKS * 16 + 511) / 512;   // 16-byte activation pieces per thread (a token row, padded to whole k-steps)
+#define KTX_SK_X(DV)                                                                        \
+  if (TP == 1) {                                                                            \
+    if (xr <= 1) return go(lin_sk_kernel<G, 1, DV, 1>);                                     \
+    if (xr <= 2) return go(lin_sk_kernel<G, 1, DV, 2>);                                     \
+    if (xr <= 4) return go(lin_sk_kernel<G, 1, DV, 4>);                                     \
+    return go(lin_sk_kernel<G, 1, DV, SK_XMAX>);                                            \
+  }                                                                                         \
+  if (TP == 2) return go(lin_sk_kernel<G, 2, DV, SK_XMAX>);                                 \
+  return go(lin_sk_kernel<G, 4, DV, SK_XMAX>);
+  switch (D) {
+    case 8: KTX_SK_X(8)
+    case 7: KTX_SK_X(7)
+    case 6: KTX_SK_X(6)
+    default: KTX_SK_X(4)
+  }
+#undef KTX_SK_X
+}
+
 template <int FMT, int G>
 int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs* gate = nullptr) {
   using F = Fmt<FMT, G>;
   const int NKS = h->NKS;
+  if constexpr (FMT == F_W4 && G == 64) {   // (the all-CU kernel is instantiated for Marlin's default group size)
+    if (!gate) {
+      const int rc = launch_sk<G>(h, p, st);
+      if (rc != KTX_LIN_NOT_FUSED) return rc;
+    }
+  }
   p.TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
   // Strips per workgroup (SW; the other 8/SW wavefronts split K).  A CU pulls ~11 B/clk whatever runs on it, so a launch
   // takes as long as its busiest CU: ceil(workgroups / CUs) workgroups' worth of bytes — c strips of weights, the
@@ -1553,8 +1658,16 @@ extern "C" int ktx_linear_create(const ktx_linear_config* cfg, ktx_linear_t* out
   else if (cfg->format == KTX_LIN_FP8) h->sc_bytes = (size_t)h->batch * ((h->nstrips + 7) / 8) * h->NKS * 4;
   hipError_t e = hipMalloc(&h->d_w, h->w_bytes);
   if (e == hipSuccess && h->sc_bytes) e = hipMalloc(&h->d_sc, h->sc_bytes);
+  if (e == hipSuccess && cfg->format == KTX_LIN_W4 && h->batch == 1) {   // meeting place of the all-CU decode GEMV
+    hipDeviceProp_t prop;
+    h->sk_ncu = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
+    e = hipMalloc(&h->d_sk_words, (size_t)h->nstrips * 64 * sizeof(unsigned long long));
+    if (e == hipSuccess) e = hipMemset(h->d_sk_words, 0, (size_t)h->nstrips * 64 * sizeof(unsigned long long));
+  }
   if (e != hipSuccess) {
     if (h->d_w) (void)hipFree(h->d_w);
+    if (h->d_sc) (void)hipFree(h->d_sc);
+    if (h->d_sk_words) (void)hipFree(h->d_sk_words);
     delete h;
     return ktx_fail(std::string("ktx_linear_create: hipMalloc: ") + hipGetErrorString(e));
   }
@@ -1568,6 +1681,7 @@ extern "C" int ktx_linear_destroy(ktx_linear_t h) {
   if (h->d_w) (void)hipFree(h->d_w);
   if (h->d_sc) (void)hipFree(h->d_sc);
   if (h->d_bias) (void)hipFree(h->d_bias);
+  if (h->d_sk_words) (void)hipFree(h->d_sk_words);
   delete h;
   return 0;
 }
@@ -1642,6 +1756,15 @@ bool dec_fits(const ktx_linear_s* h, int T) {
 }
 }  // namespace
 
+// dev probe: per-launch phase stamps (scripts/lin_stamps.py).  ktx_debug_set_ptr(0, buf) arms it: every decode GEMV launch
+// then takes the next 16-slot record of `buf` (slot 0 must be pre-filled with ~0 for the atomicMin); nullptr disarms.
+static unsigned long long* g_lin_stamps = nullptr;
+static long g_lin_stamp_next = 0;
+extern "C" int ktx_debug_set_ptr(int idx, void* p) {
+  if (idx == 0) { g_lin_stamps = (unsigned long long*)p; g_lin_stamp_next = 0; }
+  return 0;
+}
+
 static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, long ldx, long xbs, void* d_y,
                                long ldy, long ybs, ktx_stream_t stream, const ktx_linear_fusion* fu = nullptr,
                                const MlaPrepParams* prep = nullptr, const GateArgs* gate = nullptr) {
@@ -1657,6 +1780,7 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
   p.wbs = h->w_bytes / h->batch; p.scbs = h->sc_bytes / h->batch;
   if (prep) { p.prep_on = 1; p.prep = *prep; }
+  if (g_lin_stamps) p.stamps = g_lin_stamps + 16 * (g_lin_stamp_next++);
   if (fu) {
     KTX_REQUIRE(h->batch == 1, "ktx_linear_forward_fused: not for batched handles");
     KTX_REQUIRE(!fu->norm_weight || dec_eligible(h, T),

@@ -2597,7 +2597,7 @@ static int launch_gemm(const GemmParams& p, int max_tiles, hipStream_t st) {
   return 0;
 }
 
-static int g_dbg[16] = {0};  // dev knobs: [0] waves/workgroup override of the decode gate/up kernel, [1] ablation bits
+static int g_dbg[32] = {0};  // dev knobs: [0] waves/workgroup override of the decode gate/up kernel, [1] ablation bits
 template <int WBITS, bool GATE_UP>
 static int launch_gemm_stream(const GemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int MT = 4, D = (WBITS == 4) ? 4 : 2, TOK = MT * 16, CS = TOK * 16;
@@ -2672,8 +2672,8 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
 static bool g_prof_on = false;
 static bool g_force_generic = false;  // tests: route small batches through the grouped (prefill) path too
 extern "C" int ktx_debug_force_generic(int on) { g_force_generic = on != 0; return 0; }
-extern "C" int ktx_debug_set(int idx, int val) { if (idx >= 0 && idx < 16) g_dbg[idx] = val; return 0; }
-extern "C" int ktx_debug_get(int idx) { return idx >= 0 && idx < 16 ? g_dbg[idx] : 0; }
+extern "C" int ktx_debug_set(int idx, int val) { if (idx >= 0 && idx < 32) g_dbg[idx] = val; return 0; }
+extern "C" int ktx_debug_get(int idx) { return idx >= 0 && idx < 32 ? g_dbg[idx] : 0; }
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_ev[5];
 static std::vector<std::pair<hipEvent_t, hipEvent_t>> g_prof_free;
 
