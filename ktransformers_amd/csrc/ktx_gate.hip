@@ -78,7 +78,7 @@ static int gate_forward_impl(const ktx_gate_config* cfg, const int32_t* d_bsz, i
   hipStream_t st = (hipStream_t)stream;
   const dim3 grid((E + 3) / 4, qlen);
   const int epl = (E + 63) / 64;
-  GateArgs ga;
+  GateArgs ga{};
   ga.c = *cfg; ga.d_bsz = d_bsz; ga.qlen = qlen; ga.x = (const bf16_t*)d_x; ga.w = (const bf16_t*)d_w; ga.bias = d_bias;
   ga.logits = d_logits; ga.counters = d_counters; ga.topk_idx = d_topk_idx; ga.topk_w = d_topk_weight;
   ga.norm_w = (const bf16_t*)d_norm_w; ga.norm_eps = norm_eps; ga.xn_out = (bf16_t*)d_xn_out;

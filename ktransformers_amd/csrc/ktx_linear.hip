@@ -104,8 +104,10 @@ struct LinParams {
   int prep_on;
   MlaPrepParams prep;
   unsigned long long* stamps;   // dev probe (ktx_debug_set_ptr(0, buf)): 16 wall-clock slots for this launch, else nullptr
+  unsigned* cu_map;             // dev probe (ktx_debug_set_ptr(1, buf)): [1024] where each workgroup of this launch ran (XCC / SE / CU ids)
   // lin_sk_kernel (ktx_linear_sk.inc): groups per strip, the split of the groups over the workgroups, cross-workgroup meeting place
-  int sk_gps, sk_unit, sk_Q, sk_R;
+  int sk_gps, sk_unit, sk_Q, sk_R, sk_nw, sk_logits_off;
+  bf16_t* xn_out;                 // the router's normalised row for the experts that run next (workgroup 0 writes it)
   unsigned long long* sk_words;   // [nstrips][64]: one word per (token, feature) of a strip shared between workgroups
 };
 // dev probe: slot 0 / 1 = first workgroup entry / last workgroup exit of the launch (all workgroups), slots 2.. = phases of
@@ -1313,15 +1315,72 @@ struct ktx_linear_s {
   int sk_ncu = 0;
 };
 
+
+// ---- device memory of the linears: slabs, not one hipMalloc per matrix ----------------------------------------------------
+// A DeepSeek-V3 decode step walks ~200 dense matrices of 8-60 MB between its 5.6 GB expert arenas.  Allocated one by one
+// (two or three hipMallocs per handle, interleaved with the loader's multi-GB staging buffers) they end up wherever the
+// VRAM manager had room; carved out of 1 GiB slabs they are contiguous in virtual AND physical memory, one translation
+// fragment covers many of them, and a layer's matrices sit next to each other in launch order.  A slab is returned to the
+// driver when its last piece is freed.  KTX_ARENA=0 restores the plain hipMalloc / hipFree per piece (A/B).
+namespace {
+// {tag, logit} granules of the router riding in lin_sk_gate_kernel: one buffer per device, zero between launches
+constexpr int KTX_GRAN_T = 64;
+unsigned long long* g_gate_granules[64] = {nullptr};
+hipError_t gate_granules_for(int dev) {
+  if (dev < 0 || dev >= 64 || g_gate_granules[dev]) return hipSuccess;
+  const size_t nb = (size_t)KTX_GRAN_T * KTX_GATE_MAX_E * sizeof(unsigned long long) + (size_t)KTX_GRAN_T * 16 * sizeof(int);
+  hipError_t e = hipMalloc((void**)&g_gate_granules[dev], nb);
+  if (e == hipSuccess) e = hipMemset(g_gate_granules[dev], 0, nb);
+  return e;
+}
+struct LinSlab { char* base; size_t cap, used; int live; int dev; };
+std::mutex g_arena_mu;
+std::vector<LinSlab> g_slabs;
+bool arena_on() {
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("KTX_ARENA"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+hipError_t lin_alloc(void** out, size_t bytes, int dev) {
+  if (!arena_on()) return hipMalloc(out, bytes);
+  const size_t need = (bytes + 4095) & ~(size_t)4095;
+  std::lock_guard<std::mutex> lk(g_arena_mu);
+  for (auto& s : g_slabs)
+    if (s.dev == dev && s.cap - s.used >= need) { *out = s.base + s.used; s.used += need; s.live++; return hipSuccess; }
+  static size_t slab_bytes = 0;
+  if (!slab_bytes) { const char* e = getenv("KTX_ARENA_MB"); slab_bytes = (size_t)(e ? atol(e) : 1024) << 20; }
+  LinSlab s{nullptr, std::max(need, slab_bytes), need, 1, dev};
+  const hipError_t e = hipMalloc((void**)&s.base, s.cap);
+  if (e != hipSuccess) return e;
+  g_slabs.push_back(s);
+  *out = s.base;
+  return hipSuccess;
+}
+void lin_free(void* p) {
+  if (!p) return;
+  if (arena_on()) {
+    std::lock_guard<std::mutex> lk(g_arena_mu);
+    for (size_t i = 0; i < g_slabs.size(); i++) {
+      LinSlab& s = g_slabs[i];
+      if ((char*)p >= s.base && (char*)p < s.base + s.cap) {
+        if (--s.live == 0) { (void)hipFree(s.base); g_slabs.erase(g_slabs.begin() + i); }
+        return;
+      }
+    }
+  }
+  (void)hipFree(p);
+}
+}  // namespace
+
 namespace {
 
 int tile_bytes(int fmt) { return fmt == F_W4 ? 1024 : fmt == F_FP8 ? 2048 : 4096; }
 
 int set_bias(ktx_linear_s* h, const void* d_bias) {
-  if (h->d_bias) { KTX_HIP(hipFree(h->d_bias)); h->d_bias = nullptr; }
+  if (h->d_bias) { lin_free(h->d_bias); h->d_bias = nullptr; }
   if (d_bias) {
     const size_t nb = (size_t)h->cfg.out_features * h->batch * 2;
-    KTX_HIP(hipMalloc(&h->d_bias, nb));
+    KTX_HIP(lin_alloc((void**)&h->d_bias, nb, h->cfg.device));
     KTX_HIP(hipMemcpy(h->d_bias, d_bias, nb, hipMemcpyDeviceToDevice));
   }
   return 0;
@@ -1340,27 +1399,49 @@ constexpr int KTX_LIN_NOT_FUSED = -2;   // launch_dec with a router to carry: th
 //   single groups — balanced to +- one group whatever the shape; strips at workgroup borders meet through sk_words.
 // Ring depth D: the divisor of the k-steps that leaves the fewest tiles on the busiest wavefront.
 template <int G>
-int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st) {
+int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs* gate = nullptr) {
   using F = Fmt<F_W4, G>;
   const int NKS = h->NKS;
   if (h->batch != 1 || p.prep_on || !h->d_sk_words || NKS * 16 > SK_XMAX * 512 || ktx_debug_get(16) == 1) return KTX_LIN_NOT_FUSED;
+  // a router riding in the launch takes wavefront 7 of every workgroup: ring depth 8 only, rows of <= 8192 inputs, the router's
+  // own limits (gate_fused_body); dev knob 13 = 1 keeps the two launches apart (A/B, tests)
+  const int nw = gate ? 7 : 8;
+  int gate_epl = 0;
+  if (gate) {
+    const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
+    gate_epl = (E + 63) / 64;
+    // OPT-IN (dev knob 19 = 2).  Measured inside the DeepSeek-V3 decode graph (scripts/ab_decode.py, same box): 5.95 ms per
+    // step with this rider against 5.27 ms with round 2's lin_dec_gate_kernel — the router wavefront's chain of dependent
+    // round trips (row, granule + ticket, sweep) costs 4-5 us EACH inside the model graph on the slower boxes of the pool,
+    // and 256 workgroups each run it, where the old kernel's 32 router workgroups hide behind the GEMV's.
+    if (NKS % 8 || H != p.Kx || H > 8192 || H % 8 || gate_epl > 6 || !p.norm_w || !gate->granules || ktx_debug_get(13) == 1 ||
+        ktx_debug_get(19) != 2)
+      return KTX_LIN_NOT_FUSED;
+  }
   const int TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
+  // workgroups per CU: ONE.  Two (<= 128 VGPRs, <= 80 KB of LDS each; dev knob 18 = 2) were measured slower on every
+  // DeepSeek-V3 shape (scripts/lin_stamps.py --knobs 18=2: o_proj 20.4 vs 16.9 us, dense gate|up 34.5 vs 30.0): the second
+  // workgroup's activation staging competes with the first one's weight stream instead of hiding behind it.
+  const size_t smem_fixed = (size_t)NKS * 16 * TP * 16 + (size_t)NKS * F::GPK * 16 + 128;
+  const int wg_per_cu = (TP == 1 && smem_fixed + 8 * 2048 <= 80 * 1024 && ktx_debug_get(18) == 2) ? 2 : 1;
+  const int max_wg = h->sk_ncu * wg_per_cu;
   const int force_unit = ktx_debug_get(17);   // dev knob: 1 = deal single groups, 2 = deal whole strips
   int best_D = 0, best_unit = 0, best_nwg = 0;
   double best_cost = 1e30;
   for (int D : {8, 7, 6, 4}) {
-    if (NKS % D) continue;
+    if (NKS % D || (gate && D != 8)) continue;
     const int GPS = NKS / D;
     for (int mode = 0; mode < 2; mode++) {   // 0: whole strips, 1: single groups
       if (mode == 1 && (p.glu || force_unit == 2)) continue;
       if (mode == 0 && force_unit == 1 && !p.glu) continue;
       const int unit = mode == 0 ? GPS : 1;
       const long items = (long)h->nstrips * GPS / unit;
-      const int nwg = (int)std::min<long>(h->sk_ncu, items);
+      const int nwg = (int)std::min<long>(max_wg, items);
       const long per_wg = (items + nwg - 1) / nwg * unit;            // groups of the busiest workgroup
-      const long per_wave = (per_wg + 7) / 8 * D;                     // tiles of its busiest wavefront
+      const long per_wave = (per_wg + nw - 1) / nw * D;               // tiles of its busiest wavefront
       const bool shared = mode == 1 && (items % nwg != 0 || (items / nwg) % GPS != 0);
-      const double cost = (double)per_wave * 8 * 1088 + (shared ? 36.0 * 1024 : 0.0);
+      const int on_cu = nwg > h->sk_ncu ? wg_per_cu : 1;               // workgroups sharing the busiest CU
+      const double cost = (double)per_wave * 8 * 1088 * on_cu + (shared ? 36.0 * 1024 : 0.0);
       if (cost < best_cost) { best_cost = cost; best_D = D; best_unit = unit; best_nwg = nwg; }
     }
   }
@@ -1370,9 +1451,37 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st) {
   const int Q = (int)(items / nwg), R = (int)(items % nwg);
   const int max_local = ((Q + 1) * unit + GPS - 1) / GPS + 1;   // strips one workgroup can touch
   if (max_local > SK_MAX_STRIPS || (GPS + Q * unit - 1) / (Q * unit) + 1 > SK_MAXC) return KTX_LIN_NOT_FUSED;
-  const size_t smem = (size_t)NKS * 16 * TP * 16 + (size_t)NKS * F::GPK * 16 + 128 + (size_t)max_local * 8 * 64 * 4;
-  if (smem > 160 * 1024) return KTX_LIN_NOT_FUSED;
-  p.TP = TP; p.sk_gps = GPS; p.sk_unit = unit; p.sk_Q = Q; p.sk_R = R; p.sk_words = h->d_sk_words;
+  size_t smem = smem_fixed + (size_t)max_local * 8 * 64 * 4;
+  p.sk_logits_off = (int)smem;
+  if (gate) smem += (size_t)KTX_GATE_MAX_E * 4;
+  if (smem > (size_t)(160 / wg_per_cu) * 1024) return KTX_LIN_NOT_FUSED;
+  p.TP = TP; p.sk_gps = GPS; p.sk_unit = unit; p.sk_Q = Q; p.sk_R = R; p.sk_words = h->d_sk_words; p.sk_nw = nw;
+  p.xn_out = gate ? gate->xn_out : nullptr;
+  const int xr = (NKS * 16 + 511) / 512;   // 16-byte activation pieces per thread (a token row, padded to whole k-steps)
+  if (gate) {
+    const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
+    KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0 + (double)E * H * 2.0,
+              "lin_sk_gate_kernel<W4> %d->%d + router E=%d", p.Kx, p.N, E);
+    auto go_g = [&](auto kern) -> int {
+      static bool attr_set = false;   // one flag per kernel instantiation
+      if (!attr_set) {
+        KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+        attr_set = true;
+      }
+      hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, st, p, *gate);
+      KTX_HIP(hipGetLastError());
+      return 0;
+    };
+#define KTX_SK_G(EPLV, NJV)                                                                      \
+    if (TP == 1 && xr <= 1) return go_g(lin_sk_gate_kernel<G, 1, 8, 1, EPLV, NJV>);              \
+    if (TP == 1) return go_g(lin_sk_gate_kernel<G, 1, 8, 2, EPLV, NJV>);                         \
+    if (TP == 2) return go_g(lin_sk_gate_kernel<G, 2, 8, 2, EPLV, NJV>);                         \
+    return go_g(lin_sk_gate_kernel<G, 4, 8, 2, EPLV, NJV>);
+    if (gate_epl <= 1 && H <= 2048) { KTX_SK_G(1, 4) }
+    else if (gate_epl <= 4) { KTX_SK_G(4, 16) }
+    else { KTX_SK_G(6, 16) }
+#undef KTX_SK_G
+  }
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0, "lin_sk_kernel<W4> %d->%d", p.Kx, p.N);
   auto go = [&](auto kern) -> int {
     static bool attr_set = false;   // one flag per kernel instantiation
@@ -1384,7 +1493,6 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st) {
     KTX_HIP(hipGetLastError());
     return 0;
   };
-  const int xr = (NKS * 16 + 511) / 512;   // 16-byte activation pieces per thread (a token row, padded to whole k-steps)
 #define KTX_SK_X(DV)                                                                        \
   if (TP == 1) {                                                                            \
     if (xr <= 1) return go(lin_sk_kernel<G, 1, DV, 1>);                                     \
@@ -1408,10 +1516,8 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
   using F = Fmt<FMT, G>;
   const int NKS = h->NKS;
   if constexpr (FMT == F_W4 && G == 64) {   // (the all-CU kernel is instantiated for Marlin's default group size)
-    if (!gate) {
-      const int rc = launch_sk<G>(h, p, st);
-      if (rc != KTX_LIN_NOT_FUSED) return rc;
-    }
+    const int rc = launch_sk<G>(h, p, st, gate);
+    if (rc != KTX_LIN_NOT_FUSED) return rc;
   }
   p.TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
   // Strips per workgroup (SW; the other 8/SW wavefronts split K).  A CU pulls ~11 B/clk whatever runs on it, so a launch
@@ -1656,18 +1762,19 @@ extern "C" int ktx_linear_create(const ktx_linear_config* cfg, ktx_linear_t* out
   h->w_bytes = (size_t)h->batch * h->nstrips * h->NKS * tile_bytes(cfg->format);
   if (cfg->format == KTX_LIN_W4) h->sc_bytes = (size_t)h->batch * h->nstrips * h->NKS * 16 * (128 / cfg->group_size) * 2;
   else if (cfg->format == KTX_LIN_FP8) h->sc_bytes = (size_t)h->batch * ((h->nstrips + 7) / 8) * h->NKS * 4;
-  hipError_t e = hipMalloc(&h->d_w, h->w_bytes);
-  if (e == hipSuccess && h->sc_bytes) e = hipMalloc(&h->d_sc, h->sc_bytes);
+  hipError_t e = lin_alloc((void**)&h->d_w, h->w_bytes, cfg->device);
+  if (e == hipSuccess && h->sc_bytes) e = lin_alloc(&h->d_sc, h->sc_bytes, cfg->device);
   if (e == hipSuccess && cfg->format == KTX_LIN_W4 && h->batch == 1) {   // meeting place of the all-CU decode GEMV
     hipDeviceProp_t prop;
     h->sk_ncu = (hipGetDeviceProperties(&prop, cfg->device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
-    e = hipMalloc(&h->d_sk_words, (size_t)h->nstrips * 64 * sizeof(unsigned long long));
+    e = lin_alloc((void**)&h->d_sk_words, (size_t)h->nstrips * 64 * sizeof(unsigned long long), cfg->device);
+    if (e == hipSuccess) e = gate_granules_for(cfg->device);
     if (e == hipSuccess) e = hipMemset(h->d_sk_words, 0, (size_t)h->nstrips * 64 * sizeof(unsigned long long));
   }
   if (e != hipSuccess) {
-    if (h->d_w) (void)hipFree(h->d_w);
-    if (h->d_sc) (void)hipFree(h->d_sc);
-    if (h->d_sk_words) (void)hipFree(h->d_sk_words);
+    lin_free(h->d_w);
+    lin_free(h->d_sc);
+    lin_free(h->d_sk_words);
     delete h;
     return ktx_fail(std::string("ktx_linear_create: hipMalloc: ") + hipGetErrorString(e));
   }
@@ -1678,10 +1785,10 @@ extern "C" int ktx_linear_create(const ktx_linear_config* cfg, ktx_linear_t* out
 extern "C" int ktx_linear_destroy(ktx_linear_t h) {
   if (!h) return 0;
   (void)hipSetDevice(h->cfg.device);
-  if (h->d_w) (void)hipFree(h->d_w);
-  if (h->d_sc) (void)hipFree(h->d_sc);
-  if (h->d_bias) (void)hipFree(h->d_bias);
-  if (h->d_sk_words) (void)hipFree(h->d_sk_words);
+  lin_free(h->d_w);
+  lin_free(h->d_sc);
+  lin_free(h->d_bias);
+  lin_free(h->d_sk_words);
   delete h;
   return 0;
 }
@@ -1759,9 +1866,11 @@ bool dec_fits(const ktx_linear_s* h, int T) {
 // dev probe: per-launch phase stamps (scripts/lin_stamps.py).  ktx_debug_set_ptr(0, buf) arms it: every decode GEMV launch
 // then takes the next 16-slot record of `buf` (slot 0 must be pre-filled with ~0 for the atomicMin); nullptr disarms.
 static unsigned long long* g_lin_stamps = nullptr;
+static unsigned* g_lin_cu_map = nullptr;
 static long g_lin_stamp_next = 0;
 extern "C" int ktx_debug_set_ptr(int idx, void* p) {
   if (idx == 0) { g_lin_stamps = (unsigned long long*)p; g_lin_stamp_next = 0; }
+  if (idx == 1) g_lin_cu_map = (unsigned*)p;
   return 0;
 }
 
@@ -1780,7 +1889,10 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   p.ldx = ldx; p.ldy = ldy; p.xbs = xbs; p.ybs = ybs;
   p.wbs = h->w_bytes / h->batch; p.scbs = h->sc_bytes / h->batch;
   if (prep) { p.prep_on = 1; p.prep = *prep; }
-  if (g_lin_stamps) p.stamps = g_lin_stamps + 16 * (g_lin_stamp_next++);
+  if (g_lin_stamps) {
+    if (g_lin_cu_map) p.cu_map = g_lin_cu_map + 1024 * g_lin_stamp_next;
+    p.stamps = g_lin_stamps + 16 * (g_lin_stamp_next++);
+  }
   if (fu) {
     KTX_REQUIRE(h->batch == 1, "ktx_linear_forward_fused: not for batched handles");
     KTX_REQUIRE(!fu->norm_weight || dec_eligible(h, T),
@@ -1836,10 +1948,12 @@ extern "C" int ktx_linear_forward_fused_gate(ktx_linear_t h, const int32_t* d_bs
   const long ldx = fusion->x_ld ? (long)fusion->x_ld : (long)h->cfg.in_features;
   const long ldy = fusion->y_ld ? (long)fusion->y_ld : (long)(fusion->glu ? h->cfg.out_features / 2 : h->cfg.out_features);
   if (ldx == h->cfg.in_features && T > 0 && T <= 4) {   // (the router reads dense rows)
-    GateArgs ga;
+    GateArgs ga{};
     ga.c = *gate_cfg; ga.d_bsz = d_bsz; ga.qlen = T; ga.x = (const bf16_t*)d_x; ga.w = (const bf16_t*)d_gate_w; ga.bias = d_gate_bias;
     ga.logits = d_logits; ga.counters = d_counters; ga.topk_idx = d_topk_idx; ga.topk_w = d_topk_weight;
     ga.norm_w = (const bf16_t*)fusion->norm_weight; ga.norm_eps = fusion->norm_eps; ga.xn_out = (bf16_t*)d_xn_out;
+    ga.granules = (h->cfg.device >= 0 && h->cfg.device < 64 && T <= KTX_GRAN_T) ? g_gate_granules[h->cfg.device] : nullptr;
+    ga.tickets = ga.granules ? reinterpret_cast<int*>(ga.granules + (size_t)KTX_GRAN_T * KTX_GATE_MAX_E) : nullptr;
     const int rc = linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion, nullptr, &ga);
     if (rc != KTX_LIN_NOT_FUSED) return rc;
   }

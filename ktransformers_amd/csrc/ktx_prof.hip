@@ -103,3 +103,28 @@ extern "C" int ktx_timing_collect(char* buf, size_t cap, size_t* needed) {
   }
   return 0;
 }
+
+// ---- dev probe: evict the instruction caches (scripts/lin_stamps.py --thrash) --------------------------------------------
+// Inside a model every kernel of a decode step finds the instruction cache (64 KB per CU pair) filled by the ~10 kernels
+// that ran since its previous launch; a chain of identical launches does not.  Two kernels of 48 KB of straight-line code on
+// every CU put an isolated chain into the model's state, so cold-code costs can be measured per kernel.
+namespace {
+template <int ID>
+__global__ __launch_bounds__(256) void icache_thrash_kernel(float* out, float seed) {
+  float a0 = seed + ID, a1 = seed * 2.f, a2 = seed * 3.f, a3 = seed * 4.f;
+  const float b = seed + 1.5f, c = (float)ID;
+#pragma unroll
+  for (int i = 0; i < 48 * 32; i++) {   // 4 x v_fma_f32 (8 bytes each) = 32 bytes per iteration
+    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a0) : "v"(b), "v"(c));
+    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a1) : "v"(b), "v"(c));
+    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a2) : "v"(b), "v"(c));
+    asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(a3) : "v"(b), "v"(c));
+  }
+  if (a0 + a1 + a2 + a3 == 12345.678f) out[blockIdx.x] = a0;
+}
+}  // namespace
+extern "C" int ktx_debug_icache_thrash(void* d_scratch, void* stream) {
+  hipLaunchKernelGGL(icache_thrash_kernel<0>, dim3(512), dim3(256), 0, (hipStream_t)stream, (float*)d_scratch, 1.0f);
+  hipLaunchKernelGGL(icache_thrash_kernel<1>, dim3(512), dim3(256), 0, (hipStream_t)stream, (float*)d_scratch, 1.0f);
+  return 0;
+}

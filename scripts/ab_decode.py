@@ -35,6 +35,9 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "sampling: torch argmax on fp32 logits": ({}, {"KTX_TORCH_ARGMAX": "1"}),
     "mla: q_b and q-absorb as two launches": ({}, {"KTX_MLA_SEPARATE_QB": "1"}),
     "mla: merge and un-absorb as two launches": ({}, {"KTX_MLA_SEPARATE_MERGE": "1"}),
+    "lin: round-2 decode GEMVs (no all-CU kernel)": ({16: 1}, {}),
+    "lin: router as wavefront 7 of the all-CU gate|up kernel": ({19: 2}, {}),
+    "lin: two workgroups per CU": ({18: 2}, {}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}

@@ -18,6 +18,12 @@ __global__ void k_chase(const unsigned* __restrict__ next, int hops, unsigned st
   const unsigned long long c1 = __builtin_readcyclecounter(), w1 = wall_clock64();
   out[0] = c1 - c0; out[1] = w1 - w0; out[2] = i;
 }
+__global__ void k_chase_ptr(const unsigned long long* start, int hops, unsigned long long* out) {
+  const unsigned long long* q = start;
+  const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
+  for (int h = 0; h < hops; h++) q = (const unsigned long long*)__builtin_nontemporal_load(q);
+  out[0] = __builtin_readcyclecounter() - c0; out[1] = wall_clock64() - w0; out[2] = (unsigned long long)q;
+}
 // ALU spin: shader cycles vs wall ticks with every CU busy
 __global__ void k_spin(long long cycles, unsigned long long* out) {
   const unsigned long long c0 = __builtin_readcyclecounter(), w0 = wall_clock64();
@@ -63,6 +69,27 @@ int main() {
              (double)h[0] / ((double)h[1] / 100.0));
     }
     CK(hipFree(d));
+  }
+  // --- dependent-load latency across MANY allocations (the model's weights are thousands of 8-60 MB hipMallocs): every hop
+  // lands in another allocation, so it needs another translation; 64 GB in 32 MB pieces vs in 2 GB pieces
+  for (size_t piece_mb : {32, 2048}) {
+    const size_t total_mb = 64 * 1024, npiece = total_mb / piece_mb, piece = piece_mb << 20;
+    std::vector<char*> ptrs(npiece);
+    bool ok = true;
+    for (size_t i = 0; i < npiece && ok; i++) ok = hipMalloc(&ptrs[i], piece) == hipSuccess;
+    if (!ok) { printf("chase across pieces: allocation failed\n"); break; }
+    // chain: hop h sits at a pseudo-random line of piece (h * 7919) % npiece and holds the ADDRESS of the next hop
+    const int hops = 4000;
+    std::vector<unsigned long long> addr(hops);
+    srand(3);
+    for (int h = 0; h < hops; h++) addr[h] = (unsigned long long)(ptrs[((size_t)h * 7919) % npiece] + ((size_t)rand() % (piece / 128)) * 128);
+    for (int h = 0; h < hops; h++) { unsigned long long nxt = addr[(h + 1) % hops]; CK(hipMemcpy((void*)addr[h], &nxt, 8, hipMemcpyHostToDevice)); }
+    for (int rep = 0; rep < 2; rep++) {
+      hipLaunchKernelGGL(k_chase_ptr, dim3(1), dim3(1), 0, st, (const unsigned long long*)addr[0], hops, out); CK(hipStreamSynchronize(st));
+      CK(hipMemcpy(h, out, 24, hipMemcpyDeviceToHost));
+      printf("chase across %4zu x %4zu MB allocations (64 GB): %.0f ns/hop (pass %d)\n", npiece, piece_mb, (double)h[1] * 10.0 / hops, rep);
+    }
+    for (auto q : ptrs) CK(hipFree(q));
   }
   // --- boundary cost inside a graph
   for (int grid : {1, 256, 1024}) {

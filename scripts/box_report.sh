@@ -4,4 +4,4 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}
 O=$R/gpurun_out/${1:-box}; mkdir -p $O
 ( bash $R/scripts/box_info.sh; $R/scripts/box_probe; $R/scripts/dep_chain ) > $O/box_report.txt 2>&1
-grep -h "Unique ID\|sclk\|fclk\|Partition\|chase  2048\|graph of 200 empty kernels, grid  256\|stream 4\|gemv" $O/box_report.txt | grep -v "^HIP_" 
+grep -h "chase across\|Unique ID\|sclk\|fclk\|Partition\|chase  2048\|graph of 200 empty kernels, grid  256\|stream 4\|gemv" $O/box_report.txt | grep -v "^HIP_" 

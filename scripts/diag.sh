@@ -12,6 +12,8 @@ slow=$(python -c "print(1 if $ms > ${SLOW_MS:-4.6} else 0)")
 if [ "$slow" = "1" ]; then
   echo "SLOW BOX: collecting stamps"
   bash $R/scripts/box_report.sh $(basename $O) > /dev/null
+  python $R/scripts/lin_stamps.py --direct --shapes 7168x7168n,7168x7168 2>&1 | grep -v amdgpu.ids | tee $O/lin_stamps_direct.txt
+  python $R/scripts/lin_stamps.py --shapes 7168x7168n,7168x7168 2>&1 | grep -v amdgpu.ids | tee -a $O/lin_stamps_direct.txt
   LAYERS=32 python $R/scripts/model_stamps.py 2>&1 | grep -v amdgpu.ids | tee $O/model_stamps32.txt
   python $R/scripts/lin_stamps.py --shapes 7168x2112n,16384x7168,7168x4096n 2>&1 | grep -v amdgpu.ids | tee $O/lin_stamps.txt
   KTX_ARENA=0 python $R/bench.py --steps 50 --warmup 5 --no-prefill --no-secondary --no-cpu-baseline --no-pmc --no-kernels 2>/dev/null | python -c "import json,sys; d=json.load(sys.stdin); print('second bench run:', d['value'], d['ms_per_step'])"

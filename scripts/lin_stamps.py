@@ -17,9 +17,18 @@ from ktransformers_amd import _native as n
 ap = argparse.ArgumentParser()
 ap.add_argument("--shapes", default="7168x2112n,7168x2112,16384x7168,7168x4096n,1536x24576n,7168x36864n,18432x7168")
 ap.add_argument("--sw", type=int, default=0)
+ap.add_argument("--direct", action="store_true", help="square shapes: feed y straight back as the next x (scattered 32-byte writes from many workgroups), no copy kernel")
+ap.add_argument("--knobs", default="", help="ktx_debug_set pairs, e.g. 17=1,18=1")
+ap.add_argument("--thrash", action="store_true", help="evict the instruction caches between launches (two 48 KB kernels)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 n.lib.ktx_debug_set_ptr.argtypes = [C.c_int, C.c_void_p]
+n.lib.ktx_debug_icache_thrash.argtypes = [C.c_void_p, C.c_void_p]
+scratch = torch.zeros(4096, device=dev)
+for kv in filter(None, args.knobs.split(",")):
+    k, v = kv.split("=")
+    n.lib.ktx_debug_set(int(k), int(v))
+print(f"knobs: {args.knobs or '(defaults)'}")
 flush = torch.zeros(512 << 20, dtype=torch.int8, device=dev)
 for sh in args.shapes.split(","):
     norm = sh.endswith("n")
@@ -37,10 +46,22 @@ for sh in args.shapes.split(","):
     stamps = torch.zeros(L * 16, dtype=torch.int64, device=dev)
     n.lib.ktx_debug_set(8, args.sw)
 
+    ys = [torch.empty(1, N, device=dev, dtype=torch.bfloat16) for _ in range(2)]
+
+    def run_direct():
+        cur = xs[0]
+        for i, h in enumerate(hs):
+            h.forward(cur, out=ys[i & 1], norm=(nw, 1e-6) if norm else None)
+            cur = ys[i & 1]
+
     def run():
+        if args.direct and K == N:
+            return run_direct()
         for i, h in enumerate(hs):
             h.forward(xs[i & 1], out=y, norm=(nw, 1e-6) if norm else None)
             xs[(i + 1) & 1][:, :min(K, N)].copy_(y[:, :min(K, N)])     # dependent chain (a tiny copy kernel in between)
+            if args.thrash:
+                n.lib.ktx_debug_icache_thrash(C.c_void_p(scratch.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream))
 
     run()
     torch.cuda.synchronize()
@@ -68,7 +89,7 @@ for sh in args.shapes.split(","):
     ph = [(s[:, b] - s[:, a])[1:].mean().item() for a, b in ((0, 2), (2, 3), (3, 4), (4, 5), (5, 6), (6, 7), (7, 1))]
     if norm:
         print(f"      x arrived + sumsq (wave 0): {(s[:, 9] - s[:, 2])[1:].mean().item():.2f}   norm barrier: {(s[:, 10] - s[:, 9])[1:].mean().item():.2f}")
-    print(f"W4 {K}->{N}{' +norm' if norm else ''} ({mb:.1f} MB, L={L}): chain {tot / reps / L * 1e3:6.2f} us/launch | span {span:5.2f} "
+    print(f"{'[icache thrashed] ' if args.thrash else ''}{'[y -> x direct] ' if args.direct and K == N else ''}W4 {K}->{N}{' +norm' if norm else ''} ({mb:.1f} MB, L={L}): chain {tot / reps / L * 1e3:6.2f} us/launch | span {span:5.2f} "
           f"gap(+copy kernel) {gap:5.2f} | wg0: entry+{ph[0]:.2f} stage {ph[1]:.2f} sync {ph[2]:.2f} stream {ph[3]:.2f} "
           f"reduce {ph[4]:.2f} out {ph[5]:.2f} | tail (wg0 end -> last exit) {ph[6]:.2f}", flush=True)
     n.lib.ktx_debug_set(8, 0)
