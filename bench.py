@@ -55,16 +55,50 @@ MODELS = {
                rope_scaling=dict(YARN, mscale=1.0, mscale_all_dim=1.0), architectures=["DeepseekV3ForCausalLM"]),
     "v2lite": dict(max_position_embeddings=163840, rope_scaling=dict(YARN, mscale=0.707, mscale_all_dim=0.707)),
 }
+MODELS["k2"] = dict(MODELS["v3"], vocab_size=163840, num_attention_heads=64, n_routed_experts=384, n_group=1, topk_group=1,
+                    first_k_dense_replace=1, routed_scaling_factor=2.827,
+                    rope_scaling=dict(YARN, factor=32, mscale=1.0, mscale_all_dim=1.0))   # kt-kernel/bench/bench_k2_moe_amx.py:22-30
 WORKLOADS = {
-    # H/I/E/k/L/method: the routed-expert shape (kernel-level scripts under scripts/ build stand-alone layers from these)
+    # H/I/E/k/L/method: the routed-expert shape (kernel-level scripts under scripts/ build stand-alone layers from these).
+    # linear: format of the dense linears (rule `generate_op`), experts: backend of the routed experts (rule `backend`).
     "v3-int4": dict(model="v3", rules="DeepSeek-V3-Chat.yaml", layers=32, full_layers=61, dense=3,
-                    H=7168, I=2048, E=256, k=8, L=8, method="AMXINT4", heads=128,
+                    H=7168, I=2048, E=256, k=8, L=8, method="AMXINT4", heads=128, linear="W4", experts="AMXInt4",
+                    name="DeepSeek-V3 671B int4",
                     desc="DeepSeek-V3 dims, AMXINT4 routed experts + W4-g64 linears + MLA, layer subset with distinct "
                          "resident weights per layer (the 671B model is 327 GB of int4 experts: > 288 GB)"),
     "v2lite-int4": dict(model="v2lite", rules="DeepSeek-V2-Lite-Chat.yaml", layers=27, full_layers=27, dense=1,
-                        H=2048, I=1408, E=64, k=6, L=26, method="AMXINT4", heads=16,
+                        H=2048, I=1408, E=64, k=6, L=26, method="AMXINT4", heads=16, linear="W4", experts="AMXInt4",
+                        name="DeepSeek-V2-Lite int4",
                         desc="DeepSeek-V2-Lite 16B (whole model), AMXINT4 routed experts + W4-g64 linears + MLA"),
+    # BASELINE.json configs[4]: the reference's DeepSeek-V3-Chat-fp8-linear-ggml-experts.yaml combination — GGUF IQ1_S routed
+    # experts (llamafile backend) + block-fp8 linears (KLinearFP8) — the one V3-class model that fits one GPU WHOLE
+    "r1-iq1s": dict(model="v3", rules="DeepSeek-V3-Chat.yaml", layers=61, full_layers=61, dense=3,
+                    H=7168, I=2048, E=256, k=8, L=8, method="GGUF", heads=128, linear="FP8", experts="llamafile", ggml=(19, 19, 19),
+                    name="DeepSeek-R1 IQ1_S/fp8 hybrid",
+                    desc="DeepSeek-R1 (= V3 dims), WHOLE 61-layer model: GGUF IQ1_S routed experts (llamafile arithmetic) + "
+                         "block-fp8 linears (KLinearFP8) + MLA"),
+    # configs[2]: block-fp8 experts AND linears; 11.3 GB of experts per MoE layer -> layer subset
+    "v3-fp8": dict(model="v3", rules="DeepSeek-V3-Chat.yaml", layers=20, full_layers=61, dense=3,
+                   H=7168, I=2048, E=256, k=8, L=8, method="FP8", heads=128, linear="FP8", experts="FP8",
+                   name="DeepSeek-V3 671B fp8",
+                   desc="DeepSeek-V3 dims, block-fp8 (e4m3, 128x128 scales) routed experts + block-fp8 linears + MLA, layer subset"),
+    # configs[3]: Kimi-K2 dims (384 experts, 64 heads), RAWINT4 experts (compressed-tensors int4 g32), W4 linears
+    "k2-rawint4": dict(model="k2", rules="DeepSeek-V3-Chat.yaml", layers=22, full_layers=61, dense=1,
+                       H=7168, I=2048, E=384, k=8, L=8, method="RAWINT4", heads=64, linear="W4", experts="RAWINT4",
+                       name="Kimi-K2 1T int4",
+                       desc="Kimi-K2 dims (384 routed experts, 64 heads), RAWINT4 (int4 g32, bf16 scales) routed experts + "
+                            "W4-g64 linears + MLA, layer subset (one GPU holds 1/8 of an expert-parallel deployment's layers whole)"),
+    # configs[0]: kt-kernel/bench/bench_moe.py — the routed experts of Mixtral-8x7B alone, q4_k_m (Q4_K gate/up, Q6_K down)
+    "mixtral-q4km": dict(kind="experts", layers=32, H=4096, I=14336, E=8, k=2, L=32, method="GGUF", ggml=(12, 12, 14),
+                         name="Mixtral-8x7B q4_k_m experts",
+                         desc="Mixtral-8x7B routed experts only (bench_moe.py's scope): 32 layers of 8 experts, top-2, GGUF q4_k_m "
+                              "(Q4_K gate/up, Q6_K down), llamafile arithmetic"),
 }
+SECONDARY = ("v2lite-int4", "r1-iq1s", "v3-fp8", "k2-rawint4", "mixtral-q4km")
+# stored bytes per weight (+ scales) of the formats, for the algorithmic-bytes figures
+EXPERT_BPW = {"AMXINT4": 0.5, "AMXINT8": 1.0, "RAWINT4": 0.5 + 2 / 32, "FP8": 1.0 + 4 / 16384, "BF16": 2.0}
+LINEAR_BPW = {"W4": 0.5 + 2 / 64, "FP8": 1.0 + 4 / 16384, "BF16": 2.0}
+GGML_BLOCK = {12: 144, 14: 210, 19: 50}
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: HBM3E 8 TB/s spec (6.29 TB/s measured by a float4 copy)
 
 
@@ -86,6 +120,12 @@ def build_layers(wl, dev, max_len, expert_begin=0, expert_num=None, seed=0):
         g.manual_seed(seed * 1000 + li)
         h = MoEHandle(e_local, k, H, I, max_len=max_len, method=wl["method"], device=dev.index,
                       expert_begin=expert_begin, global_expert_num=E)
+        if wl["method"] == "GGUF":          # raw ggml blocks (random valid blocks: timing only, like bench_moe.py:197-224)
+            ty = wl["ggml"]
+            h.load_gguf(random_ggml_blocks(e_local, I, H, ty[0], g, dev), random_ggml_blocks(e_local, I, H, ty[1], g, dev),
+                        random_ggml_blocks(e_local, H, I, ty[2], g, dev), *ty)
+            layers.append(h)
+            continue
         # randn/10 bf16 weights (reference tests: test_moe_rawint4_accuracy.py:175-183), quantised by the GPU restatement
         # of the reference quantiser.  All E experts are generated so every EP rank sees the same global weights.
         gate = torch.randn((E, I, H), generator=g, device=dev, dtype=torch.bfloat16).mul_(0.1)
@@ -153,15 +193,50 @@ class DecodeRunner:
 # ---------------------------------------------------------------------------------------------------------------------
 # whole-model decode
 # ---------------------------------------------------------------------------------------------------------------------
-class RandomLoader:
-    """Weight source for the whole-model run: tensors are generated on the device on demand (seeded by their name), in
-    bf16, with the shapes of the meta-device skeleton — there is no network for checkpoints.  Same protocol as
-    util/loader.py."""
+def random_ggml_blocks(E, N, K, ty, g, dev):
+    """[E, N, K/256 * block_bytes] uint8: random code bytes of ggml type `ty` with small positive fp16 super-block scales, so
+    that every block is a valid finite block (what bench_moe.py feeds, :197-224, minus its chance of inf scales)."""
+    bb = GGML_BLOCK[ty]
+    t = torch.randint(0, 256, (E, N, K // 256, bb), generator=g, device=dev, dtype=torch.uint8)
+    lo, span = {12: (0.0006, 0.0006), 14: (0.0008, 0.0006), 19: (0.010, 0.006)}[ty]
+    d = (torch.rand((E, N, K // 256), generator=g, device=dev) * span + lo).to(torch.float16).view(torch.uint8)
+    off = {12: 0, 14: 208, 19: 0}[ty]
+    t[..., off:off + 2] = d.view(E, N, K // 256, 2)
+    if ty == 12:
+        t[..., 2:4] = d.view(E, N, K // 256, 2)        # dmin
+    return t.reshape(E, N, -1).contiguous()
 
-    def __init__(self, shapes, dev):
+
+def fp8_block_quant(w):
+    """DeepSeek block-fp8 of a bf16 matrix batch [..., N, K] (N, K multiples of 128 up to padding): e4m3 bytes + fp32
+    weight_scale_inv [..., ceil(N/128), ceil(K/128)] = amax / 448 per 128x128 block (the checkpoint format KLinearFP8 reads)."""
+    *lead, N, K = w.shape
+    Np, Kp = (N + 127) // 128 * 128, (K + 127) // 128 * 128
+    wf = torch.zeros((*lead, Np, Kp), dtype=torch.float32, device=w.device)
+    wf[..., :N, :K] = w.float()
+    blk = wf.view(*lead, Np // 128, 128, Kp // 128, 128)
+    sc = blk.abs().amax(dim=(-3, -1)).clamp_min(1e-12) / 448.0
+    q = (blk / sc[..., :, None, :, None]).view(*lead, Np, Kp)[..., :N, :K].contiguous().to(torch.float8_e4m3fn)
+    return q, sc.contiguous()
+
+
+class RandomLoader:
+    """Weight source for the whole-model run: tensors are generated on the device on demand (seeded by their name) with the
+    shapes of the meta-device skeleton — there is no network for checkpoints.  Same protocol as util/loader.py.
+    `linear` = "W4" (bf16 weights, quantised by the operator) | "FP8" (e4m3 weight + weight_scale_inv, as a DeepSeek fp8
+    checkpoint holds them); `experts` = AMXInt4 (bf16, quantised online) | FP8 | RAWINT4 | llamafile (raw ggml blocks)."""
+
+    def __init__(self, shapes, dev, linear="W4", experts="AMXInt4", ggml=None):
         self.shapes, self.dev, self.tensor_device_map = shapes, dev, {}
+        self.linear, self.experts, self.ggml = linear, experts, ggml
+
+    def _fp8_linear(self, name):
+        return (self.linear == "FP8" and name.startswith("model.layers.") and name.endswith(".weight") and "_proj" in name
+                and "kv_b_proj" not in name and ".experts." not in name and len(self.shapes.get(name, ())) == 2)
 
     def has_tensor(self, name):
+        if name.endswith(".weight_scale_inv"):
+            return self._fp8_linear(name[:-len("_scale_inv")])
         return name in self.shapes
 
     def _gen(self, name, shape, scale, mean=0.0):
@@ -172,6 +247,8 @@ class RandomLoader:
         return t.add_(mean) if mean else t
 
     def load_tensor(self, name, device="cpu"):
+        if name.endswith(".weight_scale_inv"):
+            return fp8_block_quant(self._gen(name[:-len("_scale_inv")], self.shapes[name[:-len("_scale_inv")]], self.shapes[name[:-len("_scale_inv")]][-1] ** -0.5))[1]
         shape = self.shapes[name]
         if "layernorm" in name or name.endswith("norm.weight"):
             return self._gen(name, shape, 0.1, 1.0)
@@ -179,7 +256,8 @@ class RandomLoader:
             return self._gen(name, shape, 1.0)
         if name.endswith("e_score_correction_bias"):
             return self._gen(name, shape, 0.1).float()
-        return self._gen(name, shape, shape[-1] ** -0.5)
+        w = self._gen(name, shape, shape[-1] ** -0.5)
+        return fp8_block_quant(w)[0] if self._fp8_linear(name) else w
 
     def get_expert_count(self, key):
         n = 0
@@ -188,12 +266,49 @@ class RandomLoader:
         return n
 
     def load_experts(self, key, device="cpu"):
+        import zlib
         n = self.get_expert_count(key)
         out = {}
+        g = torch.Generator(device=self.dev)
+        g.manual_seed(zlib.crc32(key.encode()))
         for proj in ("gate", "up", "down"):
-            shape = (n,) + tuple(self.shapes[f"{key}.0.{proj}_proj.weight"])
-            out[proj] = self._gen(f"{key}.{proj}", shape, 0.1)          # randn/10 like the reference's MoE tests
+            N, K = self.shapes[f"{key}.0.{proj}_proj.weight"]
+            if self.experts == "llamafile":
+                ty = self.ggml[("gate", "up", "down").index(proj)]
+                out[proj], out[f"{proj}_type"] = random_ggml_blocks(n, N, K, ty, g, self.dev), ty
+            elif self.experts == "RAWINT4":      # random nibbles, bf16 group scales of randn/10 magnitude
+                out[proj] = torch.randint(0, 256, (n, N, K // 2), generator=g, device=self.dev, dtype=torch.uint8)
+                out[f"{proj}_scale"] = (torch.rand((n, N, K // 32), generator=g, device=self.dev) * 0.02 + 0.01).to(torch.bfloat16)
+            elif self.experts == "FP8":
+                q, sc = [], []
+                for e0 in range(0, n, 32):        # bounded fp32 staging
+                    qq, ss = fp8_block_quant(self._gen(f"{key}.{proj}.{e0}", (min(32, n - e0), N, K), 0.1))
+                    q.append(qq.view(torch.uint8)); sc.append(ss)
+                out[proj], out[f"{proj}_scale"] = torch.cat(q), torch.cat(sc)
+            else:
+                out[proj] = self._gen(f"{key}.{proj}", (n, N, K), 0.1)          # randn/10 like the reference's MoE tests
         return out
+
+
+def rules_for(wl):
+    """The product rule file, with the two format choices of the workload written into it (what a user edits in the reference's
+    rule files too: `generate_op` of the layer linears, `backend` of the routed experts).  Returns a path."""
+    import yaml
+    src = os.path.join(ROOT, "ktransformers_amd", "optimize", "optimize_rules", wl["rules"])
+    if wl.get("linear", "W4") == "W4" and wl.get("experts", "AMXInt4") == "AMXInt4":
+        return src
+    rules = yaml.safe_load(open(src))
+    for r in rules:
+        kw = r.get("replace", {}).get("kwargs", {})
+        name = r.get("match", {}).get("name", "")
+        if kw.get("generate_op") == "KLinearMarlin" and name.startswith("^model\\.layers") and wl["linear"] == "FP8":
+            kw["generate_op"] = "KLinearFP8"
+        if "backend" in kw:
+            kw["backend"] = wl["experts"]
+    fd, path = tempfile.mkstemp(prefix="ktx_rules_", suffix=".yaml", dir="/tmp")
+    with os.fdopen(fd, "w") as f:
+        yaml.safe_dump(rules, f)
+    return path
 
 
 class GreedyFeedbackStep(torch.nn.Module):
@@ -233,11 +348,12 @@ class ModelDecodeRunner:
             with torch.device("meta"):
                 model = DeepseekForCausalLM(cfg)
             shapes = {k: tuple(v.shape) for k, v in model.state_dict().items()}
-            rules = os.path.join(ROOT, "ktransformers_amd", "optimize", "optimize_rules", wl["rules"])
+            rules = rules_for(wl)
             import contextlib
             import io
             with contextlib.redirect_stdout(io.StringIO()):                   # "Injecting ..." lines
-                optimize_and_load(model, rules, RandomLoader(shapes, dev), cfg, default_device=str(dev))
+                optimize_and_load(model, rules, RandomLoader(shapes, dev, wl.get("linear", "W4"), wl.get("experts", "AMXInt4"),
+                                                             wl.get("ggml")), cfg, default_device=str(dev))
         finally:
             torch.set_default_dtype(torch.float32)
         set_inference_mode(model, InferenceState.GENERATE)
@@ -333,11 +449,141 @@ def timed(fn, steps, warmup, dev, dist_on):
 # ---------------------------------------------------------------------------------------------------------------------
 # per-kernel timing: every library launch of REAL decode steps, bracketed by HIP events on the launch stream
 # ---------------------------------------------------------------------------------------------------------------------
-KTX_KERNEL_NAMES = ("lin_dec_kernel", "lin_dec_gate_kernel", "lin_qb_absorb_kernel", "lin_merge_unabsorb_kernel",
-                    "lin_dequant_w4_kernel", "lin_gemm_kernel", "lin_gemm_w4n_kernel",
+KTX_KERNEL_NAMES = ("lin_sk_kernel", "lin_sk_gate_kernel", "lin_dec_kernel", "lin_dec_gate_kernel", "lin_qb_absorb_kernel",
+                    "lin_merge_unabsorb_kernel", "lin_dequant_w4_kernel", "lin_gemm_kernel", "lin_gemm_w4n_kernel",
                     "gate_fused_kernel", "gate_logits_kernel", "gate_select_kernel", "moe_dec_gateup_kernel", "moe_dec_down_kernel",
-                    "mla_decode_kernel", "mla_merge_kernel", "mla_prep_kernel", "rmsnorm_kernel", "silu_mul_kernel",
-                    "argmax_bf16_kernel")
+                    "moe_dec_fp_gateup_kernel", "moe_dec_fp_down_kernel", "moe_dec_raw_gateup_kernel", "moe_dec_raw_down_kernel",
+                    "moe_dec_gguf_gateup_kernel", "moe_dec_gguf_down_kernel", "moe_prep_kernel", "moe_gemm_kernel", "moe_combine_kernel",
+                    "mla_decode_kernel", "mla_merge_kernel", "mla_prep_kernel", "mla_cache_append_kernel", "rmsnorm_kernel",
+                    "silu_mul_kernel", "argmax_bf16_kernel", "ep_gather_kernel", "ep_reduce_kernel")
+
+
+def _kclass(text):
+    """Kernel class of a rocprofv3 kernel name or of a launch label: the identifier in front of '<' / '(' / ' '."""
+    import re
+    t = re.sub(r"^void ", "", text.strip())
+    t = t.replace("(anonymous namespace)::", "")
+    m = re.match(r"[A-Za-z_0-9:]+", t)
+    return m.group(0).split("::")[-1] if m else t[:40]
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# per-kernel table of the REPLAYED GRAPH: a rocprofv3 --kernel-trace child pass of the same model and graph
+# ---------------------------------------------------------------------------------------------------------------------
+def trace_child(args, wl, dev):
+    """Child mode (run under rocprofv3 --kernel-trace): build the same model, log the launch labels (with their algorithmic
+    bytes) of one eager step, capture the step, replay it; the label list goes to stdout."""
+    from ktransformers_amd import _native
+
+    n_layers = args.layers or wl["layers"]
+    mr = ModelDecodeRunner(wl, n_layers, dev, args.ctx, 512, use_graph=False)
+    mr.step_eager()
+    torch.cuda.synchronize(dev)
+    _native.timing_enable(2)
+    try:
+        mr.step_eager()
+        torch.cuda.synchronize(dev)
+        labels = [[l, b] for l, b, _ in _native.timing_collect()]
+    finally:
+        _native.timing_enable(0)
+    mr.capture(True)
+    for _ in range(args.trace_steps + 30):
+        mr.step()
+    torch.cuda.synchronize(dev)
+    print(json.dumps({"labels": labels, "hip_graph": bool(mr.graph_ok), "layers": n_layers}), flush=True)
+
+
+def graph_kernel_table(args, ms_per_step, timeout_s=420):
+    """rocprofv3 --kernel-trace over a child that replays the SAME captured decode graph: per kernel class and shape, the
+    average in-graph duration of the last `trace_steps` steps (a rocprofv3 duration runs from the end of the predecessor to
+    the end of the kernel: the ~1.5 us boundary is inside it, and the durations of a step add up to the step).  Launch
+    labels (algorithmic bytes) come from the library's own log of one eager step of the child and are lined up per kernel
+    class.  Returns (rows, info)."""
+    import csv
+    import glob
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, {"error": "rocprofv3 not found"}
+    d = tempfile.mkdtemp(prefix="ktx_trace_", dir="/tmp")
+    cmd = [rocprof, "--kernel-trace", "--output-format", "csv", "-d", d, "--", sys.executable, os.path.abspath(__file__),
+           "--trace-child", "--workload", args.workload, "--ctx", str(args.ctx), "--layers", str(args.layers),
+           "--trace-steps", str(args.trace_steps)]
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"))
+        meta = None
+        for line in reversed(r.stdout.strip().splitlines()):
+            if line.startswith("{") and '"labels"' in line:
+                meta = json.loads(line)
+                break
+        files = glob.glob(os.path.join(d, "**", "*kernel_trace.csv"), recursive=True)
+        if not meta or not files:
+            return None, {"error": f"trace child failed rc={r.returncode}: {(r.stderr or r.stdout).strip()[-300:]}"}
+        rows = list(csv.DictReader(open(files[0])))
+    except Exception as e:
+        return None, {"error": f"{type(e).__name__}: {e}"[:300]}
+    finally:
+        shutil.rmtree(d, ignore_errors=True)
+    for x in rows:
+        x["s"], x["e"] = int(x["Start_Timestamp"]), int(x["End_Timestamp"])
+    rows.sort(key=lambda x: x["s"])
+    cuts = [i for i, x in enumerate(rows) if "argmax_bf16_kernel" in x["Kernel_Name"]]
+    steps = [rows[a + 1:b + 1] for a, b in zip(cuts, cuts[1:])]
+    if not steps:
+        return None, {"error": "no decode steps in the kernel trace"}
+    lens = [len(st) for st in steps]
+    L = max(set(lens), key=lens.count)
+    steps = [st for st in steps if len(st) == L][-args.trace_steps:]
+    # labels per kernel class, in launch order
+    lab_by_class = {}
+    for lab, nb in meta["labels"]:
+        lab_by_class.setdefault(_kclass(lab), []).append((lab, nb))
+    agg = {}
+    layer_us = []
+    for st in steps:
+        seen = {}
+        t_layers, cur = [], None
+        for x in st:
+            c = _kclass(x["Kernel_Name"])
+            us = (x["e"] - x["s"]) / 1e3
+            key, nb = f"{c} grid {x.get('Grid_Size_X', '?')}", 0
+            if c in lab_by_class:
+                i = seen.get(c, 0)
+                seen[c] = i + 1
+                n_disp = sum(1 for y in st if _kclass(y["Kernel_Name"]) == c) if i == 0 else None
+                if i == 0:
+                    seen["#" + c] = n_disp
+                if seen["#" + c] == len(lab_by_class[c]):
+                    key, nb = lab_by_class[c][i]
+            elif c not in KTX_KERNEL_NAMES:
+                key = "torch: " + c[:60]
+            a = agg.setdefault(key, [0, 0.0, nb])
+            a[0] += 1
+            a[1] += us
+            # one MoE layer = from one q_a|kv_a GEMV / attention-input launch to the next: cut at the launch that carries mla_prep
+            if key.endswith("+mla_prep") or key.startswith("mla_prep_kernel"):
+                if cur is not None:
+                    t_layers.append(cur)
+                cur = [0.0, False]
+            if cur is not None:
+                cur[0] += us
+                cur[1] = cur[1] or c.startswith("moe_dec_")
+        layer_us += [t for t, moe in t_layers if moe]
+    n = len(steps)
+    out = []
+    for key, (cnt, tot, nb) in agg.items():
+        us = tot / cnt
+        per = cnt / n
+        out.append({"kernel": key, "launches_per_step": round(per, 2), "avg_launch_us": round(us, 3), "us_per_step": round(us * per, 1),
+                    "share_of_step": round(us * per / (ms_per_step * 1e3), 4), "algorithmic_bytes_per_launch": int(nb),
+                    "GBs": round(nb / (us * 1e-6) / 1e9, 1) if nb and us > 0 else None,
+                    "frac_of_hbm_peak": round(nb / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, 4) if nb and us > 0 else None})
+    out.sort(key=lambda r: -r["us_per_step"])
+    span = sum(st[-1]["e"] - st[0]["s"] for st in steps) / n / 1e3
+    info = {"steps": n, "dispatches_per_step": L, "step_span_us": round(span, 1), "hip_graph": meta.get("hip_graph"),
+            "moe_layer_us": round(sum(layer_us) / len(layer_us), 2) if layer_us else None,
+            "source": "rocprofv3 --kernel-trace child pass replaying the captured decode graph of the same model; "
+                      "durations include the inter-kernel boundary"}
+    return out, info
 
 
 def eager_step_log(mr, dev, flush, mode, reps):
@@ -526,22 +772,56 @@ def cpu_baseline_subprocess(workload, timeout_s=300):
 
 
 # ---------------------------------------------------------------------------------------------------------------------
-def step_bytes(cfg, n_layers, ctx):
+def expert_bpw(wl):
+    """Stored bytes per routed-expert weight: (gate|up, down)."""
+    if wl["method"] == "GGUF":
+        ty = wl["ggml"]
+        return (GGML_BLOCK[ty[0]] + GGML_BLOCK[ty[1]]) / 2 / 256, GGML_BLOCK[ty[2]] / 256
+    return EXPERT_BPW[wl["method"]], EXPERT_BPW[wl["method"]]
+
+
+def step_bytes(cfg, n_layers, ctx, wl=None):
     """Algorithmic HBM bytes of one decode token through the model as built (weights as stored + KV + embedding row)."""
+    wl = wl or WORKLOADS["v3-int4"]
     H, I, Im, E, k = cfg.hidden_size, cfg.intermediate_size, cfg.moe_intermediate_size, cfg.n_routed_experts, cfg.num_experts_per_tok
     Hq, nope, rope, v, lora = cfg.num_attention_heads, cfg.qk_nope_head_dim, cfg.qk_rope_head_dim, cfg.v_head_dim, cfg.kv_lora_rank
-    w4 = 0.5 + 2 / 64                                            # W4 g64: nibble + bf16 scale per 64
+    wlin = LINEAR_BPW[wl.get("linear", "W4")]
+    w4 = LINEAR_BPW["W4"]                                      # lm_head stays W4 in every rule file used here
     if cfg.q_lora_rank:
         q_params = H * cfg.q_lora_rank + cfg.q_lora_rank * Hq * (nope + rope)
     else:
         q_params = H * Hq * (nope + rope)
-    attn = (q_params + H * (lora + rope) + Hq * v * H) * w4 + Hq * (nope + v) * lora * 2 + (ctx + 1) * (lora + rope) * 2
-    dense_mlp = 3 * H * I * w4
+    attn = (q_params + H * (lora + rope) + Hq * v * H) * wlin + Hq * (nope + v) * lora * 2 + (ctx + 1) * (lora + rope) * 2
+    dense_mlp = 3 * H * I * wlin
     n_dense = min(cfg.first_k_dense_replace, n_layers)
     n_moe = n_layers - n_dense
-    moe = k * 3 * H * Im * 0.5 + k * (2 * Im + H) * 4 + E * H * 2 + (cfg.n_shared_experts or 0) * 3 * H * Im * w4
+    gu, dn = expert_bpw(wl)
+    sc = k * (2 * Im + H) * 4 if wl["method"] in ("AMXINT4", "AMXINT8") else 0          # per-row fp32 scales
+    moe = k * (2 * H * Im * gu + H * Im * dn) + sc + E * H * 2 + (cfg.n_shared_experts or 0) * 3 * H * Im * wlin
     head = H * cfg.vocab_size * w4 + H * 2
     return int(n_layers * attn + n_dense * dense_mlp + n_moe * moe + head), int(attn + moe)
+
+
+def box_info():
+    """State of the GPU this run landed on (clocks, power cap, partition modes, firmware): boxes of the pool differ by up to
+    1.5x on the latency-bound part of the step at identical clocks, so the line says where it was measured."""
+    out = {}
+    try:
+        r = subprocess.run(["/opt/rocm/bin/rocm-smi", "--showuniqueid", "--showperflevel", "--showclocks", "--showmaxpower", "--showpower",
+                            "--showmemorypartition", "--showcomputepartition", "--showvbios", "--showdriverversion", "--showfwinfo"],
+                           capture_output=True, text=True, timeout=20)
+        keys = {"Unique ID": "unique_id", "Performance Level": "perf_level", "sclk clock level": "sclk", "mclk clock level": "mclk",
+                "fclk clock level": "fclk", "Max Graphics Package Power (W)": "power_cap_w",
+                "Current Socket Graphics Package Power (W)": "idle_power_w", "Compute Partition": "compute_partition",
+                "Memory Partition": "memory_partition", "VBIOS version": "vbios", "Driver version": "driver",
+                "SMC firmware version": "smc_fw", "MEC firmware version": "mec_fw"}
+        for line in r.stdout.splitlines():
+            for k, name in keys.items():
+                if k + ":" in line and name not in out:
+                    out[name] = line.split(k + ":", 1)[1].strip()
+    except Exception as e:   # never let the fingerprint take the bench line down
+        out["error"] = f"{type(e).__name__}: {e}"[:200]
+    return out
 
 
 def whole_model_prefill(mr, T, dev, reps=3):
@@ -594,6 +874,86 @@ def whole_model_prefill(mr, T, dev, reps=3):
                     "W4 MFMA linears), last-token logits"}
 
 
+def run_model_decode(name, args, dev, steps, warmup, dist_on=False, world=1, rank=0, n_layers=None, ctx=None, windows=0):
+    """Build the named workload's model, capture one decode step, time it.  Returns (result dict, runner)."""
+    wl = WORKLOADS[name]
+    n_layers = n_layers or wl["layers"]
+    ctx = ctx or args.ctx
+    t0 = time.perf_counter()
+    mr = ModelDecodeRunner(wl, n_layers, dev, ctx, steps * (windows + 1) + warmup + 1024, seed=rank, use_graph=not args.no_graph)
+    cfg = mr.cfg
+    n_dense = min(cfg.first_k_dense_replace, n_layers)
+    gib = sum(h.weight_bytes for h in mr.moe_handles()) / 2 ** 30
+    if rank == 0:
+        log(f"[bench] {name}: {n_layers} layers ({n_dense} dense + {n_layers - n_dense} MoE, {gib:.1f} GiB of packed experts on this rank) "
+            f"injected and loaded in {time.perf_counter() - t0:.1f}s; HIP graph: {mr.graph_ok}")
+    # bring the GPU to its sustained clocks before the W warm-up + K timed steps (a fresh process that has only loaded weights
+    # runs its first replays at idle clocks).  N > 1: every step issues collectives, so all ranks run the SAME fixed number of
+    # steps.  Declared in the JSON as `prewarm_steps`.
+    n_pre, t_pre = 0, time.perf_counter()
+    while n_pre < 100 if dist_on else (time.perf_counter() - t_pre < 1.0 and n_pre < 300):
+        for _ in range(10):
+            mr.step()
+            n_pre += 1
+        torch.cuda.synchronize(dev)
+    mr.set_position(ctx)               # the timed run starts at the configured context length again
+    dt = timed(mr.step, steps, warmup, dev, dist_on)
+    ms = dt / steps * 1e3
+    win = []
+    for _ in range(windows):           # the same K steps again, several times: how much a box moves between windows
+        win.append(timed(mr.step, steps, 0, dev, dist_on) / steps * 1e3)
+    tot_bytes, layer_bytes = step_bytes(cfg, n_layers, ctx, wl)
+    res = {"value": round(world * steps / dt, 2), "unit": "tok/s", "ms_per_step": round(ms, 4), "layers": n_layers,
+           "dense_layers": n_dense, "moe_layers": n_layers - n_dense, "ctx": ctx, "hip_graph": bool(mr.graph_ok),
+           "graph_error": mr.graph_error, "prewarm_steps": n_pre, "expert_GiB_resident": round(gib, 1),
+           "whole_step": {"algorithmic_bytes": tot_bytes, "GBs": round(tot_bytes / (ms * 1e-3) / 1e9, 1),
+                          "frac_of_hbm_peak": round(tot_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4), "moe_layer_bytes": layer_bytes}}
+    if win:
+        allw = sorted([ms] + win)
+        res["windows_ms_per_step"] = [round(w, 4) for w in [ms] + win]
+        res["median_ms_per_step"] = round(allw[len(allw) // 2], 4)
+        res["median_tok_s"] = round(world * 1e3 / allw[len(allw) // 2], 2)
+    return res, mr
+
+
+def run_experts_decode(name, args, dev, steps):
+    """`kind: experts` workloads (BASELINE.json configs[0]: kt-kernel/bench/bench_moe.py's scope): the routed experts of every
+    layer alone, one token through all of them per step, one HIP graph."""
+    wl = WORKLOADS[name]
+    layers = build_layers(wl, dev, max_len=16)
+    r = DecodeRunner(wl, layers, 1, dev)
+    r.capture()
+    for i in range(30):
+        r.step(i)
+    dt = timed(r.step, steps, 10, dev, False)
+    ms = dt / steps * 1e3
+    gu, dn = expert_bpw(wl)
+    nbytes = wl["L"] * wl["k"] * (2 * wl["H"] * wl["I"] * gu + wl["H"] * wl["I"] * dn)
+    res = {"value": round(steps / dt, 2), "unit": "tok/s (routed experts of all layers only)", "ms_per_step": round(ms, 4),
+           "layers": wl["L"], "hip_graph": True, "us_per_layer": round(ms * 1e3 / wl["L"], 2),
+           "whole_step": {"algorithmic_bytes": int(nbytes), "GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                          "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}}
+    for h in layers:
+        h.close()
+    del r, layers
+    gc.collect()
+    torch.cuda.empty_cache()
+    return res
+
+
+def llamafile_cpu_leg(wl, budget_s=10.0):
+    """CPU leg of the q4_k_m workload: the reference's own iqk kernels (third_party/llamafile/iqk_mul_mat.inc compiled unmodified
+    into oracle/_ref/libiqk_ref_*.so) over one layer's top-k experts, all host threads.  None when the library is not there."""
+    try:
+        from oracle.gguf_ref import iqk_forward_bench            # noqa: F401
+    except Exception:
+        return None
+    try:
+        return iqk_forward_bench(wl["H"], wl["I"], wl["k"], wl["ggml"], wl["L"], budget_s)
+    except Exception as e:
+        return {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -603,17 +963,23 @@ def main():
     ap.add_argument("--layers", type=int, default=0, help="decoder layers of the resident layer subset (0 = workload default)")
     ap.add_argument("--prefill-tokens", type=int, default=2048)
     ap.add_argument("--ctx", type=int, default=4096, help="cached tokens the MLA decode attends over")
+    ap.add_argument("--windows", type=int, default=4, help="extra timed windows of --steps steps after the contract's one (median reported)")
+    ap.add_argument("--trace-steps", type=int, default=20, help="decode steps the in-graph kernel table averages over")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table / roofline")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the DeepSeek-V2-Lite secondary decode number")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations")
+    ap.add_argument("--secondary", default=",".join(SECONDARY), help="comma-separated secondary workloads")
+    ap.add_argument("--strong", action="store_true", help="N > 1: ONE token stream (every rank decodes the same token; routed experts "
+                                                            "E/N per rank) instead of one stream per rank")
     ap.add_argument("--cpu-baseline-only", action="store_true")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev / test aid: take the N > 1 code path (process group, expert parallelism, exchange transport) "
                          "even with WORLD_SIZE=1, so that path can be run on a one-GPU box")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     if args.cpu_baseline_only:
@@ -630,6 +996,10 @@ def main():
     if args.pmc_child:
         pmc_child(args, wl, dev)
         return
+    if args.trace_child:
+        trace_child(args, wl, dev)
+        return
+    ep_transport, ep_exchange = None, None
     if dist_on:
         import torch.distributed as dist
 
@@ -641,7 +1011,7 @@ def main():
         enable_expert_parallel()      # experts sharded over the ranks, attention / dense parts replicated
         # decode exchange: direct peer writes over xGMI (two launches per MoE layer; checked on this node's fabric while it
         # is set up), else the two collectives.  KTX_EP_TRANSPORT=collectives forces the latter for an A/B.
-        ep_transport, ep_exchange = "collectives: all-gather + reduce-scatter per MoE layer (RCCL)", None
+        ep_transport = "collectives: all-gather + reduce-scatter per MoE layer (RCCL)"
         if os.environ.get("KTX_EP_TRANSPORT", "peer") != "collectives":
             try:
                 ep_exchange = enable_peer_exchange(wl["H"], wl["k"], 16, dev)
@@ -654,40 +1024,38 @@ def main():
 
     from ktransformers_amd import _native  # noqa: F401  (raises if the HIP library is missing: no CPU fallback)
 
-    n_layers = args.layers or wl["layers"]
-    t0 = time.perf_counter()
-    mr = ModelDecodeRunner(wl, n_layers, dev, args.ctx, args.steps + args.warmup + 1024, seed=rank,
-                           use_graph=not args.no_graph)
-    cfg = mr.cfg
-    n_dense = min(cfg.first_k_dense_replace, n_layers)
-    if rank == 0:
-        gib = sum(h.weight_bytes for h in mr.moe_handles()) / 2 ** 30
-        log(f"[bench] {n_layers} layers ({n_dense} dense + {n_layers - n_dense} MoE, {gib:.1f} GiB of packed experts on this rank) "
-            f"injected and loaded in {time.perf_counter() - t0:.1f}s; HIP graph: {mr.graph_ok}")
-    # bring the GPU to its sustained clocks before the driver's W warm-up + K timed steps (a fresh process that has only
-    # loaded weights runs its first replays at idle clocks).  N > 1: every step issues collectives, so all ranks run the SAME
-    # fixed number of steps.  Declared in the JSON as `prewarm_steps`.
-    n_pre, t_pre = 0, time.perf_counter()
-    while n_pre < 100 if dist_on else (time.perf_counter() - t_pre < 1.0 and n_pre < 300):
-        for _ in range(10):
-            mr.step()
-            n_pre += 1
-        torch.cuda.synchronize(dev)
-    mr.set_position(args.ctx)          # the timed run starts at the configured context length again
-    dt = timed(mr.step, args.steps, args.warmup, dev, dist_on)
-    ms_per_step = dt / args.steps * 1e3
-    decode_tps = world * args.steps / dt          # one token per rank per step (weak scaling)
-    tot_bytes, layer_bytes = step_bytes(cfg, n_layers, args.ctx)
-    H, I, E, k = wl["H"], wl["I"], wl["E"], wl["k"]
+    box = box_info() if rank == 0 else None     # before any work: `idle_power_w` is the idle socket power of this box
+    if wl.get("kind") == "experts":
+        out = {"metric": f"decode tokens/s ({wl['name']})", **run_experts_decode(args.workload, args, dev, args.steps),
+               "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "int8 x q4_k/q6_k -> int32 per block (fp32 out)", "data": "synthetic", "config": {"workload": wl["desc"]},
+               "box": box}
+        print(json.dumps(out), flush=True)
+        return
 
+    # N >= 2: the experts are sharded E/N per rank, so the WHOLE model fits from two GPUs on (327 GB of int4 experts / N)
+    n_layers = args.layers or (wl["full_layers"] if (world >= 2 and wl["model"] == "v3") else wl["layers"])
+    args.layers = n_layers
+    if args.strong and dist_on:
+        rank_seed = 0                                   # every rank starts from the same token: one stream
+    else:
+        rank_seed = rank
+    res, mr = run_model_decode(args.workload, args, dev, args.steps, args.warmup, dist_on, 1 if (args.strong and dist_on) else world,
+                               rank_seed, n_layers, windows=args.windows)
+    cfg = mr.cfg
+    ms_per_step = res["ms_per_step"]
+    n_dense = res["dense_layers"]
+    H, I, E, k = wl["H"], wl["I"], wl["E"], wl["k"]
     subset = n_layers < wl["full_layers"]
     out = {
-        "metric": f"decode tokens/s ({'DeepSeek-V3 671B int4' if wl['model'] == 'v3' else 'DeepSeek-V2-Lite int4'}: AMXINT4 routed "
-                  f"experts + W4 linears + MLA resident in HBM, whole-model greedy decode"
-                  + (f", {n_layers}-of-{wl['full_layers']}-layer subset" if subset else "") + ")",
-        "value": round(decode_tps, 2), "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": round(ms_per_step, 4), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": "int8xint4->int32 (bf16 io)", "data": "synthetic",
+        "metric": f"decode tokens/s ({wl['name']}: {wl['method']} routed experts + {wl['linear']} linears + MLA resident in HBM, "
+                  f"whole-model greedy decode" + (f", {n_layers}-of-{wl['full_layers']}-layer subset" if subset else "") + ")",
+        "value": res["value"], "unit": "tok/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong" if (args.strong and dist_on) else "weak",
+        "vs_baseline": None,
+        "dtype": {"AMXINT4": "int8xint4->int32 (bf16 io)", "GGUF": "q8_k x iq1_s/q4_k/q6_k -> int32 per block (fp32 acc)",
+                  "FP8": "bf16 x e4m3 -> fp32 (bf16 io)", "RAWINT4": "int8xint4->int32 per 32-group (bf16 io)"}.get(wl["method"], wl["method"]),
+        "data": "synthetic",
         "config": {"workload": f"{wl['desc']}: {n_dense} dense + {n_layers - n_dense} MoE layers"
                                + (f" of the model's {wl['dense']} + {wl['full_layers'] - wl['dense']}" if subset else "")
                                + f", decode bs=1 per GPU at ctx {args.ctx}",
@@ -695,89 +1063,120 @@ def main():
                    "dense_layers": n_dense, "moe_layers": n_layers - n_dense, "vocab": cfg.vocab_size, "ctx": args.ctx,
                    "batch_per_gpu": 1, "parallelism": f"ep{world}" if dist_on else "single",
                    "rccl_ranks": world if dist_on else 0, "ep_transport": ep_transport if dist_on else None,
-                   "hip_graph": bool(mr.graph_ok), "graph_error": mr.graph_error,
-                   "prewarm_steps": n_pre,
+                   "hip_graph": res["hip_graph"], "graph_error": res["graph_error"], "prewarm_steps": res["prewarm_steps"],
                    "step": "one greedy token through the YAML-injected model: embedding, per layer [RMSNorm, MLA attention operator "
-                           "(W4-g64 q_a|kv_a, q_b, o projections, YaRN RoPE, absorb, paged MQA over the cached context, cache "
-                           "append), RMSNorm, dense W4 MLP | router + top-k AMXINT4 routed experts + W4 shared expert], RMSNorm, "
-                           "W4 lm_head, argmax; token and position fed back inside the HIP graph; random weights"
+                           "(q_a|kv_a, q_b, o projections, YaRN RoPE, absorb, paged MQA over the cached context, cache append), "
+                           "RMSNorm, dense MLP | router + top-k routed experts + shared expert], RMSNorm, W4 lm_head, argmax; "
+                           "token and position fed back inside the HIP graph; random weights"
                            + ("; routed experts sharded expert-parallel over %d ranks (every rank's token row gathered, local "
                               "experts, fp32 partials reduced at the token's home rank; transport in ep_transport), "
-                              "attention / dense / router replicated, one token stream per rank" % world if dist_on else "")},
-        "whole_step": {"algorithmic_bytes": tot_bytes, "GBs": round(tot_bytes / (ms_per_step * 1e-3) / 1e9, 1),
-                       "frac_of_hbm_peak": round(tot_bytes / (ms_per_step * 1e-3) / 1e9 / HBM_PEAK_GBS, 4),
-                       "moe_layer_bytes": layer_bytes},
+                              "attention / dense / router replicated, %s" % (world, "ONE token stream (all ranks decode the same token)"
+                                                                            if args.strong else "one token stream per rank") if dist_on else "")},
+        "whole_step": res["whole_step"],
+        "windows_ms_per_step": res.get("windows_ms_per_step"), "median_ms_per_step": res.get("median_ms_per_step"),
+        "median_tok_s": res.get("median_tok_s"),
+        "box": box,
     }
     if subset:
         # NOT `value`: what the measured per-layer time implies for the full depth (the extra layers are MoE layers)
-        n_moe = n_layers - n_dense
         out["full_depth_extrapolation"] = {
             "note": f"extrapolated, not measured: the {wl['full_layers'] - n_layers} missing layers are MoE layers; their time is taken as "
-                    "the measured per-kernel sum of one MoE layer when the per-kernel table is present, else step time / layers",
+                    "the in-graph kernel time of one MoE layer when the per-kernel table is present, else step time / layers",
             "layers": wl["full_layers"]}
 
+    prefill = None
+    if not dist_on and not args.no_prefill:
+        # ---------------- prefill: one prompt chunk through the same resident model -----------------------------------------
+        try:
+            prefill = whole_model_prefill(mr, args.prefill_tokens, dev)
+        except Exception as e:
+            prefill = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize(dev)
+    rows_eager = None
+    if dist_on and not args.no_kernels:
+        # N > 1: every rank steps together (collectives), so the per-launch events run on all ranks; rank 0 reports
+        rows_eager, lus_eager = kernel_table(mr, dev, ms_per_step)
+        mr.set_position(args.ctx)
+    mr.close()
+    del mr
+    gc.collect()
+    torch.cuda.empty_cache()
+    if prefill is not None:
+        out["prefill"] = prefill
+
+    lus = None
+    if not args.no_kernels:
+        if not dist_on:
+            # ---------------- per-kernel table of the replayed graph + roofline of its dominant kernel ----------------------
+            rows, info = graph_kernel_table(args, ms_per_step)
+        else:
+            rows, info = rows_eager, {"source": "HIP events around every library launch of eager decode steps on rank 0 (all ranks step "
+                                                "together); N = 1 runs take this table from a rocprofv3 pass of the replayed graph",
+                                      "moe_layer_us": lus_eager}
+        if rows:
+            out["per_kernel"] = rows[:24]
+            out["per_kernel_info"] = info
+            lus = info.get("moe_layer_us")
+            top = next((r for r in rows if r["algorithmic_bytes_per_launch"]), rows[0])
+            traffic, src = (None, "skipped") if (args.no_pmc or dist_on) else pmc_traffic(args, top["kernel"])
+            out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                               "frac": round((top["GBs"] or 0.0) / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
+                               "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
+                               "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
+                               "share_of_step": top["share_of_step"],
+                               "selection": "the kernel class with the largest total time per step in the per_kernel table "
+                                            "(in-graph rocprofv3 durations at N = 1)"}
+            ksum = sum(r["us_per_step"] for r in rows)
+            out["whole_step"]["sum_of_kernels_us"] = round(ksum, 1)
+            if lus:
+                lb = out["whole_step"]["moe_layer_bytes"]
+                out["whole_step"]["moe_layer_kernel_us"] = round(lus, 1)
+                out["whole_step"]["moe_layer_frac_of_hbm_peak"] = round(lb / (lus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
+        else:
+            out["per_kernel_info"] = info
+    if subset:
+        ms_full = ms_per_step + (wl["full_layers"] - n_layers) * lus * 1e-3 if lus else ms_per_step * wl["full_layers"] / n_layers
+        out["full_depth_extrapolation"].update(ms_per_step=round(ms_full, 3), tok_s=round(1e3 / ms_full, 2))
+    if "roofline" not in out:   # no per-kernel pass: whole-step rate as the only (honest) roofline figure
+        ws = out["whole_step"]
+        out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (per-kernel pass skipped or failed)", "achieved": ws["GBs"],
+                           "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws["frac_of_hbm_peak"], "traffic": None}
+
     if not dist_on:
-        # ---------------- per-kernel table + roofline of the dominant kernel -------------------------------------------
-        if not args.no_kernels:
-            rows, lus = kernel_table(mr, dev, ms_per_step)
-            mr.set_position(args.ctx)
-            out["per_kernel"] = rows
-            if rows:
-                top = rows[0]
-                traffic, src = (None, "skipped (--no-pmc)") if args.no_pmc else pmc_traffic(args, top["kernel"])
-                out["roofline"] = {"bound": "hbm", "kernel": top["kernel"],
-                                   "achieved": top["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                                   "frac": round(top["GBs"] / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
-                                   "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
-                                   "avg_launch_us": top["avg_launch_us"], "launches_per_step": top["launches_per_step"],
-                                   "share_of_step": top["share_of_step"],
-                                   "selection": "largest measured time per step among the per_kernel rows: every library launch of real "
-                                                "decode steps (eager, whole step pre-enqueued behind L3-flushing traffic so kernels run "
-                                                "back to back on cold caches) bracketed by HIP events on the launch stream"}
-                ksum = sum(r["us_per_step"] for r in rows)
-                out["whole_step"]["sum_of_kernels_us"] = round(ksum, 1)
-                if lus:
-                    out["whole_step"]["moe_layer_kernel_us"] = round(lus, 1)
-                    out["whole_step"]["moe_layer_GBs"] = round(layer_bytes / (lus * 1e-6) / 1e9, 1)
-                    out["whole_step"]["moe_layer_frac_of_hbm_peak"] = round(layer_bytes / (lus * 1e-6) / 1e9 / HBM_PEAK_GBS, 4)
-                if subset and lus:
-                    extra = (wl["full_layers"] - n_layers) * lus * min(1.0, ms_per_step * 1e3 / ksum) * 1e-3
-                    out["full_depth_extrapolation"]["ms_per_step"] = round(ms_per_step + extra, 3)
-                    out["full_depth_extrapolation"]["tok_s"] = round(1e3 / (ms_per_step + extra), 2)
-        if subset and "tok_s" not in out.get("full_depth_extrapolation", {}):
-            ms_full = ms_per_step * wl["full_layers"] / n_layers
-            out["full_depth_extrapolation"].update(ms_per_step=round(ms_full, 3), tok_s=round(1e3 / ms_full, 2))
-        if "roofline" not in out:   # no per-kernel pass: whole-step rate as the only (honest) roofline figure
-            ws = out["whole_step"]
-            out["roofline"] = {"bound": "hbm", "kernel": "whole decode step (per-kernel pass skipped)", "achieved": ws["GBs"],
-                               "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws["frac_of_hbm_peak"], "traffic": None}
-        # ---------------- prefill: one prompt chunk through the same resident model -------------------------------------
-        if not args.no_prefill:
-            try:
-                out["prefill"] = whole_model_prefill(mr, args.prefill_tokens, dev)
-            except Exception as e:
-                out["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
-                torch.cuda.synchronize(dev)
-        mr.close()
-        del mr
-        gc.collect()
-        torch.cuda.empty_cache()
-        # ---------------- secondary: BASELINE.json configs[1] (DeepSeek-V2-Lite, whole model) ---------------------------
+        # ---------------- the other BASELINE.json configurations, as secondary fields -------------------------------------------
         if args.workload == "v3-int4" and not args.no_secondary:
-            try:
-                w2 = WORKLOADS["v2lite-int4"]
-                m2 = ModelDecodeRunner(w2, w2["layers"], dev, args.ctx, 2048, use_graph=not args.no_graph)
-                n2 = max(50, min(args.steps, 200))
-                for _ in range(100):
-                    m2.step()
-                m2.set_position(args.ctx)
-                dt2 = timed(m2.step, n2, 10, dev, False)
-                out["v2lite"] = {"value": round(n2 / dt2, 2), "unit": "tok/s", "ms_per_step": round(dt2 / n2 * 1e3, 4),
-                                 "workload": w2["desc"] + f", decode bs=1 at ctx {args.ctx}", "hip_graph": bool(m2.graph_ok)}
-                m2.close()
-                del m2
-            except Exception as e:
-                out["v2lite"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+            for name in [x for x in args.secondary.split(",") if x]:
+                w2 = WORKLOADS[name]
+                key = name.replace("-", "_")
+                try:
+                    n2 = max(30, min(args.steps, 100))
+                    if w2.get("kind") == "experts":
+                        r2 = run_experts_decode(name, args, dev, n2)
+                        if not args.no_cpu_baseline:
+                            r2["cpu_llamafile"] = llamafile_cpu_leg(w2)
+                    else:
+                        r2, m2 = run_model_decode(name, args, dev, n2, 10)
+                        m2.close()
+                        del m2
+                        if name == "r1-iq1s":     # BASELINE.json configs[4] names a 128K context: the same model again at 131072 cached tokens
+                            gc.collect()
+                            torch.cuda.empty_cache()
+                            try:
+                                r3, m3 = run_model_decode(name, args, dev, 30, 5, ctx=131072)
+                                m3.close()
+                                del m3
+                                r2["ctx_131072"] = {k2: r3[k2] for k2 in ("value", "ms_per_step", "hip_graph", "whole_step")}
+                            except Exception as e:
+                                r2["ctx_131072"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                    r2["workload"] = w2["desc"]
+                    out[key] = r2
+                except Exception as e:
+                    out[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                    torch.cuda.synchronize(dev)
+                gc.collect()
+                torch.cuda.empty_cache()
+            if "v2lite_int4" in out:
+                out["v2lite"] = out["v2lite_int4"]          # (the name round 1 / 2 lines used)
         if not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
 

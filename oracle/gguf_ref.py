@@ -251,3 +251,66 @@ class GgufOracle:
         if rc != 0:
             raise RuntimeError("ktxo_moe_forward_gguf: unsupported ggml type")
         return (y, inter) if want_inter else y
+
+
+# ---- CPU leg of bench.py's q4_k_m workload: the reference's OWN llamafile kernels, timed ------------------------------------
+def iqk_forward_bench(H: int, I: int, k: int, types, n_layers: int, budget_s: float = 10.0, threads: int | None = None):
+    """bs=1 forward of `k` routed experts per layer through the reference's unmodified iqk GEMM kernels
+    (third_party/llamafile/iqk_mul_mat.inc in oracle/_ref/libiqk_ref_*.so — what LLAMA_MOE_TP::forward_one reaches through
+    llamafile_sgemm, kt-kernel/operators/llamafile/moe.hpp:271-460): x -> Q8_K, gate / up GEMVs split over the threads by
+    output rows (iqk's own ith / nth partition), fp32 silu(gate) * up, -> Q8_K, down GEMV.  Weights: random valid blocks, two
+    distinct layers' worth (>> the host L3) used in rotation.  Returns bench.py's cpu-leg dict; tok/s = 1 / (n_layers x t_layer).
+    Bounded by `budget_s`.  Test infrastructure: only bench.py's CPU leg and tests call this."""
+    import os
+    here = os.path.dirname(os.path.abspath(__file__))
+
+    def cpu_has(flag):
+        try:
+            with open("/proc/cpuinfo") as f:
+                return any(flag in line.split() for line in f if line.startswith("flags"))
+        except OSError:
+            return False
+    so, sym, isa = (("libiqk_ref_zen4.so", "iqk_mul_mat_zen4", "AVX512-VNNI") if cpu_has("avx512_vnni") else
+                    ("libiqk_ref_avx2.so", "iqk_mul_mat", "AVX2"))
+    path = os.path.join(here, "_ref", so)
+    if not os.path.exists(path):
+        return {"value": None, "unit": "tok/s", "cores": 0, "kind": "reference", "sample": f"{so} not built (needs /root/reference at build time)"}
+    fn = getattr(C.CDLL(path), sym)
+    fn.restype = C.c_bool
+    fn.argtypes = [C.c_long, C.c_long, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_int, C.c_void_p, C.c_long, C.c_void_p,
+                   C.c_long, C.c_int, C.c_int]
+    BB = {12: 144, 14: 210, 19: 50}
+    nth = threads or max(1, min(64, (os.cpu_count() or 8) // 2))
+    rng = np.random.default_rng(0)
+
+    def blocks(N, K, ty):
+        b = rng.integers(0, 256, (N, K // 256, BB[ty]), dtype=np.uint8)
+        d = (rng.random((N, K // 256)) * 0.0006 + 0.0006).astype(np.float16).view(np.uint8).reshape(N, K // 256, 2)
+        off = {12: 0, 14: 208, 19: 0}[ty]
+        b[..., off:off + 2] = d
+        if ty == 12:
+            b[..., 2:4] = d
+        return b.reshape(N, -1)
+
+    nsets = 2
+    W = [[(blocks(I, H, types[0]), blocks(I, H, types[1]), blocks(H, I, types[2])) for _ in range(k)] for _ in range(nsets)]
+    o = GgufOracle()
+    lib = o.lib
+    lib.ktxo_iqk_bench.restype = C.c_double
+    lib.ktxo_iqk_bench.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
+    ptrs = (C.c_void_p * (nsets * k * 3))(*[m.ctypes.data for s_ in W for e_ in s_ for m in e_])
+    ty = (C.c_int * 3)(*types)
+    x = (rng.standard_normal(H) / 100).astype(np.float32)
+    fptr = C.cast(fn, C.c_void_p)
+    run = lambda it: lib.ktxo_iqk_bench(fptr, H, I, k, ty, ptrs, nsets, x.ctypes.data, nth, it)
+    t1 = run(4)
+    n = int(max(8, min(5000, budget_s / max(t1 / 4, 1e-6))))
+    dt = run(n)
+    t_layer = dt / n
+    bpw = ((BB[types[0]] + BB[types[1]]) * H * I + BB[types[2]] * H * I) / 256
+    return {"value": round(1.0 / (n_layers * t_layer), 3), "unit": "tok/s", "cores": nth, "kind": "reference",
+            "us_per_layer": round(t_layer * 1e6, 1), "GBs": round(k * bpw / t_layer / 1e9, 1),
+            "sample": f"{n} bs=1 layer forwards of the reference's iqk_mul_mat kernels ({isa} build of third_party/llamafile/iqk_mul_mat.inc), "
+                      f"H={H} I={I} top-{k}, ggml types {tuple(types)}, {nth} OpenMP threads (iqk's own row partition, barriers between the "
+                      f"three GEMV stages; oracle/iqk_bench.c), rotating over {nsets} distinct layers; "
+                      f"tok/s = 1/({n_layers} layers x t_layer)"}
