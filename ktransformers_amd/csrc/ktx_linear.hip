@@ -106,7 +106,7 @@ struct LinParams {
   unsigned long long* stamps;   // dev probe (ktx_debug_set_ptr(0, buf)): 16 wall-clock slots for this launch, else nullptr
   unsigned* cu_map;             // dev probe (ktx_debug_set_ptr(1, buf)): [1024] where each workgroup of this launch ran (XCC / SE / CU ids)
   // lin_sk_kernel (ktx_linear_sk.inc): groups per strip, the split of the groups over the workgroups, cross-workgroup meeting place
-  int sk_gps, sk_unit, sk_Q, sk_R, sk_nw, sk_logits_off;
+  int sk_gps, sk_unit, sk_Q, sk_R, sk_nw, sk_logits_off, sk_gate_wgs, sk_nwg;
   bf16_t* xn_out;                 // the router's normalised row for the experts that run next (workgroup 0 writes it)
   unsigned long long* sk_words;   // [nstrips][64]: one word per (token, feature) of a strip shared between workgroups
 };
@@ -1405,17 +1405,21 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs
   if (h->batch != 1 || p.prep_on || !h->d_sk_words || NKS * 16 > SK_XMAX * 512 || ktx_debug_get(16) == 1) return KTX_LIN_NOT_FUSED;
   // a router riding in the launch takes wavefront 7 of every workgroup: ring depth 8 only, rows of <= 8192 inputs, the router's
   // own limits (gate_fused_body); dev knob 13 = 1 keeps the two launches apart (A/B, tests)
-  const int nw = gate ? 7 : 8;
+  // Router riding in the launch: THREE implementations, chosen by dev knob 19 (scripts/ab_decode.py A/Bs them on one box):
+  //   0 (default): round 2's lin_dec_gate_kernel (this function answers "not covered" and launch_dec takes it) — still the
+  //      fastest: 4.01 ms per DeepSeek-V3 step against 4.04 / 4.13 for the two below on a fast box, 5.27 against 5.95 on a slow one;
+  //   3: the all-CU GEMV below with round 2's router workgroups (gate_fused_body) in front of its grid;
+  //   2: the router as wavefront 7 of every GEMV workgroup + one selector workgroup (sk_router_logits / sk_selector).
+  // The router's chain of dependent round trips (rows, logits, hand-off, selection) is what bounds the launch in all three.
+  const int gate_mode = ktx_debug_get(19);
+  const bool gate_wave7 = gate && gate_mode == 2;
+  const int nw = gate_wave7 ? 7 : 8;
   int gate_epl = 0;
   if (gate) {
     const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
     gate_epl = (E + 63) / 64;
-    // OPT-IN (dev knob 19 = 2).  Measured inside the DeepSeek-V3 decode graph (scripts/ab_decode.py, same box): 5.95 ms per
-    // step with this rider against 5.27 ms with round 2's lin_dec_gate_kernel — the router wavefront's chain of dependent
-    // round trips (row, granule + ticket, sweep) costs 4-5 us EACH inside the model graph on the slower boxes of the pool,
-    // and 256 workgroups each run it, where the old kernel's 32 router workgroups hide behind the GEMV's.
     if (NKS % 8 || H != p.Kx || H > 8192 || H % 8 || gate_epl > 6 || !p.norm_w || !gate->granules || ktx_debug_get(13) == 1 ||
-        ktx_debug_get(19) != 2)
+        (gate_mode != 2 && gate_mode != 3))
       return KTX_LIN_NOT_FUSED;
   }
   const int TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
@@ -1456,7 +1460,10 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs
   if (gate) smem += (size_t)KTX_GATE_MAX_E * 4;
   if (smem > (size_t)(160 / wg_per_cu) * 1024) return KTX_LIN_NOT_FUSED;
   p.TP = TP; p.sk_gps = GPS; p.sk_unit = unit; p.sk_Q = Q; p.sk_R = R; p.sk_words = h->d_sk_words; p.sk_nw = nw;
-  p.xn_out = gate ? gate->xn_out : nullptr;
+  p.xn_out = (gate && gate_wave7) ? gate->xn_out : nullptr;   // (round 2's router workgroups write xn_out themselves)
+  if (gate_wave7 && p.T > 4) return KTX_LIN_NOT_FUSED;
+  p.sk_gate_wgs = (gate && !gate_wave7) ? (gate->c.n_routed_experts + 7) / 8 * p.T : 0;
+  p.sk_nwg = nwg;
   const int xr = (NKS * 16 + 511) / 512;   // 16-byte activation pieces per thread (a token row, padded to whole k-steps)
   if (gate) {
     const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
@@ -1464,11 +1471,13 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs
               "lin_sk_gate_kernel<W4> %d->%d + router E=%d", p.Kx, p.N, E);
     auto go_g = [&](auto kern) -> int {
       static bool attr_set = false;   // one flag per kernel instantiation
-      if (!attr_set) {
-        KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+      if (!attr_set) {   // (150 KB: gate_fused_body holds ~4 KB of static LDS beside the dynamic region)
+        KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
         attr_set = true;
       }
-      hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, st, p, *gate);
+      // + the router's own workgroups in front (default), or + ONE selector workgroup behind (wavefront-7 placement)
+      const size_t smem_g = std::max(std::max(smem, (size_t)gate->c.hidden_size * 2), (size_t)4 * KTX_GATE_MAX_E * 4);
+      hipLaunchKernelGGL(kern, dim3(nwg + (gate_wave7 ? 1 : p.sk_gate_wgs)), dim3(512), smem_g, st, p, *gate);
       KTX_HIP(hipGetLastError());
       return 0;
     };

@@ -36,7 +36,8 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "mla: q_b and q-absorb as two launches": ({}, {"KTX_MLA_SEPARATE_QB": "1"}),
     "mla: merge and un-absorb as two launches": ({}, {"KTX_MLA_SEPARATE_MERGE": "1"}),
     "lin: round-2 decode GEMVs (no all-CU kernel)": ({16: 1}, {}),
-    "lin: router as wavefront 7 of the all-CU gate|up kernel": ({19: 2}, {}),
+    "lin: router as wavefront 7 of the all-CU gate|up kernel + selector workgroup": ({19: 2}, {}),
+    "lin: round-2 router workgroups in front of the all-CU gate|up kernel": ({19: 3}, {}),
     "lin: two workgroups per CU": ({18: 2}, {}),
 }
 if ONLY:
