@@ -198,12 +198,15 @@ def random_ggml_blocks(E, N, K, ty, g, dev):
     that every block is a valid finite block (what bench_moe.py feeds, :197-224, minus its chance of inf scales)."""
     bb = GGML_BLOCK[ty]
     t = torch.randint(0, 256, (E, N, K // 256, bb), generator=g, device=dev, dtype=torch.uint8)
-    lo, span = {12: (0.0006, 0.0006), 14: (0.0008, 0.0006), 19: (0.010, 0.006)}[ty]
-    d = (torch.rand((E, N, K // 256), generator=g, device=dev) * span + lo).to(torch.float16).view(torch.uint8)
+    # scales chosen so the weights come out with randn/10's spread: Q4_K w = d*sc*q - dmin*m (6-bit sc, m; q in 0..15; dmin = 7.5 d
+    # centres it), Q6_K w = d*sc*q (int8 sc, q in -32..31), IQ1_S w = d*(2s+1)*(grid +- 1/8)
+    lo, span = {12: (0.0004, 0.0002), 14: (0.00007, 0.00003), 19: (0.010, 0.006)}[ty]
+    dv = torch.rand((E, N, K // 256), generator=g, device=dev) * span + lo
+    d = dv.to(torch.float16).view(torch.uint8)
     off = {12: 0, 14: 208, 19: 0}[ty]
     t[..., off:off + 2] = d.view(E, N, K // 256, 2)
     if ty == 12:
-        t[..., 2:4] = d.view(E, N, K // 256, 2)        # dmin
+        t[..., 2:4] = (dv * 7.5).to(torch.float16).view(torch.uint8).view(E, N, K // 256, 2)        # dmin
     return t.reshape(E, N, -1).contiguous()
 
 

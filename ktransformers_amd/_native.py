@@ -924,6 +924,8 @@ class MLAWrapper:
     flashinfer_wrapper.py:78-161) over ktx_mla_decode.  plan() only records the (device) index arrays: there is no host
     planning step, so a captured graph stays valid when their contents change."""
 
+    MAX_GRAPH_HEADS = 128   # a graph-captured wrapper's workspace is sized for this many heads up front (DeepSeek-V3 / R1: 128, K2: 64)
+
     def __init__(self, max_batch_size: int, max_pages: int, use_cuda_graph: bool = True, device="cuda",
                  max_q_tokens: int | None = None, max_splits: int = 256):
         self.device = torch.device(device) if not isinstance(device, torch.device) else device
@@ -933,6 +935,7 @@ class MLAWrapper:
             self.device = torch.device("cuda", torch.cuda.current_device())
         self.max_batch_size, self.max_pages, self.max_splits = max_batch_size, max_pages, max_splits
         self.max_q_tokens = max_q_tokens or max(256, max_batch_size)
+        self.use_cuda_graph = bool(use_cuda_graph)
         self.cfg = None
         self.workspace = None
         if max_batch_size == 1:  # single-request defaults like the reference wrapper (:88-93)
@@ -957,7 +960,19 @@ class MLAWrapper:
         self.cfg = _MlaConfig(num_heads, head_dim_ckv, head_dim_kpe, page_size, float(sm_scale), self.max_splits,
                               int(max_kv_len))
         need = int(lib.ktx_mla_workspace_bytes(C.byref(self.cfg), self.max_q_tokens))
-        if self.workspace is None or self.workspace.numel() < need:
+        if self.workspace is None:
+            first = need
+            if self.use_cuda_graph and self.max_q_tokens <= 4:   # the shared decode wrapper: allocated ONCE, for the largest head count a model on this device may bring (graphs keep its address)
+                big = _MlaConfig(max(num_heads, self.MAX_GRAPH_HEADS), head_dim_ckv, head_dim_kpe, page_size, float(sm_scale),
+                                 self.max_splits, int(max_kv_len))
+                first = max(need, int(lib.ktx_mla_workspace_bytes(C.byref(big), self.max_q_tokens)))
+            self.workspace = torch.empty(first, dtype=torch.uint8, device=self.device)
+        elif self.workspace.numel() < need:
+            # captured HIP graphs hold this buffer's address (operators/attention.py shares one decode wrapper per device): a
+            # later plan that needs more (more heads: a second model on the device) must not free it under them
+            if self.use_cuda_graph:
+                raise KtxError(f"MLAWrapper.plan: the workspace ({self.workspace.numel()} B) is too small for this configuration "
+                               f"({need} B) and cannot grow: captured graphs reference it; create another wrapper")
             self.workspace = torch.empty(need, dtype=torch.uint8, device=self.device)
         self.need_plan = False
 

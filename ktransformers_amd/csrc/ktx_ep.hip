@@ -274,6 +274,10 @@ int ktx_ep_gather(ktx_ep_t ep, int T, const void* d_x, const int64_t* d_ids, con
   DevGuard dg(ep->device);
   KTX_HIP(dg.err);
   hipStream_t st = (hipStream_t)stream;
+  // put-then-spin: every workgroup of every rank must be resident at once (a queued workgroup's puts would never come).
+  // world * T workgroups of NT threads against >= 256 CUs x several per CU: far inside the residency of any gfx950 part;
+  // refused loudly beyond it instead of trusted
+  KTX_REQUIRE((long)ep->world * T <= 1024, "ktx_ep_gather: world * T exceeds the co-residency the put-then-spin exchange assumes");
   KTX_TIMED(st, (double)ep->world * T * ep->RW * 8.0, "ep_gather_kernel R=%d T=%d H=%d", ep->world, T, ep->H);
   hipLaunchKernelGGL(ep_gather_kernel, dim3(ep->world, T), dim3(NT), 0, st, d, T, (const uint32_t*)d_x, (const uint32_t*)d_ids,
                      (const uint32_t*)d_w, (uint32_t*)d_xg, (uint32_t*)d_idsg, (uint32_t*)d_wg);
@@ -291,6 +295,7 @@ int ktx_ep_reduce(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stre
   hipStream_t st = (hipStream_t)stream;
   // column slices of about 512 (two columns per thread), a whole number of them per rank
   const int S = std::max(1, (ep->H + 512 * ep->world - 1) / (512 * ep->world));
+  KTX_REQUIRE((long)ep->world * S * T <= 1024, "ktx_ep_reduce: grid exceeds the co-residency the put-then-spin exchange assumes");
   KTX_TIMED(st, (double)ep->world * T * ep->H * 8.0, "ep_reduce_kernel R=%d T=%d H=%d", ep->world, T, ep->H);
   hipLaunchKernelGGL(ep_reduce_kernel, dim3(ep->world * S, T), dim3(NT), 0, st, d, T, S, d_part, (bf16_t*)d_out);
   KTX_HIP(hipGetLastError());

@@ -561,8 +561,24 @@ __global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
   bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + TP * p.rope);                      // [TP][QW]
   uint8_t* xs2 = reinterpret_cast<uint8_t*>(qh + TP * QW);                         // [nope / 8][TP][16 B]
 
-  // ---- every weight byte this workgroup will need, requested now ------------------------------------------------------
+  // ---- requests that depend on nothing, in the order their results are needed, every one of them UNCONDITIONAL (addresses
+  // clamped, values selected afterwards): with a load inside a conditional the compiler cannot count the younger loads and
+  // waits for the whole weight burst (300 KB per workgroup) before it touches the q_a row — and the norm weights used to
+  // be fetched piece by piece after the barrier, one exposed round trip each (lin_sk_kernel's prologue, same rules).
   typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+  const int ntot = TP * npiece;
+  constexpr int XPRE = 2;   // ntot <= 1024 (q_lora <= 2048)
+  uint4 xpre[XPRE], nwpre[XPRE];
+#pragma unroll
+  for (int i = 0; i < XPRE; i++) {
+    const int idx = min(tid + i * 512, ntot - 1);
+    const int tok = idx / npiece, col = min(idx - tok * npiece, (p.Kx >> 3) - 1);
+    xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)min(tok, p.T - 1) * p.ldx + col * 8);
+    nwpre[i] = *reinterpret_cast<const uint4*>(p.norm_w + col * 8);
+  }
+  const int half_r = p.rope >> 1;
+  const int cs_tok = min(tid / half_r, p.T - 1), cs_i = tid % half_r;
+  const float cs_pos = (float)p.pos[cs_tok], cs_if = p.inv_freq[cs_i];
   uint4 w1r[UPW][NK2];
   uint2 s1r[UPW][NK2];
 #pragma unroll
@@ -590,24 +606,18 @@ __global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
   }
 
   // ---- the q_a rows: RMSNorm (q_a_layernorm) and staging exactly as lin_dec_kernel does them ---------------------------
-  const int ntot = TP * npiece;
-  constexpr int XPRE = 2;   // ntot <= 1024 (q_lora <= 2048)
-  uint4 xpre[XPRE];
 #pragma unroll
   for (int i = 0; i < XPRE; i++) {
     const int idx = tid + i * 512;
-    xpre[i] = make_uint4(0, 0, 0, 0);
-    if (idx < ntot) {
-      const int tok = idx / npiece, col = idx - tok * npiece;
-      if (tok < p.T && col * 8 < p.Kx) xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
-    }
+    const int tok = idx / npiece, col = idx - tok * npiece;
+    if (!(idx < ntot && tok < p.T && col * 8 < p.Kx)) xpre[i] = make_uint4(0, 0, 0, 0);
   }
-  if (tid < TP * (p.rope >> 1)) {   // cos / sin of the tokens' positions (mla_prep's table)
-    const int tok = tid / (p.rope >> 1), i = tid - tok * (p.rope >> 1);
+  if (tid < TP * half_r) {   // cos / sin of the tokens' positions (mla_prep's table)
+    const int tok = tid / half_r, i = tid - tok * half_r;
     if (tok < p.T) {
-      const float fr = (float)p.pos[tok] * p.inv_freq[i];
+      const float fr = cs_pos * cs_if;
       s_cs[tok * p.rope + i] = prep_rbf(cosf(fr) * p.mscale);
-      s_cs[tok * p.rope + (p.rope >> 1) + i] = prep_rbf(sinf(fr) * p.mscale);
+      s_cs[tok * p.rope + half_r + i] = prep_rbf(sinf(fr) * p.mscale);
     }
   }
   float ss[4] = {0.f, 0.f, 0.f, 0.f};
@@ -643,8 +653,11 @@ __global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
     if (idx < ntot) {   // (ntot is a multiple of 16: whole 16-lane groups take part in the shuffles)
       const int tok = idx / npiece, col = idx - tok * npiece;
       uint4 v = xpre[i];
-      if (tok < p.T && col * 8 < p.Kx)
-        v = lin_norm8(v, tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3], p.norm_w + col * 8);
+      if (tok < p.T && col * 8 < p.Kx) {
+        const float r = tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3];
+        v = make_uint4(ktx_norm_pk(v.x, r, nwpre[i].x), ktx_norm_pk(v.y, r, nwpre[i].y), ktx_norm_pk(v.z, r, nwpre[i].z),
+                       ktx_norm_pk(v.w, r, nwpre[i].w));
+      }
       *reinterpret_cast<uint4*>(xs + col * CS + tok * 16) = v;
       float sm = sum8_bf16(v);
 #pragma unroll

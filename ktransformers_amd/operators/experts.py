@@ -117,11 +117,12 @@ class KExpertsHIP(KExpertsBase):
             handle_len = self.max_len * min(world, 8)        # decode gathers every rank's tokens; prefill receives rows
         cfg = self.config
         inter = getattr(cfg, "moe_intermediate_size", None) or cfg.intermediate_size
-        if self.method == "GGUF" and "gate_type" not in w:
+        method = self.method                 # THIS load's format; the configured self.method is never changed (unload() -> load() again)
+        if method == "GGUF" and "gate_type" not in w:
             # a "llamafile" rule over a bf16 (safetensors) weight source: the reference would reject it; quantise online
             # to the int4 format instead of failing, like its AMX backends do for bf16 sources.
-            self.method = "AMXINT4"
-        elif self.method == "GGUF":
+            method = "AMXINT4"
+        elif method == "GGUF":
             from ktransformers_amd._native import GGML_BLOCK_BYTES
             types = {n: int(w[f"{n}_type"]) for n in ("gate", "up", "down")}
             if not all(t in GGML_BLOCK_BYTES for t in types.values()):
@@ -130,17 +131,25 @@ class KExpertsHIP(KExpertsBase):
                 # weights, un-quantised activations; NOT the llamafile arithmetic (Q8_K activations), and 2 bytes per weight.
                 import warnings
 
-                from ktransformers_amd.util.gguf_loader import GGML_NAMES, dequantize_expert_blocks
+                from ktransformers_amd.util.gguf_loader import GGML_NAMES, GGML_QUANT_SIZES, dequantize_expert_blocks
                 warnings.warn(f"{self.key}: GGUF expert types {[GGML_NAMES.get(t, t) for t in types.values()]} have no native "
                               "expert kernel; de-quantising to BF16 experts", RuntimeWarning, stacklevel=2)
-                E_all = self.n_routed_experts
-                w = {"gate": dequantize_expert_blocks(w["gate"], types["gate"], E_all, inter, cfg.hidden_size),
-                     "up": dequantize_expert_blocks(w["up"], types["up"], E_all, inter, cfg.hidden_size),
-                     "down": dequantize_expert_blocks(w["down"], types["down"], E_all, cfg.hidden_size, inter)}
-                self.method = "BF16"
+                E_all, e0, en = self.n_routed_experts, self.expert_begin, self.expert_count
+
+                def local(name, rows, cols):   # only THIS rank's experts are de-quantised; the others stay zero rows the slice below drops
+                    raw = w[name]
+                    flat = (raw.detach().cpu() if isinstance(raw, torch.Tensor) else torch.as_tensor(raw)).reshape(-1).view(torch.uint8)
+                    n_el, n_by = GGML_QUANT_SIZES[types[name]]
+                    per = rows * cols // n_el * n_by
+                    out = torch.zeros((E_all, rows, cols), dtype=torch.bfloat16)
+                    out[e0:e0 + en] = dequantize_expert_blocks(flat[e0 * per:(e0 + en) * per], types[name], en, rows, cols)
+                    return out
+                w = {"gate": local("gate", inter, cfg.hidden_size), "up": local("up", inter, cfg.hidden_size),
+                     "down": local("down", cfg.hidden_size, inter)}
+                method = "BF16"
         h = MoEHandle(self.expert_count, cfg.num_experts_per_tok, cfg.hidden_size, inter, max_len=handle_len,
-                      method=self.method, device=dev, expert_begin=self.expert_begin,
-                      global_expert_num=self.n_routed_experts, group_size=_GROUP_SIZE.get(self.method, 0))
+                      method=method, device=dev, expert_begin=self.expert_begin,
+                      global_expert_num=self.n_routed_experts, group_size=_GROUP_SIZE.get(method, 0))
         sl = slice(self.expert_begin, self.expert_begin + self.expert_count)
 
         def prep(t, dtype=None):
@@ -148,10 +157,10 @@ class KExpertsHIP(KExpertsBase):
             t = t[sl].to(device=dev)
             return (t.to(dtype) if dtype is not None else t).contiguous()
 
-        if self.method in ("AMXINT4", "AMXINT8", "BF16"):
+        if method in ("AMXINT4", "AMXINT8", "BF16"):
             # bf16 source weights; the integer formats are quantised online exactly like the reference's AMX backends
             h.load_bf16(prep(w["gate"], torch.bfloat16), prep(w["up"], torch.bfloat16), prep(w["down"], torch.bfloat16))
-        elif self.method == "GGUF":
+        elif method == "GGUF":
             # raw ggml blocks [E, N, K/256 * block_bytes] + type ids, as KExpertsBase.load_weights returns them
             # (reference experts.py:89-135: gate/up/down mmap blobs and gate_type/up_type/down_type)
             def blocks(t, n):
@@ -159,7 +168,7 @@ class KExpertsHIP(KExpertsBase):
                 return t.view(torch.uint8).reshape(self.n_routed_experts, n, -1)[sl].to(device=dev).contiguous()
             h.load_gguf(blocks(w["gate"], inter), blocks(w["up"], inter), blocks(w["down"], cfg.hidden_size),
                         int(w["gate_type"]), int(w["up_type"]), int(w["down_type"]))
-        elif self.method == "FP8":
+        elif method == "FP8":
             h.load_fp8(prep(w["gate"]).view(torch.uint8), prep(w["up"]).view(torch.uint8), prep(w["down"]).view(torch.uint8),
                        prep(w["gate_scale"], torch.float32), prep(w["up_scale"], torch.float32),
                        prep(w["down_scale"], torch.float32))
@@ -168,6 +177,7 @@ class KExpertsHIP(KExpertsBase):
                            prep(w["gate_scale"], torch.bfloat16), prep(w["up_scale"], torch.bfloat16),
                            prep(w["down_scale"], torch.bfloat16))
         self.handle = h
+        self.loaded_method = method          # the format this load actually built (the BF16 fallback of GGUF types without a kernel)
         if ep_on:
             self._ep = parallel.ExpertParallelMoE(h, parallel.EP_STATE["group"])
         if warmup and not ep_on:

@@ -93,6 +93,21 @@ def enable_peer_exchange(hidden: int, topk: int, max_tokens: int, device, group=
     return ex
 
 
+def check_exchange_status(group=None) -> None:
+    """Raise — on EVERY rank — if a bounded poll of the peer-write exchange has given up since the last check (a dead or
+    very slow peer: the kernels then finished on stale granules and every token since is suspect).  The collectives path
+    would have raised by itself; the peer path only sets a status word, so the decode loop asks for it at a cheap cadence
+    (util/generate.py: every 64 tokens and at the end; bench.py: after the timed region).  One tiny all-reduce."""
+    ex = EP_STATE.get("exchange")
+    if ex is None or not (dist.is_available() and dist.is_initialized()):
+        return
+    st = torch.tensor([int(ex.status())], device=ex.device, dtype=torch.int32)
+    dist.all_reduce(st, op=dist.ReduceOp.MAX, group=group if group is not None else EP_STATE.get("group"))
+    if int(st.item()) != 0:
+        raise RuntimeError(f"expert-parallel peer exchange: a poll gave up waiting for a peer (status {int(st.item())}); "
+                           "outputs since the previous check are not valid")
+
+
 def verify_peer_exchange(ex, T: int = 1) -> None:
     """One gather + reduce of rank-dependent patterns; raises unless every row and every sum arrives exactly."""
     dev, R, H, k = ex.device, ex.world, ex.H, ex.k

@@ -12,6 +12,13 @@ import torch
 from ktransformers_amd.util.utils import InferenceState
 
 
+def _check_ep() -> None:
+    """Expert-parallel runs over the peer-write transport: a poll that gave up must not pass silently (parallel.py)."""
+    from ktransformers_amd import parallel
+    if parallel.EP_STATE.get("exchange") is not None:
+        parallel.check_exchange_status()
+
+
 def set_inference_mode(model: torch.nn.Module, mode: InferenceState) -> None:
     for m in model.modules():
         if hasattr(m, "set_inference_mode") and not isinstance(getattr(type(m), "set_inference_mode", None), property):
@@ -137,5 +144,8 @@ def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_ne
         else:
             logits = model(cur, pos, past_key_values, pos[0])
         nxt = pick(logits)
+        if (i & 63) == 63:
+            _check_ep()
+    _check_ep()
     out = torch.stack(tokens)
     return (out, torch.stack(all_logits)) if return_logits else out

@@ -170,7 +170,7 @@ def dequantize_expert_blocks(raw, ggml_type: int, num_experts: int, rows: int, c
     [E, rows, cols], one expert at a time (the fp32 intermediate of a whole DeepSeek-sized tensor would not fit in host
     memory).  For expert types the HIP expert kernels do not read natively."""
     n_el, n_by = GGML_QUANT_SIZES[ggml_type]
-    flat = (raw.numpy() if isinstance(raw, torch.Tensor) else np.asarray(raw)).reshape(-1).view(np.uint8)
+    flat = (raw.detach().cpu().numpy() if isinstance(raw, torch.Tensor) else np.asarray(raw)).reshape(-1).view(np.uint8)   # (hybrid checkpoints hand over device tensors)
     per = rows * cols // n_el * n_by
     if cols % n_el or flat.size != num_experts * per:
         raise ValueError(f"expert blocks: {flat.size} bytes for {num_experts} x {rows} x {cols} of ggml type {ggml_type}")

@@ -32,3 +32,88 @@ def test_bench_cli_accepts_the_contract_flags():
     assert out.returncode == 0
     for flag in ("--gpus", "--steps", "--warmup"):
         assert flag in out.stdout
+
+
+def _bench():
+    sys.path.insert(0, ROOT)
+    import bench
+    return bench
+
+
+def test_every_baseline_configuration_has_a_bench_workload_and_a_rule_file():
+    """BASELINE.json configs[0..4] <-> bench.py workloads; the format choices of a workload are written into the product
+    rule file the way a user edits the reference's (generate_op of the layer linears, backend of the routed experts)."""
+    import yaml
+    b = _bench()
+    for name in ("v3-int4", "v2lite-int4", "r1-iq1s", "v3-fp8", "k2-rawint4", "mixtral-q4km"):
+        assert name in b.WORKLOADS
+    assert set(b.SECONDARY) == {"v2lite-int4", "r1-iq1s", "v3-fp8", "k2-rawint4", "mixtral-q4km"}
+    assert b.WORKLOADS["r1-iq1s"]["layers"] == b.WORKLOADS["r1-iq1s"]["full_layers"] == 61          # the whole model
+    rules = yaml.safe_load(open(b.rules_for(b.WORKLOADS["r1-iq1s"])))
+    ops = {r["match"].get("name", ""): r["replace"]["kwargs"] for r in rules if "kwargs" in r.get("replace", {})}
+    assert ops["^lm_head$"]["generate_op"] == "KLinearMarlin"
+    assert ops["^model\\.layers\\.(?!.*self_attn\\.kv_b_proj).*$"]["generate_op"] == "KLinearFP8"
+    assert ops["^model\\.layers\\..*\\.mlp\\.experts$"]["backend"] == "llamafile"
+    rules = yaml.safe_load(open(b.rules_for(b.WORKLOADS["k2-rawint4"])))
+    ops = {r["match"].get("name", ""): r["replace"]["kwargs"] for r in rules if "kwargs" in r.get("replace", {})}
+    assert ops["^model\\.layers\\..*\\.mlp\\.experts$"]["backend"] == "RAWINT4"
+    assert ops["^model\\.layers\\.(?!.*self_attn\\.kv_b_proj).*$"]["generate_op"] == "KLinearMarlin"
+    assert b.rules_for(b.WORKLOADS["v3-int4"]).endswith("DeepSeek-V3-Chat.yaml")                     # unmodified product file
+
+
+def test_algorithmic_bytes_per_token_follow_the_survey_figures():
+    """routed experts of one V3 layer-token = 176.2 MB int4 / 352.3 MB fp8 / 68.8 MB IQ1_S / 198.2 MB RAWINT4."""
+    from ktransformers_amd.models.modeling_deepseek import make_config
+    b = _bench()
+    H, I, k = 7168, 2048, 8
+    for name, mb in (("v3-int4", 176.2), ("v3-fp8", 352.3), ("r1-iq1s", 68.8), ("k2-rawint4", 198.2)):
+        gu, dn = b.expert_bpw(b.WORKLOADS[name])
+        got = k * (2 * H * I * gu + H * I * dn) / 1e6
+        assert abs(got - mb) / mb < 5e-3, (name, got, mb)
+    wl = b.WORKLOADS["v3-int4"]
+    cfg = make_config(**dict(b.MODELS["v3"], num_hidden_layers=32))
+    tot, layer = b.step_bytes(cfg, 32, 4096, wl)
+    assert abs(tot - 11148404736) / tot < 1e-6 and layer == 332348544                              # the round-2 figures, unchanged
+    cfg = make_config(**dict(b.MODELS["v3"], num_hidden_layers=61))
+    tot_r1, _ = b.step_bytes(cfg, 61, 4096, b.WORKLOADS["r1-iq1s"])
+    assert 20e9 < tot_r1 < 23e9                                                                     # ~21 GB per token: fp8 linears dominate
+
+
+def test_kernel_class_of_rocprof_names_and_labels():
+    b = _bench()
+    assert b._kclass("void (anonymous namespace)::lin_sk_kernel<64, 1, 7, 2>((anonymous namespace)::LinParams)") == "lin_sk_kernel"
+    assert b._kclass("void moe_dec_gateup_kernel<4, 14, 4, true, 2>(DecParams)") == "moe_dec_gateup_kernel"
+    assert b._kclass("lin_dec_gate_kernel<W4> 7168->4096 + router E=256") == "lin_dec_gate_kernel"
+    assert b._kclass("mla_decode_kernel<2,4> T=1 Hq=128 nsplit=49") == "mla_decode_kernel"
+    assert b._kclass("void at::native::vectorized_elementwise_kernel<4, at::native::CUDAFunctor_add<long> >(int)") == "vectorized_elementwise_kernel"
+
+
+def test_random_weight_sources_are_valid_blocks():
+    """The synthetic weight sources of the secondary workloads: finite fp16 super-block scales at the ggml offsets the loader
+    de-quantises from, block-fp8 round trip within e4m3's half-ulp."""
+    import numpy as np
+    import torch
+    b = _bench()
+    g = torch.Generator(device="cpu").manual_seed(0)
+    from oracle.gguf_ref import DEQUANT
+    for ty, nbytes in ((12, 144), (14, 210), (19, 50)):
+        t = b.random_ggml_blocks(2, 3, 512, ty, g, torch.device("cpu"))
+        assert tuple(t.shape) == (2, 3, 2 * nbytes)
+        w = DEQUANT[ty](t.numpy().reshape(6, -1))
+        assert np.isfinite(w).all() and 0.02 < float(np.std(w)) < 0.5 and np.abs(w).max() < 4.0, (ty, float(np.std(w)))
+    w = (torch.randn(2, 256, 384) / 10).to(torch.bfloat16)
+    q, sc = b.fp8_block_quant(w)
+    assert q.dtype == torch.float8_e4m3fn and tuple(sc.shape) == (2, 2, 3)
+    back = q.float().view(2, 2, 128, 3, 128) * sc[:, :, None, :, None]
+    err = (back.reshape(2, 256, 384) - w.float()).abs()
+    assert float((err / (w.float().abs() + 1e-3)).max()) < 0.07
+
+
+def test_llamafile_cpu_leg_runs_the_reference_kernels():
+    import pytest
+    sys.path.insert(0, ROOT)
+    from oracle.gguf_ref import iqk_forward_bench
+    r = iqk_forward_bench(512, 1024, 2, (12, 12, 14), 4, budget_s=0.5, threads=2)
+    if r["value"] is None:
+        pytest.skip(r["sample"])
+    assert r["kind"] == "reference" and r["cores"] == 2 and r["value"] > 0 and r["us_per_layer"] > 0

@@ -146,3 +146,42 @@ def test_router_riding_in_the_shared_gate_up_launch(name, I_shared, T):
                 assert abs(v - ref[e]) <= 2e-3 * abs(ref[e]) + 1e-9, (t, e, v, ref[e])
         err = (y2.float() - y0.float()).abs().max().item()
         assert err <= 2e-2 * y0.float().abs().max().item(), err
+
+
+@pytest.mark.parametrize("mode", [2, 3])
+@pytest.mark.parametrize("name,I_shared", [("deepseek_v3", 2048), ("deepseek_v2_lite", 2816), ("kimi_k2", 2048)])
+@pytest.mark.parametrize("T", [1, 3])
+def test_router_riding_in_the_all_cu_gate_up_kernel(name, I_shared, T, mode):
+    """The two opt-in placements of the router inside lin_sk_gate_kernel (dev knob 19: 3 = round 2's router workgroups in
+    front of the all-CU GEMV's grid, 2 = wavefront 7 of every GEMV workgroup + one selector workgroup sweeping {tag, logit}
+    granules) against the separate router + GEMV calls; replayed, so tickets / granules must come back to zero."""
+    from ktransformers_amd import _native as n
+    cfg = dict(CONFIGS[name])
+    E, H = cfg.pop("E"), cfg.pop("H")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(17 + T)
+    x = torch.randn((T, H), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((E, H), generator=g) * H ** -0.5).to(torch.bfloat16).to(dev)
+    nw = (1 + 0.1 * torch.randn((H,), generator=g)).to(torch.bfloat16).to(dev)
+    bias = (torch.randn((E,), generator=g) * 0.1).to(dev) if cfg["topk_method"] == "noaux_tc" else None
+    wl = (torch.randn((2 * I_shared, H), generator=g) / 10).to(torch.bfloat16).to(dev)
+    gh = n.GateHandle(E, H, cfg["top_k"], cfg["n_group"], cfg["topk_group"], cfg["scoring_func"], cfg["topk_method"],
+                      cfg["norm_topk_prob"], cfg["routed_scaling_factor"])
+    lin = n.LinearHandle(H, 2 * I_shared, "W4", 64, 64, dev)
+    lin.load_bf16(wl)
+    idx0, wt0, xn0 = gh.forward(x, w, bias, norm=(nw, 1e-6))
+    y0 = lin.forward(x, norm=(nw, 1e-6), glu=True)
+    try:
+        n.lib.ktx_debug_set(19, mode)
+        for rep in range(4):
+            idx2, wt2, xn2, y2 = n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6))
+            torch.cuda.synchronize()
+            assert bool(((xn2.float() - xn0.float()).abs() <= xn0.float().abs() * 2.0 ** -7 + 1e-30).all())
+            for t in range(T):
+                assert set(idx2[t].tolist()) == set(idx0[t].tolist()), f"token {t}: routed expert set differs (rep {rep})"
+                ref = dict(zip(idx0[t].tolist(), wt0[t].tolist()))
+                for e, v in zip(idx2[t].tolist(), wt2[t].tolist()):
+                    assert abs(v - ref[e]) <= 2e-3 * abs(ref[e]) + 1e-9, (t, e, v, ref[e])
+            assert (y2.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
+    finally:
+        n.lib.ktx_debug_set(19, 0)

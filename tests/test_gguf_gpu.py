@@ -190,7 +190,16 @@ def test_expert_types_without_a_native_kernel_are_served_as_dequantised_bf16_exp
                               backend="llamafile", max_len=16)
     with pytest.warns(RuntimeWarning, match="no native expert kernel"):
         ex.load(mode=InferenceState.GENERATE)
-    assert ex.generate_experts.method == "BF16"
+    ge = ex.generate_experts
+    assert ge.loaded_method == "BF16" and ge.method == "GGUF"       # the configured method survives the fallback ...
+    ge.unload()
+    with pytest.warns(RuntimeWarning, match="no native expert kernel"):
+        ge.load()                                                    # ... so UNLOAD -> load takes the GGUF branch again
+    assert ge.loaded_method == "BF16"
+    # a hybrid (fp8 + GGUF) checkpoint hands the raw blocks over as DEVICE tensors (util/loader.py load_experts(device=...))
+    from ktransformers_amd.util.gguf_loader import dequantize_expert_blocks
+    blk = torch.from_numpy(down.reshape(-1)).cuda()
+    assert torch.equal(dequantize_expert_blocks(blk, 8, E, H, I), dequantize_expert_blocks(blk.cpu(), 8, E, H, I))
     x = f32_to_bf16((rng.standard_normal((T, H)) / 4).astype(np.float32))
     ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
     w = rng.random((T, k)).astype(np.float32)

@@ -302,3 +302,115 @@ def test_prompt_sized_w4_dequantises_once_and_runs_a_library_gemm(K, N, G):
             os.environ.pop("KTX_W4_PROMPT_KERNEL")
         assert got.shape == ref.shape == (T, N // 2)
         assert float((got.float() - ref.float()).norm() / ref.float().norm()) < 5e-3
+
+
+# ---- lin_sk_kernel (round 3): the decode GEMV dealt over all CUs ----------------------------------------------------------
+# Shapes: DeepSeek-V3 linears (k-steps 56 / 128 / 144 / 12 / 16 -> ring depths 7 / 8 / 6 / 4), a glu pair, ragged N.
+SK_SHAPES = [(7168, 2112), (16384, 7168), (18432, 1024), (1536, 3072), (2048, 7168), (7168, 4096), (896, 200), (1408, 512)]
+
+
+def _knobs(n, **kv):
+    class K:
+        def __enter__(self):
+            for k, v in kv.items():
+                n.lib.ktx_debug_set(int(k[1:]), v)
+
+        def __exit__(self, *a):
+            for k in kv:
+                n.lib.ktx_debug_set(int(k[1:]), 0)
+    return K()
+
+
+@pytest.mark.parametrize("K,N", SK_SHAPES)
+@pytest.mark.parametrize("T", [1, 2, 4])
+def test_all_cu_decode_gemv_both_deals_against_the_reference_math(K, N, T):
+    """The all-CU decode GEMV with whole strips per workgroup (default) and with single groups dealt (knob 17 = 1: strips
+    shared between workgroups meet through the fixed-point words) against exact (q - 8) * s math, against round 2's
+    lin_dec_kernel (knob 16 = 1), and against itself: the shared-strip path adds integers, so replays are bit-identical
+    whatever the arrival order, and the meeting words must be back at zero after every launch."""
+    n = native()
+    torch.manual_seed(K * 3 + N + T)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16)
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16)
+    q, s = quantize_weights_ref(w.T.contiguous(), 64)
+    ref = linear_w4_ref(x, q, s, 64, None)
+    h = n.LinearHandle(K, N, "W4", 64, 16)
+    h.load_bf16(w.cuda())
+    xg = x.cuda()
+    y_strips = h.forward(xg)
+    close(y_strips, ref)
+    with _knobs(n, k17=1):
+        y_groups = [h.forward(xg).clone() for _ in range(4)]
+    close(y_groups[0], ref)
+    for y in y_groups[1:]:
+        assert torch.equal(y, y_groups[0]), "shared strips: replays differ (arrival-order dependence or words not reset)"
+    with _knobs(n, k16=1):
+        y_old = h.forward(xg)
+    close(y_old, ref)
+    # the two deals differ only in fp32 association (+ the 2^-32 grid of the meeting words): within one bf16 ulp of each other
+    d = (y_strips.float() - y_groups[0].float()).abs()
+    assert bool((d <= y_strips.float().abs() * 2.0 ** -7 + 1e-6).all())
+
+
+@pytest.mark.parametrize("T", [1, 3])
+def test_all_cu_decode_gemv_epilogues(T):
+    """Fused RMSNorm prologue, glu, bias and both addends through lin_sk_kernel == the same call through lin_dec_kernel up to
+    fp32 association (the arithmetic of the prologue and the epilogues is shared expression by expression)."""
+    n = native()
+    K, N = 7168, 4096
+    torch.manual_seed(5 + T)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16).cuda()
+    x = torch.randn(T, K).to(torch.bfloat16).cuda()
+    nw = (1 + 0.1 * torch.randn(K)).to(torch.bfloat16).cuda()
+    a1 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    a2 = torch.randn(T, N).to(torch.bfloat16).cuda()
+    bias = torch.randn(N).to(torch.bfloat16).cuda()
+    h = n.LinearHandle(K, N, "W4", 64, 16)
+    h.load_bf16(w, bias)
+    hg = n.LinearHandle(K, N, "W4", 64, 16)
+    hg.load_bf16(w)
+    for kw, hh in ((dict(norm=(nw, 1e-6), add1=a1, add2=a2), h), (dict(norm=(nw, 1e-6), glu=True), hg), (dict(add1=a1), h)):
+        y_new = hh.forward(x, **kw)
+        with _knobs(n, k16=1):
+            y_old = hh.forward(x, **kw)
+        with _knobs(n, k17=1):
+            y_grp = hh.forward(x, **kw)
+        for y in (y_new, y_grp):
+            d = (y.float() - y_old.float()).abs()
+            assert bool((d <= y_old.float().abs() * 2.0 ** -6 + 2e-2 * y_old.float().abs().max()).all()), float(d.max())
+            assert float((y.float() - y_old.float()).norm() / y_old.float().norm()) < 4e-3
+
+
+def test_all_cu_decode_gemv_under_a_replayed_graph_and_many_handles():
+    """Meeting words, slab arena and launch geometry under graph replay: 12 handles created and destroyed in shuffled order
+    (slabs are returned when their last piece goes), a captured chain replayed 20 times gives the same bits every time."""
+    n = native()
+    torch.manual_seed(3)
+    K, N = 2048, 1536
+    hs, ws = [], []
+    for i in range(12):
+        w = (torch.randn(N, K) / 10).to(torch.bfloat16).cuda()
+        h = n.LinearHandle(K, N, "W4", 64, 8)
+        h.load_bf16(w)
+        hs.append(h); ws.append(w)
+    for i in (1, 5, 7, 2):
+        hs[i].close()
+    live = [h for i, h in enumerate(hs) if i not in (1, 5, 7, 2)]
+    x = (torch.randn(1, K) / 10).to(torch.bfloat16).cuda()
+    ys = [torch.empty(1, N, dtype=torch.bfloat16, device="cuda") for _ in live]
+    with _knobs(n, k17=1):
+        for h, y in zip(live, ys):
+            h.forward(x, out=y)
+        torch.cuda.synchronize()
+        first = [y.clone() for y in ys]
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for h, y in zip(live, ys):
+                h.forward(x, out=y)
+        for _ in range(20):
+            for y in ys:
+                y.zero_()
+            g.replay()
+            torch.cuda.synchronize()
+            for y, f in zip(ys, first):
+                assert torch.equal(y, f)
