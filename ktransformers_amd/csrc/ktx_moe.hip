@@ -3234,9 +3234,15 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
       const int d2 = nkb2 % 4 == 0 ? 4 : nkb2 % 2 == 0 ? 2 : 1;
       if (tg == GG_Q6K && d1 == 4) d1 = 2;   // a 4-deep ring of gate AND up Q6_K tiles (3 planes each) does not fit the registers
       const int only = g_dbg[2];
+      const bool ks2 = nkb1 % 2 == 0 && g_dbg[20] != 1;
       auto tname = [](int t) { return t == GG_Q4K ? "Q4_K" : t == GG_Q6K ? "Q6_K" : "IQ1_S"; };
 #define KTX_GG_GU(WT)                                                                                                \
       do {                                                                                                           \
+        if (ks2) {   /* 4 strips x 2 k-slices per workgroup: two wavefronts per SIMD (dev knob 20 = 1: one) */       \
+          if (nkb1 % 4 == 0) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4, 2>), g1, dim3(512), lds_gu + 2 * 4 * 2 * 16 * 4, st, dp); \
+          else hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 1, 4, 2>), g1, dim3(512), lds_gu + 2 * 4 * 2 * 16 * 4, st, dp); \
+          break;                                                                                                     \
+        }                                                                                                            \
         if constexpr (WT != GG_Q6K) {   /* (never chosen for Q6_K, see d1 above: not instantiated either) */         \
           if (d1 == 4) { hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 4, 4>), g1, dim3(256), lds_gu, st, dp); break; } \
         }                                                                                                            \

@@ -83,7 +83,17 @@ def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None, random_b
                            torch.from_numpy(w).cuda()).float().cpu().numpy()
         finally:
             n.force_generic_path(False)
-        assert np.array_equal(y, yg), f"decode and grouped paths differ in {int((y != yg).sum())} of {y.size} outputs"
+        # the decode gate/up kernel adds its two k-slices' fp32 sums at the end (round 3: two wavefronts per SIMD), the grouped
+        # path folds the 256-blocks in one chain: a handful of outputs may land on the other side of a bf16 rounding ...
+        assert float((y == yg).mean()) >= 0.99 and (np.abs(y - yg) <= 2.0 ** -7 * np.abs(yg) + 1e-3 * np.abs(yg).max()).all(), \
+            f"decode and grouped paths differ in {int((y != yg).sum())} of {y.size} outputs"
+        n.lib.ktx_debug_set(20, 1)      # ... and with the k-slices off the two paths are the same chain: the same bits
+        try:
+            y1 = h.forward(torch.from_numpy(x.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(ids).cuda(),
+                           torch.from_numpy(w).cuda()).float().cpu().numpy()
+        finally:
+            n.lib.ktx_debug_set(20, 0)
+        assert np.array_equal(y1, yg), f"decode (one k-slice) and grouped paths differ in {int((y1 != yg).sum())} of {y.size} outputs"
     return h
 
 
