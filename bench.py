@@ -1012,6 +1012,9 @@ def main():
         assert wl["E"] % world == 0
         from ktransformers_amd.parallel import enable_expert_parallel, enable_peer_exchange
         enable_expert_parallel()      # experts sharded over the ranks, attention / dense parts replicated
+        if args.strong:
+            from ktransformers_amd.parallel import set_replicated_input
+            set_replicated_input(True)   # one stream: the ranks' rows are identical, only the fp32 partials travel
         # decode exchange: direct peer writes over xGMI (two launches per MoE layer; checked on this node's fabric while it
         # is set up), else the two collectives.  KTX_EP_TRANSPORT=collectives forces the latter for an A/B.
         ep_transport = "collectives: all-gather + reduce-scatter per MoE layer (RCCL)"

@@ -29,7 +29,16 @@ import torch.distributed as dist
 
 
 # Process-wide expert-parallel setting consulted by KExpertsHIP at load(): rule files cannot carry a process group.
-EP_STATE = {"enabled": False, "group": None, "exchange": None}
+EP_STATE = {"enabled": False, "group": None, "exchange": None, "replicated_input": False}
+
+
+def set_replicated_input(on: bool = True) -> None:
+    """Strong scaling (ONE token stream over all ranks): every rank holds the SAME decode rows (attention and router are
+    replicated, so they are bit-identical), so the gather half of the decode exchange is dropped — each rank runs its own
+    experts on its own copy of the rows and only the fp32 partials travel: one all-reduce (collectives) or the reduce launch
+    of the peer exchange, parts added in rank order on every rank alike, so every rank ends up with the same bits and the
+    streams cannot drift apart."""
+    EP_STATE["replicated_input"] = bool(on)
 
 
 def enable_expert_parallel(group=None, enabled: bool = True) -> None:
@@ -142,6 +151,21 @@ def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch
     `local_partial(xg, idsg, wg) -> fp32 [world*T, H]` computes this rank's experts' contribution for all gathered
     tokens (MoEHandle.forward_partial on GPU; the oracle in the gloo tests).  `exchange` (an EpExchange whose peers are
     mapped) selects the peer-write transport: two launches, partials added in rank order."""
+    if EP_STATE["replicated_input"]:
+        part = local_partial(x.contiguous(), ids.contiguous(), w.contiguous())       # fp32 [T, H]: this rank's experts only
+        if exchange is not None:
+            # the reduce launch hands row block r of `part` to rank r: every rank's block is the same T rows here
+            return exchange.reduce(part.repeat(exchange.world, 1))
+        # rank-ordered sum on every rank (all_reduce's ring order differs between ranks at fp32 rounding level, which would let
+        # the replicas drift apart): gather the R partials and add them left to right
+        world = dist.get_world_size(group)
+        Tn = part.shape[0]
+        parts = torch.empty((world * Tn, part.shape[1]), dtype=part.dtype, device=part.device)
+        dist.all_gather_into_tensor(parts, part.contiguous(), group=group)
+        out = parts[:Tn]
+        for r in range(1, world):
+            out = out + parts[r * Tn:(r + 1) * Tn]
+        return out.to(torch.bfloat16)
     if exchange is not None:
         xg, idsg, wg = exchange.gather(x.contiguous(), ids.contiguous(), w.contiguous())
         return exchange.reduce(local_partial(xg, idsg, wg))

@@ -69,6 +69,61 @@ def test_expert_parallel_decode_matches_single_process(world):
         assert (got != want).mean() < 0.05
 
 
+def _replicated_worker(rank, world, port, q):
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from ktransformers_amd import parallel
+    from oracle.oracle import FMT_AMXINT4, Oracle
+
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    o = Oracle()
+    c = make_case(31, E, K, H, I, T)
+    moe = o.make_moe(FMT_AMXINT4, c["gate"], c["up"], c["down"])
+    begin, cnt = parallel.expert_range(E, world, rank)
+    mask = np.ones(E, np.uint8)
+    mask[begin:begin + cnt] = 0
+    moe_local = dict(moe, mask=mask)
+
+    def local_partial(xg, idsg, wg):
+        xs = xg.view(torch.int16).numpy().view(np.uint16)
+        ids, w = idsg.numpy(), wg.numpy()
+        assert xs.shape[0] == T, "strong scaling: no gather, the rank sees only the one stream's rows"
+        acc = np.zeros((xs.shape[0], H), np.float32)
+        for j in range(ids.shape[1]):
+            one = o.moe_forward(moe_local, ids[:, j:j + 1], np.ones((xs.shape[0], 1), np.float32), xs)
+            acc = np.float32(bf16_to_f32(one) * w[:, j:j + 1] + acc)
+        return torch.from_numpy(acc)
+
+    parallel.set_replicated_input(True)
+    x = torch.from_numpy(c["x"].view(np.int16).copy()).view(torch.bfloat16)
+    y = parallel.ep_decode_forward(local_partial, x, torch.from_numpy(c["ids"]), torch.from_numpy(c["w"]))
+    full = o.moe_forward(moe, c["ids"], c["w"], c["x"])
+    q.put((rank, y.view(torch.int16).numpy().view(np.uint16).copy(), full.copy()))
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_strong_scaling_decode_one_stream_over_all_ranks(world):
+    """parallel.set_replicated_input: every rank holds the same rows, runs only its own experts on them, and the fp32 parts
+    are added in rank order on every rank — the ranks' outputs are IDENTICAL bits (replicas cannot drift) and within one
+    bf16 ulp of the single-process forward."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000) + 40 + world
+    procs = [ctx.Process(target=_replicated_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted((q.get(timeout=300) for _ in range(world)), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, got, want in res:
+        assert np.array_equal(got, res[0][1]), f"rank {rank} differs from rank 0"
+        a, b = bf16_to_f32(got), bf16_to_f32(want)
+        assert np.all(np.abs(a - b) <= np.abs(b) * 2.0 ** -7 + 1e-5 * np.abs(b).max()), f"rank {rank}"
+
+
 def _peer_refused_worker(rank, world, port, q):
     from ktransformers_amd import parallel
     os.environ["MASTER_ADDR"] = "127.0.0.1"

@@ -130,3 +130,12 @@ def test_bench_takes_its_multi_gpu_branch_on_one_rank():
     assert line["value"] and line["value"] > 0 and line["n_gpus"] == 1 and line["scaling"] == "weak"
     assert cfg["parallelism"] == "ep1" and cfg["rccl_ranks"] == 1 and cfg["hip_graph"] is True, cfg
     assert cfg["ep_transport"].startswith("peer writes") and cfg["ep_transport_status"] == 0, cfg
+    # round 3: the N > 1 line carries the per-kernel table and a roofline too (HIP events on rank 0, all ranks stepping together)
+    assert line["roofline"]["bound"] == "hbm" and line["per_kernel"] and line["per_kernel"][0]["us_per_step"] > 0
+    # ... and --strong is ONE token stream: the same rows on every rank, only the fp32 partials travel
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--strong", "--workload",
+                        "v2lite-int4", "--layers", "3", "--steps", "8", "--warmup", "2", "--no-prefill", "--no-secondary",
+                        "--no-cpu-baseline", "--no-kernels", "--windows", "0"], env=env, capture_output=True, text=True, timeout=280)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["value"] > 0 and line["config"]["ep_transport_status"] == 0
