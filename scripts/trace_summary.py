@@ -10,7 +10,7 @@ from collections import OrderedDict
 
 
 def short(name):
-    name = re.sub(r"^void ", "", name)
+    name = re.sub(r"^void ", "", name).replace("(anonymous namespace)::", "")
     return name.split("(")[0][:64]
 
 
