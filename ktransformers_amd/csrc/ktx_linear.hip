@@ -278,19 +278,24 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   if (p.d_bsz) bsz = min(max(*p.d_bsz, 0), p.T);
 
   // ---- the activation rows first (vmcnt retires in order and they are needed first): up to XPRE 16-byte pieces per
-  // thread go to registers now, the (rare) rest of a long multi-token block is fetched in the staging loops below
+  // thread go to registers now, the (rare) rest of a long multi-token block is fetched in the staging loops below.
+  // Round 3: these loads — and the norm weights of the same pieces — are UNCONDITIONAL (addresses clamped, values selected
+  // after the weight ring has been requested): with a load inside a conditional the compiler cannot count the younger loads
+  // and waited for the whole first ring (vmcnt(0)) before the RMSNorm, and the norm weights were fetched piece by piece behind
+  // the barrier, one exposed round trip each (scripts/lin_stamps.py: 2.5 us of the 4.6 us "stage" phase; 9-12 us inside the
+  // model graph on the slower boxes of the pool).
   constexpr int XPRE = 4;
   const int npiece = NKS * 16;   // 8-element pieces per token
   const int ntot = TP * npiece;
-  uint4 xpre[XPRE];
+  const int kpieces = p.Kx >> 3;
+  const bf16_t* nwp = p.norm_w ? p.norm_w : p.x;
+  uint4 xpre[XPRE], nwpre[XPRE];
 #pragma unroll
   for (int i = 0; i < XPRE; i++) {
-    const int idx = tid + i * 512;
-    xpre[i] = make_uint4(0, 0, 0, 0);
-    if (idx < ntot) {
-      const int tok = idx / npiece, col = idx - tok * npiece;
-      if (tok < bsz && col * 8 < p.Kx) xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + col * 8);
-    }
+    const int idx = min(tid + i * 512, ntot - 1);
+    const int tok = TP == 1 ? 0 : idx / npiece, col = min(idx - tok * npiece, kpieces - 1);
+    xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)min(tok, max(bsz, 1) - 1) * p.ldx + col * 8);
+    nwpre[i] = *reinterpret_cast<const uint4*>(nwp + col * 8);
   }
   auto piece = [&](int it, int idx) -> uint4 {   // piece `idx` of the block: register copy for the first XPRE rounds
     if (it < XPRE) return xpre[it < XPRE ? it : 0];
@@ -334,6 +339,13 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
       if (EXACT || ks0 + d < ks1) load_step(d, ks0 + d);
   }
 
+#pragma unroll
+  for (int i = 0; i < XPRE; i++) {   // pieces past the block / the row / the batch are zeros
+    const int idx = tid + i * 512;
+    const int tok = TP == 1 ? 0 : idx / npiece, col = idx - tok * npiece;
+    if (!(idx < ntot && tok < bsz && col * 8 < p.Kx)) xpre[i] = make_uint4(0, 0, 0, 0);
+  }
+
   // ---- stage the activations (every workgroup its own copy), group sums / fp8 quantisation on the way
   float rnorm[4] = {1.f, 1.f, 1.f, 1.f};
   auto sumsq_piece = [&](int idx, const uint4& v, float (&ss)[4]) {
@@ -368,10 +380,17 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
     }
     __syncthreads();
   }
-  auto stage_piece = [&](int idx, uint4 v) {
+  auto stage_piece = [&](int idx, uint4 v, int it = XPRE) {
     const int tok = idx / npiece, col = idx - tok * npiece;
-    if (p.norm_w && tok < bsz && col * 8 < p.Kx)
-      v = lin_norm8(v, tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3], p.norm_w + col * 8);
+    if (p.norm_w && tok < bsz && col * 8 < p.Kx) {
+      const float r = tok == 0 ? rnorm[0] : tok == 1 ? rnorm[1] : tok == 2 ? rnorm[2] : rnorm[3];
+      if (it < XPRE) {
+        const uint4 wv = nwpre[it < XPRE ? it : 0];
+        v = make_uint4(ktx_norm_pk(v.x, r, wv.x), ktx_norm_pk(v.y, r, wv.y), ktx_norm_pk(v.z, r, wv.z), ktx_norm_pk(v.w, r, wv.w));
+      } else {
+        v = lin_norm8(v, r, p.norm_w + col * 8);
+      }
+    }
     if constexpr (FMT == F_FP8) {
       float am = amax8_bf16(v);
 #pragma unroll
@@ -394,7 +413,7 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   // (the shuffles inside stage_piece need whole 16-lane groups: ntot is a multiple of 16 and idx advances by 512)
 #pragma unroll
   for (int i = 0; i < XPRE; i++)
-    if (tid + i * 512 < ntot) stage_piece(tid + i * 512, xpre[i]);
+    if (tid + i * 512 < ntot) stage_piece(tid + i * 512, xpre[i], i);
   for (int idx = tid + XPRE * 512; idx < ntot; idx += 512) stage_piece(idx, piece(XPRE, idx));
   LIN_STAMP(3);
   __syncthreads();
