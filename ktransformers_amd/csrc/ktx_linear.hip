@@ -1995,6 +1995,7 @@ extern "C" int ktx_linear_forward_fused_gate(ktx_linear_t h, const int32_t* d_bs
     ga.norm_w = (const bf16_t*)fusion->norm_weight; ga.norm_eps = fusion->norm_eps; ga.xn_out = (bf16_t*)d_xn_out;
     ga.granules = (h->cfg.device >= 0 && h->cfg.device < 64 && T <= KTX_GRAN_T) ? g_gate_granules[h->cfg.device] : nullptr;
     ga.tickets = ga.granules ? reinterpret_cast<int*>(ga.granules + (size_t)KTX_GRAN_T * KTX_GATE_MAX_E) : nullptr;
+    if (ktx_debug_get(21) == 1 && ktx_debug_get(19) == 0) ga.granules = nullptr;   // A/B: the round-2 store-ack hand-off in the router
     const int rc = linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion, nullptr, &ga);
     if (rc != KTX_LIN_NOT_FUSED) return rc;
   }

@@ -39,6 +39,7 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "lin: router as wavefront 7 of the all-CU gate|up kernel + selector workgroup": ({19: 2}, {}),
     "lin: round-2 router workgroups in front of the all-CU gate|up kernel": ({19: 3}, {}),
     "lin: two workgroups per CU": ({18: 2}, {}),
+    "gate: store-ack hand-off (no granules)": ({21: 1}, {}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}
