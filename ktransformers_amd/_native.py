@@ -16,7 +16,7 @@ LIB_PATH = os.path.join(_HERE, "lib", "libktx_hip.so")
 
 FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4, "GGUF": 5, "FP8_PERCHANNEL": 6}
 GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 14, 19
-GGML_BLOCK_BYTES = {12: 144, 14: 210, 19: 50}
+GGML_BLOCK_BYTES = {10: 84, 11: 110, 12: 144, 13: 176, 14: 210, 19: 50, 23: 136}   # Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ1_S, IQ4_XS
 MAT_GATE, MAT_UP, MAT_DOWN = 0, 1, 2
 
 
@@ -337,7 +337,7 @@ class MoEHandle:
         """Raw GGUF blocks (uint8 device tensors): gate/up [E, I, H/256*blk], down [E, H, I/256*blk]; ggml type ids."""
         for t, n, kdim, ty in ((gate, self.I, self.H, gate_type), (up, self.I, self.H, up_type), (down, self.H, self.I, down_type)):
             if ty not in GGML_BLOCK_BYTES:
-                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q4_K=12, Q6_K=14, IQ1_S=19)")
+                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q2_K=10, Q3_K=11, Q4_K=12, Q5_K=13, Q6_K=14, IQ1_S=19, IQ4_XS=23)")
             shape = (self.E, n, kdim // 256 * GGML_BLOCK_BYTES[ty])
             if t.dtype != torch.uint8 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
                 raise KtxError(f"load_gguf: expected contiguous uint8 {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")

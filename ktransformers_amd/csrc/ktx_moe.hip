@@ -2370,7 +2370,7 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
   KTX_REQUIRE(h->cfg.format == KTX_FMT_GGUF, "ktx_moe_load_gguf: handle was not created with KTX_FMT_GGUF");
   const int types[3] = {gate_type, up_type, down_type};
   for (int t : types)
-    KTX_REQUIRE(t == GG_Q4K || t == GG_Q6K || t == GG_IQ1S, "ktx_moe_load_gguf: supported ggml types are Q4_K (12), Q6_K (14) and IQ1_S (19)");
+    KTX_REQUIRE(gg_known(t), "ktx_moe_load_gguf: supported ggml types are Q2_K (10), Q3_K (11), Q4_K (12), Q5_K (13), Q6_K (14), IQ1_S (19) and IQ4_XS (23)");
   KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
@@ -2384,10 +2384,14 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
     const size_t src_stride = (size_t)Ns[m] * gg_src_row_bytes(types[m], Ks[m]);
     const int ntiles = (Ns[m] / 16) * (Ks[m] / 256);
     for (int e = 0; e < E; e++) {
-      if (types[m] == GG_Q4K)
-        hipLaunchKernelGGL(gg_pack_q4k_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
-      else if (types[m] == GG_IQ1S)
-        hipLaunchKernelGGL(gg_pack_iq1s_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
+      const uint8_t* sp = src[m] + e * src_stride;
+      uint8_t* dp = *dst[m] + e * h->gg_stride[m];
+      if (types[m] == GG_Q4K) hipLaunchKernelGGL(gg_pack_q4k_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_IQ1S) hipLaunchKernelGGL(gg_pack_iq1s_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_Q5K) hipLaunchKernelGGL(gg_pack_q5k_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_Q2K) hipLaunchKernelGGL(gg_pack_q23k_kernel<GG_Q2K>, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_Q3K) hipLaunchKernelGGL(gg_pack_q23k_kernel<GG_Q3K>, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_IQ4XS) hipLaunchKernelGGL(gg_pack_iq4xs_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
       else
         hipLaunchKernelGGL(gg_pack_q6k_kernel, dim3(ntiles), dim3(64), 0, 0, src[m] + e * src_stride, Ns[m], Ks[m], *dst[m] + e * h->gg_stride[m]);
     }
@@ -3188,7 +3192,7 @@ extern "C" int ktx_moe_combine(int qlen, int k, int hidden, const void* d_rows, 
 
 template <int WT, int MT, bool GATE_UP>
 static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
-  constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = WT == GG_Q6K ? 16 : 8;
+  constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = gg_nbs(WT);
   const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4 + (WT == GG_IQ1S ? 2048 * 8 : 0);
   hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
@@ -3200,6 +3204,19 @@ static int launch_gguf_mt(int mt, const GgGemmParams& p, int max_tiles, hipStrea
     case 1: return launch_gguf<WT, 1, GATE_UP>(p, max_tiles, st);
     case 2: return launch_gguf<WT, 2, GATE_UP>(p, max_tiles, st);
     default: return launch_gguf<WT, 4, GATE_UP>(p, max_tiles, st);
+  }
+}
+
+template <bool GATE_UP>
+static int launch_gguf_type(int type, int mt, const GgGemmParams& p, int max_tiles, hipStream_t st) {
+  switch (type) {
+    case GG_Q2K: return launch_gguf_mt<GG_Q2K, GATE_UP>(mt, p, max_tiles, st);
+    case GG_Q3K: return launch_gguf_mt<GG_Q3K, GATE_UP>(mt, p, max_tiles, st);
+    case GG_Q4K: return launch_gguf_mt<GG_Q4K, GATE_UP>(mt, p, max_tiles, st);
+    case GG_Q5K: return launch_gguf_mt<GG_Q5K, GATE_UP>(mt, p, max_tiles, st);
+    case GG_Q6K: return launch_gguf_mt<GG_Q6K, GATE_UP>(mt, p, max_tiles, st);
+    case GG_IQ4XS: return launch_gguf_mt<GG_IQ4XS, GATE_UP>(mt, p, max_tiles, st);
+    default: return launch_gguf_mt<GG_IQ1S, GATE_UP>(mt, p, max_tiles, st);
   }
 }
 
@@ -3218,8 +3235,8 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   {
     const int tg = h->gg_type[0], td = h->gg_type[2];
     const int nkb1 = H / 256, nkb2 = I / 256;
-    const size_t lds_gu = (size_t)H + (size_t)nkb1 * ((tg == GG_Q6K ? 16 : 8) + 1) * 4 + 8 + (tg == GG_IQ1S ? 2048 * 8 : 0);
-    const size_t lds_dn = (size_t)k * I + (size_t)k * nkb2 * ((td == GG_Q6K ? 16 : 8) + 1) * 4 + (size_t)k * (16 + 2) * 4 + 8 +
+    const size_t lds_gu = (size_t)H + (size_t)nkb1 * (gg_nbs(tg) + 1) * 4 + 8 + (tg == GG_IQ1S ? 2048 * 8 : 0);
+    const size_t lds_dn = (size_t)k * I + (size_t)k * nkb2 * (gg_nbs(td) + 1) * 4 + (size_t)k * (16 + 2) * 4 + 8 +
                           (td == GG_IQ1S ? 2048 * 8 : 0);
     if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && lds_gu <= 64 * 1024 && lds_dn <= 64 * 1024 && !g_force_generic) {
       GgDecParams dp;
@@ -3232,10 +3249,10 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
       const dim3 g1((I / 16 + 3) / 4, npairs), g2(H / 16, qlen);
       int d1 = nkb1 % 4 == 0 ? 4 : nkb1 % 2 == 0 ? 2 : 1;
       const int d2 = nkb2 % 4 == 0 ? 4 : nkb2 % 2 == 0 ? 2 : 1;
-      if (tg == GG_Q6K && d1 == 4) d1 = 2;   // a 4-deep ring of gate AND up Q6_K tiles (3 planes each) does not fit the registers
+      if ((tg == GG_Q6K || tg == GG_Q5K) && d1 == 4) d1 = 2;   // a 4-deep ring of gate AND up Q6_K / Q5_K tiles (3 planes each) does not fit the registers
       const int only = g_dbg[2];
       const bool ks2 = nkb1 % 2 == 0 && g_dbg[20] != 1;
-      auto tname = [](int t) { return t == GG_Q4K ? "Q4_K" : t == GG_Q6K ? "Q6_K" : "IQ1_S"; };
+      auto tname = [](int t) { return gg_type_name(t); };
 #define KTX_GG_GU(WT)                                                                                                \
       do {                                                                                                           \
         if (ks2) {   /* 4 strips x 2 k-slices per workgroup: two wavefronts per SIMD (dev knob 20 = 1: one) */       \
@@ -3243,7 +3260,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
           else hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 1, 4, 2>), g1, dim3(512), lds_gu + 2 * 4 * 2 * 16 * 4, st, dp); \
           break;                                                                                                     \
         }                                                                                                            \
-        if constexpr (WT != GG_Q6K) {   /* (never chosen for Q6_K, see d1 above: not instantiated either) */         \
+        if constexpr (WT != GG_Q6K && WT != GG_Q5K) {   /* (never chosen for these, see d1 above: not instantiated either) */ \
           if (d1 == 4) { hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 4, 4>), g1, dim3(256), lds_gu, st, dp); break; } \
         }                                                                                                            \
         if (d1 >= 2) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4>), g1, dim3(256), lds_gu, st, dp); \
@@ -3258,13 +3275,29 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
       if (only != 2) {
         KTX_TIMED(st, (double)npairs * (h->gg_stride[0] + h->gg_stride[1] + I * 4.0) + qlen * H * 2.0,
                   "moe_dec_gguf_gateup_kernel<%s> T=%d k=%d H=%d I=%d", tname(tg), qlen, k, H, I);
-        if (tg == GG_Q4K) KTX_GG_GU(GG_Q4K); else if (tg == GG_Q6K) KTX_GG_GU(GG_Q6K); else KTX_GG_GU(GG_IQ1S);
+        switch (tg) {
+          case GG_Q2K: KTX_GG_GU(GG_Q2K); break;
+          case GG_Q3K: KTX_GG_GU(GG_Q3K); break;
+          case GG_Q4K: KTX_GG_GU(GG_Q4K); break;
+          case GG_Q5K: KTX_GG_GU(GG_Q5K); break;
+          case GG_Q6K: KTX_GG_GU(GG_Q6K); break;
+          case GG_IQ4XS: KTX_GG_GU(GG_IQ4XS); break;
+          default: KTX_GG_GU(GG_IQ1S); break;
+        }
       }
       KTX_HIP(hipGetLastError());
       if (only != 1) {
         KTX_TIMED(st, (double)npairs * (h->gg_stride[2] + I * 4.0) + qlen * H * 2.0,
                   "moe_dec_gguf_down_kernel<%s> T=%d k=%d H=%d I=%d", tname(td), qlen, k, H, I);
-        if (td == GG_Q4K) KTX_GG_DN(GG_Q4K); else if (td == GG_Q6K) KTX_GG_DN(GG_Q6K); else KTX_GG_DN(GG_IQ1S);
+        switch (td) {
+          case GG_Q2K: KTX_GG_DN(GG_Q2K); break;
+          case GG_Q3K: KTX_GG_DN(GG_Q3K); break;
+          case GG_Q4K: KTX_GG_DN(GG_Q4K); break;
+          case GG_Q5K: KTX_GG_DN(GG_Q5K); break;
+          case GG_Q6K: KTX_GG_DN(GG_Q6K); break;
+          case GG_IQ4XS: KTX_GG_DN(GG_IQ4XS); break;
+          default: KTX_GG_DN(GG_IQ1S); break;
+        }
       }
       KTX_HIP(hipGetLastError());
 #undef KTX_GG_GU
@@ -3291,9 +3324,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   int rc;
   {
     ProfScope ps(1, st);
-    rc = h->gg_type[0] == GG_Q4K ? launch_gguf_mt<GG_Q4K, true>(mt, g1, max_tiles, st)
-         : h->gg_type[0] == GG_Q6K ? launch_gguf_mt<GG_Q6K, true>(mt, g1, max_tiles, st)
-                                   : launch_gguf_mt<GG_IQ1S, true>(mt, g1, max_tiles, st);
+    rc = launch_gguf_type<true>(h->gg_type[0], mt, g1, max_tiles, st);
   }
   if (rc) return rc;
   {
@@ -3308,9 +3339,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   g2.counters = ws->counters; g2.out = reinterpret_cast<float*>(ws->dn_buf);
   {
     ProfScope ps(3, st);
-    rc = h->gg_type[2] == GG_Q4K ? launch_gguf_mt<GG_Q4K, false>(mt, g2, max_tiles, st)
-         : h->gg_type[2] == GG_Q6K ? launch_gguf_mt<GG_Q6K, false>(mt, g2, max_tiles, st)
-                                   : launch_gguf_mt<GG_IQ1S, false>(mt, g2, max_tiles, st);
+    rc = launch_gguf_type<false>(h->gg_type[2], mt, g2, max_tiles, st);
   }
   if (rc) return rc;
   CombineParams cp{};

@@ -126,7 +126,7 @@ class KExpertsHIP(KExpertsBase):
             from ktransformers_amd._native import GGML_BLOCK_BYTES
             types = {n: int(w[f"{n}_type"]) for n in ("gate", "up", "down")}
             if not all(t in GGML_BLOCK_BYTES for t in types.values()):
-                # a ggml type the expert kernels do not read natively (they read Q4_K, Q6_K, IQ1_S): the blocks are
+                # a ggml type the expert kernels do not read natively (they read Q2_K..Q6_K, IQ1_S, IQ4_XS; not Q4_0/Q5_0/Q8_0): the blocks are
                 # de-quantised on the host with the loader's (reference-pinned) codecs and served as BF16 experts — exact
                 # weights, un-quantised activations; NOT the llamafile arithmetic (Q8_K activations), and 2 bytes per weight.
                 import warnings

@@ -13,6 +13,7 @@ ap.add_argument("--experts", type=int, default=32)
 ap.add_argument("--layers", type=int, default=6)
 ap.add_argument("--T", type=int, default=1)
 ap.add_argument("--json", default="")
+ap.add_argument("--formats", default="", help="comma-separated substrings of format names (default: all)")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 E, k, H, I, L, T = args.experts, 8, 7168, 2048, args.layers, args.T
@@ -59,6 +60,8 @@ def build(fmt):
 
 out = {}
 for fmt in ("AMXINT4", "AMXINT8", "RAWINT4", "FP8", "BF16", "GGUF q4_k_m", "GGUF IQ1_S"):
+    if args.formats and not any(f in fmt for f in args.formats.split(",")):
+        continue
     try:
         hs = build(fmt)
     except Exception as e:

@@ -34,27 +34,29 @@ def random_iq1s(E, N, K, rng):
     return b.reshape(E, N, -1)
 
 
+Q2, Q3, Q5, IQ4 = 10, 11, 13, 23          # round 3: native kernels for Q2_K, Q3_K, Q5_K, IQ4_XS as well
+BLOCK_BYTES = {Q2: 84, Q3: 110, Q4: 144, Q5: 176, Q6: 210, IQ1: 50, IQ4: 136}
+F16_FIELDS = {Q2: (80, 82), Q3: (108,), Q4: (0, 2), Q5: (0, 2), Q6: (208,), IQ1: (0,), IQ4: (0,)}     # byte offsets of the fp16 super-scales
+F16_RANGE = {Q2: (1e-3, 4e-3), Q3: (1e-4, 4e-4), Q4: (1e-4, 2e-4), Q5: (1e-4, 2e-4), Q6: (1e-5, 2e-5), IQ1: (1e-3, 4e-3), IQ4: (2e-5, 4e-5)}
+
+
 def random_kquant(t, E, N, K, rng):
-    """Random but valid Q4_K / Q6_K blocks (every byte pattern is a legal block; the fp16 super-scales are kept small) for
-    shapes where quantising real matrices in numpy would take minutes."""
-    if t == IQ1:
-        return random_iq1s(E, N, K, rng)
+    """Random but valid blocks of any native type (every byte pattern is a legal block; the fp16 super-scales are kept small and
+    positive) for shapes where quantising real matrices in numpy would take minutes, and for the types the oracle has no
+    quantiser for (Q2_K, Q3_K, IQ4_XS)."""
     nb = K // 256
-    if t == Q4:        # fp16 d | fp16 dmin | scales[12] | qs[128]
-        b = rng.integers(0, 256, (E, N, nb, 144), dtype=np.uint8)
-        dm = (rng.random((E, N, nb, 2)).astype(np.float16) * np.float16(2e-4) + np.float16(1e-4))
-        b[..., 0:4] = dm.view(np.uint8).reshape(E, N, nb, 4)
-    else:              # ql[128] | qh[64] | int8 scales[16] | fp16 d
-        b = rng.integers(0, 256, (E, N, nb, 210), dtype=np.uint8)
-        d = (rng.random((E, N, nb)).astype(np.float16) * np.float16(2e-5) + np.float16(1e-5))
-        b[..., 208:210] = d.view(np.uint8).reshape(E, N, nb, 2)
+    b = rng.integers(0, 256, (E, N, nb, BLOCK_BYTES[t]), dtype=np.uint8)
+    lo, span = F16_RANGE[t]
+    for c in F16_FIELDS[t]:
+        d = (rng.random((E, N, nb)).astype(np.float16) * np.float16(span) + np.float16(lo))
+        b[..., c:c + 2] = d.view(np.uint8).reshape(E, N, nb, 2)
     return b.reshape(E, N, -1)
 
 
 def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None, random_blocks=False):
     from ktransformers_amd import _native as n
     o = GgufOracle()
-    if random_blocks:
+    if random_blocks or any(t not in QUANT for t in types):
         r0 = np.random.default_rng(seed)
         gate, up, down = random_kquant(types[0], E, I, H, r0), random_kquant(types[1], E, I, H, r0), random_kquant(types[2], E, H, I, r0)
     else:
@@ -101,6 +103,24 @@ def run_case(E, k, H, I, T, types, seed=0, invalid=False, max_len=None, random_b
 @pytest.mark.parametrize("T", [1, 3, 19])
 def test_small(types, T):
     run_case(4, 2, 256, 512, T, types, seed=T)
+
+
+@pytest.mark.parametrize("types", [(Q5, Q5, Q6), (Q5, Q5, Q5), (Q2, Q2, Q3), (Q3, Q3, Q2), (Q2, Q2, Q2), (Q3, Q3, Q3), (IQ4, IQ4, IQ4),
+                                   (IQ4, IQ4, Q5), (Q4, Q4, Q2)])
+@pytest.mark.parametrize("T", [1, 3, 19])
+def test_small_round3_types(types, T):
+    """Q5_K (real quantiser + the q5_k_m mix), Q2_K / Q3_K / IQ4_XS (random valid blocks) against oracle/ktx_oracle_gguf.c's
+    restatements (each pinned against the reference's iqk kernels in tests/test_gguf_ref_pin_cpu.py): decode kernels (T = 1, 3),
+    grouped GEMM tiles (T = 19), every type on both sides of the activation re-quantisation."""
+    run_case(4, 2, 256, 512, T, types, seed=40 + T)
+
+
+@pytest.mark.parametrize("types", [(Q5, Q5, Q6), (Q2, Q2, Q3), (IQ4, IQ4, IQ4)])
+def test_round3_types_v3_expert_shape(types):
+    """The DeepSeek-V3 / R1 expert shape (7168 x 2048, the decode kernels' 2-k-slice variants and deep rings) for the type mixes
+    of the q5_k_m, q2_k and iq4_xs GGUF files; random valid blocks."""
+    run_case(4, 2, 7168, 2048, 1, types, seed=61, random_blocks=True)
+    run_case(4, 2, 7168, 2048, 5, types, seed=62, random_blocks=True)
 
 
 def test_invalid_ids_and_ragged_tiles():

@@ -76,3 +76,13 @@ def test_every_type_the_reference_loader_reads_dequantises_bit_for_bit(t):
     assert blocks.shape[1] == GGML_QUANT_SIZES[t][1] and want.shape[1] == GGML_QUANT_SIZES[t][0]
     got = _dequant(t, blocks.reshape(-1)).reshape(want.shape)
     assert got.dtype == np.float32 and np.array_equal(got.view(np.uint32), want.view(np.uint32))
+
+
+def test_native_expert_types_use_the_loaders_block_sizes():
+    """The ggml types the expert kernels read natively (Q2_K..Q6_K, IQ1_S, IQ4_XS; csrc/ktx_moe_gguf.inc) and the loader's table of
+    block sizes (custom_gguf.py:72-100) name the same bytes per 256-block; Q4_0 / Q5_0 / Q8_0 experts stay on the de-quantised path."""
+    from ktransformers_amd import _native
+    from ktransformers_amd.util.gguf_loader import GGML_QUANT_SIZES, GGML_TYPES
+    assert set(_native.GGML_BLOCK_BYTES) == {GGML_TYPES[n] for n in ("Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_XS")} | {19}
+    for t, nbytes in _native.GGML_BLOCK_BYTES.items():
+        assert GGML_QUANT_SIZES[t] == (256, nbytes)
