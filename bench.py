@@ -708,6 +708,22 @@ def pmc_traffic(args, label, timeout_s=300):
 # ---------------------------------------------------------------------------------------------------------------------
 # CPU baseline: the reference's own kernels on the host cores
 # ---------------------------------------------------------------------------------------------------------------------
+def host_numa_nodes():
+    """NUMA nodes of the host that hold CPUs (sysfs); 1 if it cannot be read."""
+    n = 0
+    try:
+        for d in os.listdir("/sys/devices/system/node"):
+            if d.startswith("node") and d[4:].isdigit():
+                try:
+                    if open(f"/sys/devices/system/node/{d}/cpulist").read().strip():
+                        n += 1
+                except OSError:
+                    pass
+    except OSError:
+        pass
+    return max(n, 1)
+
+
 def cpu_baseline(wl, budget_s=20.0):
     """The reference's own AVX512 MoE kernels (oracle/_ref) on this box's host cores, same expert shape, bs=1 decode.
     Bounded sample: 3 distinct layers' weights (>> the host's L3), forward rotating over them for ~budget_s.  The expert
@@ -726,7 +742,12 @@ def cpu_baseline(wl, budget_s=20.0):
     Lm = wl["full_layers"] - wl["dense"]
     ncpu = os.cpu_count() or 8
     threads = max(1, min(64, ncpu // 2))  # reference guidance: physical cores only
-    ref = Reference(threads=threads, subpools=1)
+    # the reference's NUMA tensor parallelism (one sub-pool per NUMA node, the intermediate dimension split across them):
+    # sub-pools = the host's NUMA nodes that hold CPUs.  The oracle build links the image's libnuma (the reference's own
+    # numa_run_on_node / set_mempolicy calls place each sub-pool); its hwloc core pinning is a no-op shim (no hwloc here).
+    numa_nodes = host_numa_nodes()
+    subpools = numa_nodes if (numa_nodes > 1 and threads % numa_nodes == 0 and I % (numa_nodes * 32) == 0) else 1
+    ref = Reference(threads=threads // subpools, subpools=subpools)
     rng = np.random.default_rng(0)
     nlayers = 3
     moes = []
@@ -751,10 +772,12 @@ def cpu_baseline(wl, budget_s=20.0):
             n += 1
     dt = time.perf_counter() - t0
     t_layer = dt / n
-    return {"value": round(1.0 / (Lm * t_layer), 3), "unit": "tok/s", "cores": threads, "kind": "reference",
+    return {"value": round(1.0 / (Lm * t_layer), 3), "unit": "tok/s", "cores": threads, "kind": "reference", "numa_nodes": numa_nodes,
+            "subpools": subpools,
             "us_per_layer": round(t_layer * 1e6, 1), "covers": "routed experts only (the part the reference runs on the CPU)",
             "sample": f"{n} bs=1 forwards of TP_MOE<AMX_MOE_TP<GemmKernel224Int4>> (AVX512-VNNI path, no AMX on this host), "
-                      f"H={H} I={I} k={k}, rotating over {nlayers} distinct layers of {E} experts, {threads} threads, 1 subpool; "
+                      f"H={H} I={I} k={k}, rotating over {nlayers} distinct layers of {E} experts, {threads} threads in {subpools} sub-pool(s) "
+                      f"(host NUMA nodes with CPUs: {numa_nodes}; sub-pools placed by the reference's libnuma calls, hwloc core pinning shimmed out); "
                       f"tok/s = 1/({Lm} MoE layers x t_layer) = the routed experts of the full-depth model alone; "
                       f"weight quant took {t_load:.1f}s (untimed)"}
 

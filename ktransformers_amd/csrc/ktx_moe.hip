@@ -25,6 +25,7 @@
 // Activations are int8 [rows][K]; a chunk of KC = SPC*128 k is staged in LDS as [mt][col=KC/16][tok=16][16 B] so a
 // B-fragment ds_read_b128 (lane = kc*16+tok) is bank-conflict free, and staging stores are 1 KiB contiguous per wave.
 #include <hip/hip_runtime.h>
+#include <type_traits>
 
 #include <algorithm>
 #include <cstdio>
@@ -1790,17 +1791,21 @@ __global__ __launch_bounds__(256) void moe_rawint4_gemm_kernel(RawGemmParams p) 
   }
   const int8_t* xa = xq + j * KP + 4 * L;   // A operand: lane (L, i = j) supplies token i's 4 int8 of AVX lane L
 
-  uint4 wcur[NMAT][4], scur[NMAT][4], wnxt[NMAT][4], snxt[NMAT][4];
-  auto load_step = [&](uint4(&w)[NMAT][4], uint4(&sc)[NMAT][4], int st) {
+  // Double buffer over (512-k step, matrix) pairs, ONE matrix per buffer: gate and up of a step take turns (the activation
+  // fragments are re-read from LDS for the second).  Round 2 kept both matrices of the current AND the next step in
+  // registers (128 VGPRs of operands beside 32 accumulators): the 4-token gate|up variant spilled 100 B per lane to scratch.
+  // Every accumulator still receives its blocks in the same order: results unchanged.
+  uint4 wcur[4], scur[4], wnxt[4], snxt[4];
+  auto load_step = [&](auto mc, uint4(&w)[4], uint4(&sc)[4], int st) {
+    constexpr int m = decltype(mc)::value;
 #pragma unroll
-    for (int m = 0; m < NMAT; m++)
-#pragma unroll
-      for (int rg = 0; rg < 4; rg++) {
-        w[m][rg] = *reinterpret_cast<const uint4*>(wb[m] + ((size_t)rg * NS + st) * 1024);
-        sc[m][rg] = *reinterpret_cast<const uint4*>(sb[m] + ((size_t)rg * NS + st) * 64);
-      }
+    for (int rg = 0; rg < 4; rg++) {
+      w[rg] = *reinterpret_cast<const uint4*>(wb[m] + ((size_t)rg * NS + st) * 1024);
+      sc[rg] = *reinterpret_cast<const uint4*>(sb[m] + ((size_t)rg * NS + st) * 64);
+    }
   };
-  auto compute_step = [&](uint4(&w)[NMAT][4], uint4(&sc)[NMAT][4], int st) {
+  auto compute_step = [&](auto mc, uint4(&w)[4], uint4(&sc)[4], int st) {
+    constexpr int m = decltype(mc)::value;
 #pragma unroll
     for (int kb8 = 0; kb8 < 8; kb8++) {
       const int kb = st * 8 + kb8;
@@ -1808,27 +1813,35 @@ __global__ __launch_bounds__(256) void moe_rawint4_gemm_kernel(RawGemmParams p) 
       const float4 as4 = *reinterpret_cast<const float4*>(as_l + (2 * kb + hsel) * 4);
       const float asv[4] = {as4.x, as4.y, as4.z, as4.w};
 #pragma unroll
-      for (int m = 0; m < NMAT; m++)
+      for (int rg = 0; rg < 4; rg++) {
+        const uint32_t P = kb8 < 2 ? w[rg].x : kb8 < 4 ? w[rg].y : kb8 < 6 ? w[rg].z : w[rg].w;
+        const int b_op = (kb8 & 1) ? (int)(P & 0xF0F0F0F0u) : (int)((P << 4) & 0xF0F0F0F0u);
+        const uint32_t S = kb8 < 2 ? sc[rg].x : kb8 < 4 ? sc[rg].y : kb8 < 6 ? sc[rg].z : sc[rg].w;
+        const float bs = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
+        const v4i d = __builtin_amdgcn_mfma_i32_4x4x4i8(a_op, b_op, v4i{0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
-        for (int rg = 0; rg < 4; rg++) {
-          const uint32_t P = kb8 < 2 ? w[m][rg].x : kb8 < 4 ? w[m][rg].y : kb8 < 6 ? w[m][rg].z : w[m][rg].w;
-          const int b_op = (kb8 & 1) ? (int)(P & 0xF0F0F0F0u) : (int)((P << 4) & 0xF0F0F0F0u);
-          const uint32_t S = kb8 < 2 ? sc[m][rg].x : kb8 < 4 ? sc[m][rg].y : kb8 < 6 ? sc[m][rg].z : sc[m][rg].w;
-          const float bs = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
-          const v4i d = __builtin_amdgcn_mfma_i32_4x4x4i8(a_op, b_op, v4i{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-          for (int r = 0; r < NT; r++) acc[m][rg][r] = fmaf(asv[r] * bs, (float)d[r], acc[m][rg][r]);
-        }
+        for (int r = 0; r < NT; r++) acc[m][rg][r] = fmaf(asv[r] * bs, (float)d[r], acc[m][rg][r]);
+      }
     }
   };
-
-  load_step(wcur, scur, 0);
-  for (int st = 0; st < NS; st += 2) {
-    if (st + 1 < NS) load_step(wnxt, snxt, st + 1);
-    compute_step(wcur, scur, st);
-    if (st + 1 < NS) {
-      if (st + 2 < NS) load_step(wcur, scur, st + 2);
-      compute_step(wnxt, snxt, st + 1);
+  using M0 = std::integral_constant<int, 0>;
+  using M1 = std::integral_constant<int, NMAT - 1>;
+  load_step(M0{}, wcur, scur, 0);
+  if constexpr (GATE_UP) {
+    for (int st = 0; st < NS; st++) {
+      load_step(M1{}, wnxt, snxt, st);
+      compute_step(M0{}, wcur, scur, st);
+      if (st + 1 < NS) load_step(M0{}, wcur, scur, st + 1);
+      compute_step(M1{}, wnxt, snxt, st);
+    }
+  } else {
+    for (int st = 0; st < NS; st += 2) {
+      if (st + 1 < NS) load_step(M0{}, wnxt, snxt, st + 1);
+      compute_step(M0{}, wcur, scur, st);
+      if (st + 1 < NS) {
+        if (st + 2 < NS) load_step(M0{}, wcur, scur, st + 2);
+        compute_step(M0{}, wnxt, snxt, st + 1);
+      }
     }
   }
 
