@@ -50,7 +50,9 @@ class RotaryEmbeddingV3(BaseInjectedModule):
         object.__setattr__(self, "_mscale", 1.0)
 
     def load(self):
-        dim = self.config.qk_rope_head_dim
+        # MLA models rotate the 64-wide rope part; llama-style models (Mixtral) the whole head (the replaced module's `dim`)
+        dim = getattr(self.config, "qk_rope_head_dim", None) or getattr(self.orig_module, "dim", None) \
+            or self.config.hidden_size // self.config.num_attention_heads
         inv = 1.0 / (self.config.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.float32, device=self.device) / dim))
         object.__setattr__(self, "inv_freq", inv)
 

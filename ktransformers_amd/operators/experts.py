@@ -80,7 +80,7 @@ class KExpertsHIP(KExpertsBase):
         super().__init__(key, gguf_loader, config, orig_module, device, **kwargs)
         self.n_routed_experts = n_routed_experts
         self.out_device = out_device
-        backend = kwargs.get("backend", "AMXInt4")
+        backend = kwargs.get("backend", "llamafile")      # the reference's default (experts.py:167): GGUF blocks, llamafile arithmetic
         if backend not in _BACKEND_TO_METHOD:
             raise ValueError(f"KExpertsHIP: unsupported backend {backend!r} (have {sorted(_BACKEND_TO_METHOD)})")
         self.method = _BACKEND_TO_METHOD[backend]
@@ -122,6 +122,11 @@ class KExpertsHIP(KExpertsBase):
             # a "llamafile" rule over a bf16 (safetensors) weight source: the reference would reject it; quantise online
             # to the int4 format instead of failing, like its AMX backends do for bf16 sources.
             method = "AMXINT4"
+        elif method != "GGUF" and "gate_type" in w and int(w["gate_type"]) not in (0, 1, 30):
+            # raw quantised ggml blocks under an online-quantising backend: the reference's AMX backends insist on a BF16
+            # source too (experts.py:226-228, 246-248)
+            raise ValueError(f"{self.key}: backend {self.method} quantises bf16 weights online, but the loader holds ggml type "
+                             f"{int(w['gate_type'])} blocks; use backend 'llamafile' for GGUF k-quant experts")
         elif method == "GGUF":
             from ktransformers_amd._native import GGML_BLOCK_BYTES
             types = {n: int(w[f"{n}_type"]) for n in ("gate", "up", "down")}

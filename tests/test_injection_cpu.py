@@ -264,3 +264,43 @@ def test_dict_and_safetensor_loaders(tmp_path):
         with pytest.raises(ValueError, match="No experts found"):
             ld.load_experts("nope")
         assert ld.has_tensor("L.mlp.gate.weight") and not ld.has_tensor("zzz")
+
+
+def _mixtral_skeleton():
+    from ktransformers_amd.models.modeling_mixtral import MixtralForCausalLM, make_mixtral_config
+    cfg = make_mixtral_config(vocab_size=64, hidden_size=256, intermediate_size=512, num_hidden_layers=2, num_attention_heads=4,
+                              num_key_value_heads=2, max_position_embeddings=512, rope_theta=10000.0)
+    with torch.device("meta"):
+        return cfg, MixtralForCausalLM(cfg)
+
+
+@pytest.mark.parametrize("rule_file", [os.path.join(REF_RULES, "Mixtral.yaml"),
+                                       os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "ktransformers_amd",
+                                                    "optimize", "optimize_rules", "Mixtral-8x7B.yaml")])
+def test_mixtral_rule_files_inject(rule_file):
+    """BASELINE config C1's model: the reference's own Mixtral.yaml (read where it lies) and this package's rule file inject into
+    the Mixtral skeleton — rotary embedding, every linear of the layers (the router's nn.Linear included, as in the reference),
+    lm_head, the sparse MoE block and its experts; the attention core and the norms stay the skeleton's."""
+    import contextlib
+    import io
+
+    from ktransformers_amd.models.modeling_mixtral import MixtralAttention, MixtralRMSNorm
+    from ktransformers_amd.operators.experts import KExpertsHIP, KMistralSparseMoEBlock
+    from ktransformers_amd.operators.linear import KTransformersLinear
+    from ktransformers_amd.operators.RoPE import RotaryEmbedding
+    if not os.path.exists(rule_file):
+        pytest.skip("needs the reference checkout (build container only)")
+    cfg, model = _mixtral_skeleton()
+    with contextlib.redirect_stdout(io.StringIO()):
+        optimize_and_load(model, rule_file, DictLoader({}), cfg, default_device="cuda:0", load=False)
+    layer = model.model.layers[1]
+    assert isinstance(layer.block_sparse_moe, KMistralSparseMoEBlock) and layer.block_sparse_moe.top_k == 2
+    ex = layer.block_sparse_moe.experts
+    assert isinstance(ex, KTransformersExperts) and isinstance(ex.generate_experts, KExpertsHIP)
+    assert ex.generate_experts.method == "GGUF" and ex.generate_experts.n_routed_experts == 8        # llamafile: the reference's default backend
+    assert isinstance(layer.block_sparse_moe.gate, KTransformersLinear)
+    assert isinstance(layer.self_attn, MixtralAttention) and isinstance(layer.self_attn.rotary_emb, RotaryEmbedding)
+    for n in ("q_proj", "k_proj", "v_proj", "o_proj"):
+        assert isinstance(getattr(layer.self_attn, n), KTransformersLinear)
+    assert isinstance(model.lm_head, KTransformersLinear) and isinstance(layer.input_layernorm, MixtralRMSNorm)
+    assert not isinstance(model.model.embed_tokens, KTransformersLinear)
