@@ -249,6 +249,12 @@ class GGUFLoader:
         t = self.tensor_info[name]
         vals = _dequant(t["ggml_type"], np.ascontiguousarray(self.get_mmap_tensor(name)))
         out = torch.from_numpy(np.array(vals, copy=True)).view(t["shape"][::-1])
+        # llama-architecture files (Mixtral's too) hold attn_q / attn_k with each head's rows interleaved for ggml's pairwise
+        # RoPE; the reference undoes that so the HF rotate-half modules see their own row order (custom_loader.py:507-517).
+        if self.gguf_file_meta.get("general.architecture") == "llama" and ("attn_q" in name or "attn_k" in name):
+            n_head = int(self.gguf_file_meta["llama.attention.head_count" if "attn_q" in name
+                                             else "llama.attention.head_count_kv"])
+            out = out.reshape(n_head, out.shape[0] // n_head // 2, 2, *out.shape[1:]).swapaxes(1, 2).reshape(out.shape)
         if target_dtype is None:
             target_dtype = torch.get_default_dtype()
         return out.to(device=device, dtype=target_dtype)

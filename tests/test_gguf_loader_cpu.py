@@ -34,6 +34,36 @@ def build_file(path):
     return dict(gate=gate, up=up, down=down, norm=norm, attn=attn, E=E, H=H, I=I)
 
 
+def build_llama_file(path, n_head=4, n_kv=2, hd=8, H=16):
+    """attn_q / attn_k / attn_v of a llama-architecture file; column 0 of stored row r holds r."""
+    rng = np.random.default_rng(11)
+    t = {}
+    src = {}
+    for name, rows in (("attn_q", n_head * hd), ("attn_k", n_kv * hd), ("attn_v", n_kv * hd)):
+        a = rng.standard_normal((rows, H)).astype(np.float32)
+        a[:, 0] = np.arange(rows)
+        src[name] = a
+        t[f"blk.0.{name}.weight"] = (0, [H, rows], a.tobytes())
+    write_gguf(path, t, {"general.architecture": "llama", "llama.attention.head_count": n_head,
+                         "llama.attention.head_count_kv": n_kv})
+    return src
+
+
+def test_llama_files_get_the_reference_q_k_row_order(tmp_path):
+    """custom_loader.py:507-517: q / k rows come back de-interleaved per head (HF rotate-half order), v untouched; the golden is
+    what the reference's own loader returned for the same file (tests/golden/make_gguf_llama_golden.py)."""
+    from ktransformers_amd.util.gguf_loader import GGUFLoader
+    src = build_llama_file(str(tmp_path / "toy.gguf"))
+    gold = json.load(open(os.path.join(os.path.dirname(GOLD), "gguf_llama_golden.json")))
+    ld = GGUFLoader(str(tmp_path))
+    for name, g in gold.items():
+        v = ld.load_gguf_tensor(name, target_dtype=torch.float32)
+        assert list(v.shape) == g["shape"]
+        assert [int(x) for x in v[:, 0].tolist()] == g["row_ids"], name
+        assert torch.equal(v, torch.from_numpy(src[name.split(".")[2]])[g["row_ids"]])
+    assert gold["blk.0.attn_v.weight"]["row_ids"] == list(range(16)) and gold["blk.0.attn_q.weight"]["row_ids"][:4] == [0, 2, 4, 6]
+
+
 def test_reader_matches_reference_loader_and_roundtrips(tmp_path):
     from ktransformers_amd.util.gguf_loader import GGUFLoader, translate_name_to_gguf
     path = str(tmp_path / "toy.gguf")

@@ -5,7 +5,11 @@ injected with this package's Mixtral rule file and compared with a restatement t
   * router: softmax -> top-2 -> renormalise -> bf16 weights (archive/ktransformers/operators/experts.py:1084-1090);
   * experts: oracle/ktx_oracle_gguf.c (LLAMA_MOE_TP::forward_one's arithmetic);
   * attention core, norms, residual stream: fp32 torch.
-bf16 pipeline against an fp32 one: logits norm-wise <= 3e-2; token-by-token decode reproduces the prompt pass."""
+bf16 pipeline against an fp32 one: logits norm-wise <= 3e-2; token-by-token decode reproduces the prompt pass.
+The prompt is margin-selected: a top-2 router fed by a bf16 residual stream flips whenever the 2nd and 3rd logits are closer than
+the stream's own rounding (the first draft's prompt had an exact bf16 tie and seven gaps below 0.02, and one flipped token moved
+the norm-wise error to 7e-2), so the prompt seed is one (found by scanning seeds on the CPU restatement) whose smallest 2nd-vs-3rd log-probability gap over all (layer,
+token) decisions is > 0.15 — the test re-derives the gap and asserts it, so the selection is visible, not silent."""
 import os
 
 import numpy as np
@@ -51,7 +55,13 @@ def write_file(path, w):
             t[name + ".weight"] = (ty, [k, n, E], a.tobytes())
         else:
             t[name + ".weight"] = (0, list(a.shape[::-1]), a.tobytes())
-    write_gguf(path, t, {"general.architecture": "llama", "llama.expert_count": E})
+    write_gguf(path, t, {"general.architecture": "llama", "llama.expert_count": E, "llama.attention.head_count": NH,
+                         "llama.attention.head_count_kv": NKV})
+
+
+def hf_rows(a, n_head):
+    """Row order the reference's loader gives attn_q / attn_k of a llama-architecture file (custom_loader.py:507-517)."""
+    return a.reshape(n_head, a.shape[0] // n_head // 2, 2, a.shape[1]).swapaxes(1, 2).reshape(a.shape)
 
 
 def q4(wf32):
@@ -61,7 +71,10 @@ def q4(wf32):
     return dequant_w4(q, s, 64, False).T.double()            # [N, K]
 
 
-def reference_logits(w, ids):
+PROMPT_SEED, PROMPT_LEN, MIN_GAP = 92, 12, 0.15
+
+
+def reference_logits(w, ids, gaps=None):
     o = GgufOracle()
     bf = lambda t: t.to(torch.bfloat16).float()  # noqa: E731
     T = len(ids)
@@ -73,6 +86,9 @@ def reference_logits(w, ids):
     rot = lambda x: torch.cat([-x[..., HD // 2:], x[..., :HD // 2]], -1)  # noqa: E731
     norm = lambda x, g: x * torch.rsqrt((x * x).mean(-1, keepdim=True) + EPS) * bf(torch.from_numpy(g))  # noqa: E731
     lin = lambda x, name: (x.double() @ q4(w[name]).T).float()  # noqa: E731
+    w = dict(w)
+    for l in range(L):
+        w[f"blk.{l}.attn_q"], w[f"blk.{l}.attn_k"] = hf_rows(w[f"blk.{l}.attn_q"], NH), hf_rows(w[f"blk.{l}.attn_k"], NKV)
     for l in range(L):
         x = norm(h, w[f"blk.{l}.attn_norm"])
         q = lin(x, f"blk.{l}.attn_q").view(T, NH, HD).transpose(0, 1)
@@ -87,6 +103,9 @@ def reference_logits(w, ids):
         x = norm(h, w[f"blk.{l}.ffn_norm"])
         logits = bf(lin(x, f"blk.{l}.ffn_gate_inp"))                                            # the linear returns bf16
         p, sel = torch.topk(logits.softmax(-1), K, dim=-1)
+        if gaps is not None:
+            top = torch.topk(logits.log_softmax(-1), K + 1, dim=-1).values
+            gaps.append(float((top[:, K - 1] - top[:, K]).min()))
         p = bf(p / p.sum(-1, keepdim=True))
         y = o.moe_forward(w[f"blk.{l}.ffn_gate_exps"], w[f"blk.{l}.ffn_up_exps"], w[f"blk.{l}.ffn_down_exps"],
                           (GGML_TYPE_Q4_K, GGML_TYPE_Q4_K, GGML_TYPE_Q6_K), E, H, I, sel.numpy().astype(np.int64),
@@ -123,8 +142,10 @@ def test_prompt_and_decode_match_the_restated_model(mixtral):
     from ktransformers_amd.util.generate import set_inference_mode
     from ktransformers_amd.util.utils import InferenceState
     model, cfg, w = mixtral
-    ids = np.random.default_rng(5).integers(0, V, 21)
-    ref = reference_logits(w, torch.from_numpy(ids))
+    ids = np.random.default_rng(PROMPT_SEED).integers(0, V, PROMPT_LEN)
+    gaps = []
+    ref = reference_logits(w, torch.from_numpy(ids), gaps)
+    assert min(gaps) > MIN_GAP, gaps                        # every routing decision of the prompt is outside bf16 noise
     dev = torch.device("cuda", 0)
     x = torch.from_numpy(ids).to(dev)[None]
     pos = torch.arange(len(ids), device=dev)[None]
@@ -135,7 +156,8 @@ def test_prompt_and_decode_match_the_restated_model(mixtral):
     with torch.no_grad():
         logits = model(x, pos, cache, pos[0])[0].float().cpu()
     rel = float((logits - ref).norm() / ref.norm())
-    assert rel < 3e-2, rel
+    per_token = ((logits - ref).norm(dim=-1) / ref.norm(dim=-1)).tolist()
+    assert rel < 3e-2, (rel, per_token)
     set_inference_mode(model, InferenceState.GENERATE)
     cache = MixtralKVCache(cfg, 64, dev)
     outs = []
