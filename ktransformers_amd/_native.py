@@ -43,6 +43,13 @@ class _LinearFusion(C.Structure):
                 ("add2", C.c_void_p), ("add2_ld", C.c_int64), ("x_ld", C.c_int64), ("y_ld", C.c_int64), ("glu", C.c_int32)]
 
 
+class _GemmArgs(C.Structure):
+    _fields_ = [("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32), ("batch", C.c_int32),
+                ("A", C.c_void_p), ("lda", C.c_int64), ("a_bs", C.c_int64), ("B", C.c_void_p), ("ldb", C.c_int64), ("b_bs", C.c_int64),
+                ("Y", C.c_void_p), ("ldy", C.c_int64), ("y_bs", C.c_int64), ("bias", C.c_void_p), ("out_f32", C.c_int32),
+                ("variant", C.c_int32)]
+
+
 class _MoeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
@@ -146,6 +153,8 @@ def _load() -> C.CDLL:
     lib.ktx_debug_get.argtypes = [C.c_int]
     lib.ktx_timing_enable.argtypes = [C.c_int]
     lib.ktx_timing_collect.argtypes = [C.c_char_p, C.c_size_t, C.POINTER(C.c_size_t)]
+    lib.ktx_gemm_bf16_nt.argtypes = [C.POINTER(_GemmArgs), C.c_void_p]
+    lib.ktx_split_f32_bf16x3.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.ktx_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
     return lib
 
@@ -159,7 +168,7 @@ STREAM_CALLS = frozenset((
     "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
     "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_mla_prefill", "ktx_linear_forward",
     "ktx_linear_forward_batched", "ktx_linear_forward_batched_prep", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
-    "ktx_mla_prep", "ktx_argmax"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
+    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
 TRACE: list | None = None
 HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
 
@@ -601,7 +610,8 @@ class LinearHandle:
         self._bias_t = None if bias is None else self._chk(bias, torch.bfloat16, (self.N,), "bias")
         return self._bias_t
 
-    # ---- prompt-sized W4 calls: de-quantise once (Marlin's rounding), then a plain library GEMM ------------------------------
+    # ---- prompt-sized W4 calls: de-quantise once (Marlin's rounding), then the library's own BF16 GEMM (csrc/ktx_gemm.hip;
+    # KTX_VENDOR_GEMM=1 sends the product to torch's F.linear instead — the A/B switch of scripts/gemm_bench.py) ------------
     PROMPT_MIN_T = 512          # below this the hand-written W4 GEMM (no scratch pass) is faster
     _DEQ_SCRATCH: dict = {}
 
@@ -620,7 +630,10 @@ class LinearHandle:
         if buf is None or buf.numel() < need:
             buf = LinearHandle._DEQ_SCRATCH[self.device] = torch.empty(need, dtype=torch.bfloat16, device=self.device)
         w = self.dequant_bf16(buf[:need].view(self.N, self.K))
-        y = torch.nn.functional.linear(x2, w, getattr(self, "_bias_t", None))
+        if os.environ.get("KTX_VENDOR_GEMM"):
+            y = torch.nn.functional.linear(x2, w, getattr(self, "_bias_t", None))
+        else:
+            y = gemm_bf16_nt(x2, w, bias=getattr(self, "_bias_t", None))
         if glu:   # rows are interleaved per 16-row strip as [8 gate | 8 up]
             T = y.shape[0]
             y = silu_mul(y.view(T, self.N // 16, 2, 8).permute(0, 2, 1, 3).reshape(T, self.N))
@@ -817,7 +830,7 @@ def linear_force_gemm(on: bool) -> None:
 class GateHandle:
     """Router parameters of one MoE layer + the two-launch HIP router (include/ktx_gate.h)."""
 
-    LOGITS_HIP_MAX_T = 64  # above this the fp32 logits GEMM goes to the BLAS library (a plain library GEMM)
+    LOGITS_HIP_MAX_T = 64  # above this the logits come from the prompt-sized MFMA GEMM (csrc/ktx_gemm.hip)
 
     def __init__(self, n_routed_experts: int, hidden_size: int, top_k: int, n_group: int = 1, topk_group: int = 1,
                  scoring_func: str = "sigmoid", topk_method: str = "noaux_tc", norm_topk_prob: bool = True,
@@ -831,6 +844,17 @@ class GateHandle:
                                float(routed_scaling_factor))
         self.E, self.H, self.k = n_routed_experts, hidden_size, top_k
         self._counters: dict = {}
+
+    def _planes_of(self, weight: torch.Tensor) -> torch.Tensor:
+        """bf16 operand(s) of the large-batch logits GEMM: a bf16 weight as it is; an fp32 weight as its three exact bf16 planes
+        [3E, H] (split once per weight tensor and version)."""
+        if weight.dtype == torch.bfloat16:
+            return weight.contiguous()
+        key = (weight.data_ptr(), weight._version, weight.device)
+        hit = getattr(self, "_planes", None)
+        if hit is None or hit[0] != key:
+            hit = self._planes = (key, split_f32_bf16x3(weight.to(torch.float32)))
+        return hit[1]
 
     def forward(self, x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None,
                 bsz_tensor: torch.Tensor | None = None, norm: tuple | None = None):
@@ -874,9 +898,19 @@ class GateHandle:
                                        b.data_ptr() if b is not None else None, logits.data_ptr(), cnt.data_ptr(),
                                        idx.data_ptr(), wt.data_ptr(), st))
             return idx, wt
-        # large batches: F.linear in fp32, exactly the reference's expression (modeling_deepseek_v3.py:434-437) — a plain
-        # library GEMM — then the HIP selection kernel
-        logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
+        # large batches: the reference's F.linear(x.float(), weight.float()) (modeling_deepseek_v3.py:434-437).  A bf16 x and an
+        # fp32 weight: the weight is split ONCE into three bf16 planes that add up to it exactly, so every product of the three
+        # plane GEMMs is exact in the fp32 accumulator and the logits are fp32-GEMM grade on the MFMA units (csrc/ktx_gemm.hip;
+        # planes summed smallest first).  Anything else (fp32 activations, odd shapes) keeps the torch expression.
+        logits = None
+        if (x.dtype == torch.bfloat16 and weight.dim() == 2 and weight.dtype in (torch.bfloat16, torch.float32)
+                and weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0 and not os.environ.get("KTX_VENDOR_GEMM")):
+            planes = self._planes_of(weight)
+            l3 = gemm_bf16_nt(x.reshape(T, -1), planes, out_f32=True)
+            E_ = weight.shape[0]
+            logits = l3 if planes.shape[0] == E_ else ((l3[:, 2 * E_:] + l3[:, E_:2 * E_]) + l3[:, :E_]).contiguous()
+        if logits is None:
+            logits = torch.nn.functional.linear(x.to(torch.float32), weight.to(torch.float32)).contiguous()
         idx = torch.empty((T, self.k), dtype=torch.int64, device=dev)
         w = torch.empty((T, self.k), dtype=torch.float32, device=dev)
         b = None
@@ -1066,6 +1100,50 @@ def _bf16_rows(t: torch.Tensor, what: str) -> torch.Tensor:
     if t.dtype != torch.bfloat16 or not t.is_cuda or t.stride(-1) != 1:
         raise KtxError(f"{what}: expected a bf16 device tensor with unit inner stride, got {t.dtype} on {t.device}")
     return t
+
+
+def gemm_bf16_nt(a: torch.Tensor, b: torch.Tensor, out: torch.Tensor | None = None, bias: torch.Tensor | None = None,
+                 out_f32: bool = False, variant: int = 0) -> torch.Tensor:
+    """The library's own prompt-sized GEMM (include/ktx_gemm.h): out[..., m, n] = sum_k a[..., m, k] * b[..., n, k] (+ bias[n]),
+    bf16 operands, fp32 accumulation, bf16 (or fp32) result.  a: [M, K] or [batch, M, K]; b: [N, K] or [batch, N, K]; a 2-D
+    operand is shared by every batch entry of a 3-D one.  Rows must be k-contiguous; row / batch strides may be anything
+    that keeps 16-byte alignment."""
+    if a.dtype != torch.bfloat16 or b.dtype != torch.bfloat16 or a.device != b.device or a.device.type != "cuda":
+        raise KtxError(f"gemm_bf16_nt: bf16 operands on one HIP device expected, got {a.dtype} {a.device} / {b.dtype} {b.device}")
+    if a.dim() not in (2, 3) or b.dim() not in (2, 3) or a.shape[-1] != b.shape[-1]:
+        raise KtxError(f"gemm_bf16_nt: shapes {tuple(a.shape)} x {tuple(b.shape)}^T do not multiply")
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    if b.stride(-1) != 1:
+        b = b.contiguous()
+    batch = a.shape[0] if a.dim() == 3 else (b.shape[0] if b.dim() == 3 else 1)
+    if (a.dim() == 3 and a.shape[0] != batch) or (b.dim() == 3 and b.shape[0] != batch):
+        raise KtxError("gemm_bf16_nt: batch sizes differ")
+    M, N, K = a.shape[-2], b.shape[-2], a.shape[-1]
+    odt = torch.float32 if out_f32 else torch.bfloat16
+    batched = a.dim() == 3 or b.dim() == 3
+    if out is None:
+        out = torch.empty((batch, M, N) if batched else (M, N), dtype=odt, device=a.device)
+    elif out.dtype != odt or out.device != a.device or tuple(out.shape) != ((batch, M, N) if batched else (M, N)) or out.stride(-1) != 1:
+        raise KtxError(f"gemm_bf16_nt: out must be {odt} {(batch, M, N) if batched else (M, N)} with unit inner stride")
+    if bias is not None and (bias.dtype != torch.bfloat16 or tuple(bias.shape) != (N,) or bias.device != a.device or not bias.is_contiguous()):
+        raise KtxError(f"gemm_bf16_nt: bias must be contiguous bf16 [{N}] on {a.device}")
+    args = _GemmArgs(M, N, K, batch, a.data_ptr(), a.stride(-2), a.stride(0) if a.dim() == 3 else 0,
+                     b.data_ptr(), b.stride(-2), b.stride(0) if b.dim() == 3 else 0,
+                     out.data_ptr(), out.stride(-2), out.stride(0) if batched else 0,
+                     bias.data_ptr() if bias is not None else None, 1 if out_f32 else 0, int(variant))
+    check(lib.ktx_gemm_bf16_nt(C.byref(args), _stream_ptr(a.device)))
+    return out
+
+
+def split_f32_bf16x3(w: torch.Tensor) -> torch.Tensor:
+    """fp32 [rows, K] -> bf16 [3 * rows, K]: planes hi | mid | lo with w == hi + mid + lo exactly (include/ktx_gemm.h)."""
+    if w.dtype != torch.float32 or w.dim() != 2 or w.device.type != "cuda":
+        raise KtxError("split_f32_bf16x3: fp32 [rows, K] on a HIP device expected")
+    w = w.contiguous()
+    out = torch.empty((3 * w.shape[0], w.shape[1]), dtype=torch.bfloat16, device=w.device)
+    check(lib.ktx_split_f32_bf16x3(w.data_ptr(), w.numel(), out.data_ptr(), _stream_ptr(w.device)))
+    return out
 
 
 def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float, native_rounding: bool = True,

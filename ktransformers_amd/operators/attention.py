@@ -344,9 +344,15 @@ class KDeepseekV2Attention(BaseInjectedModule):
         kv_pad = (kv_len + 63) // 64 * 64
         lat = rows.new_zeros((kv_pad, lora))
         lat[:kv_len] = rows[:kv_len, :lora]                                 # zero rows past the context: exact-zero K / V there
-        # kv_b_proj as two batched library GEMMs (plain bf16 GEMMs -> hipBLASLt): K_nope [H, kv, 128] and V^T [H, 128, kv]
-        k_nope = torch.matmul(lat.unsqueeze(0), self.q_absorb.transpose(1, 2))
-        v_t = torch.matmul(self.out_absorb, lat.t().unsqueeze(0))
+        # kv_b_proj as two batched GEMMs of the library's own kernel (csrc/ktx_gemm.hip; the latent rows are the shared operand):
+        # K_nope [H, kv, 128] = latent @ W_UK[h]^T and V^T [H, 128, kv] = W_UV[h] @ latent^T.  KTX_VENDOR_GEMM=1: torch.matmul (A/B)
+        if os.environ.get("KTX_VENDOR_GEMM"):
+            k_nope = torch.matmul(lat.unsqueeze(0), self.q_absorb.transpose(1, 2))
+            v_t = torch.matmul(self.out_absorb, lat.t().unsqueeze(0))
+        else:
+            from ktransformers_amd._native import gemm_bf16_nt
+            k_nope = gemm_bf16_nt(lat, self.q_absorb)
+            v_t = gemm_bf16_nt(self.out_absorb, lat)
         q3 = q.unflatten(1, (H, nope + rope))
         attn = mla_prefill(q3[:, :, :nope], q_pe, k_nope.contiguous(), rows[:, lora:], v_t.contiguous(), kv_len, self.softmax_scale)
         return attn.reshape(q_len, H * self.v_head_dim)
