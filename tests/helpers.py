@@ -123,3 +123,29 @@ def write_gguf(path, tensors, meta=None, alignment=32):
     pad = (alignment - len(head) % alignment) % alignment
     with open(path, "wb") as f:
         f.write(head + b"\0" * pad + blob)
+
+
+def hash_bf16(shape, seed, scale, device="cpu", center=0.0):
+    """Deterministic pseudo-random bf16 tensor whose BITS are identical on the CPU and on the GPU: an integer hash of the
+    element index (int64 arithmetic, exact everywhere) -> the sum of two 16-bit uniforms (exact in fp32) -> one fp32 multiply
+    and add -> torch's round-to-nearest-even bf16 cast.  Standard deviation `scale`, mean `center`, triangular distribution.
+    Lets a GPU test rebuild on the device the gigabytes of weights a CPU golden run was made with, from a seed
+    (tests/golden/make_v3_layer_golden.py)."""
+    import torch
+    n = int(np.prod(shape))
+    out = torch.empty(n, dtype=torch.bfloat16, device=device)
+    step = 1 << 24
+    k = np.float32(scale / 26754.68)      # sqrt(2 * (65536^2 - 1) / 12): the std of the sum of two 16-bit uniforms
+    for a in range(0, n, step):
+        i = torch.arange(a, min(n, a + step), dtype=torch.int64, device=device)
+        x = (i * 0x9E3779B1 + (seed + 1) * 0x85EBCA77) & 0xFFFFFFFF
+        x ^= x >> 15
+        x = (x * 0x2C1B3C6D) & 0xFFFFFFFF
+        x ^= x >> 12
+        x = (x * 0x297A2D39) & 0xFFFFFFFF
+        x ^= x >> 15
+        v = ((x & 0xFFFF).to(torch.float32) + (x >> 16).to(torch.float32) - 65535.0) * float(k)
+        if center:
+            v = v + float(np.float32(center))
+        out[a:a + i.numel()] = v.to(torch.bfloat16)
+    return out.view(*shape)
