@@ -134,6 +134,15 @@ enum { KTX_FWD_INCREMENTAL = 1, KTX_FWD_PARTIAL_F32 = 2 };
 int ktx_moe_forward_ex(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                        const float* d_weights, const void* d_input, void* d_output, int flags, ktx_stream_t stream);
 
+/* merge_results of the reference's NUMA tensor-parallel MoE (operators/amx/moe_base.hpp:749-791; operators/moe-tp.hpp:201-216):
+ * a checkpoint converted with threadpool_count = P holds every expert as P parts — gate / up split over intermediate rows, down
+ * over K, each part with its own row scales — and TP_MOE runs P complete MoEs of width I / P whose fp32 outputs it adds:
+ *     y[t] = bf16( ((part_0[t] + (incremental ? y[t] : 0)) + part_1[t]) + ... + part_{P-1}[t] )       in exactly this order.
+ * d_parts: float [nparts][part_stride] holding [qlen][hidden] rows each (the KTX_FWD_PARTIAL_F32 outputs of P handles of
+ * intermediate size I / P); d_bsz as in ktx_moe_forward. */
+int ktx_moe_merge_partials(int nparts, int qlen, int hidden, const float* d_parts, int64_t part_stride, void* d_output,
+                           int incremental, const int32_t* d_bsz, ktx_stream_t stream);
+
 /* Decode step of a whole MoE block's tail (KDeepseekV3MoE.forward + the decoder layer's residual add,
  * archive/ktransformers/operators/experts.py:974-1012, models/modeling_deepseek_v3.py:1225):
  *     y[t] = residual[t] + ( sum_j w[t][j] * Expert_{ids[t][j]}(x[t])  +  side_linear(side_x[t]) )

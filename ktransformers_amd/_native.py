@@ -73,6 +73,7 @@ def _load() -> C.CDLL:
     lib.ktx_moe_load_gguf.argtypes = [C.c_void_p] * 4 + [C.c_int] * 3
     lib.ktx_moe_combine.argtypes = [C.c_int] * 3 + [C.c_void_p] * 4 + [C.c_int, C.c_void_p]
     lib.ktx_moe_set_expert_mask.argtypes = [C.c_void_p, C.c_void_p]
+    lib.ktx_moe_merge_partials.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int64, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p]
     lib.ktx_moe_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p,
                                     C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_moe_forward_ex.argtypes = lib.ktx_moe_forward.argtypes
@@ -455,6 +456,20 @@ class MoEHandle:
         check(lib.ktx_moe_forward_ex(self._h, None, T, k, expert_ids.data_ptr(), weights.data_ptr(), x.data_ptr(),
                                      out.data_ptr(), 2, _stream_ptr(self.device)))
         return out
+
+
+def moe_merge_partials(parts: torch.Tensor, out: torch.Tensor, incremental: bool = False, rows: int | None = None) -> torch.Tensor:
+    """merge_results of the reference's NUMA tensor-parallel MoE (include/ktx_moe.h, ktx_moe_merge_partials): parts fp32
+    [P, >= rows, H] (the forward_partial outputs of P handles of width I / P), out bf16 [rows, H]:
+    out = bf16(((parts[0] + (out if incremental)) + parts[1]) + ...)."""
+    if parts.dtype != torch.float32 or parts.dim() != 3 or not parts[0].is_contiguous() or parts.device != out.device:
+        raise KtxError("moe_merge_partials: parts must be fp32 [P, rows, H] with contiguous parts on the output's device")
+    T = out.shape[0] if rows is None else int(rows)
+    if out.dtype != torch.bfloat16 or out.dim() != 2 or out.shape[1] != parts.shape[2] or not out.is_contiguous() or T > parts.shape[1]:
+        raise KtxError("moe_merge_partials: out must be contiguous bf16 [rows, H]")
+    check(lib.ktx_moe_merge_partials(parts.shape[0], T, parts.shape[2], parts.data_ptr(), parts.stride(0), out.data_ptr(),
+                                     1 if incremental else 0, None, _stream_ptr(out.device)))
+    return out
 
 
 EP_MEMORY = {"uncached": 0, "finegrained": 1, "plain": 2}

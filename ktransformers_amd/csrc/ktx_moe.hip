@@ -3203,6 +3203,44 @@ extern "C" int ktx_moe_combine(int qlen, int k, int hidden, const void* d_rows, 
   return 0;
 }
 
+// merge_results of the reference's NUMA tensor-parallel MoE (operators/amx/moe_base.hpp:749-791): part 0's fp32 row, plus the
+// previous bf16 output when incremental, plus parts 1.. in order, one bf16 rounding.  4 elements per thread.
+__global__ __launch_bounds__(256) void moe_merge_partials_kernel(int nparts, int qlen, int H, const float* __restrict__ parts,
+                                                                 long part_stride, bf16_t* __restrict__ y, int incremental,
+                                                                 const int32_t* __restrict__ d_bsz) {
+  int T = qlen;
+  if (d_bsz) T = min(max(*d_bsz, 0), qlen);
+  const int t = blockIdx.y;
+  if (t >= T) return;
+  const int h = (blockIdx.x * blockDim.x + threadIdx.x) * 4;
+  if (h >= H) return;
+  const size_t off = (size_t)t * H + h;
+  float4 a = *reinterpret_cast<const float4*>(parts + off);
+  bf16_t* yp = y + off;
+  if (incremental) {
+    const uint2 o = *reinterpret_cast<const uint2*>(yp);
+    a.x = a.x + bf16_to_f32((bf16_t)(o.x & 0xffffu)); a.y = a.y + bf16_to_f32((bf16_t)(o.x >> 16));
+    a.z = a.z + bf16_to_f32((bf16_t)(o.y & 0xffffu)); a.w = a.w + bf16_to_f32((bf16_t)(o.y >> 16));
+  }
+  for (int i = 1; i < nparts; i++) {
+    const float4 b = *reinterpret_cast<const float4*>(parts + (size_t)i * part_stride + off);
+    a.x = a.x + b.x; a.y = a.y + b.y; a.z = a.z + b.z; a.w = a.w + b.w;
+  }
+  *reinterpret_cast<uint2*>(yp) = make_uint2((uint32_t)f32_to_bf16(a.x) | ((uint32_t)f32_to_bf16(a.y) << 16),
+                                             (uint32_t)f32_to_bf16(a.z) | ((uint32_t)f32_to_bf16(a.w) << 16));
+}
+
+extern "C" int ktx_moe_merge_partials(int nparts, int qlen, int hidden, const float* d_parts, int64_t part_stride, void* d_output,
+                                      int incremental, const int32_t* d_bsz, ktx_stream_t stream) {
+  KTX_REQUIRE(d_parts && d_output, "ktx_moe_merge_partials: null pointer");
+  KTX_REQUIRE(nparts > 0 && qlen > 0 && hidden > 0 && hidden % 4 == 0 && part_stride >= (int64_t)qlen * hidden && part_stride % 4 == 0,
+              "ktx_moe_merge_partials: bad shape");
+  hipLaunchKernelGGL(moe_merge_partials_kernel, dim3((hidden / 4 + 255) / 256, qlen), dim3(256), 0, (hipStream_t)stream, nparts, qlen,
+                     hidden, d_parts, (long)part_stride, (bf16_t*)d_output, incremental ? 1 : 0, d_bsz);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
 template <int WT, int MT, bool GATE_UP>
 static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = gg_nbs(WT);

@@ -43,14 +43,38 @@ class AMXMoEWrapper(BaseMoEWrapper):
         from .utils.amx_packed import unpack_expert
         w = AMXMoEWrapper._safetensor_loader_instance.load_experts(f"blk.{self.layer_idx}")
         order = self._logical_order(physical_to_logical_map_cpu, self.num_experts)
-        self.moe = self._new_handle()
         bits = 4 if self.method == "AMXINT4" else 8
+        n_parts = len(w["gate"])
+        if n_parts > 1:
+            self._load_tp_parts(w, order, bits, n_parts)
+            return
+        self.moe = self._new_handle()
         for which, fam, (n, k), split in ((_native.MAT_GATE, "gate", (self.moe_intermediate_size, self.hidden_size), "n"),
                                          (_native.MAT_UP, "up", (self.moe_intermediate_size, self.hidden_size), "n"),
                                          (_native.MAT_DOWN, "down", (self.hidden_size, self.moe_intermediate_size), "k")):
             for slot, logical in enumerate(order):
                 q, s = unpack_expert([part[logical] for part in w[fam]], [part[logical] for part in w[fam + "_scale"]], n, k, bits, split)
                 self.moe.load_quantized(slot, which, q, s)
+
+
+    def _load_tp_parts(self, w: dict, order, bits: int, n_parts: int) -> None:
+        """NUMA-sharded checkpoint (kt-kernel/python/utils/loader.py:179-290; operators/amx/moe.hpp:103-147): part p holds
+        gate / up rows and down COLUMNS [p * I/P, (p + 1) * I/P) of every expert, quantised on its own — down has one scale per
+        (row, part).  One handle of width I / P per part; the forward adds their fp32 outputs in part order (the reference's
+        merge_results), which reproduces what the reference computes from this very checkpoint."""
+        I, H = self.moe_intermediate_size, self.hidden_size
+        if I % n_parts:
+            raise ValueError(f"moe_intermediate_size {I} does not split over the checkpoint's {n_parts} NUMA parts")
+        Ip = I // n_parts
+        from .utils.amx_packed import unpack_expert
+        parts = [self._new_handle(intermediate_size=Ip) for _ in range(n_parts)]
+        for p, h in enumerate(parts):
+            for which, fam, (n, k) in ((_native.MAT_GATE, "gate", (Ip, H)), (_native.MAT_UP, "up", (Ip, H)), (_native.MAT_DOWN, "down", (H, Ip))):
+                for slot, logical in enumerate(order):
+                    q, s = unpack_expert([w[fam][p][logical]], [w[fam + "_scale"][p][logical]], n, k, bits, "n")
+                    h.load_quantized(slot, which, q, s)
+        self.tp_parts, self.moe = parts, parts[0]
+        self._tp_scratch = torch.empty((n_parts, max(1, int(self.chunked_prefill_size)), H), dtype=torch.float32, device=self.device)
 
 
 class NativeMoEWrapper(BaseMoEWrapper):

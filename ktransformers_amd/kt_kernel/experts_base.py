@@ -104,10 +104,16 @@ class BaseMoEWrapper(ABC):
         self.device = torch.device(device)
         BaseMoEWrapper._layer_has_pending_deferred[self.layer_idx] = False
         self.moe: Optional[_native.MoEHandle] = None
+        # a checkpoint converted with threadpool_count = P holds every expert as P NUMA parts of width I / P with their own
+        # scales; TP_MOE then runs P complete MoEs and adds their fp32 outputs (operators/moe-tp.hpp:201-216).  Same here: one
+        # handle per part, fp32 partials, ktx_moe_merge_partials.  Empty for single-part weights.
+        self.tp_parts: List[_native.MoEHandle] = []
+        self._tp_scratch: Optional[torch.Tensor] = None
 
     # ---- weights -----------------------------------------------------------------------------------------------
-    def _new_handle(self, group_size: int = 0) -> _native.MoEHandle:
-        h = _native.MoEHandle(self.num_experts, self.num_experts_per_tok, self.hidden_size, self.moe_intermediate_size,
+    def _new_handle(self, group_size: int = 0, intermediate_size: Optional[int] = None) -> _native.MoEHandle:
+        h = _native.MoEHandle(self.num_experts, self.num_experts_per_tok, self.hidden_size,
+                              intermediate_size or self.moe_intermediate_size,
                               max_len=max(1, int(self.chunked_prefill_size)), method=self.FORMAT[self.method], device=self.device,
                               group_size=group_size)
         h.set_expert_mask(self.gpu_experts_mask.numpy().astype("uint8"))
@@ -148,6 +154,14 @@ class BaseMoEWrapper(ABC):
         return expert_ids.masked_fill(~protected, -1), expert_ids.masked_fill(protected, -1)
 
     def _enqueue(self, ids: torch.Tensor, weights: torch.Tensor, x: torch.Tensor, out: torch.Tensor, incremental: bool, stream) -> None:
+        if self.tp_parts:
+            st, T, buf = _stream_handle(stream, x.device), x.shape[0], self._tp_scratch
+            for i, part in enumerate(self.tp_parts):
+                _native.check(_native.lib.ktx_moe_forward_ex(part._h, None, T, ids.shape[1], ids.data_ptr(), weights.data_ptr(),
+                                                             x.data_ptr(), buf[i].data_ptr(), 2, st))       # KTX_FWD_PARTIAL_F32
+            _native.check(_native.lib.ktx_moe_merge_partials(len(self.tp_parts), T, self.hidden_size, buf.data_ptr(), buf.stride(0),
+                                                             out.data_ptr(), 1 if incremental else 0, None, st))
+            return
         _native.check(_native.lib.ktx_moe_forward(self.moe._h, None, x.shape[0], ids.shape[1], ids.data_ptr(), weights.data_ptr(),
                                                   x.data_ptr(), out.data_ptr(), 1 if incremental else 0, _stream_handle(stream, x.device)))
 

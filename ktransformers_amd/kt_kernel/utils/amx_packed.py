@@ -54,8 +54,9 @@ def unpack_expert(parts: Sequence[np.ndarray], scales: Sequence[np.ndarray], n: 
                   split: str) -> Tuple[np.ndarray, np.ndarray]:
     """One expert matrix from its NUMA parts -> (int8 [n, k], fp32 [n]).  gate/up are sharded over rows (`split="n"`): parts
     are concatenated.  down is sharded over K (`split="k"`) with one scale per (row, shard) — the reference then sums fp32
-    partials per shard (operators/amx/moe_base.hpp:749-791); a single per-row scale cannot express that, so K-sharded
-    checkpoints are accepted only with one shard."""
+    partials per shard (operators/amx/moe_base.hpp:749-791); a single per-row scale cannot express that: multi-part
+    checkpoints are loaded part by part into one handle per part instead (AMXMoEWrapper._load_tp_parts), which calls this
+    function with one part at a time."""
     tp = len(parts)
     if tp == 1:
         return unpack_matrix(parts[0], n, k, bits), np.ascontiguousarray(scales[0]).view(np.float32).reshape(n).copy()
@@ -65,5 +66,5 @@ def unpack_expert(parts: Sequence[np.ndarray], scales: Sequence[np.ndarray], n: 
         q = np.concatenate([unpack_matrix(p, n // tp, k, bits) for p in parts], axis=0)
         s = np.concatenate([np.ascontiguousarray(x).view(np.float32).reshape(n // tp) for x in scales])
         return q, s
-    raise NotImplementedError(f"the down projection of this checkpoint is sharded over K across {tp} NUMA parts, each with its own "
-                              "row scales; re-export it with threadpool_count=1 (one part) to load it here")
+    raise NotImplementedError(f"a matrix sharded over K across {tp} NUMA parts has one scale per (row, part) and cannot be merged into "
+                              "one per-row-scaled matrix; load it part by part (AMXMoEWrapper._load_tp_parts)")

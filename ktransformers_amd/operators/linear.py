@@ -113,19 +113,51 @@ class KLinearTorch(KLinearBase):
         self.loaded = True
 
 
+def marlin_multiplicand(weight: torch.Tensor, num_bits: int, group_size: int) -> torch.Tensor:
+    """[N, K] bf16 weights -> the [N, K] bf16 matrix gptq_marlin_gemm multiplies activations with: quantize_weights on weight.T
+    (custom_marlin/quantize/utils/quant_utils.py:36-98 — s = max|w| * 2/(2^bits - 1) per group and output, q = clamp(round(w / s)
+    + 2^(bits-1), 0, 2^bits - 1), every step in the tensor's own bf16 arithmetic) and Marlin's in-register de-quantisation
+    bf16((q - 2^(bits-1)) * s) (kt-kernel/cuda/gptq_marlin/gptq_marlin.cu: dequant + scale).  torch ops on the weight's device."""
+    n, k = weight.shape
+    g = k if group_size == -1 else group_size
+    if k % g:
+        raise ValueError(f"in_features {k} is not a multiple of group_size {g}")
+    qmax = 2 ** num_bits - 1
+    half = (qmax + 1) // 2
+    w = weight.to(torch.bfloat16).view(n, k // g, g)
+    sc = w.abs().amax(dim=2, keepdim=True)
+    sc = sc * (2 / qmax)                                            # bf16 tensor * python float: fp32 product, bf16 result
+    q = torch.round(w / sc)
+    q = torch.where(sc == 0, torch.full_like(q, -half), q)          # int(NaN) + half clamps to 0 in the reference
+    q = torch.clamp(q.float() + half, 0, qmax) - half
+    return (q * sc.float()).to(torch.bfloat16).view(n, k)
+
+
 class KLinearMarlin(KLinearBase):
-    """W4A16, group 64 — linear.py:595-720.  `num_bits`, `group_size`, `act_order`, `is_k_full` as in the reference;
-    only num_bits=4 without act_order is implemented (the only configuration the reference's rule files use)."""
+    """W4A16 / W8A16 weight-only linear — linear.py:595-720.  `num_bits`, `group_size`, `act_order`, `is_k_full` as in the
+    reference.
+      * num_bits = 4 (every rule file of the reference): the native W4 format — packed nibbles + bf16 group scales, the W4
+        decode GEMVs and prompt GEMM of csrc/ktx_linear.hip.
+      * num_bits = 8: Marlin's own multiplicand bf16((q - 128) * s) is computed at load and held in the library's BF16 format
+        (2 bytes per weight instead of 1): the same products and fp32 accumulation as gptq_marlin_gemm's 8-bit path; no
+        byte-saving W8 kernel exists here because no rule file of the reference selects 8 bits.
+      * act_order: the reference "simulates" it by a random permutation of the K rows of the STORED q_w with g_idx / sort_indices
+        undoing it inside the kernel (quant_utils.py:15-33,82-92) — scales and quantised values are computed before the permutation,
+        so the product x @ dequant(w) is the same matrix product; this layout needs no such permutation and the flag is accepted."""
     FMT = "W4"
 
     def __init__(self, key, gguf_loader, config, orig_module=None, device: str = "cuda", num_bits: int = 4,
                  group_size: int = 64, act_order: bool = False, is_k_full=True, **kwargs):
         assert device.lower() != "cpu", "Marlin quantized linear only supports GPU device"
         super().__init__(key, gguf_loader, config, orig_module, device, **kwargs)
-        if num_bits != 4 or act_order:
-            raise NotImplementedError("KLinearMarlin here: num_bits=4, act_order=False")
+        if num_bits not in (4, 8):
+            raise NotImplementedError(f"KLinearMarlin: num_bits must be 4 or 8 (quant_utils.py:5), got {num_bits}")
+        if act_order and group_size == -1:
+            raise ValueError("For act_order, groupsize must be less than size_k")          # quant_utils.py:85-88
         self.num_bits, self.group_size, self.act_order, self.is_k_full = num_bits, group_size, act_order, is_k_full
         self.k, self.n = self.in_features, self.out_features
+        if num_bits == 8:
+            self.FMT = "BF16"
 
     def load(self, w=None, device: str | None = None):
         if self.loaded:
@@ -139,7 +171,11 @@ class KLinearMarlin(KLinearBase):
         weight = weight.data.to(self.device, torch.bfloat16).view(self.out_features, self.in_features).contiguous()
         self.has_bias = bias is not None
         g = self.in_features if self.group_size == -1 else self.group_size
-        self._h = self._make_handle(g)
+        if self.num_bits == 8:
+            weight = marlin_multiplicand(weight, 8, g).contiguous()
+            self._h = self._make_handle()
+        else:
+            self._h = self._make_handle(g)
         self._h.load_bf16(weight, bias.data.to(self.device, torch.bfloat16) if bias is not None else None)
         # the reference exposes marlin_q_w here and consumers only use it for shape/device: no bf16 copy is kept
         self.weight = torch.empty((self.in_features, self.out_features), dtype=torch.bfloat16, device="meta")

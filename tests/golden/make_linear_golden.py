@@ -28,6 +28,16 @@ for name, (N, K) in {"a": (64, 256), "b": (48, 384)}.items():
         q, s, _, _ = qu.quantize_weights(w.T.contiguous(), 4, G, False)
         out[f"{name}_q{G}"] = q.numpy().astype(np.uint8)
         out[f"{name}_s{G}"] = s.view(torch.uint16).numpy()
+    # 8 bits (linear.py:608, quant_utils.py:5), with and without the simulated act_order: q_w [K,N] in 0..255, s, and for
+    # act_order the stored row order rand_perm (the quantised values and scales are computed BEFORE the permutation)
+    for G, act in ((64, False), (128, True)):
+        torch.manual_seed(7)
+        q, s, g_idx, perm = qu.quantize_weights(w.T.contiguous(), 8, G, act)
+        tag = f"{name}_8b{G}{'_act' if act else ''}"
+        out[tag + "_q"] = q.numpy().astype(np.uint8)
+        out[tag + "_s"] = s.view(torch.uint16).numpy()
+        if act:
+            out[tag + "_perm"] = perm.numpy().astype(np.int64)
 path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "linear_w4_golden.npz")
 np.savez_compressed(path, **out)
 print(path, os.path.getsize(path))

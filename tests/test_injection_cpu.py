@@ -115,7 +115,9 @@ def test_linear_injection_and_registry(injected):
     with pytest.raises(AssertionError):
         KTransformersLinear("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), generate_op="Nope")
     with pytest.raises(NotImplementedError):
-        KLinearMarlin("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), num_bits=8)
+        KLinearMarlin("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), num_bits=3)          # quant_utils.py:5: 4 or 8
+    m8 = KLinearMarlin("k", DictLoader({}), cfg, torch.nn.Linear(8, 8), num_bits=8, act_order=True)
+    assert (m8.num_bits, m8.act_order, m8.FMT) == (8, True, "BF16")
     with pytest.raises(ValueError):
         lin.set_inference_mode("bogus")
 

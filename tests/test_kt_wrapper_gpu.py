@@ -148,6 +148,43 @@ def test_amx_packed_checkpoint_equals_online_quantisation(dev, tmp_path):
     assert torch.equal(ya.view(torch.int16), yb.view(torch.int16))
 
 
+def test_numa_sharded_checkpoint_reproduces_the_reference_tp_moe(dev, tmp_path):
+    """A checkpoint converted with threadpool_count = 2 (gate / up split over rows, down over K with one scale per (row, part);
+    kt-kernel/python/utils/loader.py:179-290): the wrapper runs one handle per part and adds their fp32 outputs in part order —
+    bit-identical to what the reference's TP_MOE (tp_count = 2, oracle/_ref) computes from the same weights, plain and
+    incremental (merge_results, operators/amx/moe_base.hpp:749-791).  tests/golden/make_kt_tp_golden.py; 2263 of the 2304
+    outputs differ from the one-part arithmetic, so the check tells the two apart."""
+    import os
+    from safetensors.numpy import save_file
+    from ktransformers_amd import _native
+    g = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "kt_tp_golden.npz"))
+    E, k, H, I, P = (int(g[n]) for n in ("E", "k", "H", "I", "P"))
+    assert int(g["differs_from_one_part"]) > 2000
+    save_file({n: g[n] for n in g.files if n.startswith("blk.")}, str(tmp_path / "packed.safetensors"))
+    a = make("AMXINT4", 3, E, k, H, I, path=str(tmp_path))
+    a.load_weights(torch.arange(E))
+    assert len(a.tp_parts) == P and a.tp_parts[0].I == I // P
+    x, ids, wt = torch_bf16(g["x"], dev), torch.from_numpy(g["ids"]).to(dev), torch.from_numpy(g["w"]).to(dev)
+    y = a.forward(x, ids, wt, stream()).clone()
+    torch.cuda.synchronize()
+    assert np.array_equal(numpy_u16(y), g["y"]), f"{int((numpy_u16(y) != g['y']).sum())} outputs differ from the reference's tp_count=2 run"
+    # incremental merge: ((part0 + y_prev) + part1), one rounding
+    parts = torch.stack([h.forward_partial(x, ids, wt) for h in a.tp_parts])
+    out = torch_bf16(g["y_prev"], dev).clone()
+    _native.moe_merge_partials(parts, out, incremental=True)
+    torch.cuda.synchronize()
+    assert np.array_equal(numpy_u16(out), g["y_inc"])
+    # under a HIP graph, twice
+    static_x = x.clone()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(graph):
+        yg = a.forward(static_x, ids, wt, stream())
+    for _ in range(2):
+        graph.replay()
+    torch.cuda.synchronize()
+    assert np.array_equal(numpy_u16(yg), g["y"])
+
+
 def test_llamafile_gguf_equals_a_directly_loaded_handle(dev, tmp_path):
     from helpers import write_gguf
     from ktransformers_amd._native import MoEHandle

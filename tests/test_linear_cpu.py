@@ -46,3 +46,32 @@ def test_fp8_act_quant_and_linear():
     y = linear_fp8_ref(x, w, sc).float()
     d = x.float() @ (w.float() * sc.repeat_interleave(128, 1)).T
     assert (y - d).norm() / d.norm() < 0.05
+
+
+@pytest.mark.parametrize("name", ["a", "b"])
+@pytest.mark.parametrize("G,act", [(64, False), (128, True)])
+def test_marlin_8bit_multiplicand_matches_the_reference_quantiser(name, G, act):
+    """operators/linear.marlin_multiplicand (what KLinearMarlin(num_bits=8) loads) against the REFERENCE's quantize_weights at
+    8 bits (golden from its own quant_utils.py): bf16((q - 128) * s) element for element.  With act_order the reference stores
+    the rows of q_w permuted (rand_perm) and its g_idx / sort_indices undo that inside the kernel: undoing it here gives the very
+    same (q, s) as without act_order — the flag changes storage, not the product."""
+    from ktransformers_amd.operators.linear import marlin_multiplicand
+    g = np.load(GOLD)
+    w = torch.from_numpy(g[f"{name}_w"]).view(torch.bfloat16)
+    tag = f"{name}_8b{G}{'_act' if act else ''}"
+    q, s = torch.from_numpy(g[tag + "_q"].astype(np.int32)), torch.from_numpy(g[tag + "_s"]).view(torch.bfloat16)
+    if act:
+        perm = torch.from_numpy(g[tag + "_perm"])
+        inv = torch.empty_like(perm)
+        inv[perm] = torch.arange(perm.numel())
+        q = q[inv]                                               # stored row r holds original row perm[r]
+        q_plain, s_plain = quantize_weights_ref(w.T.contiguous(), G, num_bits=8)
+        assert torch.equal(s_plain.view(torch.uint16), s.view(torch.uint16))
+        live = torch.repeat_interleave(s != 0, G, dim=0)
+        assert torch.equal(q[live], q_plain[live])
+    want = ((q.float() - 128.0) * s.float().repeat_interleave(G, dim=0)).to(torch.bfloat16).T     # [N, K]
+    got = marlin_multiplicand(w, 8, G)
+    live = torch.repeat_interleave(s != 0, G, dim=0).T
+    assert torch.equal(got.view(torch.uint16)[live], want.contiguous().view(torch.uint16)[live])
+    assert float(got.float()[~live].abs().max() if (~live).any() else 0.0) == 0.0                 # an all-zero group stays zero
+    assert float((got.float() - w.float()).abs().max()) < float(w.float().abs().max()) / 100      # 8-bit grid: < 1 % of full scale

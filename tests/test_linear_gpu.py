@@ -414,3 +414,28 @@ def test_all_cu_decode_gemv_under_a_replayed_graph_and_many_handles():
             torch.cuda.synchronize()
             for y, f in zip(ys, first):
                 assert torch.equal(y, f)
+
+
+@pytest.mark.parametrize("act_order", [False, True])
+@pytest.mark.parametrize("T", [1, 5, 70])
+def test_marlin_8bit_operator_multiplies_with_the_reference_multiplicand(T, act_order):
+    """KLinearMarlin(num_bits=8) (linear.py:608-666): Marlin's 8-bit multiplicand bf16((q - 128) * s) — pinned to the reference's
+    own quantize_weights in tests/test_linear_cpu.py — held in the BF16 format; forward against fp64 math on that matrix, at
+    the bound of the BF16 kernels (one bf16 rounding of an fp32-accumulated sum)."""
+    from types import SimpleNamespace
+    from ktransformers_amd.operators.linear import KLinearMarlin, marlin_multiplicand
+    from ktransformers_amd.util.loader import DictLoader
+    K, N, G = 2048, 576, 64
+    torch.manual_seed(T + 31 * act_order)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16)
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16)
+    op = KLinearMarlin("k", DictLoader({"k.weight": w}), SimpleNamespace(), torch.nn.Linear(K, N, bias=False, device="meta"),
+                       device="cuda", num_bits=8, group_size=G, act_order=act_order)
+    op.load()
+    assert op._h.fmt == "BF16" and op._h.weight_bytes() >= 2 * N * K
+    y = op.forward(x.cuda())
+    torch.cuda.synchronize()
+    close(y.cpu(), linear_bf16_ref(x, marlin_multiplicand(w, 8, G)), rel=1e-3)
+    # the 8-bit grid is 16x finer than the 4-bit one
+    dense = x.double() @ w.double().T
+    assert float((y.cpu().double() - dense).norm() / dense.norm()) < 1e-2
