@@ -669,7 +669,12 @@ __device__ __forceinline__ void pf_store_tile(const PfTile& t, bf16_t* Ks, bf16_
   *reinterpret_cast<uint4*>(vd + 96 * PF_VROW) = t.v3;
 }
 
-__global__ __launch_bounds__(256) void mla_prefill_kernel(MlaPrefillParams p) {
+// MINW = wavefronts per SIMD the register allocation must allow.  Unconstrained (MINW = 1) the compiler takes 340 VGPRs: ONE
+// wavefront per SIMD, one workgroup per CU, so the QK MFMAs, the softmax VALU chain, the PV MFMAs and the staging of the next
+// tile run strictly one after the other (0.10 of the MFMA peak).  MINW = 2 caps the allocation at 256 (7 values
+// spill to scratch) and two workgroups share a CU: one's softmax runs under the other's MFMAs.  Dev knob 22 = 1 selects MINW = 1.
+template <int MINW>
+__global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);      // [64][PF_KROW]
   bf16_t* Vs = Ks + PF_BN * PF_KROW;                 // [128][PF_VROW]
@@ -817,7 +822,8 @@ extern "C" int ktx_mla_prefill(int T, int num_heads, int kv_len, int kv_pad, flo
   hipStream_t st = (hipStream_t)stream;
   // per (query, key, head): 2*(192 + 128) flop over the causal half
   KTX_TIMED(st, 0.0, "mla_prefill_kernel T=%d Hq=%d kv=%d", T, num_heads, kv_len);
-  hipLaunchKernelGGL(mla_prefill_kernel, dim3((T + 127) / 128, num_heads), dim3(256), lds, st, p);
+  if (ktx_debug_get(22) == 1) hipLaunchKernelGGL(mla_prefill_kernel<1>, dim3((T + 127) / 128, num_heads), dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(mla_prefill_kernel<2>, dim3((T + 127) / 128, num_heads), dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

@@ -139,11 +139,14 @@ def test_decode_at_128k_context():
 
 
 # ---- non-absorbed prompt attention (ktx_mla_prefill) ----------------------------------------------------------------------
+@pytest.mark.parametrize("knob22", [0, 1])
 @pytest.mark.parametrize("H,T,kv_len", [(4, 130, 130), (3, 70, 201), (16, 128, 128), (2, 257, 1000), (128, 64, 64)])
-def test_prefill_expanded_against_fp32_attention(H, T, kv_len):
+def test_prefill_expanded_against_fp32_attention(H, T, kv_len, knob22):
     """Causal softmax(q k^T) v over qk 192 (128 nope + 64 shared rope) / v 128 in fp32 on the same bf16 operands; the queries are
     the last T keys; the padded key rows are zero as the operator makes them."""
+    from ktransformers_amd import _native
     from ktransformers_amd._native import mla_prefill
+    _native.check(_native.lib.ktx_debug_set(22, knob22))      # 0: the default (<= 256 registers, two workgroups per CU); 1: the unconstrained build
     g = torch.Generator().manual_seed(H * 1000 + T + kv_len)
     kv_pad = (kv_len + 63) // 64 * 64
     q = torch.randn((T, H, 192), generator=g).to(torch.bfloat16).to(DEV)
@@ -155,8 +158,11 @@ def test_prefill_expanded_against_fp32_attention(H, T, kv_len):
     v[:, :kv_len] = torch.randn((H, kv_len, 128), generator=g).to(torch.bfloat16).to(DEV)
     sm_scale = 192 ** -0.5
     q_pe = q[:, :, 128:].contiguous()
-    out = mla_prefill(q[:, :, :128], q_pe, k_nope, cache[:, 512:], v.transpose(1, 2).contiguous(), kv_len, sm_scale)
-    torch.cuda.synchronize()
+    try:
+        out = mla_prefill(q[:, :, :128], q_pe, k_nope, cache[:, 512:], v.transpose(1, 2).contiguous(), kv_len, sm_scale)
+        torch.cuda.synchronize()
+    finally:
+        _native.check(_native.lib.ktx_debug_set(22, 0))
     k = torch.cat([k_nope[:, :kv_len].float(), cache[:kv_len, 512:].float()[None].expand(H, -1, -1)], dim=-1)    # [H, kv, 192]
     s = torch.einsum("thd,hkd->htk", q.float(), k) * sm_scale
     pos = torch.arange(T, device=DEV)[:, None] + (kv_len - T)
