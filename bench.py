@@ -872,7 +872,7 @@ def whole_model_prefill(mr, T, dev, reps=3):
                 times.append(time.perf_counter() - t0)
     # one more pass with the library's per-launch log on: where a prompt chunk spends its time
     from ktransformers_amd import _native
-    per_kernel = []
+    per_kernel, lib_ms = [], None
     try:
         _native.timing_enable(1)
         with torch.no_grad():
@@ -885,6 +885,7 @@ def whole_model_prefill(mr, T, dev, reps=3):
             a[0] += 1
             a[1] += us or 0.0
         tot = sum(v[1] for v in agg.values())
+        lib_ms = tot / 1e3
         per_kernel = [{"kernel": k2, "launches": v[0], "total_ms": round(v[1] / 1e3, 3), "share": round(v[1] / tot, 4)}
                       for k2, v in sorted(agg.items(), key=lambda kv: -kv[1][1])][:12]
     finally:
@@ -896,8 +897,13 @@ def whole_model_prefill(mr, T, dev, reps=3):
     moe_flop = 2 * 3 * cfg.hidden_size * cfg.moe_intermediate_size * cfg.num_experts_per_tok * T * n_moe
     return {"value": round(T / dt, 1), "unit": "tok/s", "tokens": T, "ms_per_chunk": round(dt * 1e3, 3),
             "layers": cfg.num_hidden_layers, "routed_expert_TOPs_share": round(moe_flop / dt / 1e12, 1), "per_kernel": per_kernel,
-            "what": "whole resident model, one prompt chunk from an empty cache (absorbed MLA, grouped int8-MFMA expert GEMMs, "
-                    "W4 MFMA linears), last-token logits"}
+            # every launch of libktx_hip.so is event-bracketed in that extra pass; the rest of the chunk is torch glue
+            # (elementwise adds, the GLU row permutation, copies, index ops) and launch gaps — no vendor GEMM is called
+            "library_kernel_ms": None if lib_ms is None else round(lib_ms, 3),
+            "outside_library_share": None if lib_ms is None else round(max(0.0, 1.0 - lib_ms / (dt * 1e3)), 4),
+            "vendor_gemm": bool(os.environ.get("KTX_VENDOR_GEMM")),
+            "what": "whole resident model, one prompt chunk from an empty cache (non-absorbed MLA prompt attention, grouped int8-MFMA "
+                    "expert GEMMs, W4 linears expanded once per call + the library's own BF16 MFMA GEMM), last-token logits"}
 
 
 def run_model_decode(name, args, dev, steps, warmup, dist_on=False, world=1, rank=0, n_layers=None, ctx=None, windows=0):
