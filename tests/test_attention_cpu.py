@@ -27,7 +27,12 @@ def test_oracle_matches_reference_eager_attention(name):
         outs.append(o)
     dec = torch.cat(outs, 0)
     assert float((dec.float() - out.float()).norm() / out.float().norm()) < 1e-2
-    assert torch.equal(hist, rows)
+    # the new cache rows of the two passes: the same arithmetic, but the host BLAS's bf16 GEMM is not batch-invariant on every
+    # CPU (M = 1 takes a GEMV path with another summation order on AMX / AVX512-BF16 hosts): a last-place flip of a few
+    # elements (through the RMSNorm: two places) is the most the two may differ by
+    d = (hist.float() - rows.float()).abs()
+    assert float((d / rows.float().abs().clamp_min(2.0 ** -6)).max()) <= 2.0 ** -6
+    assert float((d > 0).float().mean()) < 0.01
 
 
 def test_yarn_tables_and_scale():
