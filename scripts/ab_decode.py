@@ -40,10 +40,31 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "lin: round-2 router workgroups in front of the all-CU gate|up kernel": ({19: 3}, {}),
     "lin: two workgroups per CU": ({18: 2}, {}),
     "gate: store-ack hand-off (no granules)": ({21: 1}, {}),
+    "attn: one workgroup per head (q_b + absorb, merge + un-absorb)": ({23: 1}, {}),
+    "attn: two workgroups per head (q_b + absorb, merge + un-absorb)": ({23: 2}, {}),
+    "read-ahead: both sets, 128 wgs": ({}, {"KTX_PREFETCH": "1"}),
+    "read-ahead: set 1 only, 128 wgs": ({}, {"KTX_PREFETCH": "s1"}),
+    "read-ahead: set 2 only, 128 wgs": ({}, {"KTX_PREFETCH": "s2"}),
+    "read-ahead: both sets, 48 wgs": ({}, {"KTX_PREFETCH": "1", "KTX_PREFETCH_WGS": "48"}),
+    "read-ahead: both sets, 256 wgs": ({}, {"KTX_PREFETCH": "1", "KTX_PREFETCH_WGS": "256"}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}
 res = {k: [] for k in CONFIGS}
+toks = {}
+
+
+def token_trace(n_steps=8):
+    """The tokens of n_steps greedy steps from a fixed state (position ctx, token 1): every configuration must produce the same."""
+    mr.set_position(args.ctx)
+    mr.cur.fill_(1)
+    out = []
+    for _ in range(n_steps):
+        mr.step()
+        out.append(int(mr.cur.item()))
+    return out
+
+
 for r in range(args.rounds):
     for name, (knobs, env) in CONFIGS.items():
         for i, v in knobs.items():
@@ -52,17 +73,32 @@ for r in range(args.rounds):
             os.environ[k] = v
         try:
             mr.capture(True)
+            if not mr.graph_ok:
+                print(f"  !! {name}: graph capture failed ({mr.graph_error}); timed eagerly", flush=True)
+            if r == 0:
+                toks[name] = token_trace()
+                if toks[name] != toks["default"]:
+                    print(f"  !! {name}: tokens differ from default: {toks[name]} vs {toks['default']}", flush=True)
             for _ in range(40):
                 mr.step()
             mr.set_position(args.ctx)
             dt = bench.timed(mr.step, args.steps, 10, dev, False)
             res[name].append(dt / args.steps * 1e3)
+            print(f"round {r} {name:32s} {res[name][-1]:.3f} ms/step", flush=True)
+        except Exception as e:      # one configuration failing (a capture error, say) must not lose the others
+            if name == "default":
+                raise
+            print(f"round {r} {name:32s} FAILED: {type(e).__name__}: {e}", flush=True)
+            torch.cuda.synchronize(dev)
         finally:
             for i in knobs:
                 n.lib.ktx_debug_set(i, 0)
             for k in env:
                 os.environ.pop(k, None)
-        print(f"round {r} {name:32s} {res[name][-1]:.3f} ms/step", flush=True)
 base = min(res["default"])
 for name, v in res.items():
-    print(f"{name:32s} best {min(v):.3f} ms  median {sorted(v)[len(v) // 2]:.3f} ms  vs default {min(v) / base:.3f}x", flush=True)
+    if not v:
+        print(f"{name:32s} no result", flush=True)
+        continue
+    print(f"{name:32s} best {min(v):.3f} ms  median {sorted(v)[len(v) // 2]:.3f} ms  vs default {min(v) / base:.3f}x  "
+          f"tokens {'same' if toks.get(name) == toks.get('default') else 'DIFFER'}", flush=True)
