@@ -1004,6 +1004,9 @@ def main():
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations")
     ap.add_argument("--secondary", default=",".join(SECONDARY), help="comma-separated secondary workloads")
+    ap.add_argument("--time-budget", type=float, default=1500.0,
+                    help="seconds of wall clock after which no further OPTIONAL section (PMC passes, secondary workloads) is started: the "
+                         "JSON line is printed once, at the end, and must not be lost to a caller's time limit")
     ap.add_argument("--strong", action="store_true", help="N > 1: ONE token stream (every rank decodes the same token; routed experts "
                                                             "E/N per rank) instead of one stream per rank")
     ap.add_argument("--cpu-baseline-only", action="store_true")
@@ -1017,6 +1020,15 @@ def main():
     if args.cpu_baseline_only:
         print(json.dumps(cpu_baseline(wl)), flush=True)
         return
+
+    t_start = time.perf_counter()
+    timing = {}                      # seconds per section of this run -> the JSON line ("timing_s")
+
+    def lap(name, t0):
+        timing[name] = round(time.perf_counter() - t0, 1)
+
+    def over_budget():
+        return time.perf_counter() - t_start > args.time_budget
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1075,8 +1087,10 @@ def main():
         rank_seed = 0                                   # every rank starts from the same token: one stream
     else:
         rank_seed = rank
+    t_sec = time.perf_counter()
     res, mr = run_model_decode(args.workload, args, dev, args.steps, args.warmup, dist_on, 1 if (args.strong and dist_on) else world,
                                rank_seed, n_layers, windows=args.windows)
+    lap("decode", t_sec)
     cfg = mr.cfg
     ms_per_step = res["ms_per_step"]
     n_dense = res["dense_layers"]
@@ -1112,6 +1126,22 @@ def main():
         "median_tok_s": res.get("median_tok_s"),
         "box": box,
     }
+    # the headline measurement exists from here on: a caller's SIGTERM (time limit) prints what there is instead of nothing
+    import signal
+
+    def _salvage(signum, frame):
+        if rank == 0:
+            out["truncated"] = f"signal {signum} after {time.perf_counter() - t_start:.0f}s: the sections not yet run are missing"
+            out["timing_s"] = timing
+            out.setdefault("roofline", {"bound": "hbm", "kernel": "whole decode step (per-kernel pass not reached)", "achieved": out["whole_step"]["GBs"],
+                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["whole_step"]["frac_of_hbm_peak"], "traffic": None})
+            print(json.dumps(out), flush=True)
+        os._exit(0)
+
+    try:
+        signal.signal(signal.SIGTERM, _salvage)
+    except (ValueError, OSError):
+        pass
     if subset:
         # NOT `value`: what the measured per-layer time implies for the full depth (the extra layers are MoE layers)
         out["full_depth_extrapolation"] = {
@@ -1122,11 +1152,13 @@ def main():
     prefill = None
     if not dist_on and not args.no_prefill:
         # ---------------- prefill: one prompt chunk through the same resident model -----------------------------------------
+        t_sec = time.perf_counter()
         try:
             prefill = whole_model_prefill(mr, args.prefill_tokens, dev)
         except Exception as e:
             prefill = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.synchronize(dev)
+        lap("prefill", t_sec)
     rows_eager = None
     if dist_on and not args.no_kernels:
         # N > 1: every rank steps together (collectives), so the per-launch events run on all ranks; rank 0 reports
@@ -1141,9 +1173,11 @@ def main():
 
     lus = None
     if not args.no_kernels:
+        t_sec = time.perf_counter()
         if not dist_on:
             # ---------------- per-kernel table of the replayed graph + roofline of its dominant kernel ----------------------
             rows, info = graph_kernel_table(args, ms_per_step)
+            lap("per_kernel_trace_child", t_sec)
         else:
             rows, info = rows_eager, {"source": "HIP events around every library launch of eager decode steps on rank 0 (all ranks step "
                                                 "together); N = 1 runs take this table from a rocprofv3 pass of the replayed graph",
@@ -1153,7 +1187,10 @@ def main():
             out["per_kernel_info"] = info
             lus = info.get("moe_layer_us")
             top = next((r for r in rows if r["algorithmic_bytes_per_launch"]), rows[0])
-            traffic, src = (None, "skipped") if (args.no_pmc or dist_on) else pmc_traffic(args, top["kernel"])
+            t_sec = time.perf_counter()
+            traffic, src = (None, "skipped") if (args.no_pmc or dist_on) else \
+                ((None, f"skipped: --time-budget {args.time_budget:.0f}s reached") if over_budget() else pmc_traffic(args, top["kernel"]))
+            lap("pmc_child_passes", t_sec)
             out["roofline"] = {"bound": "hbm", "kernel": top["kernel"], "achieved": top["GBs"], "peak": HBM_PEAK_GBS, "unit": "GB/s",
                                "frac": round((top["GBs"] or 0.0) / HBM_PEAK_GBS, 4), "traffic": traffic, "traffic_source": src,
                                "algorithmic_bytes_per_launch": top["algorithmic_bytes_per_launch"],
@@ -1178,11 +1215,21 @@ def main():
                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws["frac_of_hbm_peak"], "traffic": None}
 
     if not dist_on:
+        # the reference's CPU path first (short, and part of the contract's line), then the optional configurations
+        if not args.no_cpu_baseline:
+            t_sec = time.perf_counter()
+            out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
+            lap("cpu_baseline", t_sec)
         # ---------------- the other BASELINE.json configurations, as secondary fields -------------------------------------------
         if args.workload == "v3-int4" and not args.no_secondary:
             for name in [x for x in args.secondary.split(",") if x]:
                 w2 = WORKLOADS[name]
                 key = name.replace("-", "_")
+                if over_budget():
+                    out[key] = {"value": None, "skipped": f"--time-budget {args.time_budget:.0f}s reached after "
+                                                          f"{time.perf_counter() - t_start:.0f}s; run bench.py --workload {name}"}
+                    continue
+                t_sec = time.perf_counter()
                 try:
                     n2 = max(30, min(args.steps, 100))
                     if w2.get("kind") == "experts":
@@ -1208,12 +1255,11 @@ def main():
                 except Exception as e:
                     out[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
                     torch.cuda.synchronize(dev)
+                lap(key, t_sec)
                 gc.collect()
                 torch.cuda.empty_cache()
             if "v2lite_int4" in out:
                 out["v2lite"] = out["v2lite_int4"]          # (the name round 1 / 2 lines used)
-        if not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
 
     if dist_on and ep_exchange is not None:
         # a poll that gave up during the run means a rank computed on rows that never arrived: the number is void, say so
@@ -1222,6 +1268,12 @@ def main():
         out["config"]["ep_transport_status"] = int(st.item())
         if int(st.item()) != 0:
             out["value"], out["error"] = None, "peer-write exchange: a poll gave up waiting for a peer during the run"
+    timing["total"] = round(time.perf_counter() - t_start, 1)
+    out["timing_s"] = timing
+    try:
+        signal.signal(signal.SIGTERM, signal.SIG_DFL)      # the line is complete: no salvage print beside it
+    except (ValueError, OSError):
+        pass
     if rank == 0:
         print(json.dumps(out), flush=True)
     if dist_on:

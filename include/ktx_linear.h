@@ -135,9 +135,7 @@ int ktx_linear_debug_get_w4(ktx_linear_t h, uint8_t* q, uint16_t* s);
  * ktx_mla_prep, in ONE launch for a decode step (T <= 4): everything between the merged q_a|kv_a projection and the MLA kernel
  * (archive/ktransformers/operators/attention.py:360-418: q_b_proj, q_a_layernorm, torch.matmul(q_nope, q_absorb), rotary).
  * One workgroup per head streams the head's q_b rows (W4) and its W_UK block (BF16 batched handle) — both requested up front —
- * so the two GEMVs share one memory round trip instead of being two dependent launches (a single token: two workgroups per
- * head, each with all of the head's q_nope rows and a share of the W_UK strips, so that 128 heads put a workgroup on every CU;
- * the kv half then rides in one of them).  Arithmetic and roundings are those
+ * so the two GEMVs share one memory round trip instead of being two dependent launches.  Arithmetic and roundings are those
  * of ktx_linear_forward_fused(q_b, norm) / ktx_linear_forward_batched(q_absorb) / ktx_mla_prep.  d_kv may be NULL (no kv half).
  * Ask ktx_linear_qb_absorb_eligible first: the combined kernel exists for W4 g64 q_b with q_lora_rank 1536, nope 128,
  * rope <= 64, kv_lora 512 (DeepSeek-V3 / R1, Kimi-K2, DeepSeek-V2); everything else keeps the separate calls. */
@@ -159,14 +157,10 @@ int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_out, ktx_str
  * archive/ktransformers/operators/attention.py:465-468) of a decode step (T <= 4) in ONE launch: h = the batched BF16 W_UV
  * handle (batch = heads, kv_lora 512 -> v_head_dim 128); d_part_o / d_part_ml / nsplit = what ktx_mla_decode_partials
  * (include/ktx_mla.h) left in its workspace.  y[t*ldy + head*y_batch_stride + n] = W_UV[head] . merged[t][head], with the
- * merged row rounded to bf16 exactly where ktx_mla_decode_append rounds it (two workgroups per head: both merge, each holds
- * half of W_UV[head]).  Ask ktx_linear_merge_eligible first. */
+ * merged row rounded to bf16 exactly where ktx_mla_decode_append rounds it.  Ask ktx_linear_merge_eligible first. */
 int ktx_linear_merge_eligible(ktx_linear_t h, int T, int nsplit, int num_heads);
 int ktx_linear_forward_batched_merge(ktx_linear_t h, int T, const float* d_part_o, const float* d_part_ml, int nsplit,
                                      int num_heads, void* d_y, int64_t ldy, int64_t y_batch_stride, ktx_stream_t stream);
-
-/* ktx_prefetch (include/ktx_ops.h) over the packed weights and scales of a loaded handle. */
-int ktx_linear_prefetch(ktx_linear_t h, int workgroups, ktx_stream_t stream);
 
 #ifdef __cplusplus
 }

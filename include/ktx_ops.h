@@ -62,13 +62,6 @@ int ktx_mla_prep(int T, int num_heads, int nope_dim, int rope_dim, int kv_lora, 
 size_t ktx_argmax_workspace_bytes(int rows);
 int ktx_argmax_bf16(const void* d_x, int64_t ldx, int rows, int n, int64_t* d_out, void* d_workspace, ktx_stream_t stream);
 
-/* Read-ahead: a launch that only READS [d_ptr, d_ptr + bytes) (16-byte aligned start; a tail shorter than 16 bytes is not
- * touched) with `workgroups` small workgroups and writes nothing.  Meant for a side stream forked from the decode stream: the
- * weights of the NEXT launches of a batch-1 step are pulled into the die-level Infinity Cache while the current, latency-bound
- * launches leave HBM idle (the reference hides the same latency by running its CPU experts beside the GPU attention,
- * archive/ktransformers/operators/experts.py:974-1012).  No effect on any result.  Opt-in (KTX_PREFETCH, util/prefetch.py). */
-int ktx_prefetch(const void* d_ptr, size_t bytes, int workgroups, ktx_stream_t stream);
-
 #ifdef __cplusplus
 }
 #endif

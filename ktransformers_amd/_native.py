@@ -150,8 +150,6 @@ def _load() -> C.CDLL:
     lib.ktx_ep_set_spin_seconds.argtypes = [C.c_void_p, C.c_double]
     lib.ktx_profile_enable.argtypes = [C.c_int]
     lib.ktx_debug_force_generic.argtypes = [C.c_int]
-    lib.ktx_prefetch.argtypes = [C.c_void_p, C.c_size_t, C.c_int, C.c_void_p]
-    lib.ktx_linear_prefetch.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_debug_set.argtypes = [C.c_int, C.c_int]
     lib.ktx_debug_get.argtypes = [C.c_int]
     lib.ktx_timing_enable.argtypes = [C.c_int]
@@ -611,11 +609,6 @@ class LinearHandle:
         if getattr(self, "_h", None):
             lib.ktx_linear_destroy(self._h)
             self._h = None
-
-    def prefetch(self, stream: "torch.cuda.Stream", workgroups: int = 128) -> None:
-        """Read the packed weights (and scales) once on `stream` (ktx_linear_prefetch): read-ahead into the Infinity Cache for the
-        launches that follow on the decode stream.  No effect on results."""
-        check(lib.ktx_linear_prefetch(self._h, int(workgroups), stream.cuda_stream))
 
     def __del__(self):
         try:
@@ -1206,16 +1199,6 @@ def silu_mul(gate_up: torch.Tensor, bsz_tensor: torch.Tensor | None = None) -> t
 
 
 _ARGMAX_WS: dict = {}
-
-
-def prefetch_tensor(t: torch.Tensor, stream: "torch.cuda.Stream", workgroups: int = 128) -> None:
-    """ktx_prefetch over the storage of a contiguous device tensor (read-ahead on `stream`; writes nothing)."""
-    if not t.is_cuda or not t.is_contiguous():
-        raise KtxError("prefetch_tensor: a contiguous device tensor is required")
-    ptr, nbytes = t.data_ptr(), t.numel() * t.element_size()
-    head = (-ptr) % 16                       # the kernel reads whole 16-byte units from an aligned start
-    if nbytes - head >= 16:
-        check(lib.ktx_prefetch(ptr + head, nbytes - head, int(workgroups), stream.cuda_stream))
 
 
 def argmax_bf16(logits: torch.Tensor) -> torch.Tensor:

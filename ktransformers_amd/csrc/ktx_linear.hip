@@ -38,7 +38,6 @@ typedef __bf16 lv8bf __attribute__((ext_vector_type(8)));
 #include "ktx_gate_dev.inc"   // the router's device code: it can ride in the decode GEMV's launch (lin_dec_gate_kernel)
 
 extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
-extern "C" int ktx_prefetch(const void* d_ptr, size_t bytes, int workgroups, ktx_stream_t stream);   // ktx_ops.hip (include/ktx_ops.h)
 
 namespace {
 
@@ -559,14 +558,17 @@ struct QbAbsorbParams {
   int prep_on; MlaPrepParams prep;
 };
 
-// One workgroup's share of a head.  UPW = (strip, k-half) units of q_b per wavefront over the head's first `nstr` strips (the
-// nope strips come first), S2W = absorb strips per wavefront starting at strip s2_first, ROPE = this workgroup owns the head's
-// rope strips (RoPE of q_pe -> q_pe_out), PREP = it also runs the kv half of mla_prep for token 0 (T == 1) out of registers
-// requested in front of everything else.  <3, 4, true, false> over all 12 strips is the one-workgroup-per-head kernel.
-template <int G, int NK2, int UPW, int S2W, bool ROPE, bool PREP>
-__device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t* smem, const int h, const int nstr, const int s2_first) {
+template <int G, int NK2>   // NK2 = k-steps per k-half of q_b (q_lora / 256)
+__global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
   using F1 = Fmt<F_W4, G>;
-  constexpr int TP = 4, CS = TP * 16;
+  constexpr int TP = 4, CS = TP * 16, UPW = 3, S2W = 4;   // units (strip, k-half) per wave; absorb strips per wave
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  if (p.prep_on && blockIdx.x == 0) {
+    float* s_cs = reinterpret_cast<float*>(smem);
+    for (int t = 0; t < p.prep.T; t++) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
+    return;
+  }
+  const int h = blockIdx.x - (p.prep_on ? 1 : 0);
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int NKS1 = 2 * NK2, npiece = NKS1 * 16, QW = p.nope + p.rope;
@@ -583,20 +585,6 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
   // waits for the whole weight burst (300 KB per workgroup) before it touches the q_a row — and the norm weights used to
   // be fetched piece by piece after the barrier, one exposed round trip each (lin_sk_kernel's prologue, same rules).
   typedef unsigned int u4v __attribute__((ext_vector_type(4)));
-  const int half_r = p.rope >> 1;
-  // (PREP) the kv row of token 0, its norm weights, the k_pe pair and the RoPE angle operands: the oldest requests of this
-  // workgroup, so waiting for them waits for nothing else
-  uint4 kv_raw = make_uint4(0, 0, 0, 0), kv_nw = make_uint4(0, 0, 0, 0);
-  uint32_t kpe_pr = 0;
-  float kv_pos = 0.f, kv_if = 0.f;
-  if constexpr (PREP) {
-    const int nvec = p.prep.kvl >> 3;
-    kv_raw = *reinterpret_cast<const uint4*>(p.prep.kv + min(tid, nvec - 1) * 8);
-    kv_nw = *reinterpret_cast<const uint4*>(p.prep.nw + min(tid, nvec - 1) * 8);
-    kpe_pr = *reinterpret_cast<const uint32_t*>(p.prep.kv + p.prep.kvl + 2 * min(tid, half_r - 1));
-    kv_pos = (float)p.prep.pos[0];
-    kv_if = p.prep.inv_freq[min(tid, half_r - 1)];
-  }
   const int ntot = TP * npiece;
   constexpr int XPRE = 2;   // ntot <= 1024 (q_lora <= 2048)
   uint4 xpre[XPRE], nwpre[XPRE];
@@ -607,17 +595,14 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
     xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)min(tok, p.T - 1) * p.ldx + col * 8);
     nwpre[i] = *reinterpret_cast<const uint4*>(p.norm_w + col * 8);
   }
-  float cs_pos = 0.f, cs_if = 0.f;
-  if constexpr (ROPE) {
-    const int cs_tok = min(tid / half_r, p.T - 1), cs_i = tid % half_r;
-    cs_pos = (float)p.pos[cs_tok];
-    cs_if = p.inv_freq[cs_i];
-  }
+  const int half_r = p.rope >> 1;
+  const int cs_tok = min(tid / half_r, p.T - 1), cs_i = tid % half_r;
+  const float cs_pos = (float)p.pos[cs_tok], cs_if = p.inv_freq[cs_i];
   uint4 w1r[UPW][NK2];
   uint2 s1r[UPW][NK2];
 #pragma unroll
   for (int i = 0; i < UPW; i++) {
-    const int u = wave * UPW + i, sih = min(u >> 1, nstr - 1), kh = u & 1;   // a surplus unit re-reads the last strip, stores nothing
+    const int u = wave * UPW + i, sih = min(u >> 1, p.SPH - 1), kh = u & 1;   // a surplus unit re-reads the last strip, stores nothing
     const size_t strip = (size_t)h * p.SPH + sih;
     const uint8_t* wp = p.w1 + (strip * NKS1 + (size_t)kh * NK2) * 1024 + lane * 16;
     const bf16_t* sp = p.sc1 + ((strip * NKS1 + (size_t)kh * NK2) * 16 + (lane & 15)) * F1::GPK;
@@ -631,61 +616,12 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
   uint4 w2r[S2W][4];
 #pragma unroll
   for (int i = 0; i < S2W; i++) {
-    const uint8_t* wp = p.w2 + (size_t)h * p.wbs2 + (size_t)(s2_first + wave * S2W + i) * 4096 + lane * 16;
+    const uint8_t* wp = p.w2 + (size_t)h * p.wbs2 + (size_t)(wave * S2W + i) * 4096 + lane * 16;
 #pragma unroll
     for (int q = 0; q < 4; q++) {
       const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + q * 1024));
       w2r[i][q] = make_uint4(v.x, v.y, v.z, v.w);
     }
-  }
-
-  // ---- (PREP) latent RMSNorm + k_pe RoPE of token 0 while the weight tiles are in flight: mla_prep_token_block's arithmetic,
-  // operand for operand, fed from the registers above (s_cs / nred are free until the q_a rows arrive)
-  if constexpr (PREP) {
-    const MlaPrepParams& pp = p.prep;
-    const int nvec = pp.kvl >> 3;
-    float* p_cs = s_cs;     // [rope]
-    float* p_red = nred;    // [8]
-    if (tid < half_r) {
-      const float fr = kv_pos * kv_if;
-      p_cs[tid] = prep_rbf(cosf(fr) * pp.mscale);
-      p_cs[half_r + tid] = prep_rbf(sinf(fr) * pp.mscale);
-    }
-    float ss = 0.f;
-    float v[8];
-    {
-      const uint32_t d[4] = {kv_raw.x, kv_raw.y, kv_raw.z, kv_raw.w};
-#pragma unroll
-      for (int i = 0; i < 4; i++) { v[2 * i] = __uint_as_float(d[i] << 16); v[2 * i + 1] = __uint_as_float(d[i] & 0xffff0000u); }
-      if (tid < nvec) {
-#pragma unroll
-        for (int e = 0; e < 8; e++) ss += v[e] * v[e];
-      }
-    }
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
-    if (lane == 0) p_red[wave] = ss;
-    __syncthreads();
-    float tot = 0.f;
-    for (int w = 0; w < 8; w++) tot += p_red[w];
-    if (tid < nvec) {
-      const float r = 1.0f / sqrtf(tot / (float)pp.kvl + pp.eps);
-      const uint32_t wd[4] = {kv_nw.x, kv_nw.y, kv_nw.z, kv_nw.w};
-      uint32_t o[4];
-#pragma unroll
-      for (int i = 0; i < 4; i++) {
-        const float a = __uint_as_float(wd[i] << 16) * prep_rbf(v[2 * i] * r), b = __uint_as_float(wd[i] & 0xffff0000u) * prep_rbf(v[2 * i + 1] * r);
-        o[i] = prep_rne_bf16(a) | (prep_rne_bf16(b) << 16);
-      }
-      *reinterpret_cast<uint4*>(pp.ckv + tid * 8) = make_uint4(o[0], o[1], o[2], o[3]);
-    }
-    if (tid < half_r) {   // prep_rope_pair on the pair held in kpe_pr
-      const float c = p_cs[tid], s = p_cs[half_r + tid];
-      const float u1 = __uint_as_float(kpe_pr << 16), u2 = __uint_as_float(kpe_pr & 0xffff0000u);
-      pp.kpe[tid] = (bf16_t)prep_rne_bf16(prep_rbf(u1 * c) + prep_rbf(-u2 * s));
-      pp.kpe[half_r + tid] = (bf16_t)prep_rne_bf16(prep_rbf(u2 * c) + prep_rbf(u1 * s));
-    }
-    __syncthreads();   // p_red = nred is written again below
   }
 
   // ---- the q_a rows: RMSNorm (q_a_layernorm) and staging exactly as lin_dec_kernel does them ---------------------------
@@ -695,14 +631,12 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
     const int tok = idx / npiece, col = idx - tok * npiece;
     if (!(idx < ntot && tok < p.T && col * 8 < p.Kx)) xpre[i] = make_uint4(0, 0, 0, 0);
   }
-  if constexpr (ROPE) {
-    if (tid < TP * half_r) {   // cos / sin of the tokens' positions (mla_prep's table)
-      const int tok = tid / half_r, i = tid - tok * half_r;
-      if (tok < p.T) {
-        const float fr = cs_pos * cs_if;
-        s_cs[tok * p.rope + i] = prep_rbf(cosf(fr) * p.mscale);
-        s_cs[tok * p.rope + half_r + i] = prep_rbf(sinf(fr) * p.mscale);
-      }
+  if (tid < TP * half_r) {   // cos / sin of the tokens' positions (mla_prep's table)
+    const int tok = tid / half_r, i = tid - tok * half_r;
+    if (tok < p.T) {
+      const float fr = cs_pos * cs_if;
+      s_cs[tok * p.rope + i] = prep_rbf(cosf(fr) * p.mscale);
+      s_cs[tok * p.rope + half_r + i] = prep_rbf(sinf(fr) * p.mscale);
     }
   }
   float ss[4] = {0.f, 0.f, 0.f, 0.f};
@@ -765,16 +699,15 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
         const int ks = kh * NK2 + s_;
         w4_kstep<G>(w1r[i][s_], s1r[i][s_], xb0 + (size_t)ks * 16 * CS, CS, aux + ks * F1::GPK * 4, 4, acc);
       }
-      if (lane < 16 && sih < nstr) {
+      if (lane < 16 && sih < p.SPH) {
 #pragma unroll
         for (int r = 0; r < 4; r++) red1[((sih * 2 + kh) * 4 + r) * 16 + lane] = acc[r];
       }
     }
   }
   __syncthreads();
-  const int QN = nstr * 16;   // q columns this workgroup holds (all of the head's, or its nope part)
-  for (int idx = tid; idx < TP * QN; idx += 512) {   // the k-halves in order, one bf16 rounding (lin_dec_kernel's epilogue)
-    const int r = idx / QN, n = idx - r * QN, sih = n >> 4, f = n & 15;
+  for (int idx = tid; idx < TP * QW; idx += 512) {   // the k-halves in order, one bf16 rounding (lin_dec_kernel's epilogue)
+    const int r = idx / QW, n = idx - r * QW, sih = n >> 4, f = n & 15;
     float v = 0.f;
     v += red1[((sih * 2 + 0) * 4 + r) * 16 + f];
     v += red1[((sih * 2 + 1) * 4 + r) * 16 + f];
@@ -783,13 +716,11 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
   __syncthreads();
   // ---- RoPE of q_pe (global), staging of q_nope for the absorb product (LDS) ------------------------------------------------
   {
-    if constexpr (ROPE) {
-      const int half = p.rope >> 1;
-      for (int idx = tid; idx < p.T * half; idx += 512) {
-        const int tok = idx / half, i = idx - tok * half;
-        prep_rope_pair(qh + tok * QW + p.nope, p.q_pe + ((size_t)tok * p.H + h) * p.rope, i, half, s_cs[tok * p.rope + i],
-                       s_cs[tok * p.rope + half + i]);
-      }
+    const int half = p.rope >> 1;
+    for (int idx = tid; idx < p.T * half; idx += 512) {
+      const int tok = idx / half, i = idx - tok * half;
+      prep_rope_pair(qh + tok * QW + p.nope, p.q_pe + ((size_t)tok * p.H + h) * p.rope, i, half, s_cs[tok * p.rope + i],
+                     s_cs[tok * p.rope + half + i]);
     }
     const int np2 = p.nope >> 3;
     for (int idx = tid; idx < TP * np2; idx += 512) {
@@ -806,38 +737,12 @@ __device__ __forceinline__ void qb_absorb_body(const QbAbsorbParams& p, uint8_t*
       v4f acc = {0.f, 0.f, 0.f, 0.f};
       lin_step<F_BF16, 128>(w2r[i], make_uint2(0, 0), xb0, CS, nullptr, 4, acc);
       if (lane < 16) {
-        const int n = (s2_first + wave * S2W + i) * 16 + lane;
+        const int n = (wave * S2W + i) * 16 + lane;
 #pragma unroll
         for (int r = 0; r < 4; r++)
           if (r < p.T) p.q_nope[((size_t)r * p.H + h) * p.lora + n] = f32_to_bf16(0.f + acc[r]);
       }
     }
-  }
-}
-
-// PARTS = 1: one workgroup per head (+ block 0 = the kv half of mla_prep for every token when prep_on).
-// PARTS = 2 (T == 1, nope 128, kv_lora 512, heads % 8 == 0): two workgroups per head, 2 * heads workgroups in all — with 128
-// heads one per CU instead of one on every other CU.  Part A = all 12 strips of q_b (the rope strips and RoPE are its alone)
-// + absorb strips 0..7; part B = the 8 nope strips of q_b again (98 KB re-read: the absorb product needs all of q_nope) +
-// absorb strips 8..31: 189 / 200 KB per workgroup instead of 297.  No meeting between the parts: every output element is
-// computed by one workgroup with the expressions and the order of PARTS = 1 (bit-identical results).  Blocks b and b + 8 are
-// the two parts of one head: consecutive workgroup ids go round the 8 XCDs, so the parts share an L2 and the second read of
-// the nope strips is an L2 hit more often than not.  The kv half of mla_prep rides in head 0's part B (qb_absorb_body PREP).
-template <int G, int NK2, int PARTS>   // NK2 = k-steps per k-half of q_b (q_lora / 256)
-__global__ __launch_bounds__(512) void lin_qb_absorb_kernel(QbAbsorbParams p) {
-  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  if constexpr (PARTS == 1) {
-    if (p.prep_on && blockIdx.x == 0) {
-      float* s_cs = reinterpret_cast<float*>(smem);
-      for (int t = 0; t < p.prep.T; t++) mla_prep_token_block<512>(p.prep, t, s_cs, s_cs + 512);
-      return;
-    }
-    qb_absorb_body<G, NK2, 3, 4, true, false>(p, smem, blockIdx.x - (p.prep_on ? 1 : 0), p.SPH, 0);
-  } else {
-    const int b = blockIdx.x, part = (b >> 3) & 1, h = ((b >> 4) << 3) | (b & 7);
-    if (part == 0) qb_absorb_body<G, NK2, 3, 1, true, false>(p, smem, h, p.SPH, 0);
-    else if (h == 0 && p.prep_on) qb_absorb_body<G, NK2, 2, 3, false, true>(p, smem, h, p.nope >> 4, 8);
-    else qb_absorb_body<G, NK2, 2, 3, false, false>(p, smem, h, p.nope >> 4, 8);
   }
 }
 
@@ -855,43 +760,20 @@ struct MergeUnabsorbParams {
   bf16_t* y; long ldy, ybs;                // y[t*ldy + h*ybs + n]
 };
 
-// PARTS = 2: two workgroups per head (2 * heads in all; blocks b and b + 8 = the parts of one head, on one XCD).  Both merge the
-// head's splits (the partials are read twice, mostly out of the shared L2), each holds HALF of W_UV: wavefront w < 4 of part q
-// runs strip 4 q + w over all four k-steps — the arithmetic and order of PARTS = 1, so the outputs are bit-identical — and
-// wavefronts 4..7 only take part in the merge.  64 + 100 KB per workgroup instead of 128 + 100 (49 splits).
-template <bool HAS_STRIP>
-__device__ __forceinline__ void merge_unabsorb_body(const MergeUnabsorbParams& p, uint8_t* smem, float* s_w, float* s_red, const int h,
-                                                    const int strip);
-
-template <int PARTS>
 __global__ __launch_bounds__(512) void lin_merge_unabsorb_kernel(MergeUnabsorbParams p) {
+  constexpr int TP = 4, CS = TP * 16;
   __shared__ float s_w[256];
   __shared__ float s_red[16];
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-  if constexpr (PARTS == 1) {
-    merge_unabsorb_body<true>(p, smem, s_w, s_red, blockIdx.x, wave);
-  } else {
-    const int b = blockIdx.x, part = (b >> 3) & 1, h = ((b >> 4) << 3) | (b & 7);
-    // two code paths, not a conditional around the weight loads: inside each path every load is unconditional (exact vmcnt)
-    if (wave < 4) merge_unabsorb_body<true>(p, smem, s_w, s_red, h, part * 4 + wave);
-    else merge_unabsorb_body<false>(p, smem, s_w, s_red, h, 0);
-  }
-}
-
-template <bool HAS_STRIP>
-__device__ __forceinline__ void merge_unabsorb_body(const MergeUnabsorbParams& p, uint8_t* smem, float* s_w, float* s_red, const int h,
-                                                    const int strip) {
-  constexpr int TP = 4, CS = TP * 16;
   float* s_acc = reinterpret_cast<float*>(smem);                         // [8][K]
   uint8_t* xs = smem + (size_t)8 * p.K * 4;                              // [K / 8][TP][16 B]
-  const int tid = threadIdx.x, lane = tid & 63;
+  const int h = blockIdx.x, tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   typedef unsigned int u4v __attribute__((ext_vector_type(4)));
   // ---- the head's weight tiles: wave = strip (N = 128 -> 8 strips), 4 k-steps x 4 planes
   uint4 wr[4][4];
-  if constexpr (HAS_STRIP) {
-    const uint8_t* wp = p.w + (size_t)h * p.wbs + (size_t)strip * p.NKS * 4096 + lane * 16;
+  {
+    const uint8_t* wp = p.w + (size_t)h * p.wbs + (size_t)wave * p.NKS * 4096 + lane * 16;
 #pragma unroll
     for (int ks = 0; ks < 4; ks++)
 #pragma unroll
@@ -977,18 +859,16 @@ __device__ __forceinline__ void merge_unabsorb_body(const MergeUnabsorbParams& p
     __syncthreads();
   }
   // ---- the un-absorb GEMV: wave = strip, the k-steps in order (lin_dec_kernel's BF16 arithmetic with one k-slice)
-  if constexpr (HAS_STRIP) {
-    const int kc = lane >> 4, tokp = (lane & 15) & (TP - 1);
-    const uint8_t* xb0 = xs + tokp * 16 + kc * 4 * CS;
-    v4f acc = {0.f, 0.f, 0.f, 0.f};
+  const int kc = lane >> 4, tokp = (lane & 15) & (TP - 1);
+  const uint8_t* xb0 = xs + tokp * 16 + kc * 4 * CS;
+  v4f acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int ks = 0; ks < 4; ks++) lin_step<F_BF16, 128>(wr[ks], make_uint2(0, 0), xb0 + (size_t)ks * 16 * CS, CS, nullptr, 4, acc);
-    if (lane < 16) {
-      const int n = strip * 16 + lane;
+  for (int ks = 0; ks < 4; ks++) lin_step<F_BF16, 128>(wr[ks], make_uint2(0, 0), xb0 + (size_t)ks * 16 * CS, CS, nullptr, 4, acc);
+  if (lane < 16) {
+    const int n = wave * 16 + lane;
 #pragma unroll
-      for (int r = 0; r < 4; r++)
-        if (r < p.T && n < p.N) p.y[(size_t)r * p.ldy + (size_t)h * p.ybs + n] = f32_to_bf16(0.f + acc[r]);
-    }
+    for (int r = 0; r < 4; r++)
+      if (r < p.T && n < p.N) p.y[(size_t)r * p.ldy + (size_t)h * p.ybs + n] = f32_to_bf16(0.f + acc[r]);
   }
 }
 
@@ -2151,14 +2031,6 @@ extern "C" int ktx_linear_forward_batched_prep(ktx_linear_t h, int T, const void
   return linear_forward_impl(h, nullptr, T, d_x, ldx, x_batch_stride, d_y, ldy, y_batch_stride, stream, nullptr, &pp);
 }
 
-// Grids of the two per-head decode launches (ktx_linear_forward_qb_absorb, ktx_linear_forward_batched_merge): dev knob 23 = 1
-// one workgroup per head, 2 = two per head, 0 = the default below.
-constexpr bool HEADS_SPLIT_DEFAULT = false;
-static bool heads_split_on() {
-  const int k = ktx_debug_get(23);
-  return k == 2 || (k == 0 && HEADS_SPLIT_DEFAULT);
-}
-
 static bool qb_absorb_ok(const ktx_linear_s* qb, const ktx_linear_s* ab, int T, int H, int nope, int rope, int lora) {
   return qb && ab && qb->loaded && ab->loaded && T >= 1 && T <= 4 && !g_lin_force_gemm && ktx_debug_get(15) != 1 &&
          qb->cfg.format == KTX_LIN_W4 && qb->cfg.group_size == 64 && qb->batch == 1 && !qb->d_bias &&
@@ -2210,13 +2082,7 @@ extern "C" int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_abs
   KTX_TIMED(st, (double)q_b->w_bytes + (double)q_b->sc_bytes + (double)q_absorb->w_bytes +
                     (double)T * (p.Kx + num_heads * (kv_lora + rope_dim)) * 2.0,
             "lin_qb_absorb_kernel<W4> %d->%dx%d ->%d%s", p.Kx, num_heads, QW, kv_lora, d_kv ? " +mla_prep" : "");
-  // two workgroups per head (dev knob 23): a single token, the head dimensions the split is written for, heads a multiple of 8
-  // (the parts of a head are 8 workgroup ids apart: same XCD)
-  const bool split = heads_split_on() && T == 1 && nope_dim == 128 && kv_lora == 512 && num_heads % 8 == 0;
-  if (split)
-    hipLaunchKernelGGL((lin_qb_absorb_kernel<64, 6, 2>), dim3(2 * num_heads), dim3(512), std::max(smem, (size_t)520 * 4 + 2048), st, p);
-  else
-    hipLaunchKernelGGL((lin_qb_absorb_kernel<64, 6, 1>), dim3(num_heads + p.prep_on), dim3(512), std::max(smem, (size_t)520 * 4 + 2048), st, p);
+  hipLaunchKernelGGL((lin_qb_absorb_kernel<64, 6>), dim3(num_heads + p.prep_on), dim3(512), std::max(smem, (size_t)520 * 4 + 2048), st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }
@@ -2246,11 +2112,7 @@ extern "C" int ktx_linear_forward_batched_merge(ktx_linear_t h, int T, const flo
   hipStream_t st = (hipStream_t)stream;
   KTX_TIMED(st, (double)h->w_bytes + (double)T * num_heads * (p.K + p.N) * 2.0,
             "lin_merge_unabsorb_kernel<BF16> %d->%d x%d nsplit=%d", p.K, p.N, num_heads, nsplit);
-  // two workgroups per head (dev knob 23), see the kernel
-  if (heads_split_on() && num_heads % 8 == 0 && p.N == 128)
-    hipLaunchKernelGGL(lin_merge_unabsorb_kernel<2>, dim3(2 * num_heads), dim3(512), smem, st, p);
-  else
-    hipLaunchKernelGGL(lin_merge_unabsorb_kernel<1>, dim3(num_heads), dim3(512), smem, st, p);
+  hipLaunchKernelGGL(lin_merge_unabsorb_kernel, dim3(num_heads), dim3(512), smem, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }
@@ -2268,13 +2130,6 @@ extern "C" int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_o
     default: hipLaunchKernelGGL(lin_dequant_w4_kernel<128>, dim3(ntiles), dim3(64), 0, st, (const uint4*)h->d_w, (const bf16_t*)h->d_sc, N, Kx, h->NKS, (bf16_t*)d_out, (long)ld_out); break;
   }
   KTX_HIP(hipGetLastError());
-  return 0;
-}
-
-extern "C" int ktx_linear_prefetch(ktx_linear_t h, int workgroups, ktx_stream_t stream) {
-  KTX_REQUIRE(h && h->loaded, "ktx_linear_prefetch: needs a loaded handle");
-  if (int rc = ktx_prefetch(h->d_w, h->w_bytes, workgroups, stream)) return rc;
-  if (h->d_sc && h->sc_bytes) return ktx_prefetch(h->d_sc, h->sc_bytes, std::max(1, workgroups / 8), stream);
   return 0;
 }
 

@@ -263,41 +263,6 @@ extern "C" int ktx_silu_mul(const void* d_gu, int64_t ldg, void* d_y, int T, int
   return 0;
 }
 
-// ---- read-ahead of weight bytes (ktx_prefetch): a kernel that only READS a byte range, launched on a side stream beside the
-// latency-bound launches of a decode step so that the next launches find their weights in the die-level Infinity Cache (256
-// MiB, memory side: it serves every XCD) instead of HBM.  Plain 16-byte loads, 8 in flight per lane; the values are folded into
-// one word that is compared with a constant so the loads cannot be dropped; nothing is ever written.  Few, small workgroups
-// (256 threads, no LDS, a handful of registers): they fit beside a resident 512-thread GEMV workgroup on the same CU.
-__global__ __launch_bounds__(256) void prefetch_kernel(const uint4* __restrict__ p, size_t n16, unsigned* __restrict__ sink) {
-  const size_t stride = (size_t)gridDim.x * 256;
-  size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-  unsigned acc = 0;
-  for (; i + 7 * stride < n16; i += 8 * stride) {
-    uint4 v[8];
-#pragma unroll
-    for (int u = 0; u < 8; u++) v[u] = p[i + u * stride];
-#pragma unroll
-    for (int u = 0; u < 8; u++) acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
-  }
-  for (; i < n16; i += stride) {
-    const uint4 v = p[i];
-    acc ^= v.x ^ v.y ^ v.z ^ v.w;
-  }
-  if (sink && acc == 0x9e3779b9u) *sink = acc;   // (sink is NULL in every call the library makes)
-}
-
-extern "C" int ktx_prefetch(const void* d_ptr, size_t bytes, int workgroups, ktx_stream_t stream) {
-  KTX_REQUIRE(d_ptr || bytes == 0, "ktx_prefetch: null pointer");
-  KTX_REQUIRE(((uintptr_t)d_ptr & 15) == 0, "ktx_prefetch: the range must start on a 16-byte boundary");
-  const size_t n16 = bytes / 16;
-  if (n16 == 0) return 0;
-  const int nwg = (int)std::min<size_t>((size_t)std::min(std::max(workgroups, 1), 4096), (n16 + 255) / 256);
-  KTX_TIMED((hipStream_t)stream, (double)bytes, "prefetch_kernel %zu KiB", bytes >> 10);
-  hipLaunchKernelGGL(prefetch_kernel, dim3(nwg), dim3(256), 0, (hipStream_t)stream, (const uint4*)d_ptr, n16, (unsigned*)nullptr);
-  KTX_HIP(hipGetLastError());
-  return 0;
-}
-
 extern "C" size_t ktx_argmax_workspace_bytes(int rows) { return (size_t)(rows > 0 ? rows : 0) * (2 * ARGMAX_WGS + 1) * 4; }
 
 extern "C" int ktx_argmax_bf16(const void* d_x, int64_t ldx, int rows, int n, int64_t* d_out, void* d_workspace,

@@ -148,12 +148,10 @@ class DeepseekDecoderLayer(nn.Module):
         self.input_layernorm = DeepseekRMSNorm(config.hidden_size, config.rms_norm_eps)
         self.post_attention_layernorm = DeepseekRMSNorm(config.hidden_size, config.rms_norm_eps)
 
-    def forward(self, hidden_states, position_ids=None, past_key_value=None, cache_position=None, after_attention=None, **kwargs):
+    def forward(self, hidden_states, position_ids=None, past_key_value=None, cache_position=None, **kwargs):
         """DeepseekV3DecoderLayer.forward (modeling_deepseek_v3.py:1188-1262).  When the injected operators expose the
         fusion hooks, input_layernorm runs inside the attention's first GEMV and both residual adds inside the epilogues
-        of o_proj / the MLP's down_proj (same roundings, fewer launches); otherwise the plain sequence.
-        `after_attention` (a callable, the decode read-ahead's second fork point: util/prefetch.py) runs once the attention
-        operator has enqueued its launches."""
+        of o_proj / the MLP's down_proj (same roundings, fewer launches); otherwise the plain sequence."""
         attn, mlp = self.self_attn, self.mlp
         if getattr(type(attn), "SUPPORTS_FUSION", False):
             hidden_states, _, past_key_value = attn(hidden_states, position_ids=position_ids, past_key_value=past_key_value,
@@ -165,8 +163,6 @@ class DeepseekDecoderLayer(nn.Module):
             hidden_states, _, past_key_value = attn(hidden_states, position_ids=position_ids,
                                                     past_key_value=past_key_value, cache_position=cache_position)
             hidden_states = residual + hidden_states
-        if after_attention is not None:
-            after_attention()
         residual = hidden_states
         if getattr(type(mlp), "SUPPORTS_FUSION", False):   # post_attention_layernorm runs inside the MLP's first launch
             return mlp(hidden_states, **{type(mlp).RESIDUAL_KW: residual, type(mlp).PRE_NORM_KW: self.post_attention_layernorm})
@@ -184,23 +180,8 @@ class DeepseekModel(nn.Module):
 
     def forward(self, input_ids=None, position_ids=None, past_key_values=None, cache_position=None, inputs_embeds=None):
         h = inputs_embeds if inputs_embeds is not None else self.embed_tokens(input_ids)
-        from ktransformers_amd.util import prefetch
-        mode = prefetch.enabled() if (h.is_cuda and h.shape[-2] == 1) else ""      # a single-token decode step, opted in
-        if not mode:
-            for layer in self.layers:
-                h = layer(h, position_ids=position_ids, past_key_value=past_key_values, cache_position=cache_position)
-            return self.norm(h)
-        pf = self.__dict__.get("_prefetcher")
-        if pf is None:
-            pf = self.__dict__["_prefetcher"] = prefetch.DecodePrefetcher(self.layers)
-        dev = h.device
-        try:
-            for i, layer in enumerate(self.layers):
-                pf.layer_start(i, dev, mode)
-                h = layer(h, position_ids=position_ids, past_key_value=past_key_values, cache_position=cache_position,
-                          after_attention=lambda i=i: pf.attention_done(i, dev, mode))
-        finally:
-            pf.join(dev)         # (a captured graph must see the side stream re-joined)
+        for layer in self.layers:
+            h = layer(h, position_ids=position_ids, past_key_value=past_key_values, cache_position=cache_position)
         return self.norm(h)
 
 

@@ -40,13 +40,6 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "lin: round-2 router workgroups in front of the all-CU gate|up kernel": ({19: 3}, {}),
     "lin: two workgroups per CU": ({18: 2}, {}),
     "gate: store-ack hand-off (no granules)": ({21: 1}, {}),
-    "attn: one workgroup per head (q_b + absorb, merge + un-absorb)": ({23: 1}, {}),
-    "attn: two workgroups per head (q_b + absorb, merge + un-absorb)": ({23: 2}, {}),
-    "read-ahead: both sets, 128 wgs": ({}, {"KTX_PREFETCH": "1"}),
-    "read-ahead: set 1 only, 128 wgs": ({}, {"KTX_PREFETCH": "s1"}),
-    "read-ahead: set 2 only, 128 wgs": ({}, {"KTX_PREFETCH": "s2"}),
-    "read-ahead: both sets, 48 wgs": ({}, {"KTX_PREFETCH": "1", "KTX_PREFETCH_WGS": "48"}),
-    "read-ahead: both sets, 256 wgs": ({}, {"KTX_PREFETCH": "1", "KTX_PREFETCH_WGS": "256"}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}

@@ -194,19 +194,11 @@ def test_merge_riding_the_unabsorb_launch(Hq, kv_len, T):
     attn = w.run(qn, qp, ckv, k_pe)
     ref = oabs.forward_batched(attn)
     assert n.lib.ktx_linear_merge_eligible(oabs._h, T, 1, Hq)
-    per_grid = {}
-    for grid in (1, 2):      # dev knob 23: 1 = one workgroup per head, 2 = two (half of W_UV each)
-        n.lib.ktx_debug_set(23, grid)
-        try:
-            for rep in range(2):
-                parts = w.run_partials(qn, qp, ckv, k_pe)
-                got = n.merge_and_unabsorb(oabs, parts, T, Hq)
-                torch.cuda.synchronize()
-                a, b = got.float(), ref.float()
-                assert torch.isfinite(a).all()
-                assert float((a - b).norm() / b.norm()) < 2e-3
-                assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())
-            per_grid[grid] = got.clone()
-        finally:
-            n.lib.ktx_debug_set(23, 0)
-    assert torch.equal(per_grid[1], per_grid[2]), "the two grids run the same arithmetic in the same order"
+    for rep in range(2):
+        parts = w.run_partials(qn, qp, ckv, k_pe)
+        got = n.merge_and_unabsorb(oabs, parts, T, Hq)
+        torch.cuda.synchronize()
+        a, b = got.float(), ref.float()
+        assert torch.isfinite(a).all()
+        assert float((a - b).norm() / b.norm()) < 2e-3
+        assert float((a - b).abs().max()) <= 2e-2 * float(b.abs().max())

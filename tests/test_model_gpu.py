@@ -102,38 +102,6 @@ def test_generation_through_a_captured_graph_equals_eager(model_and_gold):
         assert int(eager[0]) == int(ref_last.argmax())
 
 
-def test_decode_read_ahead_changes_no_result(model_and_gold):
-    """KTX_PREFETCH (util/prefetch.py): read-only launches on a side stream forked from the decode stream — same tokens and the
-    same logits bit for bit, eager and through a captured graph; the side launches are there (launch log) and cover the
-    layer's own later weights (set 1) and the next layer's first ones (set 2)."""
-    from ktransformers_amd import _native
-    from ktransformers_amd.util.generate import prefill_and_generate
-    model, cache, g = model_and_gold
-    ids = torch.from_numpy(g["input_ids"]).cuda()[None]
-    cache.reset()
-    base, lb = prefill_and_generate(model, ids, cache, max_new_tokens=6, use_cuda_graph=False, return_logits=True)
-    try:
-        for mode in ("1", "s1", "s2"):
-            os.environ["KTX_PREFETCH"] = mode
-            os.environ["KTX_PREFETCH_WGS"] = "16"
-            for use_graph in (False, True):
-                cache.reset()
-                _native.timing_enable(2)
-                _native.timing_collect()
-                toks, lg = prefill_and_generate(model, ids, cache, max_new_tokens=6, use_cuda_graph=use_graph, return_logits=True)
-                torch.cuda.synchronize()
-                labels = [lab for lab, _, _ in _native.timing_collect()]
-                _native.timing_enable(0)
-                assert torch.equal(toks, base) and torch.equal(lg, lb), (mode, use_graph)
-                assert any("prefetch_kernel" in lab for lab in labels), (mode, use_graph, labels[:8])
-    finally:
-        _native.timing_enable(0)
-        os.environ.pop("KTX_PREFETCH", None)
-        os.environ.pop("KTX_PREFETCH_WGS", None)
-    plan = model.model.__dict__["_prefetcher"]._plan(1)
-    assert len(plan.early) >= 3 and len(plan.head) >= 2 and len(plan.tensors) == 1      # o_proj, W_UV, shared gate|up (+ down); q_a|kv_a, q_b (+ W_UK)
-
-
 def test_serving_variant_block_honours_bsz_tensor(model_and_gold):
     """KDeepseekV3MoEV2.forward(hidden, bsz_tensor, cuda_graph_idx) (experts.py:1172-1213) on the injected MoE block: with all
     rows valid it equals the single-request block, with fewer the valid rows are unchanged."""
