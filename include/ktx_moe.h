@@ -185,7 +185,9 @@ int ktx_debug_force_generic(int on);
  * 0 auto), idx 13 = 1 makes ktx_linear_forward_fused_gate issue its two launches instead of the combined kernel (A/B, tests),
  * idx 14 = 1 makes ktx_moe_forward_side run the side linear as a launch of its own (A/B, tests), idx 15 = 1 makes
  * ktx_linear_qb_absorb_eligible answer no (A/B), idx 22 = 1 runs the non-absorbed prompt attention kernel with its
- * unconstrained register allocation (one wavefront per SIMD; A/B of scripts/mla_prefill_bench.py). */
+ * unconstrained register allocation (one wavefront per SIMD; A/B of scripts/mla_prefill_bench.py), idx 25 = experts per
+ * router workgroup in ktx_linear_forward_fused_gate's combined kernel: 1 -> 8 (rounds 2-3), 2 -> 2, 0 -> 4 where the grid has room
+ * (same logits and selection bit for bit). */
 int ktx_debug_set(int idx, int val);
 int ktx_debug_get(int idx);
 /* Per-launch timing of every kernel of the library (bench.py's per-kernel table; ktx_prof.hip).  mode 1: each launch is

@@ -525,11 +525,11 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
 // the rest of the chip.  Row blockIdx.y == 0 (dispatched first: the longer chain) = router workgroups, 8 experts each, of
 // token blockIdx.x / gate_nwg; rows 1.. = the GEMV's grid.  Same device code as the stand-alone kernels.
 template <int G, int D, int EPL, int NJ>
-__global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs ga, int gate_nwg) {
+__global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs ga, int gate_nwg, int gate_epw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (blockIdx.y == 0) {
     const int t = blockIdx.x / gate_nwg;
-    if (t < ga.qlen) gate_fused_body<EPL, NJ, 8>(ga, blockIdx.x - t * gate_nwg, gate_nwg, t, smem);
+    if (t < ga.qlen) gate_fused_body<EPL, NJ, 8>(ga, blockIdx.x - t * gate_nwg, gate_nwg, t, smem, gate_epw);
     return;
   }
   lin_dec_body<F_W4, G, D, M_EXACT>(p, blockIdx.x, blockIdx.y - 1, gridDim.x, smem);
@@ -1616,7 +1616,12 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
   if (gate) {   // the router rides in this launch (lin_dec_gate_kernel) — W4 g64, whole k-slices, router grid inside one row
     if constexpr (FMT == F_W4 && G == 64) {
       const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
-      const int nwg = (E + 7) / 8, epl = (E + 63) / 64;
+      // router workgroups: 4 experts each where the router row of the grid has room for them (the 8 wavefronts of a workgroup
+      // then stream half the router rows: the logits exist earlier on the launch's critical chain), else 8; dev knob 25 = 1: always 8
+      // (knob 25 = 2: 2 experts each — 5.385 vs 5.399 ms per step on one slow-class box, within the spread of the windows: not the default)
+      const int want = ktx_debug_get(25) == 1 ? 8 : ktx_debug_get(25) == 2 ? 2 : 4;
+      const int epw = (int)grid.x >= ((E + want - 1) / want) * p.T ? want : 8;
+      const int nwg = (E + epw - 1) / epw, epl = (E + 63) / 64;
       const int d = p.SPS % 8 == 0 ? 8 : p.SPS % 7 == 0 ? 7 : p.SPS % 4 == 0 ? 4 : p.SPS % 2 == 0 ? 2 : 0;
       if (p.prep_on || h->batch != 1 || nsl * p.SPS != NKS || dma_depth || d == 0 || (int)grid.x < nwg * p.T || H != p.Kx ||
           H > 8192 || epl > 6 || ktx_debug_get(13) == 1)
@@ -1631,7 +1636,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
           KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
           attr_set = true;
         }
-        hipLaunchKernelGGL(kern, grid_g, dim3(512), smem_g, st, p, *gate, nwg);
+        hipLaunchKernelGGL(kern, grid_g, dim3(512), smem_g, st, p, *gate, nwg, epw);
         KTX_HIP(hipGetLastError());
         return 0;
       };

@@ -40,6 +40,8 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "lin: round-2 router workgroups in front of the all-CU gate|up kernel": ({19: 3}, {}),
     "lin: two workgroups per CU": ({18: 2}, {}),
     "gate: store-ack hand-off (no granules)": ({21: 1}, {}),
+    "gate: 8 experts per router workgroup (32 workgroups at E = 256)": ({25: 1}, {}),
+    "gate: 2 experts per router workgroup (128 workgroups at E = 256)": ({25: 2}, {}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}

@@ -149,6 +149,16 @@ def test_router_riding_in_the_shared_gate_up_launch(name, I_shared, T):
                 assert abs(v - ref[e]) <= 2e-3 * abs(ref[e]) + 1e-9, (t, e, v, ref[e])
         err = (y2.float() - y0.float()).abs().max().item()
         assert err <= 2e-2 * y0.float().abs().max().item(), err
+    # router workgroups of 4 experts (default where the grid has room) vs 8 (dev knob 25 = 1): the same dot product per expert,
+    # the same selection code, the same GEMV workgroups — every output bit for bit
+    try:
+        n.lib.ktx_debug_set(25, 1)
+        for rep in range(2):
+            idx3, wt3, xn3, y3 = n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6))
+            torch.cuda.synchronize()
+            assert torch.equal(idx3, idx2) and torch.equal(wt3, wt2) and torch.equal(xn3, xn2) and torch.equal(y3, y2)
+    finally:
+        n.lib.ktx_debug_set(25, 0)
 
 
 @pytest.mark.parametrize("mode", [2, 3])
