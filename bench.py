@@ -986,6 +986,40 @@ def llamafile_cpu_leg(wl, budget_s=10.0):
         return {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
 
 
+class RunClock:
+    """Wall clock of one bench run: seconds per section (-> `timing_s` of the JSON line) and the point after which no further
+    OPTIONAL section is started (--time-budget), so that the single JSON line — printed at the end — is not lost to a caller's
+    time limit."""
+
+    def __init__(self, budget_s: float, now=time.perf_counter):
+        self.now, self.budget_s = now, float(budget_s)
+        self.t_start = now()
+        self.timing = {}
+
+    def lap(self, name: str, t0: float) -> None:
+        self.timing[name] = round(self.now() - t0, 1)
+
+    def elapsed(self) -> float:
+        return self.now() - self.t_start
+
+    def over_budget(self) -> bool:
+        return self.elapsed() > self.budget_s
+
+
+def truncated_line(out: dict, clock: RunClock, signum: int) -> dict:
+    """The line as far as the run got when a SIGTERM arrives after the headline measurement: marked `truncated`, with the
+    section timings, and with the whole-step rate as `roofline` if the per-kernel pass had not been reached (never overwriting
+    a measured one)."""
+    line = dict(out)
+    line["truncated"] = f"signal {signum} after {clock.elapsed():.0f}s: the sections not yet run are missing"
+    line["timing_s"] = dict(clock.timing)
+    if "roofline" not in line:
+        ws = line["whole_step"]
+        line["roofline"] = {"bound": "hbm", "kernel": "whole decode step (per-kernel pass not reached)", "achieved": ws["GBs"],
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ws["frac_of_hbm_peak"], "traffic": None}
+    return line
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1021,14 +1055,8 @@ def main():
         print(json.dumps(cpu_baseline(wl)), flush=True)
         return
 
-    t_start = time.perf_counter()
-    timing = {}                      # seconds per section of this run -> the JSON line ("timing_s")
-
-    def lap(name, t0):
-        timing[name] = round(time.perf_counter() - t0, 1)
-
-    def over_budget():
-        return time.perf_counter() - t_start > args.time_budget
+    clock = RunClock(args.time_budget)
+    t_start, timing, lap, over_budget = clock.t_start, clock.timing, clock.lap, clock.over_budget
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1131,11 +1159,7 @@ def main():
 
     def _salvage(signum, frame):
         if rank == 0:
-            out["truncated"] = f"signal {signum} after {time.perf_counter() - t_start:.0f}s: the sections not yet run are missing"
-            out["timing_s"] = timing
-            out.setdefault("roofline", {"bound": "hbm", "kernel": "whole decode step (per-kernel pass not reached)", "achieved": out["whole_step"]["GBs"],
-                                        "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": out["whole_step"]["frac_of_hbm_peak"], "traffic": None})
-            print(json.dumps(out), flush=True)
+            print(json.dumps(truncated_line(out, clock, signum)), flush=True)
         os._exit(0)
 
     try:

@@ -117,3 +117,25 @@ def test_llamafile_cpu_leg_runs_the_reference_kernels():
     if r["value"] is None:
         pytest.skip(r["sample"])
     assert r["kind"] == "reference" and r["cores"] == 2 and r["value"] > 0 and r["us_per_layer"] > 0
+
+
+def test_time_budget_clock_and_the_truncated_line():
+    """bench.py prints ONE line, at the end: RunClock stops optional sections from starting past --time-budget, and a SIGTERM
+    after the headline measurement prints what exists (truncated_line) — marked, timed, with a roofline that never replaces
+    a measured one."""
+    b = _bench()
+    t = [100.0]
+    clock = b.RunClock(30.0, now=lambda: t[0])
+    t0 = t[0]
+    t[0] += 12.34
+    clock.lap("decode", t0)
+    assert clock.timing == {"decode": 12.3} and not clock.over_budget() and abs(clock.elapsed() - 12.34) < 1e-9
+    t[0] += 20.0
+    assert clock.over_budget()
+    out = {"metric": "m", "value": 1.0, "whole_step": {"GBs": 2000.0, "frac_of_hbm_peak": 0.25}}
+    line = b.truncated_line(out, clock, 15)
+    assert "truncated" in line and "signal 15 after 32s" in line["truncated"] and line["timing_s"] == {"decode": 12.3}
+    assert line["roofline"]["achieved"] == 2000.0 and line["roofline"]["frac"] == 0.25 and line["roofline"]["traffic"] is None
+    assert "truncated" not in out and "roofline" not in out                      # the run's own dict is not touched
+    out["roofline"] = {"kernel": "measured"}
+    assert b.truncated_line(out, clock, 15)["roofline"] == {"kernel": "measured"}
