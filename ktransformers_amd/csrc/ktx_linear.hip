@@ -522,7 +522,7 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
 // The MoE router riding in the launch of the shared experts' gate|up GEMV (ktx_linear_forward_fused_gate): both read the same
 // post-attention hidden row and neither needs the other's result (KDeepseekV3MoE.forward, operators/experts.py:974-1012 runs
 // the shared experts beside the routed ones), the router is a latency chain on E/8 workgroups and the GEMV a weight stream on
-// the rest of the chip.  Row blockIdx.y == 0 (dispatched first: the longer chain) = router workgroups, 8 experts each, of
+// the rest of the chip.  Row blockIdx.y == 0 (dispatched first: the longer chain) = router workgroups, gate_epw (4 or 8) experts each, of
 // token blockIdx.x / gate_nwg; rows 1.. = the GEMV's grid.  Same device code as the stand-alone kernels.
 template <int G, int D, int EPL, int NJ>
 __global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs ga, int gate_nwg, int gate_epw) {
