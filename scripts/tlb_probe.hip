@@ -1,0 +1,132 @@
+// tlb_probe.hip — VERDICT r3 item 2: why does a dependent first touch cost 3-5 us inside the model's decode graph on some boxes
+// and 1-1.5 us on others, while isolated chains of the same kernels are fast everywhere?
+//
+// Hypothesis under test: address translation.  A decode step streams 11 GB of weights out of a 150 GB working set between two
+// touches of the small hot buffers (activation rows, norm weights, tickets), so their translations are gone from the TLBs when
+// the next kernel's first load needs them; an isolated chain never leaves a few MB.  The probe reproduces exactly that
+// difference and nothing else:
+//     [ stream(region r of the arena) ; touch(hot) ] x N      captured in ONE graph, r cycling over the arena
+// with the streamed region either fixed (cache thrash only: its pages stay translated) or walking over `arena_gb` of distinct
+// memory (cache + TLB thrash).  touch = thread 0 of every workgroup times, with s_memtime, a first load from the hot buffer
+// (translation + cache miss), a second dependent load from another line of the SAME page (cache miss only) and a third from
+// a line of a different, never-touched-this-round 2 MB page of the hot allocation.
+//   hipcc --offload-arch=gfx950 -O3 scripts/tlb_probe.hip -o scripts/tlb_probe && scripts/tlb_probe [arena_gb=48]
+#include <hip/hip_runtime.h>
+#include <algorithm>
+#include <cstdio>
+#include <cstdlib>
+#include <vector>
+
+#define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+
+__global__ __launch_bounds__(512) void stream_kernel(const u4v* __restrict__ src, size_t n16, unsigned* sink) {
+  unsigned acc = 0;
+  const size_t stride = (size_t)gridDim.x * 512;
+  size_t i = (size_t)blockIdx.x * 512 + threadIdx.x;
+  for (; i + 3 * stride < n16; i += 4 * stride) {
+    const u4v a = __builtin_nontemporal_load(src + i), b = __builtin_nontemporal_load(src + i + stride);
+    const u4v c = __builtin_nontemporal_load(src + i + 2 * stride), d = __builtin_nontemporal_load(src + i + 3 * stride);
+    acc += a.x ^ b.y ^ c.z ^ d.w;
+  }
+  if (acc == 0x12345678u) sink[0] = acc;
+}
+
+// hot: >= 6 MB.  out[wg][4] = {first load, second load same page, third load other 2 MB page, total} in 100 MHz ticks
+__global__ __launch_bounds__(512) void touch_kernel(const unsigned* hot, unsigned long long* out, int round, unsigned* sink) {
+  if (threadIdx.x != 0) return;
+  const unsigned* p = hot + (size_t)blockIdx.x * 64;   // one 256-byte line per workgroup inside the first 64 KB
+  const unsigned long long t0 = wall_clock64();
+  unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = wall_clock64();
+  const unsigned* p2 = hot + (128 * 1024 / 4) + (size_t)blockIdx.x * 64 + (v & 1);   // other line, same 2 MB page
+  v += __hip_atomic_load(p2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t2 = wall_clock64();
+  const unsigned* p3 = hot + ((size_t)(2 + (round & 1) * 2) << 20) / 4 + (size_t)blockIdx.x * 64 + (v & 1);   // another 2 MB page
+  v += __hip_atomic_load(p3, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t3 = wall_clock64();
+  // the model's actual pattern: a line that ANOTHER workgroup (another XCD: block b runs on XCD b % 8) wrote with a plain store in the
+  // previous kernel of the chain; then this workgroup writes its own line for the next round
+  unsigned* h2 = const_cast<unsigned*>(hot) + ((size_t)6 << 20) / 4;
+  const unsigned* p4 = h2 + (size_t)((blockIdx.x + 1) % gridDim.x) * 64 + (v & 1);
+  v += *(volatile const unsigned*)p4;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t4 = wall_clock64();
+  h2[(size_t)blockIdx.x * 64] = (unsigned)round;
+  unsigned long long* o = out + ((size_t)round * gridDim.x + blockIdx.x) * 4;
+  o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2; o[3] = t4 - t3;
+  if (v == 0x9abcdef0u) sink[1] = v;
+}
+
+static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
+
+int main(int argc, char** argv) {
+  const int arena_gb = argc > 1 ? atoi(argv[1]) : 48;
+  const int N = 48, NWG = 256;
+  std::vector<char*> chunks;
+  for (int i = 0; i < arena_gb; i++) {
+    char* p = nullptr;
+    if (hipMalloc((void**)&p, (size_t)1 << 30) != hipSuccess) break;
+    chunks.push_back(p);
+  }
+  printf("arena: %zu GiB in 1 GiB allocations\n", chunks.size());
+  if (chunks.size() < 4) return 1;
+  for (auto c : chunks) CK(hipMemsetAsync(c, 1, (size_t)1 << 30, 0));
+  unsigned *hot, *sink;
+  unsigned long long* out;
+  CK(hipMalloc((void**)&hot, 8 << 20));
+  CK(hipMemset(hot, 0, 8 << 20));
+  CK(hipMalloc((void**)&sink, 64));
+  CK(hipMalloc((void**)&out, (size_t)N * NWG * 4 * 8));
+  hipStream_t st;
+  CK(hipStreamCreate(&st));
+  CK(hipDeviceSynchronize());
+  struct Cfg { const char* name; size_t bytes; int walk; };   // walk: 0 = the same region every round, 1 = a new region every round
+  const Cfg cfgs[] = {
+      {"no stream between touches            ", 0, 0},
+      {"stream 64 MB, same region            ", (size_t)64 << 20, 0},
+      {"stream 64 MB, walking the arena      ", (size_t)64 << 20, 1},
+      {"stream 512 MB, same region           ", (size_t)512 << 20, 0},
+      {"stream 512 MB, walking the arena     ", (size_t)512 << 20, 1},
+      {"stream 1 GB, walking the arena       ", (size_t)1 << 30, 1},
+  };
+  printf("%-40s %10s %10s %10s %10s | %s\n", "between two touches", "1st load", "2nd same", "3rd other", "peer-wrote", "us, median over workgroups and rounds (p90 of the 1st and of the peer-written line in brackets)");
+  for (const Cfg& c : cfgs) {
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int r = 0; r < N; r++) {
+      if (c.bytes) {
+        const size_t per = (size_t)1 << 30;
+        const size_t off = c.walk ? ((size_t)r * c.bytes) % (chunks.size() * per) : 0;
+        const char* base = chunks[off / per] + off % per;
+        hipLaunchKernelGGL(stream_kernel, dim3(NWG), dim3(512), 0, st, (const u4v*)base, c.bytes / 16, sink);
+      }
+      hipLaunchKernelGGL(touch_kernel, dim3(NWG), dim3(512), 0, st, hot, out, r, sink);
+    }
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    for (int w = 0; w < 3; w++) CK(hipGraphLaunch(ge, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)N * NWG * 4);
+    CK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> a, b, d, e;
+    for (int r = 8; r < N; r++)
+      for (int w = 0; w < NWG; w++) {
+        const unsigned long long* o = &h[((size_t)r * NWG + w) * 4];
+        a.push_back(o[0] * 0.01); b.push_back(o[1] * 0.01); d.push_back(o[2] * 0.01); e.push_back(o[3] * 0.01);
+      }
+    std::vector<double> as = a;
+    std::sort(as.begin(), as.end());
+    std::vector<double> es = e;
+    std::sort(es.begin(), es.end());
+    printf("%-40s %10.2f %10.2f %10.2f %10.2f | (%.2f, %.2f)\n", c.name, med(a), med(b), med(d), med(e), as[as.size() * 9 / 10], es[es.size() * 9 / 10]);
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
+  }
+  return 0;
+}
