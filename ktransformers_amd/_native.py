@@ -50,6 +50,20 @@ class _GemmArgs(C.Structure):
                 ("variant", C.c_int32)]
 
 
+class _AttnDecodeArgs(C.Structure):   # include/ktx_attn.h: ktx_attn_decode_args
+    _fields_ = [("qkv_a", C.c_void_p), ("q_b", C.c_void_p), ("q_absorb", C.c_void_p), ("out_absorb", C.c_void_p), ("o_proj", C.c_void_p),
+                ("num_heads", C.c_int32), ("nope_dim", C.c_int32), ("rope_dim", C.c_int32), ("kv_lora", C.c_int32), ("v_dim", C.c_int32),
+                ("q_lora", C.c_int32), ("hidden", C.c_int32),
+                ("d_x", C.c_void_p), ("d_y", C.c_void_p),
+                ("d_in_norm_w", C.c_void_p), ("in_norm_eps", C.c_float),
+                ("d_qa_norm_w", C.c_void_p), ("qa_norm_eps", C.c_float),
+                ("d_kv_norm_w", C.c_void_p), ("kv_norm_eps", C.c_float),
+                ("d_position", C.c_void_p), ("d_inv_freq", C.c_void_p), ("mscale", C.c_float),
+                ("d_ckv", C.c_void_p), ("d_k_pe", C.c_void_p), ("ckv_token_stride", C.c_int64), ("kpe_token_stride", C.c_int64),
+                ("page_size", C.c_int32), ("d_kv_indptr", C.c_void_p), ("d_kv_indices", C.c_void_p), ("d_kv_len", C.c_void_p),
+                ("kv_len_hint", C.c_int32), ("sm_scale", C.c_float), ("phases", C.c_int32), ("last", C.c_int32)]
+
+
 class _MoeConfig(C.Structure):
     _fields_ = [(n, C.c_int32) for n in (
         "expert_num", "num_experts_per_tok", "hidden_size", "intermediate_size", "max_len", "format", "group_size",
@@ -157,6 +171,12 @@ def _load() -> C.CDLL:
     lib.ktx_gemm_bf16_nt.argtypes = [C.POINTER(_GemmArgs), C.c_void_p]
     lib.ktx_split_f32_bf16x3.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.ktx_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
+    lib.ktx_attn_decode_eligible.argtypes = [C.POINTER(_AttnDecodeArgs)]
+    lib.ktx_attn_decode.argtypes = [C.POINTER(_AttnDecodeArgs), C.c_void_p]
+    lib.ktx_attn_status.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
+    lib.ktx_attn_reset.argtypes = [C.c_int]
+    lib.ktx_attn_debug_read.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
+    lib.ktx_attn_debug_stamps.argtypes = [C.c_void_p]
     return lib
 
 
@@ -169,7 +189,7 @@ STREAM_CALLS = frozenset((
     "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
     "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_mla_prefill", "ktx_linear_forward",
     "ktx_linear_forward_batched", "ktx_linear_forward_batched_prep", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
-    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
+    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt", "ktx_attn_decode"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
 TRACE: list | None = None
 HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
 
@@ -836,6 +856,67 @@ def qb_absorb_and_prep(q_b: "LinearHandle", qabs: "LinearHandle", q_a: torch.Ten
                                            kv.stride(0), kv_norm_weight.data_ptr(), float(eps), ckv.data_ptr(), kpe.data_ptr(),
                                            positions.data_ptr(), inv_freq.data_ptr(), float(mscale), _stream_ptr(dev)))
     return q_nope, q_pe, ckv, kpe
+
+
+ATTN_PHASE_ALL = 31
+ATTN_ARRAYS = {"qkv": 0, "ckv_new": 1, "kpe_new": 2, "q_lat": 3, "q_pe": 4, "merged": 5, "attn_out": 6, "part_ml": 7, "part_o": 8, "qx": 9}
+
+
+def attn_decode_args(qkv_a: "LinearHandle", q_b: "LinearHandle", qabs: "LinearHandle", oabs: "LinearHandle", o_proj: "LinearHandle",
+                     x: torch.Tensor, out: torch.Tensor, in_norm: tuple, qa_norm: tuple, kv_norm: tuple, position: torch.Tensor,
+                     inv_freq: torch.Tensor, mscale: float, num_heads: int, nope: int, rope: int, kv_lora: int, v_dim: int,
+                     ckv_pages: torch.Tensor, kpe_pages: torch.Tensor, page_size: int, kv_indptr: torch.Tensor,
+                     kv_indices: torch.Tensor | None, kv_len: torch.Tensor, kv_len_hint: int, sm_scale: float,
+                     phases: int = ATTN_PHASE_ALL, last: bool = True) -> _AttnDecodeArgs:
+    """Arguments of the one-launch MLA decode step (include/ktx_attn.h).  x / out: bf16 [hidden] rows; the norm tuples are
+    (bf16 weight, eps); position int64 [1]; kv_len int32 [1] = context length including the new token; the cache views as in
+    MLAWrapper.run.  The caller keeps every tensor alive until the launch is enqueued."""
+    for t, what in ((x, "x"), (out, "out"), (in_norm[0], "input norm"), (qa_norm[0], "q_a norm"), (kv_norm[0], "kv_a norm")):
+        if t.dtype != torch.bfloat16 or not t.is_contiguous():
+            raise KtxError(f"attn_decode: {what} must be contiguous bf16")
+    if position.dtype != torch.int64 or inv_freq.dtype != torch.float32 or kv_len.dtype != torch.int32 or kv_indptr.dtype != torch.int32:
+        raise KtxError("attn_decode: position int64, inv_freq fp32, kv_len / kv_indptr int32")
+    if ckv_pages.stride(-1) != 1 or kpe_pages.stride(-1) != 1 or ckv_pages.dtype != torch.bfloat16:
+        raise KtxError("attn_decode: kv tensors must be bf16 with unit inner stride")
+    ckv_ts, kpe_ts = ckv_pages.stride(-2), kpe_pages.stride(-2)
+    if ckv_pages.stride(0) != ckv_ts * page_size or kpe_pages.stride(0) != kpe_ts * page_size:
+        raise KtxError("attn_decode: pages must be contiguous runs of page_size tokens")
+    return _AttnDecodeArgs(qkv_a._h, q_b._h, qabs._h, oabs._h, o_proj._h, num_heads, nope, rope, kv_lora, v_dim, q_b.K, x.numel(),
+                           x.data_ptr(), out.data_ptr(), in_norm[0].data_ptr(), float(in_norm[1]), qa_norm[0].data_ptr(),
+                           float(qa_norm[1]), kv_norm[0].data_ptr(), float(kv_norm[1]), position.data_ptr(), inv_freq.data_ptr(),
+                           float(mscale), ckv_pages.data_ptr(), kpe_pages.data_ptr(), ckv_ts, kpe_ts, page_size, kv_indptr.data_ptr(),
+                           kv_indices.data_ptr() if kv_indices is not None else None, kv_len.data_ptr(), int(kv_len_hint),
+                           float(sm_scale), int(phases), 1 if last else 0)
+
+
+def attn_decode_eligible(args: _AttnDecodeArgs) -> bool:
+    return bool(lib.ktx_attn_decode_eligible(C.byref(args)))
+
+
+def attn_decode(args: _AttnDecodeArgs, device, phases: int | None = None, last: bool | None = None) -> None:
+    """Enqueue the launch (or, with `phases`, one launch of a split chain: the caller issues the subsets in phase order and marks
+    the final one `last`)."""
+    if phases is not None:
+        args.phases = int(phases)
+    if last is not None:
+        args.last = 1 if last else 0
+    check(lib.ktx_attn_decode(C.byref(args), _stream_ptr(device)))
+
+
+def attn_status(device) -> int:
+    dev = torch.device(device)
+    st = C.c_uint32(0)
+    check(lib.ktx_attn_status(dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(st)))
+    return int(st.value)
+
+
+def attn_debug_read(device, name: str, shape, dtype=torch.bfloat16) -> torch.Tensor:
+    dev = torch.device(device)
+    out = torch.empty(shape, dtype=dtype, device=dev)
+    torch.cuda.synchronize(dev)
+    check(lib.ktx_attn_debug_read(dev.index if dev.index is not None else torch.cuda.current_device(), ATTN_ARRAYS[name], out.data_ptr(),
+                                  out.numel() * out.element_size()))
+    return out
 
 
 def linear_force_gemm(on: bool) -> None:

@@ -1,0 +1,1166 @@
+// ktx_attn.hip — the attention half of a DeepSeek-V3 decoder layer for ONE decode token as ONE persistent launch (C ABI:
+// include/ktx_attn.h).  Reference chain: archive/ktransformers/operators/attention.py:349-523 (forward_linux_flashinfer) with
+// modeling_deepseek_v3.py:1200-1219 around it.
+//
+// Why.  As five dependent launches (lin_sk_kernel q_a|kv_a, lin_qb_absorb_kernel, mla_decode_kernel, lin_merge_unabsorb_kernel,
+// lin_sk_kernel o_proj) this chain takes 64 us of a 122 us layer for 130 MB of weights (21 us at 6.2 TB/s): every launch pays
+// the boundary, a first-touch round trip for its input, a ramp of its weight stream and a tail, and two of them run on 128
+// workgroups — half the chip's CUs, each CU pulling ~24 GB/s whatever runs on it.  Here the five stages are
+// PHASES of one launch of 2 x heads = 256 workgroups, one per CU:
+//   A  input RMSNorm + q_a|kv_a GEMV                      one 16-row strip per workgroup (132 of them)
+//   B  q_a_layernorm + q_b rows of a head + RoPE + absorb  TWO workgroups per head: each computes half of the head's q_b rows, the
+//      + (one workgroup) kv_a_layernorm, k_pe RoPE, cache append    halves swap their q_nope pieces, each produces half of the absorbed row
+//   C  split-KV attention over the paged latent cache      (32 heads) x (KV split) per workgroup, mla_decode_kernel<2,4>'s tile loop
+//   D  merge of the splits + un-absorb                     two workgroups per head: each merges half of the 512 dims, they swap,
+//                                                          each produces half of the head's v_dim outputs
+//   E  o_proj + residual                                   whole strips dealt to all workgroups
+// A phase's weights are requested BEFORE the workgroup starts waiting for the phase's input (they depend on nothing), so the
+// weight stream runs across the hand-offs; a phase's input arrives through the device workspace: the producer stores it
+// write-through (sc1), drains, and sets a per-workgroup flag to the launch's epoch; consumers poll exactly the flags they
+// depend on (one wavefront, relaxed device-scope loads) and read the payload with sc1 loads (MI355X_MICROARCH.md
+// §inter-workgroup visibility: sc1 stores + sc1 loads need no fence).  The epoch lives in the workspace and is advanced by the
+// last workgroup to leave, so a captured graph replays with fresh flags and nothing has to be zeroed.
+//
+// Arithmetic.  Every phase restates its stand-alone kernel: same k-steps (ktx_w4_step.inc), same fixed summation orders, same
+// roundings, same KV split rule (ktx_mla_decode_nsplit) — tests/test_attn_fused_gpu.py holds the outputs of all five phases
+// bit-identical to the five-launch path.  Every poll is bounded: a hand-off that does not arrive within KTX_ATTN_SPIN_TICKS sets the
+// workspace status word and the launch runs to its end with undefined results instead of hanging the GPU.
+#include "ktx_common.h"
+
+#include <mutex>
+
+#include "../../include/ktx_attn.h"
+#include "../../include/ktx_mla.h"
+#include "ktx_internal.h"
+#include "ktx_prep.inc"
+
+extern "C" int ktx_debug_get(int idx);   // ktx_moe.hip (include/ktx_moe.h)
+
+namespace {
+
+#include "ktx_w4_step.inc"
+
+typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+typedef __bf16 av8bf __attribute__((ext_vector_type(8)));
+typedef short av4s16 __attribute__((ext_vector_type(4)));
+
+constexpr int NT = 512;                 // threads per workgroup (8 wavefronts)
+constexpr int DA = 7;                   // phase A: k-steps per wavefront (hidden = 8 * 7 * 128)
+constexpr int NK2 = 6;                  // phase B: k-steps per k-half of q_b (q_lora = 2 * 6 * 128)
+constexpr int NOPE = 128, ROPE = 64, LORA = 512, VDIM = 128, QW = NOPE + ROPE;
+constexpr int SPH = QW / 16;            // q_b strips per head (12)
+constexpr int MAXS = 64;                // KV splits (one flag lane each)
+constexpr int KROW = LORA + ROPE + 8;   // staged latent row: 584 elements (ktx_mla.hip)
+constexpr int TILE = 32;
+constexpr unsigned long long SPIN_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock
+
+// ---- workspace (one per device) -------------------------------------------------------------------------------------------
+// header words
+constexpr int W_EPOCH = 0, W_EXIT = 1, W_STATUS = 2;
+struct WsLayout {   // byte offsets from the workspace base
+  unsigned fA, fKV, fB, fX, fC, fM, fD;                 // flag arrays (u32 each)
+  unsigned qkv, ckv_new, kpe_new, qx, q_lat, q_pe, om, attn_out, part_ml, part_o;
+  unsigned total;
+};
+__host__ __device__ inline WsLayout ws_layout(int H, int nA) {
+  WsLayout L;
+  unsigned o = 256;
+  auto take = [&](unsigned bytes) { const unsigned r = o; o += (bytes + 255u) & ~255u; return r; };
+  const int NWG = 2 * H;
+  L.fA = take(4 * (nA > NWG ? nA : NWG)); L.fKV = take(4); L.fB = take(4 * NWG); L.fX = take(4 * NWG); L.fC = take(4 * NWG);
+  L.fM = take(4 * NWG); L.fD = take(4 * NWG);
+  L.qkv = take(2 * 16 * nA); L.ckv_new = take(2 * LORA); L.kpe_new = take(2 * ROPE);
+  L.qx = take(2 * H * NOPE); L.q_lat = take(2 * H * LORA); L.q_pe = take(2 * H * ROPE); L.om = take(2 * H * LORA);
+  L.attn_out = take(2 * H * VDIM); L.part_ml = take(4 * H * MAXS * 2); L.part_o = take(4u * H * MAXS * LORA);
+  L.total = o;
+  return L;
+}
+
+struct AttnParams {
+  // phase A
+  const uint8_t* wA; const bf16_t* scA; int nksA, nA;
+  const bf16_t* x; const bf16_t* in_norm_w; float in_eps; int hidden;
+  // phase B
+  const uint8_t* wB; const bf16_t* scB; int nksB;
+  const uint8_t* wUK; size_t wbsUK;
+  const bf16_t* qa_norm_w; float qa_eps; int q_lora;
+  const bf16_t* kv_norm_w; float kv_eps;
+  const int64_t* pos; const float* inv_freq; float mscale;
+  int H;
+  // phase C
+  bf16_t* ckv; bf16_t* kpe; long long ckv_ts, kpe_ts;
+  const int32_t *kv_indptr, *kv_indices, *kv_len;
+  int page_size, nsplit; float sm_scale;
+  // phase D
+  const uint8_t* wUV; size_t wbsUV;
+  // phase E
+  const uint8_t* wE; const bf16_t* scE; int nksE, nE, eQ, eR;
+  bf16_t* y;
+  // workspace
+  uint8_t* ws; unsigned ws_bytes;
+  int last;
+  unsigned long long* stamps;
+};
+
+#define AT_STAMP(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = wall_clock64(); } while (0)
+
+// ---- hand-off primitives -----------------------------------------------------------------------------------------------------
+__device__ __forceinline__ unsigned ld_word(const unsigned* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void st_word(unsigned* q, unsigned v) { __hip_atomic_store(q, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t ws_rsrc(const AttnParams& p) {
+  return __builtin_amdgcn_make_buffer_rsrc(p.ws, 0, (int)p.ws_bytes, 0x00020000);
+}
+// write-through (sc1) 16-byte store / sc1 16-byte load at a byte offset of the workspace
+__device__ __forceinline__ void ws_store16(__amdgpu_buffer_rsrc_t r, unsigned off, const uint4& v) {
+  const u4v d = {v.x, v.y, v.z, v.w};
+  __builtin_amdgcn_raw_buffer_store_b128(d, r, (int)off, 0, 16);
+}
+__device__ __forceinline__ uint4 ws_load16(__amdgpu_buffer_rsrc_t r, unsigned off) {
+  const u4v d = __builtin_amdgcn_raw_buffer_load_b128(r, (int)off, 0, 16);
+  return make_uint4(d.x, d.y, d.z, d.w);
+}
+// every store of this wavefront has left the CU (write-through stores are visible device-wide once acknowledged)
+__device__ __forceinline__ void drain_stores() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// ONE wavefront waits until flags[idx(k * 64 + lane)] == epoch for every k * 64 + lane < n.  Bounded; a timeout (or another
+// workgroup's earlier timeout) sets / sees the status word and returns.
+template <class IDX>
+__device__ __forceinline__ void poll_flags(const AttnParams& p, const unsigned* flags, int n, unsigned epoch, int code, IDX idx) {
+  const int lane = threadIdx.x & 63;
+  unsigned* hdr = reinterpret_cast<unsigned*>(p.ws);
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+    for (int k = lane; k < n; k += 64) ok = ok && ld_word(flags + idx(k)) == epoch;
+    if (__all(ok)) return;
+    if (ld_word(hdr + W_STATUS) != 0) return;
+    if (wall_clock64() - t0 > SPIN_TICKS) {
+      if (lane == 0) st_word(hdr + W_STATUS, (unsigned)code);
+      return;
+    }
+    __builtin_amdgcn_s_sleep(2);
+  }
+}
+
+// ---- k-steps (restated from ktx_linear_sk.inc / ktx_linear.hip: same expressions, same order) ---------------------------------
+// W4 g64, one token row: acc += s_g * ( sum_{k in g} x_k (128 + q_k) - 136 sum_{k in g} x_k )
+__device__ __forceinline__ void w4_kstep1(const uint4& w, const uint2& sc, const uint8_t* xb, const float* aux, float& acc) {
+  const uint32_t P[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+  for (int gi = 0; gi < 2; gi++) {
+    v4f tmp = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int jj = 0; jj < 2; jj++) {
+      const int j = gi * 2 + jj;
+      const uint4 xa = *reinterpret_cast<const uint4*>(xb + j * 4 * 16);
+      tmp = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w4_as_v8bf(xa), w4_as_v8bf(w4_frag(P[j])), tmp, 0, 0, 0);
+    }
+    const float s = w4_scale(sc, gi);
+    acc = fmaf(s, fmaf(-136.f, aux[gi * 4], tmp[0]), acc);
+  }
+}
+// BF16 tile of four 1 KiB planes, one k-step of 128: plane j contracts k = kc * 32 + j * 8 + e
+__device__ __forceinline__ void bf16_kstep(const uint4 (&w)[4], const uint8_t* xb, v4f& acc) {
+#pragma unroll
+  for (int j = 0; j < 4; j++) {
+    const uint4 xa = *reinterpret_cast<const uint4*>(xb + j * 16);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w4_as_v8bf(xa), w4_as_v8bf(w[j]), acc, 0, 0, 0);
+  }
+}
+__device__ __forceinline__ uint4 nt_load16(const uint8_t* q) {
+  const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(q));
+  return make_uint4(v.x, v.y, v.z, v.w);
+}
+// group sum of a staged 16-byte piece over the G / 8 = 8 consecutive lanes of its scale group (DPP row operations)
+__device__ __forceinline__ float group_sum64(const uint4& v) {
+  float s = sum8_bf16(v);
+  s += ktx_dpp_f<KTX_DPP_QUAD_1032>(s);
+  s += ktx_dpp_f<KTX_DPP_QUAD_2301>(s);
+  s += ktx_dpp_f<KTX_DPP_ROW_HALF_MIRROR>(s);
+  return s;
+}
+__device__ __forceinline__ float sumsq8(const uint4& v) {
+  const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+  float pq = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; e++) {
+    const float a = __uint_as_float(d4[e] << 16), b = __uint_as_float(d4[e] & 0xffff0000u);
+    pq += a * a + b * b;
+  }
+  return pq;
+}
+__device__ __forceinline__ uint4 norm8(const uint4& v, float r, const uint4& w) {
+  return make_uint4(ktx_norm_pk(v.x, r, w.x), ktx_norm_pk(v.y, r, w.y), ktx_norm_pk(v.z, r, w.z), ktx_norm_pk(v.w, r, w.w));
+}
+
+// ---- MLA tile helpers (restated from ktx_mla.hip) ---------------------------------------------------------------------------------
+__device__ __forceinline__ av8bf as_av8bf(const uint4& u) {
+  union { uint4 u; av8bf v; } c;
+  c.u = u;
+  return c.v;
+}
+__device__ __forceinline__ av8bf load_v_frag(const bf16_t* base) {
+  typedef __attribute__((address_space(3))) av4s16 lds_v4;
+  const av4s16 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base));
+  const av4s16 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_v4*)(base + 4 * KROW));
+  union { av4s16 h[2]; av8bf v; } c;
+  c.h[0] = lo;
+  c.h[1] = hi;
+  return c.v;
+}
+// (the LDS destination is passed as a BYTE ADDRESS computed from the dynamic region's base: a generic pointer whose provenance the
+// compiler has lost needs a run-time address-space cast here, which this compiler mis-selects in some phase combinations)
+__device__ __forceinline__ void dma_row(const bf16_t* gsrc_lane, uint32_t lds_byte_addr) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(gsrc_lane), "s"(lds_addr)
+               : "memory");
+}
+
+// n items over m bins: bins < R take Q + 1 (ktx_linear_sk.inc)
+__device__ __forceinline__ int split_begin(int Q, int R, int b) { return b * Q + (b < R ? b : R); }
+__device__ __forceinline__ int wave_begin(int Gb, int n, int w) {
+  w = w < 8 ? w : 8;
+  const int qb = n >> 3, rb = n - qb * 8;
+  return Gb + w * qb + (w < rb ? w : rb);
+}
+
+constexpr int PH_A = KTX_ATTN_PHASE_QKV_A, PH_B = KTX_ATTN_PHASE_QB, PH_C = KTX_ATTN_PHASE_MLA, PH_D = KTX_ATTN_PHASE_MERGE,
+              PH_E = KTX_ATTN_PHASE_OPROJ;
+
+// =====================================================================================================================================
+template <int MASK>
+__global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;   // LDS byte address of the dynamic region
+  const int w = blockIdx.x, H = p.H, NWG = 2 * H;
+  const int h = w & (H - 1), part = w / H;           // phases B and D: head and which half (H is a power of two times ... see eligibility)
+  unsigned* hdr = reinterpret_cast<unsigned*>(p.ws);
+  const WsLayout L = ws_layout(H, p.nA);
+  const __amdgpu_buffer_rsrc_t rs = ws_rsrc(p);
+  unsigned* fA = reinterpret_cast<unsigned*>(p.ws + L.fA);
+  unsigned* fKV = reinterpret_cast<unsigned*>(p.ws + L.fKV);
+  unsigned* fB = reinterpret_cast<unsigned*>(p.ws + L.fB);
+  unsigned* fX = reinterpret_cast<unsigned*>(p.ws + L.fX);
+  unsigned* fC = reinterpret_cast<unsigned*>(p.ws + L.fC);
+  unsigned* fM = reinterpret_cast<unsigned*>(p.ws + L.fM);
+  unsigned* fD = reinterpret_cast<unsigned*>(p.ws + L.fD);
+  AT_STAMP(0);
+  const unsigned epoch = ld_word(hdr + W_EPOCH);
+
+  // =========================== requests that depend on nothing =====================================================================
+  // ---- phase A: the layer input row + input_layernorm weights (needed first), then the strip's 7 tiles of this wavefront
+  constexpr int XRA = 2;                                   // 16-byte pieces per thread: hidden <= 8192
+  const int npieceA = p.hidden >> 3;
+  const bool doA = (MASK & PH_A) && w < p.nA;
+  uint4 xrA[XRA], nwA[XRA];
+  uint4 wrA[DA];
+  uint2 srA[DA];
+  if constexpr ((MASK & PH_A) != 0) {
+#pragma unroll
+    for (int i = 0; i < XRA; i++) {
+      const int pc = min(tid + i * NT, npieceA - 1);
+      xrA[i] = *reinterpret_cast<const uint4*>(p.x + pc * 8);
+      nwA[i] = *reinterpret_cast<const uint4*>(p.in_norm_w + pc * 8);
+    }
+    const int sA = min(w, p.nA - 1);
+    const long tile0 = (long)sA * p.nksA + wave * DA;
+#pragma unroll
+    for (int d = 0; d < DA; d++) {
+      wrA[d] = nt_load16(p.wA + (tile0 + d) * 1024 + lane * 16);
+      srA[d] = load_w4_scales<2>(p.scA + ((tile0 + d) * 16 + (lane & 15)) * 2);
+    }
+  }
+  // ---- phase B: q_a_layernorm weights, rope table inputs, the head's q_b tiles (waves 0..5: one strip, both k-halves) and
+  // absorb tiles (waves 0..5: one strip, waves 6..7: five strips)
+  uint4 nwB = make_uint4(0, 0, 0, 0);
+  float ropePos = 0.f, ropeIf = 0.f;
+  uint4 w1r[2][NK2];
+  uint2 s1r[2][NK2];
+  uint4 w2r[5][4];
+  auto prefetch_B = [&]() {
+    nwB = *reinterpret_cast<const uint4*>(p.qa_norm_w + min(tid, (p.q_lora >> 3) - 1) * 8);
+    ropePos = (float)p.pos[0];
+    ropeIf = p.inv_freq[tid & (ROPE / 2 - 1)];
+    if (wave < 6) {
+      const size_t strip = (size_t)h * SPH + part * 6 + wave;
+#pragma unroll
+      for (int kh = 0; kh < 2; kh++) {
+        const uint8_t* wp = p.wB + (strip * p.nksB + (size_t)kh * NK2) * 1024 + lane * 16;
+        const bf16_t* sp = p.scB + ((strip * p.nksB + (size_t)kh * NK2) * 16 + (lane & 15)) * 2;
+#pragma unroll
+        for (int s_ = 0; s_ < NK2; s_++) {
+          w1r[kh][s_] = nt_load16(wp + (size_t)s_ * 1024);
+          s1r[kh][s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
+        }
+      }
+      const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + wave) * 4096 + lane * 16;
+#pragma unroll
+      for (int q = 0; q < 4; q++) w2r[0][q] = nt_load16(wp2 + q * 1024);
+    } else {
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + 6 + (wave - 6) * 5 + i) * 4096 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) w2r[i][q] = nt_load16(wp2 + q * 1024);
+      }
+    }
+  };
+  if constexpr ((MASK & PH_B) != 0) prefetch_B();
+
+  // =========================== phase A ===================================================================================
+  if constexpr ((MASK & PH_A) != 0) {
+    if (doA) {
+      uint8_t* xs = smem;                                                       // [npiece][16 B]
+      float* aux = reinterpret_cast<float*>(smem + (size_t)p.nksA * 16 * 16);   // [nksA * 2][4]
+      float* nred = aux + (size_t)p.nksA * 2 * 4;                               // [8][4]
+      float* table = nred + 32;                                                 // [8][64]
+      bf16_t* ostage = reinterpret_cast<bf16_t*>(table + 8 * 64);               // [16]
+#pragma unroll
+      for (int i = 0; i < XRA; i++)
+        if (!(tid + i * NT < npieceA)) xrA[i] = make_uint4(0, 0, 0, 0);
+      float ss = 0.f;
+#pragma unroll
+      for (int i = 0; i < XRA; i++) ss += sumsq8(xrA[i]);
+      const float wsum = wave_sum(ss);
+      if (lane == 0) nred[wave * 4] = wsum;
+      __syncthreads();
+      float tot = nred[0];
+#pragma unroll
+      for (int v = 1; v < 8; v++) tot += nred[v * 4];
+      const float rnorm = 1.0f / sqrtf(tot / (float)p.hidden + p.in_eps);
+#pragma unroll
+      for (int i = 0; i < XRA; i++) {
+        const int pc = tid + i * NT;
+        if (pc < p.nksA * 16) {
+          const uint4 v = norm8(xrA[i], rnorm, nwA[i]);
+          *reinterpret_cast<uint4*>(xs + (size_t)pc * 16) = v;
+          const float s = group_sum64(v);
+          if ((pc & 7) == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) aux[(pc >> 3) * 4 + r] = s;
+          }
+        }
+      }
+      __syncthreads();
+      AT_STAMP(1);
+      const int kc = lane >> 4;
+      const uint8_t* xb0 = xs + kc * 16;
+      for (int s = w; s < p.nA; s += NWG) {   // (one strip per workgroup at DeepSeek-V3's 132 strips; further ones re-request their tiles)
+        if (s != w) {
+          const long tile0 = (long)s * p.nksA + wave * DA;
+#pragma unroll
+          for (int d = 0; d < DA; d++) {
+            wrA[d] = nt_load16(p.wA + (tile0 + d) * 1024 + lane * 16);
+            srA[d] = load_w4_scales<2>(p.scA + ((tile0 + d) * 16 + (lane & 15)) * 2);
+          }
+          __syncthreads();   // table / ostage of the previous strip have been consumed
+        }
+        float acc = 0.f;
+        const int ks0 = wave * DA;
+#pragma unroll
+        for (int d = 0; d < DA; d++) w4_kstep1(wrA[d], srA[d], xb0 + (size_t)(ks0 + d) * 256, aux + (ks0 + d) * 8, acc);
+        if (lane < 16) table[wave * 64 + lane] = acc;
+        __syncthreads();
+        if (wave == 0) {
+          if (lane < 16) {
+            float v = 0.f;
+#pragma unroll
+            for (int u = 0; u < 8; u++) v += table[u * 64 + lane];
+            ostage[lane] = f32_to_bf16(v);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          if (lane < 2) ws_store16(rs, L.qkv + s * 32 + lane * 16, *reinterpret_cast<const uint4*>(ostage + lane * 8));
+          drain_stores();
+          if (lane == 0) st_word(fA + s, epoch);
+        }
+      }
+    }
+    AT_STAMP(2);
+  }
+
+  // =========================== phase B ===================================================================================
+  // LDS of phase B (the phase A region is dead for this workgroup once its strip is published; a barrier separates them)
+  if constexpr ((MASK & PH_B) != 0) {
+    __syncthreads();
+    bf16_t* kvraw = reinterpret_cast<bf16_t*>(smem);                              // [576]
+    uint8_t* xsB = smem + 1280;                                                   // [q_lora / 8][16 B]
+    float* auxB = reinterpret_cast<float*>(xsB + (size_t)(p.q_lora >> 3) * 16);   // [nksB * 2][4]
+    float* nredB = auxB + p.nksB * 2 * 4;                                         // [8][4]
+    float* red1 = nredB + 32;                                                     // [6][2][16]
+    float* s_cs = red1 + 6 * 2 * 16;                                              // [64]: cos | sin
+    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [96] this half's q_b outputs
+    bf16_t* stage = qh + 96;                                                      // [256] publication staging
+    uint8_t* xs2 = reinterpret_cast<uint8_t*>(stage + 256);                       // [16][16 B] the head's q_nope
+    float* s_redK = reinterpret_cast<float*>(xs2 + 256);                          // [8] (kv prep)
+
+    if (wave == 7) poll_flags(p, fA, p.nA, epoch, 0xA1, [](int k) { return k; });
+    __syncthreads();
+    AT_STAMP(3);
+    // ---- the phase A output row [q_a | ckv | k_pe]: q_a pieces -> RMSNorm -> staging; kv pieces -> LDS
+    const int npq = p.q_lora >> 3, npall = p.nA * 2;
+    uint4 xp = make_uint4(0, 0, 0, 0);
+    if (tid < npall) xp = ws_load16(rs, L.qkv + tid * 16);
+    if (tid >= npq && tid < npall) *reinterpret_cast<uint4*>(kvraw + (tid - npq) * 8) = xp;
+    {
+      const float q = tid < npq ? sumsq8(xp) : 0.f;
+      const float wsum = wave_sum(q);
+      if (lane == 0) nredB[wave * 4] = wsum;
+    }
+    if (tid < ROPE / 2) {   // cos / sin of the token's position (mla_prep's table: bf16-rounded, times mscale)
+      const float fr = ropePos * ropeIf;
+      s_cs[tid] = prep_rbf(cosf(fr) * p.mscale);
+      s_cs[ROPE / 2 + tid] = prep_rbf(sinf(fr) * p.mscale);
+    }
+    __syncthreads();
+    {
+      float tot = 0.f;
+      for (int v = 0; v < 8; v++) tot += nredB[v * 4];
+      const float rn = 1.0f / sqrtf(tot / (float)p.q_lora + p.qa_eps);
+      if (tid < p.nksB * 16) {
+        uint4 v = xp;
+        if (tid < npq) v = norm8(xp, rn, nwB);
+        else v = make_uint4(0, 0, 0, 0);
+        *reinterpret_cast<uint4*>(xsB + (size_t)tid * 16) = v;
+        const float sm = group_sum64(v);
+        if ((tid & 7) == 0) auxB[(tid >> 3) * 4] = sm;
+      }
+    }
+    // ---- one workgroup: kv_a_layernorm + k_pe RoPE (mla_prep_token_block's arithmetic) -> workspace + cache append
+    if (w == NWG - 1) {
+      float v8[8];
+      float ss = 0.f;
+      if (tid < LORA / 8) {
+        const uint4 raw = *reinterpret_cast<const uint4*>(kvraw + tid * 8);
+        const uint32_t d[4] = {raw.x, raw.y, raw.z, raw.w};
+#pragma unroll
+        for (int i = 0; i < 4; i++) { v8[2 * i] = __uint_as_float(d[i] << 16); v8[2 * i + 1] = __uint_as_float(d[i] & 0xffff0000u); }
+#pragma unroll
+        for (int e = 0; e < 8; e++) ss += v8[e] * v8[e];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) ss += __shfl_xor(ss, o, 64);
+      if (lane == 0) s_redK[wave] = ss;
+      __syncthreads();
+      float tot = 0.f;
+      for (int v = 0; v < 8; v++) tot += s_redK[v];
+      // cache row of the new token (StaticCache.update, custom_cache.py:189-195): position kv_len - 1, clamped to the owned pages
+      int kl = p.kv_len[0];
+      const int pb = p.kv_indptr[0];
+      kl = min(kl, (p.kv_indptr[1] - pb) * p.page_size);
+      const int app = kl - 1;
+      size_t trow = 0;
+      if (app >= 0) {
+        const int page = p.kv_indices ? p.kv_indices[pb + app / p.page_size] : pb + app / p.page_size;
+        trow = (size_t)page * p.page_size + app % p.page_size;
+      }
+      if (tid < LORA / 8) {
+        const float r = 1.0f / sqrtf(tot / (float)LORA + p.kv_eps);
+        const uint4 wr = *reinterpret_cast<const uint4*>(p.kv_norm_w + tid * 8);
+        const uint32_t wd[4] = {wr.x, wr.y, wr.z, wr.w};
+        uint32_t o[4];
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+          const float a = __uint_as_float(wd[i] << 16) * prep_rbf(v8[2 * i] * r), b = __uint_as_float(wd[i] & 0xffff0000u) * prep_rbf(v8[2 * i + 1] * r);
+          o[i] = prep_rne_bf16(a) | (prep_rne_bf16(b) << 16);
+        }
+        const uint4 ov = make_uint4(o[0], o[1], o[2], o[3]);
+        ws_store16(rs, L.ckv_new + tid * 16, ov);
+        if (app >= 0) *reinterpret_cast<uint4*>(p.ckv + trow * p.ckv_ts + tid * 8) = ov;
+      }
+      if (tid < ROPE / 2) prep_rope_pair(kvraw + LORA, stage, tid, ROPE / 2, s_cs[tid], s_cs[ROPE / 2 + tid]);
+      __syncthreads();
+      if (tid < ROPE / 8) {
+        const uint4 ov = *reinterpret_cast<const uint4*>(stage + tid * 8);
+        ws_store16(rs, L.kpe_new + tid * 16, ov);
+        if (app >= 0) *reinterpret_cast<uint4*>(p.kpe + trow * p.kpe_ts + tid * 8) = ov;
+      }
+      drain_stores();
+      __syncthreads();
+      if (tid == 0) st_word(fKV, epoch);
+    }
+    __syncthreads();
+    AT_STAMP(4);
+    // ---- q_b rows of this half: waves 0..5 = one strip each, two k-halves summed in order (lin_qb_absorb_kernel)
+    const int kc = lane >> 4;
+    if (wave < 6) {
+      const uint8_t* xb0 = xsB + kc * 16;
+#pragma unroll
+      for (int kh = 0; kh < 2; kh++) {
+        float acc = 0.f;
+#pragma unroll
+        for (int s_ = 0; s_ < NK2; s_++) {
+          const int ks = kh * NK2 + s_;
+          w4_kstep1(w1r[kh][s_], s1r[kh][s_], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
+        }
+        if (lane < 16) red1[(wave * 2 + kh) * 16 + lane] = acc;
+      }
+    }
+    __syncthreads();
+    if (tid < 96) {
+      const int sih = tid >> 4, f = tid & 15;
+      float v = 0.f;
+      v += red1[(sih * 2 + 0) * 16 + f];
+      v += red1[(sih * 2 + 1) * 16 + f];
+      qh[tid] = f32_to_bf16(v);
+    }
+    __syncthreads();
+    // this half's q values: part 0 = q_nope[0, 96); part 1 = q_nope[96, 128) | q_pe[0, 64)
+    if (part == 1 && tid < ROPE / 2) prep_rope_pair(qh + 32, stage, tid, ROPE / 2, s_cs[tid], s_cs[ROPE / 2 + tid]);
+    {
+      const int npc = part == 0 ? 12 : 4;   // 16-byte pieces of q_nope this half owns
+      if (tid < npc) ws_store16(rs, L.qx + (h * NOPE + part * 96) * 2 + tid * 16, *reinterpret_cast<const uint4*>(qh + tid * 8));
+    }
+    __syncthreads();
+    if (part == 1 && tid < ROPE / 8) ws_store16(rs, L.q_pe + h * ROPE * 2 + tid * 16, *reinterpret_cast<const uint4*>(stage + tid * 8));
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) st_word(fX + w, epoch);
+    const int partner = h + (1 - part) * H;
+    if (wave == 7) poll_flags(p, fX, 1, epoch, 0xB1, [partner](int) { return partner; });
+    __syncthreads();
+    if (tid < 16) *reinterpret_cast<uint4*>(xs2 + tid * 16) = ws_load16(rs, L.qx + h * NOPE * 2 + tid * 16);
+    __syncthreads();
+    AT_STAMP(5);
+    // ---- absorb: this half's 16 strips of W_UK[h]^T q_nope, one k-step of 128 each
+    {
+      const uint8_t* xb2 = xs2 + kc * 4 * 16;
+      const int na = wave < 6 ? 1 : 5;
+#pragma unroll
+      for (int i = 0; i < 5; i++) {
+        if (i < na) {
+          v4f acc = {0.f, 0.f, 0.f, 0.f};
+          bf16_kstep(w2r[i], xb2, acc);
+          const int a = wave < 6 ? wave : 6 + (wave - 6) * 5 + i;
+          if (lane < 16) stage[a * 16 + lane] = f32_to_bf16(0.f + acc[0]);
+        }
+      }
+    }
+    __syncthreads();
+    if (tid < 32) ws_store16(rs, L.q_lat + (h * LORA + part * 256) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stage + tid * 8));
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) st_word(fB + w, epoch);
+    AT_STAMP(6);
+  }
+
+  // =========================== phase C: split-KV attention ===========================================================================
+  // workgroup (hg, split): hg = w / 64 (32 heads), split = w % 64 < nsplit; XCD = w % 8 is the same for the four head groups of a split
+  const int hg = w >> 6, split = w & 63;
+  const bool doC = (MASK & PH_C) && split < p.nsplit && hg < H / 32;
+  // phase D's weights (waves 0..3: one strip of W_UV[h], 4 k-steps x 4 planes) are requested before phase C starts waiting
+  uint4 wrD[4][4];
+  auto prefetch_D = [&]() {
+    if (wave < 4) {
+      const uint8_t* wp = p.wUV + (size_t)h * p.wbsUV + (size_t)(part * 4 + wave) * 4 * 4096 + lane * 16;
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++)
+#pragma unroll
+        for (int q = 0; q < 4; q++) wrD[ks][q] = nt_load16(wp + (size_t)ks * 4096 + q * 1024);
+    }
+  };
+  if constexpr ((MASK & PH_D) != 0) prefetch_D();
+  if constexpr ((MASK & PH_C) != 0) {
+    __syncthreads();
+    if (doC) {
+      constexpr int HBW = 2, DSPLIT = 4, NWV = 8, NDT = 32 / DSPLIT, NQ = (18 + DSPLIT - 1) / DSPLIT;
+      bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584]
+      bf16_t* Kp = Kt + 2 * TILE * KROW;                                   // [2][32][64]
+      bf16_t* Pt = Kp + 2 * TILE * ROPE;                                   // [8][16][32]
+      float* Sx = reinterpret_cast<float*>(Pt + NWV * 16 * TILE);          // [8][8][64]
+      const int hbw = wave / DSPLIT, ds = wave % DSPLIT;
+      const int head0 = (hg * HBW + hbw) * 16;
+      int kl = p.kv_len[0];
+      const int page_base = p.kv_indptr[0];
+      kl = min(kl, (p.kv_indptr[1] - page_base) * p.page_size);
+      const int kv_end = max(kl, 0), app_pos = kl - 1;
+      const int ntiles = (kv_end + TILE - 1) / TILE;
+      const int t_begin = split, t_end = ntiles, t_step = p.nsplit;
+      const bf16_t* app_ckv = reinterpret_cast<const bf16_t*>(p.ws + L.ckv_new);
+      const bf16_t* app_kpe = reinterpret_cast<const bf16_t*>(p.ws + L.kpe_new);
+
+      v4f o[NDT];
+#pragma unroll
+      for (int i = 0; i < NDT; i++) o[i] = v4f{0.f, 0.f, 0.f, 0.f};
+      float m_run[4], l_run[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { m_run[r] = -__builtin_inff(); l_run[r] = 0.f; }
+
+      auto stage_tile = [&](int tile, int buf) {   // buf = which of the two staged tiles
+        const uint32_t dK = smem_lds + (uint32_t)buf * (TILE * KROW * 2);
+        const uint32_t dP = smem_lds + (uint32_t)(2 * TILE * KROW * 2) + (uint32_t)buf * (TILE * ROPE * 2);
+        const int tok0 = tile * TILE;
+        const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
+        const int page0 = p.kv_indices ? p.kv_indices[pidx_] : pidx_;
+        const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
+        const int last = kv_end - 1 - tok0;
+#pragma unroll
+        for (int r = wave; r < TILE; r += NWV) {
+          const int rr = min(r, last);
+          const bf16_t* src = p.ckv + (row0 + rr) * p.ckv_ts;
+          if (tok0 + rr == app_pos) src = app_ckv;
+          dma_row(src + lane * 8, dK + (uint32_t)r * (KROW * 2));
+        }
+        if (wave < 4) {
+          const int r = wave * 8 + (lane >> 3), rr = min(r, last);
+          const int g = (lane & 7) ^ (lane >> 3);
+          const bf16_t* src = p.kpe + (row0 + rr) * p.kpe_ts;
+          if (tok0 + rr == app_pos) src = app_kpe;
+          dma_row(src + g * 8, dP + (uint32_t)wave * (8 * ROPE * 2));
+        }
+      };
+
+      const bool work = t_begin < t_end;
+      // the newest row comes from the workspace (phase B's prep workgroup): the split that owns its tile waits for it first
+      const bool need_new = work && app_pos >= 0 && (app_pos / TILE) % p.nsplit == split;
+      if (need_new) {
+        if (wave == 7) poll_flags(p, fKV, 1, epoch, 0xC0, [](int) { return 0; });
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the row is fetched by LDS-DMA (a plain load)
+        __syncthreads();
+      }
+      if (work) stage_tile(t_begin, 0);   // depends on nothing else: in flight while the q rows are awaited
+      // ---- q rows of this workgroup's 32 heads: produced by the 64 phase-B workgroups (head, half)
+      if (wave == 7) poll_flags(p, fB, 64, epoch, 0xC1, [=](int k) { return hg * 32 + (k & 31) + (k >> 5) * H; });
+      __syncthreads();
+      AT_STAMP(7);
+      av8bf qf[NQ];
+      {
+        const int hq = head0 + (lane & 15);
+        const unsigned qn = L.q_lat + (unsigned)(hq * LORA + (lane >> 4) * 8) * 2;
+        const unsigned qr = L.q_pe + (unsigned)(hq * ROPE + (lane >> 4) * 8) * 2;
+#pragma unroll
+        for (int j = 0; j < NQ; j++) {
+          const int s = ds + j * DSPLIT;   // wave-uniform
+          qf[j] = as_av8bf(make_uint4(0, 0, 0, 0));
+          if (s < 16) qf[j] = as_av8bf(ws_load16(rs, qn + s * 64));
+          else if (s < 18) qf[j] = as_av8bf(ws_load16(rs, qr + (s - 16) * 64));
+        }
+      }
+      if (work) {
+        bf16_t* Pw = Pt + wave * 16 * TILE;
+        int cur = 0;
+        for (int tile = t_begin; tile < t_end; tile += t_step, cur ^= 1) {
+          bf16_t* Kc = Kt + cur * TILE * KROW;
+          const bf16_t* Pc = Kp + cur * TILE * ROPE;
+          const int tok0 = tile * TILE;
+          const int ntok = min(TILE, kv_end - tok0);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tile + t_step < t_end) stage_tile(tile + t_step, cur ^ 1);
+
+          v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+          const bf16_t* kb0 = Kc + (lane & 15) * KROW + (lane >> 4) * 8;
+          const bf16_t* kb1 = kb0 + 16 * KROW;
+#pragma unroll
+          for (int j = 0; j < NQ; j++) {
+            const int s = ds + j * DSPLIT;
+            if (s < 16) {
+              const av8bf b0 = as_av8bf(*reinterpret_cast<const uint4*>(kb0 + s * 32));
+              const av8bf b1 = as_av8bf(*reinterpret_cast<const uint4*>(kb1 + s * 32));
+              s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b0, s0, 0, 0, 0);
+              s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b1, s1, 0, 0, 0);
+            } else if (s < 18) {
+              const int row = lane & 15, q = (s - 16) * 4 + (lane >> 4);
+              const bf16_t* pr = Pc + row * ROPE + ((q ^ (row & 7)) * 8);
+              const av8bf b0 = as_av8bf(*reinterpret_cast<const uint4*>(pr));
+              const av8bf b1 = as_av8bf(*reinterpret_cast<const uint4*>(pr + 16 * ROPE));
+              s0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b0, s0, 0, 0, 0);
+              s1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(qf[j], b1, s1, 0, 0, 0);
+            }
+          }
+          {   // the head block's partial score tiles meet in LDS; fixed order -> identical S in every wave
+            float* sx = Sx + wave * 512 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { sx[r * 64] = s0[r]; sx[(4 + r) * 64] = s1[r]; }
+            __syncthreads();
+            const float* sr = Sx + hbw * DSPLIT * 512 + lane;
+#pragma unroll
+            for (int r = 0; r < 4; r++) { s0[r] = sr[r * 64]; s1[r] = sr[(4 + r) * 64]; }
+#pragma unroll
+            for (int d = 1; d < DSPLIT; d++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) { s0[r] += sr[d * 512 + r * 64]; s1[r] += sr[d * 512 + (4 + r) * 64]; }
+          }
+          const bool v0 = (lane & 15) < ntok, v1 = 16 + (lane & 15) < ntok;
+          float alpha[4];
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float a = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
+            const float b = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
+            const float mx = row16_max(fmaxf(a, b));
+            const float m_new = fmaxf(m_run[r], mx);
+            const float pa = __expf(a - m_new), pb = __expf(b - m_new);
+            const float sum = row16_sum(pa + pb);
+            alpha[r] = __expf(m_run[r] - m_new);
+            l_run[r] = l_run[r] * alpha[r] + sum;
+            m_run[r] = m_new;
+            const int hrow = (lane >> 4) * 4 + r;
+            const uint32_t pk = ktx_pk_bf16(pa, pb);
+            Pw[hrow * TILE + (lane & 15)] = (bf16_t)(pk & 0xffffu);
+            Pw[hrow * TILE + 16 + (lane & 15)] = (bf16_t)(pk >> 16);
+          }
+          __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+          __builtin_amdgcn_wave_barrier();
+          const av8bf pf = as_av8bf(*reinterpret_cast<const uint4*>(Pw + (lane & 15) * TILE + (lane >> 4) * 8));
+          const bf16_t* vb = Kc + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * KROW + (lane & 3) * 4 + ds * NDT * 16;
+#pragma unroll
+          for (int i = 0; i < NDT; i++) {
+#pragma unroll
+            for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
+            const av8bf b = load_v_frag(vb + i * 16);
+            o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
+          }
+        }
+      }
+      AT_STAMP(8);
+      // ---- partial results (ktx_mla_decode_partials' layout): (m, l) per head and split; the un-normalised O rows leave through
+      // LDS so that every store is a whole 16 bytes (write-through)
+      float* part_ml = reinterpret_cast<float*>(p.ws + L.part_ml);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int hrow = (lane >> 4) * 4 + r;
+        if ((lane & 15) == 0 && ds == 0) {
+          const unsigned long long ml = ((unsigned long long)__float_as_uint(l_run[r]) << 32) | __float_as_uint(m_run[r]);
+          __hip_atomic_store(reinterpret_cast<unsigned long long*>(part_ml + ((size_t)(head0 + hrow) * p.nsplit + split) * 2), ml,
+                             __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+      }
+      if (work) {
+        __syncthreads();   // every wavefront is done with the staged tiles: their LDS becomes the transpose buffer
+        constexpr int OROW = 132;   // floats per staged row (128 + pad)
+        float* Ot = reinterpret_cast<float*>(smem) + wave * 16 * OROW;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int hrow = (lane >> 4) * 4 + r;
+#pragma unroll
+          for (int i = 0; i < NDT; i++) Ot[hrow * OROW + i * 16 + (lane & 15)] = o[i][r];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; it++) {
+          const int idx = it * 64 + lane, row = idx >> 5, c4 = idx & 31;
+          const uint4 v = *reinterpret_cast<const uint4*>(Ot + row * OROW + c4 * 4);
+          ws_store16(rs, L.part_o + (unsigned)((((head0 + row) * p.nsplit + split) * LORA + ds * 128 + c4 * 4) * 4), v);
+        }
+      }
+      drain_stores();
+      __syncthreads();
+      if (tid == 0) st_word(fC + w, epoch);
+    }
+    AT_STAMP(9);
+  }
+
+  // =========================== phase D: merge of the splits + un-absorb ========================================================
+  // phase E's first ring tiles are requested before phase D starts waiting
+  const int GPS_E = p.nksE >> 3;
+  int Gb = 0, Ge = 0, gbE = 0, geE = 0;
+  uint4 wrE[8];
+  uint2 srE[8];
+  auto load_E = [&](int d, long tile) {
+    wrE[d] = nt_load16(p.wE + tile * 1024 + lane * 16);
+    srE[d] = load_w4_scales<2>(p.scE + (tile * 16 + (lane & 15)) * 2);
+  };
+  auto prefetch_E = [&]() {
+    const int nwgE = min(NWG, p.nE);
+    if (w < nwgE) { Gb = split_begin(p.eQ, p.eR, w) * GPS_E; Ge = split_begin(p.eQ, p.eR, w + 1) * GPS_E; }
+    gbE = wave_begin(Gb, Ge - Gb, wave); geE = wave_begin(Gb, Ge - Gb, wave + 1);
+    if (geE > gbE) {
+#pragma unroll
+      for (int d = 0; d < 8; d++) load_E(d, (long)gbE * 8 + d);
+    }
+  };
+  if constexpr ((MASK & PH_E) != 0) prefetch_E();
+  if constexpr ((MASK & PH_D) != 0) {
+    __syncthreads();
+    const int S = p.nsplit;
+    float* s_w = reinterpret_cast<float*>(smem);              // [64]
+    float* s_red = s_w + 64;                                  // [16]
+    float* s_acc = s_red + 16;                                // [8][256]
+    bf16_t* stageD = reinterpret_cast<bf16_t*>(s_acc + 8 * 256);   // [256]
+    uint8_t* xsD = reinterpret_cast<uint8_t*>(stageD + 256);       // [64][16 B]
+    const int hgD = h >> 5;
+    if (wave == 7) poll_flags(p, fC, S, epoch, 0xD1, [=](int k) { return hgD * 64 + k; });
+    __syncthreads();
+    AT_STAMP(10);
+    const int sl = wave, dg = lane;   // split lane, dim group (8 dims) — lanes 0..31 cover this half's 256 dims
+    const size_t base = (size_t)h * S;
+    unsigned long long mlraw = 0;
+    if (tid < S) mlraw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.ws + L.part_ml) + base + tid, __ATOMIC_RELAXED,
+                                           __HIP_MEMORY_SCOPE_AGENT);
+    const float2 ml = tid < S ? make_float2(__uint_as_float((unsigned)mlraw), __uint_as_float((unsigned)(mlraw >> 32))) : make_float2(0.f, 0.f);
+    uint4 fa[8], fb[8];
+    if (dg < 32) {
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int sidx = min(sl + 8 * u, S - 1);
+        const unsigned off = L.part_o + (unsigned)(((base + sidx) * LORA + part * 256 + dg * 8) * 4);
+        fa[u] = ws_load16(rs, off);
+        fb[u] = ws_load16(rs, off + 16);
+      }
+    }
+    float mstar = ml.y > 0.f ? ml.x : -__builtin_inff();
+    mstar = wave_max(mstar);
+    if (lane == 0) s_red[wave] = mstar;
+    __syncthreads();
+    mstar = s_red[0];
+#pragma unroll
+    for (int v = 1; v < 8; v++) mstar = fmaxf(mstar, s_red[v]);
+    const float wgt = ml.y > 0.f ? __expf(ml.x - mstar) : 0.f;
+    if (tid < S) s_w[tid] = wgt;
+    float lsum = wave_sum(ml.y * wgt);
+    if (lane == 0) s_red[8 + wave] = lsum;
+    __syncthreads();
+    lsum = 0.f;
+#pragma unroll
+    for (int v = 0; v < 8; v++) lsum += s_red[8 + v];
+    if (dg < 32) {
+      float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int sidx = sl + 8 * u;
+        const float wv = sidx < S ? s_w[sidx] : 0.f;
+        if (wv > 0.f) {   // a dead split's row may be stale memory: selected away, not multiplied by 0
+          acc[0] += __uint_as_float(fa[u].x) * wv; acc[1] += __uint_as_float(fa[u].y) * wv; acc[2] += __uint_as_float(fa[u].z) * wv; acc[3] += __uint_as_float(fa[u].w) * wv;
+          acc[4] += __uint_as_float(fb[u].x) * wv; acc[5] += __uint_as_float(fb[u].y) * wv; acc[6] += __uint_as_float(fb[u].z) * wv; acc[7] += __uint_as_float(fb[u].w) * wv;
+        }
+      }
+#pragma unroll
+      for (int q = 0; q < 8; q++) s_acc[sl * 256 + dg * 8 + q] = acc[q];
+    }
+    __syncthreads();
+    {
+      const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
+      if (tid < 256) {
+        float v = 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) v += s_acc[i * 256 + tid];
+        stageD[tid] = f32_to_bf16(v * inv);
+      }
+    }
+    __syncthreads();
+    if (tid < 32) ws_store16(rs, L.om + (unsigned)(h * LORA + part * 256) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stageD + tid * 8));
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) st_word(fM + w, epoch);
+    const int partner = h + (1 - part) * H;
+    if (wave == 7) poll_flags(p, fM, 1, epoch, 0xD2, [partner](int) { return partner; });
+    __syncthreads();
+    if (tid < 64) *reinterpret_cast<uint4*>(xsD + tid * 16) = ws_load16(rs, L.om + (unsigned)(h * LORA) * 2 + tid * 16);
+    __syncthreads();
+    AT_STAMP(11);
+    // ---- un-absorb: waves 0..3 = one strip of this half each, the 4 k-steps in order (lin_merge_unabsorb_kernel)
+    if (wave < 4) {
+      const int kc = lane >> 4;
+      const uint8_t* xb0 = xsD + kc * 4 * 16;
+      v4f acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < 4; ks++) bf16_kstep(wrD[ks], xb0 + (size_t)ks * 256, acc);
+      if (lane < 16) stageD[wave * 16 + lane] = f32_to_bf16(0.f + acc[0]);
+    }
+    __syncthreads();
+    if (tid < 8) ws_store16(rs, L.attn_out + (unsigned)(h * VDIM + part * 64) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stageD + tid * 8));
+    drain_stores();
+    __syncthreads();
+    if (tid == 0) st_word(fD + w, epoch);
+    AT_STAMP(12);
+  }
+
+  // =========================== phase E: o_proj + residual ================================================================================
+  if constexpr ((MASK & PH_E) != 0) {
+    __syncthreads();
+    const int nksE = p.nksE;
+    uint8_t* xsE = smem;                                                          // [nksE * 16][16 B]
+    float* auxE = reinterpret_cast<float*>(smem + (size_t)nksE * 16 * 16);        // [nksE * 2][4]
+    float* tableE = auxE + (size_t)nksE * 2 * 4;                                  // [strips of this workgroup][8][64]
+    if (wave == 7) poll_flags(p, fD, NWG, epoch, 0xE1, [](int k) { return k; });
+    __syncthreads();
+    AT_STAMP(13);
+    {
+      const int np = nksE * 16;
+      for (int pc = tid; pc < np; pc += NT) {   // (whole wavefronts: np is a multiple of 64)
+        const uint4 v = ws_load16(rs, L.attn_out + (unsigned)pc * 16);
+        *reinterpret_cast<uint4*>(xsE + (size_t)pc * 16) = v;
+        const float s = group_sum64(v);
+        if ((pc & 7) == 0) {
+#pragma unroll
+          for (int r = 0; r < 4; r++) auxE[(pc >> 3) * 4 + r] = s;
+        }
+      }
+    }
+    __syncthreads();
+    const int s_first = Gb / GPS_E;
+    if (geE > gbE) {
+      const int kc = lane >> 4;
+      const uint8_t* xb0 = xsE + kc * 16;
+      int strip = gbE / GPS_E, kg = gbE - strip * GPS_E;
+      float acc = 0.f;
+      auto flush = [&]() {
+        if (lane < 16) tableE[((size_t)(strip - s_first) * 8 + wave) * 64 + lane] = acc;
+      };
+      int g = gbE;
+      while (true) {
+        const int seg_end = min((strip + 1) * GPS_E, geE);
+        const bool last_seg = seg_end == geE;
+        const int n_inner = seg_end - g - (last_seg ? 1 : 0);
+        for (int i = 0; i < n_inner; i++, g++, kg++) {
+          const int ks0 = kg * 8;
+#pragma unroll
+          for (int d = 0; d < 8; d++) {
+            w4_kstep1(wrE[d], srE[d], xb0 + (size_t)(ks0 + d) * 256, auxE + (ks0 + d) * 8, acc);
+            load_E(d, (long)(g + 1) * 8 + d);
+            __builtin_amdgcn_sched_barrier(0);
+          }
+        }
+        if (last_seg) {
+          const int ks0 = kg * 8;
+#pragma unroll
+          for (int d = 0; d < 8; d++) w4_kstep1(wrE[d], srE[d], xb0 + (size_t)(ks0 + d) * 256, auxE + (ks0 + d) * 8, acc);
+          flush();
+          break;
+        }
+        flush();
+        acc = 0.f;
+        kg = 0;
+        strip++;
+      }
+    }
+    __syncthreads();
+    AT_STAMP(14);
+    const int n_local = Ge > Gb ? (Ge - 1) / GPS_E - s_first + 1 : 0;
+    for (int sl = wave; sl < n_local; sl += 8) {
+      const int s = s_first + sl, g0 = s * GPS_E, g1 = g0 + GPS_E;
+      float v = 0.f;
+#pragma unroll
+      for (int u = 0; u < 8; u++) {
+        const int wb = wave_begin(Gb, Ge - Gb, u), we = wave_begin(Gb, Ge - Gb, u + 1);
+        if (we > wb && wb < g1 && we > g0) v += tableE[((size_t)sl * 8 + u) * 64 + lane];
+      }
+      const int n = s * 16 + lane;
+      if (lane < 16 && n < p.hidden) {
+        bf16_t o = f32_to_bf16(v);
+        o = f32_to_bf16(bf16_to_f32(p.x[n]) + bf16_to_f32(o));   // hidden = residual + attn (modeling_deepseek_v3.py:1219)
+        p.y[n] = o;
+      }
+    }
+    AT_STAMP(15);
+  }
+
+  // =========================== the step's last launch advances the epoch =========================================================================
+  if (p.last) {
+    __syncthreads();
+    if (tid == 0) {
+      const unsigned old = __hip_atomic_fetch_add(hdr + W_EXIT, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (old == gridDim.x - 1) {
+        st_word(hdr + W_EXIT, 0u);
+        unsigned e = epoch + 1u;
+        if (e == 0u) e = 1u;
+        st_word(hdr + W_EPOCH, e);
+      }
+    }
+  }
+}
+
+// =====================================================================================================================================
+// host
+// =====================================================================================================================================
+struct DevWs { uint8_t* base = nullptr; size_t bytes = 0; int H = 0, nA = 0; };
+std::mutex g_mu;
+DevWs g_ws[64];
+unsigned long long* g_stamps = nullptr;
+
+int ws_for(int dev, int H, int nA, uint8_t** out, unsigned* bytes) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  KTX_REQUIRE(dev >= 0 && dev < 64, "ktx_attn: device index out of range");
+  DevWs& d = g_ws[dev];
+  const WsLayout L = ws_layout(H, nA);
+  if (d.base && (d.H != H || d.nA != nA)) return ktx_fail("ktx_attn: one attention geometry per device (the workspace is shared by the layers of a model)");
+  if (!d.base) {
+    KTX_HIP(hipMalloc((void**)&d.base, L.total));
+    KTX_HIP(hipMemset(d.base, 0, L.total));
+    const unsigned one = 1;
+    KTX_HIP(hipMemcpy(d.base + 4 * W_EPOCH, &one, 4, hipMemcpyHostToDevice));
+    d.bytes = L.total; d.H = H; d.nA = nA;
+  }
+  *out = d.base;
+  *bytes = (unsigned)d.bytes;
+  return 0;
+}
+
+struct DeviceGuard {
+  int prev = -1;
+  explicit DeviceGuard(int dev) { if (hipGetDevice(&prev) != hipSuccess) prev = -1; if (prev != dev) (void)hipSetDevice(dev); else prev = -1; }
+  ~DeviceGuard() { if (prev >= 0) (void)hipSetDevice(prev); }
+};
+
+int check_args(const ktx_attn_decode_args* a, KtxLinearRaw (&r)[5], int* nsplit_out) {
+  KTX_REQUIRE(a, "ktx_attn_decode: null args");
+  ktx_linear_t hs[5] = {a->qkv_a, a->q_b, a->q_absorb, a->out_absorb, a->o_proj};
+  for (int i = 0; i < 5; i++) {
+    KTX_REQUIRE(hs[i], "ktx_attn_decode: null operator handle");
+    if (ktx_linear_raw(hs[i], &r[i]) != 0) return -1;
+    KTX_REQUIRE(r[i].loaded, "ktx_attn_decode: an operator has no weights loaded");
+    KTX_REQUIRE(r[i].device == r[0].device, "ktx_attn_decode: operators on different devices");
+    KTX_REQUIRE(r[i].bias == nullptr, "ktx_attn_decode: projections with bias are not covered");
+  }
+  const int H = a->num_heads;
+  KTX_REQUIRE(a->nope_dim == NOPE && a->rope_dim == ROPE && a->kv_lora == LORA && a->v_dim == VDIM, "ktx_attn_decode: nope 128 / rope 64 / kv_lora 512 / v 128 only");
+  KTX_REQUIRE(H == 128, "ktx_attn_decode: 128 heads only (two workgroups per head on 256 CUs)");
+  KTX_REQUIRE(a->hidden == DA * 8 * 128 && a->q_lora == NK2 * 2 * 128, "ktx_attn_decode: hidden 7168 / q_lora 1536 only");
+  const int W4 = KTX_LIN_W4, BF = KTX_LIN_BF16;
+  KTX_REQUIRE(r[0].format == W4 && r[0].group_size == 64 && r[0].batch == 1 && r[0].in_features == a->hidden &&
+                  r[0].out_features == a->q_lora + LORA + ROPE, "ktx_attn_decode: qkv_a must be the merged W4 g64 q_a|kv_a linear");
+  KTX_REQUIRE(r[1].format == W4 && r[1].group_size == 64 && r[1].batch == 1 && r[1].in_features == a->q_lora &&
+                  r[1].out_features == H * QW, "ktx_attn_decode: q_b must be W4 g64 [heads * 192, q_lora]");
+  KTX_REQUIRE(r[2].format == BF && r[2].batch == H && r[2].in_features == NOPE && r[2].out_features == LORA, "ktx_attn_decode: q_absorb must be BF16 [heads][512, 128]");
+  KTX_REQUIRE(r[3].format == BF && r[3].batch == H && r[3].in_features == LORA && r[3].out_features == VDIM, "ktx_attn_decode: out_absorb must be BF16 [heads][128, 512]");
+  KTX_REQUIRE(r[4].format == W4 && r[4].group_size == 64 && r[4].batch == 1 && r[4].in_features == H * VDIM &&
+                  r[4].out_features == a->hidden && r[4].NKS % 8 == 0, "ktx_attn_decode: o_proj must be W4 g64 [hidden, heads * 128]");
+  KTX_REQUIRE(a->page_size > 0 && a->page_size % TILE == 0 && a->ckv_token_stride % 8 == 0 && a->kpe_token_stride % 8 == 0,
+              "ktx_attn_decode: page_size must be a multiple of 32 and the token strides multiples of 8 elements");
+  int ncu = 0;
+  KTX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, r[0].device));
+  KTX_REQUIRE(ncu >= 2 * H, "ktx_attn_decode: fewer CUs than workgroups (every workgroup must be resident)");
+  ktx_mla_config mc{H, LORA, ROPE, a->page_size, a->sm_scale, 256, a->kv_len_hint};
+  const int ns = ktx_mla_decode_nsplit(&mc, 1, (size_t)1 << 40);
+  KTX_REQUIRE(ns >= 1 && ns <= MAXS, "ktx_attn_decode: the KV split rule asks for a split count this launch does not cover (context too long)");
+  *nsplit_out = ns;
+  return 0;
+}
+
+template <int MASK>
+int launch(const AttnParams& p, int nwg, hipStream_t st) {
+  static bool attr_set = false;
+  constexpr size_t LDS = 108 * 1024;
+  if (!attr_set) {
+    KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(attn_decode_kernel<MASK>, dim3(nwg), dim3(NT), LDS, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int ktx_attn_debug_stamps(unsigned long long* d_buf) {
+  g_stamps = d_buf;
+  return 0;
+}
+
+extern "C" int ktx_attn_decode_eligible(const ktx_attn_decode_args* a) {
+  KtxLinearRaw r[5];
+  int ns = 0;
+  if (ktx_debug_get(26) == 1) { ktx_fail("ktx_attn_decode: switched off (dev knob 26)"); return 0; }
+  return check_args(a, r, &ns) == 0 ? 1 : 0;
+}
+
+extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t stream) {
+  KtxLinearRaw r[5];
+  int nsplit = 0;
+  if (check_args(a, r, &nsplit) != 0) return -1;
+  KTX_REQUIRE(a->d_x && a->d_y && a->d_in_norm_w && a->d_qa_norm_w && a->d_kv_norm_w && a->d_position && a->d_inv_freq && a->d_ckv &&
+                  a->d_k_pe && a->d_kv_indptr && a->d_kv_len, "ktx_attn_decode: null pointer");
+  KTX_REQUIRE(a->phases > 0 && a->phases <= KTX_ATTN_PHASE_ALL, "ktx_attn_decode: bad phase mask");
+  const int dev = r[0].device, H = a->num_heads, NWG = 2 * H;
+  DeviceGuard guard(dev);
+  AttnParams p{};
+  p.wA = r[0].w; p.scA = (const bf16_t*)r[0].sc; p.nksA = r[0].NKS; p.nA = r[0].nstrips;
+  p.x = (const bf16_t*)a->d_x; p.in_norm_w = (const bf16_t*)a->d_in_norm_w; p.in_eps = a->in_norm_eps; p.hidden = a->hidden;
+  p.wB = r[1].w; p.scB = (const bf16_t*)r[1].sc; p.nksB = r[1].NKS;
+  p.wUK = r[2].w; p.wbsUK = (size_t)r[2].nstrips * r[2].NKS * 4096;
+  p.qa_norm_w = (const bf16_t*)a->d_qa_norm_w; p.qa_eps = a->qa_norm_eps; p.q_lora = a->q_lora;
+  p.kv_norm_w = (const bf16_t*)a->d_kv_norm_w; p.kv_eps = a->kv_norm_eps;
+  p.pos = a->d_position; p.inv_freq = a->d_inv_freq; p.mscale = a->mscale;
+  p.H = H;
+  p.ckv = (bf16_t*)a->d_ckv; p.kpe = (bf16_t*)a->d_k_pe; p.ckv_ts = a->ckv_token_stride; p.kpe_ts = a->kpe_token_stride;
+  p.kv_indptr = a->d_kv_indptr; p.kv_indices = a->d_kv_indices; p.kv_len = a->d_kv_len;
+  p.page_size = a->page_size; p.nsplit = nsplit; p.sm_scale = a->sm_scale;
+  p.wUV = r[3].w; p.wbsUV = (size_t)r[3].nstrips * r[3].NKS * 4096;
+  p.wE = r[4].w; p.scE = (const bf16_t*)r[4].sc; p.nksE = r[4].NKS; p.nE = r[4].nstrips;
+  {
+    const int nwgE = std::min(NWG, p.nE);
+    p.eQ = p.nE / nwgE; p.eR = p.nE % nwgE;
+    KTX_REQUIRE(p.eQ + 1 <= 4, "ktx_attn_decode: o_proj has more strips per workgroup than the LDS table holds");
+  }
+  p.y = (bf16_t*)a->d_y;
+  KTX_REQUIRE(p.nksA == DA * 8 && p.nksB == 2 * NK2 && p.nA <= NWG, "ktx_attn_decode: unexpected tile counts");
+  if (ws_for(dev, H, p.nA, &p.ws, &p.ws_bytes) != 0) return -1;
+  p.last = a->last ? 1 : 0;
+  p.stamps = g_stamps;
+  hipStream_t st = (hipStream_t)stream;
+  // algorithmic bytes of the phases in this launch (weights as stored + the context's latent rows)
+  double bytes = 0;
+  auto lin_bytes = [](const KtxLinearRaw& q) {
+    const double tile = q.format == KTX_LIN_W4 ? 1024.0 : 4096.0;
+    const double sc = q.format == KTX_LIN_W4 ? (double)q.nstrips * q.NKS * 16 * (128 / q.group_size) * 2 : 0.0;
+    return ((double)q.nstrips * q.NKS * tile + sc) * q.batch;
+  };
+  if (a->phases & PH_A) bytes += lin_bytes(r[0]);
+  if (a->phases & PH_B) bytes += lin_bytes(r[1]) + lin_bytes(r[2]);
+  if (a->phases & PH_C) bytes += (double)std::max(a->kv_len_hint, 1) * (LORA + ROPE) * 2.0;
+  if (a->phases & PH_D) bytes += lin_bytes(r[3]);
+  if (a->phases & PH_E) bytes += lin_bytes(r[4]);
+  KTX_TIMED(st, bytes, "attn_decode_kernel<%d> H=%d nsplit=%d", a->phases, H, nsplit);
+  switch (a->phases) {
+#ifdef KTX_ATTN_ONLY_MASK
+    case KTX_ATTN_ONLY_MASK: return launch<KTX_ATTN_ONLY_MASK>(p, NWG, st);
+    default: return -1;
+  }
+}
+#else
+    case 31: return launch<31>(p, NWG, st);
+    case 1: return launch<1>(p, NWG, st);
+    case 2: return launch<2>(p, NWG, st);
+    case 4: return launch<4>(p, NWG, st);
+    case 8: return launch<8>(p, NWG, st);
+    case 16: return launch<16>(p, NWG, st);
+    case 3: return launch<3>(p, NWG, st);
+    case 24: return launch<24>(p, NWG, st);
+    case 28: return launch<28>(p, NWG, st);
+    default: return ktx_fail("ktx_attn_decode: this phase subset is not instantiated (31, single phases, 3, 24, 28)");
+  }
+}
+#endif
+
+extern "C" int ktx_attn_status(int device, uint32_t* status_out) {
+  KTX_REQUIRE(status_out && device >= 0 && device < 64, "ktx_attn_status: bad arguments");
+  *status_out = 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ws[device].base) return 0;
+  DeviceGuard guard(device);
+  KTX_HIP(hipMemcpy(status_out, g_ws[device].base + 4 * W_STATUS, 4, hipMemcpyDeviceToHost));
+  return 0;
+}
+
+// dev / tests: copy one of the workspace arrays of the last launch into a device buffer.  which: 0 qkv (A's output row), 1 ckv_new,
+// 2 kpe_new, 3 q_lat [H][512], 4 q_pe [H][64], 5 merged rows [H][512], 6 attn_out [H][128], 7 part_ml [H][S][2] fp32, 8 part_o
+// [H][S][512] fp32 (S = the split count of the last launch's geometry: pass bytes accordingly), 9 qx [H][128]
+extern "C" int ktx_attn_debug_read(int device, int which, void* d_dst, size_t bytes) {
+  KTX_REQUIRE(device >= 0 && device < 64 && d_dst, "ktx_attn_debug_read: bad arguments");
+  std::lock_guard<std::mutex> lk(g_mu);
+  const DevWs& d = g_ws[device];
+  KTX_REQUIRE(d.base, "ktx_attn_debug_read: no workspace on this device yet");
+  const WsLayout L = ws_layout(d.H, d.nA);
+  const unsigned offs[10] = {L.qkv, L.ckv_new, L.kpe_new, L.q_lat, L.q_pe, L.om, L.attn_out, L.part_ml, L.part_o, L.qx};
+  KTX_REQUIRE(which >= 0 && which < 10 && offs[which] + bytes <= d.bytes, "ktx_attn_debug_read: bad array or size");
+  DeviceGuard guard(device);
+  KTX_HIP(hipMemcpy(d_dst, d.base + offs[which], bytes, hipMemcpyDeviceToDevice));
+  return 0;
+}
+
+extern "C" int ktx_attn_reset(int device) {
+  KTX_REQUIRE(device >= 0 && device < 64, "ktx_attn_reset: bad device");
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_ws[device].base) return 0;
+  DeviceGuard guard(device);
+  KTX_HIP(hipDeviceSynchronize());
+  const unsigned z[2] = {0, 0};
+  KTX_HIP(hipMemcpy(g_ws[device].base + 4 * W_EXIT, z, 8, hipMemcpyHostToDevice));   // exit counter + status
+  return 0;
+}

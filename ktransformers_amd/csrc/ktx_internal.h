@@ -2,6 +2,7 @@
 // libktx_hip.so.
 #ifndef KTX_INTERNAL_H
 #define KTX_INTERNAL_H
+#include <stddef.h>
 #include <stdint.h>
 
 #include "../../include/ktx_linear.h"
@@ -15,5 +16,10 @@ struct KtxLinearRaw {
   bool loaded;
 };
 int ktx_linear_raw(ktx_linear_t h, KtxLinearRaw* out);
+
+// KV split count ktx_mla_decode_partials would take for this call when it runs the 2x4 workgroup shape (0 otherwise): the
+// one-launch decode step (ktx_attn.hip) splits the context the same way (ktx_mla.hip owns the rule)
+struct ktx_mla_config;
+extern "C" int ktx_mla_decode_nsplit(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes);
 
 #endif

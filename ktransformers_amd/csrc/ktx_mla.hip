@@ -486,21 +486,9 @@ extern "C" int ktx_mla_decode_partials(const ktx_mla_config* cfg, const void* d_
                          workspace_bytes, stream, nsplit_out);
 }
 
-static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
-                           void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
-                           const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
-                           const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
-                           const void* d_new_ckv, const void* d_new_kpe, void* d_out, float* d_lse,
-                           void* d_workspace, size_t workspace_bytes, void* stream, int* partials_nsplit) {
-  KTX_REQUIRE((d_new_ckv == nullptr) == (d_new_kpe == nullptr), "ktx_mla_decode_append: give both new_ckv and new_kpe or neither");
-  KTX_REQUIRE(cfg && d_q_nope && d_q_pe && d_ckv && d_k_pe && d_workspace, "ktx_mla_decode: null pointer");
-  KTX_REQUIRE(d_qo_indptr && d_kv_indptr && d_kv_len_arr, "ktx_mla_decode: null index array");
-  KTX_REQUIRE(cfg->head_dim_ckv == MLA_DC && cfg->head_dim_kpe == MLA_DR, "ktx_mla_decode: only kv_lora_rank 512 + rope 64");
-  KTX_REQUIRE(cfg->num_heads > 0 && cfg->num_heads % 16 == 0, "ktx_mla_decode: num_heads must be a multiple of 16");
-  KTX_REQUIRE(batch > 0 && total_q_tokens > 0 && cfg->page_size > 0, "ktx_mla_decode: bad sizes");
-  KTX_REQUIRE(cfg->page_size % MLA_TILE == 0, "ktx_mla_decode: page_size must be a multiple of 32 (the reference's caches use 64 and 256)");
-  KTX_REQUIRE(ckv_token_stride % 8 == 0 && kpe_token_stride % 8 == 0, "ktx_mla_decode: token strides must be multiples of 8 elements");
-  hipStream_t st = (hipStream_t)stream;
+// Workgroup shape and KV split count of a decode call — one place, because the one-launch decode step (ktx_attn.hip) must
+// split the context exactly as the stand-alone kernel does to reproduce its partials bit for bit.
+static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes, int* shape_out, int* nsplit_out) {
   const int Hq = cfg->num_heads;
   // workgroup shape (head blocks x dim slices): decode-sized calls of many-headed models take 2x4 (32 heads share one staged
   // KV tile, 128 output dims per wave), prompts of those models 4x2, everything else 1x4
@@ -513,8 +501,7 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
     const int fs = ktx_debug_get(6);
     if ((fs == 1) || (fs == 2 && Hq % 32 == 0) || (fs == 4 && Hq % 64 == 0)) shape = fs;
   }
-  const bool wide = shape == 4;
-  const int hbw = shape, nwv = shape == 1 ? 4 : 8;
+  const int hbw = shape;
   const int hblocks = Hq / (16 * hbw);
   // KV splits: one 32-token tile per workgroup whenever the grid stays under ~2048 workgroups (measured on 16 heads: extra
   // tiles per workgroup cost more than the extra partials cost the merge kernel), bounded by the workspace — and by the
@@ -539,6 +526,37 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
   // instantiation); longer contexts simply put more 32-token tiles into each split
   nsplit = std::min(nsplit, std::min(256, std::max(1, cfg->max_splits)));
   nsplit = (int)std::min<size_t>((size_t)nsplit, workspace_bytes / ((size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float)));
+  *shape_out = shape;
+  *nsplit_out = nsplit;
+}
+extern "C" int ktx_mla_decode_nsplit(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes) {   // ktx_internal.h
+  int shape = 0, nsplit = 0;
+  if (!cfg || total_q_tokens <= 0) return 0;
+  mla_pick_shape(cfg, total_q_tokens, workspace_bytes, &shape, &nsplit);
+  return shape == 2 ? nsplit : 0;   // the one-launch step is built on the 2x4 workgroup shape only
+}
+
+static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, const void* d_q_pe, void* d_ckv,
+                           void* d_k_pe, int64_t ckv_token_stride, int64_t kpe_token_stride,
+                           const int32_t* d_qo_indptr, const int32_t* d_kv_indptr, const int32_t* d_kv_indices,
+                           const int32_t* d_kv_len_arr, const int32_t* d_bsz, int batch, int total_q_tokens,
+                           const void* d_new_ckv, const void* d_new_kpe, void* d_out, float* d_lse,
+                           void* d_workspace, size_t workspace_bytes, void* stream, int* partials_nsplit) {
+  KTX_REQUIRE((d_new_ckv == nullptr) == (d_new_kpe == nullptr), "ktx_mla_decode_append: give both new_ckv and new_kpe or neither");
+  KTX_REQUIRE(cfg && d_q_nope && d_q_pe && d_ckv && d_k_pe && d_workspace, "ktx_mla_decode: null pointer");
+  KTX_REQUIRE(d_qo_indptr && d_kv_indptr && d_kv_len_arr, "ktx_mla_decode: null index array");
+  KTX_REQUIRE(cfg->head_dim_ckv == MLA_DC && cfg->head_dim_kpe == MLA_DR, "ktx_mla_decode: only kv_lora_rank 512 + rope 64");
+  KTX_REQUIRE(cfg->num_heads > 0 && cfg->num_heads % 16 == 0, "ktx_mla_decode: num_heads must be a multiple of 16");
+  KTX_REQUIRE(batch > 0 && total_q_tokens > 0 && cfg->page_size > 0, "ktx_mla_decode: bad sizes");
+  KTX_REQUIRE(cfg->page_size % MLA_TILE == 0, "ktx_mla_decode: page_size must be a multiple of 32 (the reference's caches use 64 and 256)");
+  KTX_REQUIRE(ckv_token_stride % 8 == 0 && kpe_token_stride % 8 == 0, "ktx_mla_decode: token strides must be multiples of 8 elements");
+  hipStream_t st = (hipStream_t)stream;
+  const int Hq = cfg->num_heads;
+  int shape = 0, nsplit = 0;
+  mla_pick_shape(cfg, total_q_tokens, workspace_bytes, &shape, &nsplit);
+  const bool wide = shape == 4;
+  const int hbw = shape, nwv = shape == 1 ? 4 : 8;
+  const int hblocks = Hq / (16 * hbw);
   KTX_REQUIRE(nsplit >= 1, "ktx_mla_decode: workspace too small");
   const size_t need = (size_t)total_q_tokens * Hq * nsplit * (MLA_DC + 2) * sizeof(float);
   KTX_REQUIRE(workspace_bytes >= need, "ktx_mla_decode: workspace too small");
