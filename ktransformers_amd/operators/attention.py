@@ -177,6 +177,10 @@ class KDeepseekV2Attention(BaseInjectedModule):
             raise ValueError("KDeepseekV2Attention needs the paged latent cache (past_key_value)")
         dev = hidden_states.device
         H, nope, rope, lora = self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim, self.kv_lora_rank
+        if q_len == 1 and pre_norm is not None and residual is not None:
+            fused = self._fused_decode(hidden_states, pre_norm, residual, position_ids, past_key_value)
+            if fused is not None:
+                return fused.reshape(bsz, q_len, -1), None, past_key_value
         x = hidden_states.reshape(q_len, -1)
 
         norm = None if pre_norm is None else (pre_norm.weight, pre_norm.variance_epsilon)
@@ -252,13 +256,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
             # kv_len is read on the device: positions + 1 (attention.py:430-433); the kernel appends the new row itself.
             # Every layer of a step sees the same position tensor: derive kv_len once per step, not once per layer.
             # (keyed on the capture state too: a value computed in an eager warm-up must not leak into a captured graph)
-            key = (id(position_ids), position_ids._version, torch.cuda.is_current_stream_capturing())
-            memo = getattr(past_key_value, "_kv_len_memo", None)
-            if memo is not None and memo[0] == key and memo[1] is position_ids:
-                kv_len = memo[2]
-            else:
-                kv_len = (pos + 1).to(torch.int32)
-                past_key_value._kv_len_memo = (key, position_ids, kv_len)
+            kv_len, _ = self._kv_len_of(position_ids, past_key_value)
             # split count: a launch-grid constant of the captured graph — size it for the context seen now plus headroom
             # (longer contexts later just put several tiles in a split)
             seen = int(past_key_value.get_seq_length(self.layer_idx))
@@ -291,6 +289,73 @@ class KDeepseekV2Attention(BaseInjectedModule):
             attn = self.mla_wrapper.run(q_nope, q_pe, ckv_pages, kpe_pages)
         out = oabs.forward_batched(attn[:, :H])                             # [T, H, v]
         return self._project_out(out.reshape(q_len, H * self.v_head_dim), residual, bsz, q_len), None, past_key_value
+
+    # ---- the whole decode step as ONE launch (csrc/ktx_attn.hip) -------------------------------------------------------------
+    @staticmethod
+    def _gen_handle(mod):
+        """The W4 LinearHandle a KTransformersLinear (or a merged operator) decodes with, or None."""
+        lin = mod
+        if hasattr(mod, "generate_linear"):
+            lin = mod.generate_linear if getattr(mod, "mode", None) == InferenceState.GENERATE else getattr(mod, "prefill_linear", None)
+        h = getattr(lin, "_h", None)
+        return h if h is not None and getattr(h, "fmt", None) == "W4" else None
+
+    def _kv_len_of(self, position_ids, past_key_value):
+        """kv_len = positions + 1 on the device, derived once per step (every layer sees the same position tensor)."""
+        key = (id(position_ids), position_ids._version, torch.cuda.is_current_stream_capturing())
+        memo = getattr(past_key_value, "_kv_len_memo", None)
+        if memo is not None and memo[0] == key and memo[1] is position_ids:
+            return memo[2], memo[3]
+        pos = position_ids.reshape(-1).to(torch.int64)
+        kv_len = (pos + 1).to(torch.int32)
+        past_key_value._kv_len_memo = (key, position_ids, kv_len, pos)
+        return kv_len, pos
+
+    def _fused_decode(self, hidden_states, pre_norm, residual, position_ids, past_key_value):
+        """q_a|kv_a -> q_b + absorb + RoPE + latent norm + cache append -> split-KV attention -> merge + un-absorb -> o_proj +
+        residual as ONE persistent launch (include/ktx_attn.h) when this layer has the covered geometry (DeepSeek-V3 / R1 attention
+        dimensions, W4 g64 projections, the identity / paged single-request cache); None otherwise — the caller then takes the
+        five-launch path, whose kernels this launch restates bit for bit.  KTX_ATTN_SEPARATE=1 forces the five launches (A/B)."""
+        ok = getattr(self, "_fused_ok", None)
+        if ok is False or os.environ.get("KTX_ATTN_SEPARATE") or self.q_lora_rank is None or self._qkv is None:
+            return None
+        if (hidden_states.dtype != torch.bfloat16 or not hidden_states.is_contiguous() or residual.data_ptr() != hidden_states.data_ptr()
+                or residual.shape != hidden_states.shape or past_key_value is None):
+            return None
+        from ktransformers_amd import _native as N
+        dev = hidden_states.device
+        H, nope, rope, lora = self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim, self.kv_lora_rank
+        handles = (self._gen_handle(self._qkv[0]), self._gen_handle(self.q_b_proj), self._gen_handle(self.o_proj))
+        if any(h is None for h in handles):
+            object.__setattr__(self, "_fused_ok", False)
+            return None
+        qabs, oabs = self.get_absorbed()
+        capacity = past_key_value.max_pages * past_key_value.page_size
+        seen = int(past_key_value.get_seq_length(self.layer_idx))
+        if seen + 1 > capacity:     # the reference's indexed assignment raises here (custom_cache.py:189-195)
+            raise IndexError(f"KDeepseekV2Attention: position {seen} is beyond the cache ({capacity} tokens)")
+        hint = min(seen + 512, capacity)
+        kv_len, pos = self._kv_len_of(position_ids, past_key_value)
+        inv_freq, mscale = self._rope_params(dev)
+        cache = past_key_value.key_cache[self.layer_idx]                   # [pages, page, 1, lora + rope]
+        kv_indptr, kv_indices = _cache_page_arrays(past_key_value, self.layer_idx, dev)
+        identity = bool(getattr(past_key_value, "identity_page_table", False)) and not _NO_IDENTITY()
+        ln, kln = self.q_a_layernorm, self.kv_a_layernorm
+        out = torch.empty_like(hidden_states)
+        keep = (pre_norm.weight.to(torch.bfloat16), ln.weight.to(torch.bfloat16), kln.weight.to(torch.bfloat16))
+        args = N.attn_decode_args(handles[0], handles[1], qabs, oabs, handles[2], hidden_states.reshape(-1), out.reshape(-1),
+                                  (keep[0], pre_norm.variance_epsilon), (keep[1], ln.variance_epsilon), (keep[2], kln.variance_epsilon),
+                                  pos, inv_freq, mscale, H, nope, rope, lora, self.v_head_dim, cache[:, :, 0, :lora], cache[:, :, 0, lora:],
+                                  past_key_value.page_size, kv_indptr, None if identity else kv_indices, kv_len, hint, self.softmax_scale)
+        if ok is None:
+            ok = N.attn_decode_eligible(args)
+            object.__setattr__(self, "_fused_ok", ok)
+            if not ok:
+                return None
+        N.attn_decode(args, dev)
+        past_key_value.note_appended(self.layer_idx, 1)
+        object.__setattr__(self, "_decode_plan", kv_len)
+        return out
 
     def _decode_qb_handle(self, q_len, q_a, kv, qabs):
         """The q_b_proj LinearHandle when this call can take the combined q_b + q-absorb launch: a decode step through the

@@ -13,10 +13,16 @@ from ktransformers_amd.util.utils import InferenceState
 
 
 def _check_ep() -> None:
-    """Expert-parallel runs over the peer-write transport: a poll that gave up must not pass silently (parallel.py)."""
-    from ktransformers_amd import parallel
+    """Bounded in-launch hand-offs must not fail silently: the expert-parallel peer-write transport (parallel.py) and the
+    one-launch attention step (include/ktx_attn.h) only set a status word when a poll gives up."""
+    from ktransformers_amd import _native, parallel
     if parallel.EP_STATE.get("exchange") is not None:
         parallel.check_exchange_status()
+    if torch.cuda.is_available():
+        st = _native.attn_status(torch.device("cuda", torch.cuda.current_device()))
+        if st != 0:
+            raise RuntimeError(f"one-launch attention step: a hand-off inside the launch timed out (status {st:#x}); "
+                               "outputs since the previous check are not valid")
 
 
 def set_inference_mode(model: torch.nn.Module, mode: InferenceState) -> None:
