@@ -103,6 +103,7 @@ struct AttnParams {
 };
 
 #define AT_STAMP(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 0) p.stamps[i] = wall_clock64(); } while (0)
+#define AT_STAMP7(i) do { if (p.stamps && blockIdx.x == 0 && threadIdx.x == 448) p.stamps[i] = wall_clock64(); } while (0)
 
 // ---- hand-off primitives -----------------------------------------------------------------------------------------------------
 __device__ __forceinline__ unsigned ld_word(const unsigned* q) { return __hip_atomic_load(q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -250,6 +251,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   unsigned* fM = reinterpret_cast<unsigned*>(p.ws + L.fM);
   unsigned* fD = reinterpret_cast<unsigned*>(p.ws + L.fD);
   AT_STAMP(0);
+  AT_STAMP7(23);
   const unsigned epoch = ld_word(hdr + W_EPOCH);
 
   // =========================== requests that depend on nothing =====================================================================
@@ -267,6 +269,9 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       xrA[i] = *reinterpret_cast<const uint4*>(p.x + pc * 8);
       nwA[i] = *reinterpret_cast<const uint4*>(p.in_norm_w + pc * 8);
     }
+    // The CU's memory pipe is a FIFO shared by its wavefronts: without this barrier a wavefront that runs ahead queues its 40 KiB of
+    // weight requests in front of the others' input-row requests, and the row (needed first) arrives behind the whole burst.
+    asm volatile("s_barrier" ::: "memory");
     const int sA = min(w, p.nA - 1);
     const long tile0 = (long)sA * p.nksA + wave * DA;
 #pragma unroll
@@ -279,9 +284,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // absorb tiles (waves 0..5: one strip, waves 6..7: five strips)
   uint4 nwB = make_uint4(0, 0, 0, 0);
   float ropePos = 0.f, ropeIf = 0.f;
-  uint4 w1r[2][NK2];
-  uint2 s1r[2][NK2];
-  uint4 w2r[5][4];
+  // one register file for both wave roles: waves 0..5 hold rb[0..11] = their q_b strip (k-half kh, step s_ at kh * 6 + s_) and
+  // rb[12..15] = their absorb strip; waves 6..7 hold rb[4 i .. 4 i + 3] = absorb strip i of their five
+  uint4 rb[20];
+  uint2 sb[2 * NK2];
   auto prefetch_B = [&]() {
     nwB = *reinterpret_cast<const uint4*>(p.qa_norm_w + min(tid, (p.q_lora >> 3) - 1) * 8);
     ropePos = (float)p.pos[0];
@@ -294,23 +300,36 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         const bf16_t* sp = p.scB + ((strip * p.nksB + (size_t)kh * NK2) * 16 + (lane & 15)) * 2;
 #pragma unroll
         for (int s_ = 0; s_ < NK2; s_++) {
-          w1r[kh][s_] = nt_load16(wp + (size_t)s_ * 1024);
-          s1r[kh][s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
+          rb[kh * NK2 + s_] = nt_load16(wp + (size_t)s_ * 1024);
+          sb[kh * NK2 + s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
         }
       }
       const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + wave) * 4096 + lane * 16;
 #pragma unroll
-      for (int q = 0; q < 4; q++) w2r[0][q] = nt_load16(wp2 + q * 1024);
+      for (int q = 0; q < 4; q++) rb[12 + q] = nt_load16(wp2 + q * 1024);
     } else {
 #pragma unroll
       for (int i = 0; i < 5; i++) {
         const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + 6 + (wave - 6) * 5 + i) * 4096 + lane * 16;
 #pragma unroll
-        for (int q = 0; q < 4; q++) w2r[i][q] = nt_load16(wp2 + q * 1024);
+        for (int q = 0; q < 4; q++) rb[i * 4 + q] = nt_load16(wp2 + q * 1024);
       }
     }
   };
-  if constexpr ((MASK & PH_B) != 0) prefetch_B();
+  // Phase B's 136 KiB are requested behind phase A's k-steps (workgroups with a strip of phase A): issued first they cost the
+  // wavefront ~2 us of instruction issue in front of its first wait, and their wave-role branches make the compiler drain the
+  // whole queue (vmcnt(0)) at the first consumer behind them (measured with the stamps: the input row was staged 6.4 us after
+  // entry with the requests in front, 2.9 us behind; phase A's k-steps ended at 7.0 us with the requests in front of them).
+  if constexpr ((MASK & PH_B) != 0) {
+    if (!doA) {
+      // (workgroups without a strip of phase A: their 136 KiB each would compete chip-wide with the 7 MB of phase A tiles the step
+      // is waiting for — measured: those tiles took 6 us to arrive — so they start ~1.5 us late)
+      if constexpr ((MASK & PH_A) != 0) __builtin_amdgcn_s_sleep(56);
+      prefetch_B();
+    }
+  }
+  AT_STAMP(18);
+  AT_STAMP7(25);
 
   // =========================== phase A ===================================================================================
   if constexpr ((MASK & PH_A) != 0) {
@@ -328,7 +347,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       for (int i = 0; i < XRA; i++) ss += sumsq8(xrA[i]);
       const float wsum = wave_sum(ss);
       if (lane == 0) nred[wave * 4] = wsum;
+      AT_STAMP(16);
+      AT_STAMP7(24);
       __syncthreads();
+      AT_STAMP(17);
       float tot = nred[0];
 #pragma unroll
       for (int v = 1; v < 8; v++) tot += nred[v * 4];
@@ -350,21 +372,18 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       AT_STAMP(1);
       const int kc = lane >> 4;
       const uint8_t* xb0 = xs + kc * 16;
-      for (int s = w; s < p.nA; s += NWG) {   // (one strip per workgroup at DeepSeek-V3's 132 strips; further ones re-request their tiles)
-        if (s != w) {
-          const long tile0 = (long)s * p.nksA + wave * DA;
-#pragma unroll
-          for (int d = 0; d < DA; d++) {
-            wrA[d] = nt_load16(p.wA + (tile0 + d) * 1024 + lane * 16);
-            srA[d] = load_w4_scales<2>(p.scA + ((tile0 + d) * 16 + (lane & 15)) * 2);
-          }
-          __syncthreads();   // table / ostage of the previous strip have been consumed
-        }
+      {   // (the host admits at most one strip per workgroup: nA <= 2 x heads)
+        const int s = w;
         float acc = 0.f;
         const int ks0 = wave * DA;
 #pragma unroll
         for (int d = 0; d < DA; d++) w4_kstep1(wrA[d], srA[d], xb0 + (size_t)(ks0 + d) * 256, aux + (ks0 + d) * 8, acc);
+        // phase B's requests go out HERE: nothing older is pending any more, so the wave-role branches inside (whose request counts
+        // the compiler cannot line up: it drains the queue at their join) cost nothing, and the replies fly during the hand-off
+        if constexpr ((MASK & PH_B) != 0) prefetch_B();
         if (lane < 16) table[wave * 64 + lane] = acc;
+        AT_STAMP(19);
+        AT_STAMP7(26);
         __syncthreads();
         if (wave == 0) {
           if (lane < 16) {
@@ -496,12 +515,14 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
 #pragma unroll
         for (int s_ = 0; s_ < NK2; s_++) {
           const int ks = kh * NK2 + s_;
-          w4_kstep1(w1r[kh][s_], s1r[kh][s_], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
+          w4_kstep1(rb[ks], sb[ks], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
         }
         if (lane < 16) red1[(wave * 2 + kh) * 16 + lane] = acc;
       }
     }
+    AT_STAMP(20);
     __syncthreads();
+    AT_STAMP(21);
     if (tid < 96) {
       const int sih = tid >> 4, f = tid & 15;
       float v = 0.f;
@@ -521,22 +542,29 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     drain_stores();
     __syncthreads();
     if (tid == 0) st_word(fX + w, epoch);
+    AT_STAMP(22);
     const int partner = h + (1 - part) * H;
     if (wave == 7) poll_flags(p, fX, 1, epoch, 0xB1, [partner](int) { return partner; });
     __syncthreads();
+    AT_STAMP(27);
     if (tid < 16) *reinterpret_cast<uint4*>(xs2 + tid * 16) = ws_load16(rs, L.qx + h * NOPE * 2 + tid * 16);
     __syncthreads();
     AT_STAMP(5);
     // ---- absorb: this half's 16 strips of W_UK[h]^T q_nope, one k-step of 128 each
     {
       const uint8_t* xb2 = xs2 + kc * 4 * 16;
-      const int na = wave < 6 ? 1 : 5;
+      if (wave < 6) {
+        v4f acc = {0.f, 0.f, 0.f, 0.f};
+        const uint4 wt[4] = {rb[12], rb[13], rb[14], rb[15]};
+        bf16_kstep(wt, xb2, acc);
+        if (lane < 16) stage[wave * 16 + lane] = f32_to_bf16(0.f + acc[0]);
+      } else {
 #pragma unroll
-      for (int i = 0; i < 5; i++) {
-        if (i < na) {
+        for (int i = 0; i < 5; i++) {
           v4f acc = {0.f, 0.f, 0.f, 0.f};
-          bf16_kstep(w2r[i], xb2, acc);
-          const int a = wave < 6 ? wave : 6 + (wave - 6) * 5 + i;
+          const uint4 wt[4] = {rb[i * 4], rb[i * 4 + 1], rb[i * 4 + 2], rb[i * 4 + 3]};
+          bf16_kstep(wt, xb2, acc);
+          const int a = 6 + (wave - 6) * 5 + i;
           if (lane < 16) stage[a * 16 + lane] = f32_to_bf16(0.f + acc[0]);
         }
       }
@@ -554,17 +582,18 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   const int hg = w >> 6, split = w & 63;
   const bool doC = (MASK & PH_C) && split < p.nsplit && hg < H / 32;
   // phase D's weights (waves 0..3: one strip of W_UV[h], 4 k-steps x 4 planes) are requested before phase C starts waiting
+  // (measured, profiles/r04_a_*: spreading these 64 KiB over the KV tiles of phase C — one k-step per tile, behind the tile's own
+  // requests — made the q poll 1.2 us faster and the tile loop 2.4 us slower: every tile's wait is a wait for ALL of the wavefront's
+  // requests.  One burst in front of the q poll it is.)
   uint4 wrD[4][4];
-  auto prefetch_D = [&]() {
-    if (wave < 4) {
-      const uint8_t* wp = p.wUV + (size_t)h * p.wbsUV + (size_t)(part * 4 + wave) * 4 * 4096 + lane * 16;
-#pragma unroll
-      for (int ks = 0; ks < 4; ks++)
-#pragma unroll
-        for (int q = 0; q < 4; q++) wrD[ks][q] = nt_load16(wp + (size_t)ks * 4096 + q * 1024);
-    }
-  };
-  if constexpr ((MASK & PH_D) != 0) prefetch_D();
+  const uint8_t* wpD = p.wUV + (size_t)h * p.wbsUV + (size_t)(part * 4 + (wave & 3)) * 4 * 4096 + lane * 16;
+#define KTX_PF_D(KS)                                                                                   \
+  do {                                                                                                 \
+    if (wave < 4) {                                                                                    \
+      _Pragma("unroll") for (int q = 0; q < 4; q++) wrD[KS][q] = nt_load16(wpD + (KS) * 4096 + q * 1024); \
+    }                                                                                                  \
+  } while (0)
+  if constexpr ((MASK & PH_D) != 0) { KTX_PF_D(0); KTX_PF_D(1); KTX_PF_D(2); KTX_PF_D(3); }
   if constexpr ((MASK & PH_C) != 0) {
     __syncthreads();
     if (doC) {

@@ -101,6 +101,10 @@ def timeit(gr, reps=30):
 
 cfgs = [("five launches", five), ("one launch", lambda l: fused(l)), ("phases as 5 launches", lambda l: fused(l, (1, 2, 4, 8, 16))),
         ("3 + 4 + 24", lambda l: fused(l, (3, 4, 24))), ("3 + 28", lambda l: fused(l, (3, 28)))]
+import subprocess
+print(subprocess.run("/opt/rocm/bin/rocm-smi --showuniqueid | grep Unique", shell=True, capture_output=True, text=True).stdout.strip())
+if len(sys.argv) > 3:
+    cfgs = [c for c in cfgs if c[0] in ("five launches", "one launch")]
 graphs = [(name, capture(fn)) for name, fn in cfgs]
 ref_y = None
 for rnd in range(2):
@@ -125,3 +129,10 @@ print("stamps of workgroup 0, last layer (us from entry):")
 for i, nme in enumerate(names):
     if t[i]:
         print(f"  {nme:24s} {(t[i] - t[0]) * 0.01:7.2f}")
+extra = {18: "wave 0: every request of the prologue issued", 16: "wave 0: x landed, sum of squares done", 17: "wave 0: past the norm barrier",
+         19: "wave 0: its 7 k-steps of phase A done", 23: "wave 7: entry", 25: "wave 7: requests issued", 24: "wave 7: x landed, sum of squares done",
+         26: "wave 7: its 7 k-steps of phase A done", 20: "B: wave 0 q_b k-steps done", 21: "B: past the q_b barrier",
+         22: "B: own q_nope piece published", 27: "B: partner's piece polled"}
+for i, nme in extra.items():
+    if t[i]:
+        print(f"  [{nme}] {(t[i] - t[0]) * 0.01:7.2f}")
