@@ -458,7 +458,7 @@ KTX_KERNEL_NAMES = ("lin_sk_kernel", "lin_sk_gate_kernel", "lin_dec_kernel", "li
                     "moe_dec_fp_gateup_kernel", "moe_dec_fp_down_kernel", "moe_dec_raw_gateup_kernel", "moe_dec_raw_down_kernel",
                     "moe_dec_gguf_gateup_kernel", "moe_dec_gguf_down_kernel", "moe_prep_kernel", "moe_gemm_kernel", "moe_combine_kernel",
                     "mla_decode_kernel", "mla_merge_kernel", "mla_prep_kernel", "mla_cache_append_kernel", "rmsnorm_kernel",
-                    "silu_mul_kernel", "argmax_bf16_kernel", "ep_gather_kernel", "ep_reduce_kernel")
+                    "silu_mul_kernel", "argmax_bf16_kernel", "ep_gather_kernel", "ep_reduce_kernel", "attn_decode_kernel", "moe_layer_kernel")
 
 
 def _kclass(text):

@@ -3404,3 +3404,5 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   KTX_HIP(hipGetLastError());
   return 0;
 }
+
+#include "ktx_moe_layer.inc"

@@ -340,10 +340,58 @@ class _KMoEBlock(BaseInjectedModule):
         y = y.view(*orig_shape)
         return y if residual is None else residual + y
 
+    def _fused_decode(self, hidden_states, residual, pre_norm):
+        """post_attention_layernorm -> router || shared gate|up -> routed gate/up -> routed down + shared down + both adds as ONE
+        persistent launch (include/ktx_moe.h: ktx_moe_layer_decode) when the block has the covered geometry (DeepSeek-V3 / R1: 256
+        AMXINT4 experts of 2048 x 7168 on this device, top-8, W4 shared experts with the merged gate|up operator); None otherwise — the
+        caller then takes the three-launch path, whose kernels this launch restates bit for bit.  OPT-IN (KTX_MOE_FUSED=1): inside the
+        whole-model graph it measured 5.03 against 4.79 ms per step on the slower class of boxes and equal on the faster one
+        (profiles/r04_d_ab_fused_slowbox.txt), so the three launches stay the default; KTX_MOE_SEPARATE=1 always forces them."""
+        ok = getattr(self, "_fused_ok", None)
+        if ok is False or not os.environ.get("KTX_MOE_FUSED") or os.environ.get("KTX_MOE_SEPARATE") or pre_norm is None or residual is None:
+            return None
+        if (hidden_states.numel() != hidden_states.shape[-1] or hidden_states.dtype != torch.bfloat16 or not hidden_states.is_contiguous()
+                or residual.data_ptr() != hidden_states.data_ptr() or not hidden_states.is_cuda):
+            return None
+        side = self._router_side_linear(hidden_states, pre_norm)
+        ex = self.experts
+        op = getattr(ex, "generate_experts", None) if getattr(ex, "mode", None) == InferenceState.GENERATE else \
+            getattr(ex, "prefill_experts", None)
+        if side is None or not isinstance(op, KExpertsHIP) or op._ep is not None or op.handle is None:
+            return None
+        tail = self._tail_side(hidden_states, residual, op)      # (only its down_proj handle is used: same conditions)
+        if tail is None:
+            return None
+        from ktransformers_amd import _native as N
+        gate = self.gate
+        w = gate.orig_module.weight
+        bias = getattr(gate.orig_module, "e_score_correction_bias", None)
+        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+            cached = getattr(self, "_fused_bias", None)
+            if cached is None or cached[0] is not bias:
+                cached = (bias, bias.detach().to(torch.float32).contiguous())
+                object.__setattr__(self, "_fused_bias", cached)
+            bias = cached[1]
+        out = torch.empty_like(hidden_states)
+        nw = pre_norm.weight if pre_norm.weight.dtype == torch.bfloat16 else pre_norm.weight.to(torch.bfloat16)
+        args = N.moe_layer_args(op.handle, side, tail[0], gate._handle(), w if w.is_contiguous() else w.contiguous(), bias,
+                                hidden_states.reshape(-1), out.reshape(-1), (nw, pre_norm.variance_epsilon))
+        if ok is None:
+            ok = N.moe_layer_decode_eligible(args)
+            object.__setattr__(self, "_fused_ok", ok)
+            if not ok:
+                return None
+        N.moe_layer_decode(args, hidden_states.device)
+        return out
+
     def _forward(self, hidden_states, residual=None, pre_norm=None):
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
         shared_act = None
+        if sequence_length == 1 and orig_shape[0] == 1:
+            fused = self._fused_decode(hidden_states, residual, pre_norm)
+            if fused is not None:
+                return fused
         side = self._router_side_linear(hidden_states, pre_norm)
         if side is not None:
             # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)

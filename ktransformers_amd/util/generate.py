@@ -19,10 +19,11 @@ def _check_ep() -> None:
     if parallel.EP_STATE.get("exchange") is not None:
         parallel.check_exchange_status()
     if torch.cuda.is_available():
-        st = _native.attn_status(torch.device("cuda", torch.cuda.current_device()))
-        if st != 0:
-            raise RuntimeError(f"one-launch attention step: a hand-off inside the launch timed out (status {st:#x}); "
-                               "outputs since the previous check are not valid")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        for what, st in (("attention", _native.attn_status(dev)), ("MoE", _native.moe_layer_status(dev))):
+            if st != 0:
+                raise RuntimeError(f"one-launch {what} step: a hand-off inside the launch timed out (status {st:#x}); "
+                                   "outputs since the previous check are not valid")
 
 
 def set_inference_mode(model: torch.nn.Module, mode: InferenceState) -> None:

@@ -62,6 +62,32 @@ __global__ __launch_bounds__(512) void touch_kernel(const unsigned* hot, unsigne
   if (v == 0x9abcdef0u) sink[1] = v;
 }
 
+// Part 2: latency of ONE load per workgroup from memory nobody has touched for a long time, by what is cold about it:
+//   mode 0  the same line every round                      (everything hot)
+//   mode 1  a new 256-byte line of an often-used 2 MB page (cache miss, translation hot)
+//   mode 2  a new 2 MB page every round                    (cache miss + translation miss)
+//   mode 3  a new 2 MB page, then a second line of it      (second = cache miss with the translation just fetched)
+__global__ __launch_bounds__(64) void cold_kernel(const unsigned* arena, size_t arena_words, unsigned long long* out, int round, int mode,
+                                                  unsigned* sink) {
+  if (threadIdx.x != 0) return;
+  const size_t wg = blockIdx.x, nwg = gridDim.x;
+  size_t off = 0;
+  if (mode == 0) off = wg * 64;
+  else if (mode == 1) off = wg * (4096 / 4) + (size_t)(round % 16) * 64;
+  else off = (((size_t)round * nwg + wg) * ((size_t)2 << 20) / 4 + (wg % 7) * 1024) % (arena_words - (1 << 20));
+  const unsigned* p = arena + off;
+  const unsigned long long t0 = wall_clock64();
+  unsigned v = __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t1 = wall_clock64();
+  v += __hip_atomic_load(p + 4096 + (v & 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // +16 KB: same 2 MB page, other line
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  const unsigned long long t2 = wall_clock64();
+  unsigned long long* o = out + ((size_t)round * nwg + wg) * 4;
+  o[0] = t1 - t0; o[1] = t2 - t1;
+  if (v == 0x9abcdef0u) sink[2] = v;
+}
+
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv) {
@@ -127,6 +153,35 @@ int main(int argc, char** argv) {
     printf("%-40s %10.2f %10.2f %10.2f %10.2f | (%.2f, %.2f)\n", c.name, med(a), med(b), med(d), med(e), as[as.size() * 9 / 10], es[es.size() * 9 / 10]);
     (void)hipGraphExecDestroy(ge);
     (void)hipGraphDestroy(g);
+  }
+  // ---- part 2: cold lines / cold pages (one arena allocation of 1 GiB chunks is contiguous in VA only per chunk: stay inside chunks)
+  printf("\nfirst load of a workgroup from ...                  1st load   2nd line of the same page | us, median (p90)\n");
+  const char* names[3] = {"the same line every round (hot)          ", "a new line of an often-used page         ", "a new 2 MB page every round              "};
+  for (int mode = 0; mode < 3; mode++) {
+    for (int nwg : {256, 16}) {
+      hipGraph_t g;
+      hipGraphExec_t ge;
+      CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+      for (int r = 0; r < N; r++) {
+        const char* base = chunks[(r * 7) % chunks.size()];
+        hipLaunchKernelGGL(cold_kernel, dim3(nwg), dim3(64), 0, st, (const unsigned*)base, ((size_t)1 << 30) / 4, out, r, mode, sink);
+      }
+      CK(hipStreamEndCapture(st, &g));
+      CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+      CK(hipGraphLaunch(ge, st));
+      CK(hipStreamSynchronize(st));
+      std::vector<unsigned long long> h((size_t)N * nwg * 4);
+      CK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
+      std::vector<double> a, b;
+      for (int r = 4; r < N; r++)
+        for (int w = 0; w < nwg; w++) { a.push_back(h[((size_t)r * nwg + w) * 4] * 0.01); b.push_back(h[((size_t)r * nwg + w) * 4 + 1] * 0.01); }
+      std::vector<double> as = a, bs = b;
+      std::sort(as.begin(), as.end());
+      std::sort(bs.begin(), bs.end());
+      printf("%s %3d WGs %8.2f (%5.2f) %8.2f (%5.2f)\n", names[mode], nwg, med(a), as[as.size() * 9 / 10], med(b), bs[bs.size() * 9 / 10]);
+      (void)hipGraphExecDestroy(ge);
+      (void)hipGraphDestroy(g);
+    }
   }
   return 0;
 }
