@@ -64,6 +64,11 @@ int ktx_ep_gather(ktx_ep_t ep, int T, const void* d_x, const int64_t* d_ids, con
                   float* d_wg, ktx_stream_t stream);
 /* part fp32 [R*T,H] (this rank's experts' contribution to every gathered token) -> out bf16 [T,H] for this rank's tokens */
 int ktx_ep_reduce(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stream_t stream);
+/* The same reduce for a sequence WITHOUT gathers (one token stream replicated on every rank: each rank's experts see the same
+ * rows, `bench.py --strong`): the launch owns its call tag (advanced on the device by its last workgroup) and alternates between
+ * two partial regions, so back-to-back calls — also replays of a captured graph — never match granules of an earlier call.
+ * Do not interleave with ktx_ep_gather / ktx_ep_reduce pairs inside one step. */
+int ktx_ep_reduce_only(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stream_t stream);
 
 /* 0 = healthy; otherwise the code of the first poll that gave up (1 = gather, 2 = reduce).  Synchronises `stream`. */
 int ktx_ep_status(ktx_ep_t ep, ktx_stream_t stream, int* status_out);

@@ -167,6 +167,7 @@ def _load() -> C.CDLL:
     lib.ktx_ep_import_ptr.argtypes = [C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_ep_gather.argtypes = [C.c_void_p, C.c_int] + [C.c_void_p] * 7
     lib.ktx_ep_reduce.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+    lib.ktx_ep_reduce_only.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_ep_status.argtypes = [C.c_void_p, C.c_void_p, C.POINTER(C.c_int)]
     lib.ktx_ep_set_spin_seconds.argtypes = [C.c_void_p, C.c_double]
     lib.ktx_profile_enable.argtypes = [C.c_int]
@@ -574,8 +575,9 @@ class EpExchange:
                                 wg.data_ptr(), _stream_ptr(self.device)))
         return xg, idsg, wg
 
-    def reduce(self, part: torch.Tensor, out: torch.Tensor | None = None) -> torch.Tensor:
-        """part fp32 [R*T,H] -> bf16 [T,H]: the partials of this rank's tokens added in rank order, rounded once."""
+    def reduce(self, part: torch.Tensor, out: torch.Tensor | None = None, reduce_only: bool = False) -> torch.Tensor:
+        """part fp32 [R*T,H] -> bf16 [T,H]: the partials of this rank's tokens added in rank order, rounded once.
+        reduce_only: this call is not preceded by a gather (replicated token stream): ktx_ep_reduce_only, which owns its call tag."""
         n = part.shape[0]
         if part.dtype != torch.float32 or part.dim() != 2 or part.shape[1] != self.H or n % self.world or not part.is_contiguous():
             raise KtxError(f"EpExchange.reduce: part must be contiguous fp32 [{self.world}*T,{self.H}]")
@@ -584,7 +586,8 @@ class EpExchange:
             out = torch.empty((T, self.H), dtype=torch.bfloat16, device=self.device)
         elif out.dtype != torch.bfloat16 or out.shape != (T, self.H) or not out.is_contiguous():
             raise KtxError("EpExchange.reduce: out must be contiguous bf16 [T,H]")
-        check(lib.ktx_ep_reduce(self._h, T, part.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
+        fn = lib.ktx_ep_reduce_only if reduce_only else lib.ktx_ep_reduce
+        check(fn(self._h, T, part.data_ptr(), out.data_ptr(), _stream_ptr(self.device)))
         return out
 
     def status(self) -> int:

@@ -28,8 +28,10 @@ struct EpDev {
 };
 
 __device__ __forceinline__ size_t g_off(const EpDev& d, int src, int t) { return HDR + ((size_t)src * d.maxT + t) * d.RW; }
-__device__ __forceinline__ size_t p_off(const EpDev& d, int src, int t) {
-  return HDR + (size_t)d.world * d.maxT * d.RW + ((size_t)src * d.maxT + t) * d.H;
+// two partial regions: the gather + reduce pair always uses region 0 (the gather between two reduces orders the ranks); a
+// reduce-ONLY sequence (ktx_ep_reduce_only) alternates between them by the parity of its call tag
+__device__ __forceinline__ size_t p_off(const EpDev& d, int src, int t, int region = 0) {
+  return HDR + (size_t)d.world * d.maxT * d.RW + (((size_t)region * d.world + src) * d.maxT + t) * d.H;
 }
 __device__ __forceinline__ void put(uint64_t* p, uint32_t data, uint32_t tag) {
   __hip_atomic_store(p, (uint64_t)data | ((uint64_t)tag << 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
@@ -92,17 +94,25 @@ __global__ __launch_bounds__(NT) void ep_gather_kernel(EpDev d, int T, const uin
 
 // grid (world * S, T): workgroup (b, t) first sends sub-range b % S of part[row of rank b / S] to that rank, then reduces
 // column slice b of this rank's token t.
+// SELF (ktx_ep_reduce_only: one token stream replicated on every rank, no gather in front): the launch owns its call tag — header
+// word 4, advanced by the LAST workgroup to leave (word 6 counts the leavers), so every workgroup of the launch has read it
+// before it moves — and writes the partial region of the tag's parity: rank A can be at most one call ahead of rank B (it needs
+// B's partials of call n + 1 to finish call n + 1, and B sends those only after it has consumed call n), so two regions suffice.
+// Without this the reduce re-used the tag the last gather left behind and summed whatever granules the previous call had left
+// (ADVICE r3, high).
+template <bool SELF>
 __global__ __launch_bounds__(NT) void ep_reduce_kernel(EpDev d, int T, int S, const float* __restrict__ part,
                                                        bf16_t* __restrict__ out) {
   const int b = blockIdx.x, t = blockIdx.y, tid = threadIdx.x;
   uint32_t* hdr = reinterpret_cast<uint32_t*>(d.base[d.rank]);
-  const uint32_t tag = __hip_atomic_load(&hdr[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (b == 0 && t == 0 && tid == 0) hdr[0] = next_tag(hdr[0]);
+  const uint32_t tag = __hip_atomic_load(&hdr[SELF ? 4 : 1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  const int region = SELF ? (int)(tag & 1u) : 0;
+  if (!SELF && b == 0 && t == 0 && tid == 0) hdr[0] = next_tag(hdr[0]);
   const int p = b / S, s = b % S;
   if (p != d.rank) {
     const int cw = (d.H + S - 1) / S, lo = s * cw, hi = min(d.H, lo + cw);
     const float* srow = part + ((size_t)p * T + t) * d.H;
-    uint64_t* dst = d.base[p] + p_off(d, d.rank, t);
+    uint64_t* dst = d.base[p] + p_off(d, d.rank, t, region);
     for (int c = lo + tid; c < hi; c += NT) put(dst + c, __float_as_uint(srow[c]), tag);
   }
   const int nsl = d.world * S, sw = (d.H + nsl - 1) / nsl, lo = b * sw, hi = min(d.H, lo + sw);
@@ -116,7 +126,7 @@ __global__ __launch_bounds__(NT) void ep_reduce_kernel(EpDev d, int T, int S, co
 #pragma unroll
       for (int r = 0; r < KTX_EP_MAX_WORLD; ++r) {
         if (r < d.world && r != d.rank) {
-          v[r] = peek(rbase + p_off(d, r, t) + c);
+          v[r] = peek(rbase + p_off(d, r, t, region) + c);
           ok &= (uint32_t)(v[r] >> 32) == tag;
         }
       }
@@ -136,6 +146,16 @@ __global__ __launch_bounds__(NT) void ep_reduce_kernel(EpDev d, int T, int S, co
       }
     }
     out[(size_t)t * d.H + c] = f32_to_bf16(acc);
+  }
+  if constexpr (SELF) {
+    __syncthreads();
+    if (tid == 0) {
+      const uint32_t left = __hip_atomic_fetch_add(&hdr[6], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (left == gridDim.x * gridDim.y - 1) {
+        __hip_atomic_store(&hdr[6], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&hdr[4], next_tag(tag), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
   }
 }
 
@@ -174,7 +194,7 @@ int ktx_ep_create(int device, int world, int rank, int max_tokens, int hidden, i
   ktx_ep_s* ep = new ktx_ep_s;
   ep->device = device; ep->world = world; ep->rank = rank; ep->maxT = max_tokens; ep->H = hidden; ep->k = topk;
   ep->RW = hidden / 2 + 3 * topk;
-  ep->bytes = ((size_t)HDR + (size_t)world * max_tokens * ((size_t)ep->RW + hidden)) * sizeof(uint64_t);
+  ep->bytes = ((size_t)HDR + (size_t)world * max_tokens * ((size_t)ep->RW + 2 * (size_t)hidden)) * sizeof(uint64_t);
   void* p = nullptr;
   hipError_t e = memory_kind == 2 ? hipMalloc(&p, ep->bytes)
                                   : hipExtMallocWithFlags(&p, ep->bytes, memory_kind == 0 ? hipDeviceMallocUncached
@@ -183,7 +203,7 @@ int ktx_ep_create(int device, int world, int rank, int max_tokens, int hidden, i
     delete ep;
     return ktx_fail(std::string("ktx_ep_create: allocating the symmetric buffer: ") + hipGetErrorString(e));
   }
-  const uint32_t hdr[3] = {1u, 0u, 0u};   // first gather uses tag 1 and makes the reduce tag 1
+  const uint32_t hdr[8] = {1u, 0u, 0u, 0u, 1u, 0u, 0u, 0u};   // first gather uses tag 1 and makes the reduce tag 1; word 4 = the reduce-only tag
   e = hipMemset(p, 0, ep->bytes);
   if (e == hipSuccess) e = hipMemcpy(p, hdr, sizeof(hdr), hipMemcpyHostToDevice);
   if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -285,7 +305,14 @@ int ktx_ep_gather(ktx_ep_t ep, int T, const void* d_x, const int64_t* d_ids, con
   return 0;
 }
 
+static int ep_reduce_impl(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stream_t stream, bool self);
 int ktx_ep_reduce(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stream_t stream) {
+  return ep_reduce_impl(ep, T, d_part, d_out, stream, false);
+}
+int ktx_ep_reduce_only(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stream_t stream) {
+  return ep_reduce_impl(ep, T, d_part, d_out, stream, true);
+}
+static int ep_reduce_impl(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stream_t stream, bool self) {
   EpDev d;
   if (int rc = ep_dev(ep, T, &d, "ktx_ep_reduce")) return rc;
   KTX_REQUIRE(d_part && d_out, "ktx_ep_reduce: null pointer");
@@ -296,8 +323,9 @@ int ktx_ep_reduce(ktx_ep_t ep, int T, const float* d_part, void* d_out, ktx_stre
   // column slices of about 512 (two columns per thread), a whole number of them per rank
   const int S = std::max(1, (ep->H + 512 * ep->world - 1) / (512 * ep->world));
   KTX_REQUIRE((long)ep->world * S * T <= 1024, "ktx_ep_reduce: grid exceeds the co-residency the put-then-spin exchange assumes");
-  KTX_TIMED(st, (double)ep->world * T * ep->H * 8.0, "ep_reduce_kernel R=%d T=%d H=%d", ep->world, T, ep->H);
-  hipLaunchKernelGGL(ep_reduce_kernel, dim3(ep->world * S, T), dim3(NT), 0, st, d, T, S, d_part, (bf16_t*)d_out);
+  KTX_TIMED(st, (double)ep->world * T * ep->H * 8.0, "ep_reduce_kernel R=%d T=%d H=%d%s", ep->world, T, ep->H, self ? " (reduce only)" : "");
+  if (self) hipLaunchKernelGGL(ep_reduce_kernel<true>, dim3(ep->world * S, T), dim3(NT), 0, st, d, T, S, d_part, (bf16_t*)d_out);
+  else hipLaunchKernelGGL(ep_reduce_kernel<false>, dim3(ep->world * S, T), dim3(NT), 0, st, d, T, S, d_part, (bf16_t*)d_out);
   KTX_HIP(hipGetLastError());
   return 0;
 }

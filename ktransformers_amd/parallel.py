@@ -154,8 +154,10 @@ def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch
     if EP_STATE["replicated_input"]:
         part = local_partial(x.contiguous(), ids.contiguous(), w.contiguous())       # fp32 [T, H]: this rank's experts only
         if exchange is not None:
-            # the reduce launch hands row block r of `part` to rank r: every rank's block is the same T rows here
-            return exchange.reduce(part.repeat(exchange.world, 1))
+            # the reduce launch hands row block r of `part` to rank r: every rank's block is the same T rows here.  No gather runs
+            # in this mode, so the launch must own its call tag (ktx_ep_reduce_only): with the plain reduce every call would
+            # re-use the tag the set-up check left behind and could add a previous call's granules
+            return exchange.reduce(part.repeat(exchange.world, 1), reduce_only=True)
         # rank-ordered sum on every rank (all_reduce's ring order differs between ranks at fp32 rounding level, which would let
         # the replicas drift apart): gather the R partials and add them left to right
         world = dist.get_world_size(group)

@@ -81,6 +81,32 @@ def main():
                 raw_ok.append(bool(torch.equal(xg.view(torch.int16), torch.cat(x).view(torch.int16)) and torch.equal(ig, torch.cat(i))
                                    and torch.equal(wg, torch.cat(w))
                                    and torch.equal(out.view(torch.int16), acc.to(torch.bfloat16).view(torch.int16))))
+            # reduce-ONLY sequences (the replicated-stream mode: no gather between the calls), eager and as replays of ONE captured
+            # launch: every call must add THIS call's partials — a stale granule of the previous call has the right shape and
+            # the wrong numbers, so changing data tells
+            ro_ok = []
+            sp = torch.zeros(world * Tr, Hr, dtype=torch.float32, device=dev)
+            so = torch.zeros(Tr, Hr, dtype=torch.bfloat16, device=dev)
+            exr.reduce(sp, out=so, reduce_only=True)          # (warm-up outside the capture)
+            torch.cuda.synchronize()
+            dist.barrier()
+            gro = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gro):
+                exr.reduce(sp, out=so, reduce_only=True)
+            for rnd in range(6):
+                part = [torch.randn(world * Tr, Hr, generator=g).to(dev) for _ in range(world)]
+                acc = part[0][rank * Tr:(rank + 1) * Tr]
+                for q in range(1, world):
+                    acc = acc + part[q][rank * Tr:(rank + 1) * Tr]
+                if rnd % 2 == 0:
+                    out = exr.reduce(part[rank], reduce_only=True)
+                else:
+                    sp.copy_(part[rank])
+                    gro.replay()
+                    out = so
+                torch.cuda.synchronize()
+                ro_ok.append(bool(torch.equal(out.view(torch.int16), acc.to(torch.bfloat16).view(torch.int16))))
+            raw_ok.extend(ro_ok)
             raw_ok.append(exr.status() == 0)
             dist.barrier()
             keep.append(exr)     # stays mapped until the process ends: no free / re-allocate / re-map cycle of shared memory
