@@ -724,10 +724,46 @@ def host_numa_nodes():
     return max(n, 1)
 
 
-def cpu_baseline(wl, budget_s=20.0):
-    """The reference's own AVX512 MoE kernels (oracle/_ref) on this box's host cores, same expert shape, bs=1 decode.
-    Bounded sample: 3 distinct layers' weights (>> the host's L3), forward rotating over them for ~budget_s.  The expert
-    COUNT is cut to 32 per layer to bound host memory and set-up time: a bs=1 forward touches k experts whatever E is."""
+def host_cpu_info():
+    """What the CPU leg ran on: logical CPUs this process may use, sockets, hardware threads per core, model name."""
+    info = {"logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)}
+    try:
+        sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
+        n = 0
+        for part in sib.split(","):
+            a, _, b = part.partition("-")
+            n += (int(b) - int(a) + 1) if b else 1
+        info["threads_per_core"] = max(n, 1)
+    except (OSError, ValueError):
+        info["threads_per_core"] = 1
+    try:
+        pk = set()
+        for d in os.listdir("/sys/devices/system/cpu"):
+            if d.startswith("cpu") and d[3:].isdigit():
+                try:
+                    pk.add(open(f"/sys/devices/system/cpu/{d}/topology/physical_package_id").read().strip())
+                except OSError:
+                    pass
+        info["sockets"] = max(len(pk), 1)
+    except OSError:
+        info["sockets"] = 1
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                info["model"] = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return info
+
+
+def cpu_baseline(wl, budget_s=16.0, prefill_budget_s=8.0):
+    """The reference's own AVX512 MoE kernels (oracle/_ref) on this box's host cores, same expert shape: a bs=1 decode leg and a
+    prompt leg.  Threads: ONE per physical core the process may use, pinned by the reference's own worker pool (its hwloc calls are
+    served from sysfs by oracle/shim/hwloc.h), one sub-pool per NUMA node — the placement kt-kernel/README.md asks for.
+    Bounded sample: 3 distinct layers' weights (>> the host's L3), forwards rotating over them.  The expert COUNT is cut to 32 per
+    layer to bound host memory and set-up time: a bs=1 forward touches k experts whatever E is, and the prompt leg keeps the
+    per-expert GEMM shape of the real chunk (see `prefill.sample`)."""
     import numpy as np
 
     try:
@@ -740,16 +776,16 @@ def cpu_baseline(wl, budget_s=20.0):
     H, I, k = wl["H"], wl["I"], wl["k"]
     E = min(wl["E"], 32)
     Lm = wl["full_layers"] - wl["dense"]
-    ncpu = os.cpu_count() or 8
-    threads = max(1, min(64, ncpu // 2))  # reference guidance: physical cores only
-    # the reference's NUMA tensor parallelism (one sub-pool per NUMA node, the intermediate dimension split across them):
-    # sub-pools = the host's NUMA nodes that hold CPUs.  The oracle build links the image's libnuma (the reference's own
-    # numa_run_on_node / set_mempolicy calls place each sub-pool); its hwloc core pinning is a no-op shim (no hwloc here).
+    host = host_cpu_info()
     numa_nodes = host_numa_nodes()
-    subpools = numa_nodes if (numa_nodes > 1 and threads % numa_nodes == 0 and I % (numa_nodes * 32) == 0) else 1
+    threads = max(1, host["logical_cpus"] // host["threads_per_core"])      # physical cores (reference guidance)
+    subpools = numa_nodes if (numa_nodes > 1 and I % (numa_nodes * 32) == 0) else 1
+    threads -= threads % subpools
+    threads = max(threads, subpools)
     ref = Reference(threads=threads // subpools, subpools=subpools)
     rng = np.random.default_rng(0)
     nlayers = 3
+    T_PRE = 256
     moes = []
     t_load = time.perf_counter()
     # one block of randn/10 bf16 values, re-used with cheap permutations so that every matrix of every layer is
@@ -759,27 +795,55 @@ def cpu_baseline(wl, budget_s=20.0):
         gate = np.roll(base, li + 1, axis=0)
         up = np.ascontiguousarray(base[::-1]) if li % 2 == 0 else np.roll(base, -(li + 2), axis=0)
         down = np.roll(base, li + 3, axis=0).reshape(E, H, I)
-        moes.append(ref.make_moe(FMT_AMXINT4, gate, up, down, k=k, max_len=32))
+        moes.append(ref.make_moe(FMT_AMXINT4, gate, up, down, k=k, max_len=T_PRE))
     t_load = time.perf_counter() - t_load
     x = f32_to_bf16((rng.standard_normal((1, H), dtype=np.float32) / 100))
     sets = [(np.stack([rng.permutation(E)[:k]]).astype(np.int64), rng.random((1, k), dtype=np.float32)) for _ in range(64)]
     for i in range(30):
         ref.moe_forward(moes[i % nlayers], sets[i % 64][0], sets[i % 64][1], x)
     n, t0 = 0, time.perf_counter()
-    while time.perf_counter() - t0 < budget_s and n < 20000:
+    while time.perf_counter() - t0 < budget_s and n < 40000:
         for _ in range(25):
             ref.moe_forward(moes[n % nlayers], sets[n % 64][0], sets[n % 64][1], x)
             n += 1
     dt = time.perf_counter() - t0
     t_layer = dt / n
-    return {"value": round(1.0 / (Lm * t_layer), 3), "unit": "tok/s", "cores": threads, "kind": "reference", "numa_nodes": numa_nodes,
-            "subpools": subpools,
-            "us_per_layer": round(t_layer * 1e6, 1), "covers": "routed experts only (the part the reference runs on the CPU)",
-            "sample": f"{n} bs=1 forwards of TP_MOE<AMX_MOE_TP<GemmKernel224Int4>> (AVX512-VNNI path, no AMX on this host), "
-                      f"H={H} I={I} k={k}, rotating over {nlayers} distinct layers of {E} experts, {threads} threads in {subpools} sub-pool(s) "
-                      f"(host NUMA nodes with CPUs: {numa_nodes}; sub-pools placed by the reference's libnuma calls, hwloc core pinning shimmed out); "
-                      f"tok/s = 1/({Lm} MoE layers x t_layer) = the routed experts of the full-depth model alone; "
-                      f"weight quant took {t_load:.1f}s (untimed)"}
+    layer_bytes = k * (3 * H * I * 0.5 + (2 * I + H) * 4)                     # int4 weights + per-row fp32 scales of the k experts
+    out = {"value": round(1.0 / (Lm * t_layer), 3), "unit": "tok/s", "cores": threads, "kind": "reference", "numa_nodes": numa_nodes,
+           "subpools": subpools, "host": host, "pinned": "one worker per physical core, bound by the reference's worker pool (sysfs-backed hwloc shim)",
+           "us_per_layer": round(t_layer * 1e6, 1), "GBs": round(layer_bytes / t_layer / 1e9, 1),
+           "covers": "routed experts only (the part the reference runs on the CPU)",
+           "sample": f"{n} bs=1 forwards of TP_MOE<AMX_MOE_TP<GemmKernel224Int4>> (AVX512-VNNI path, no AMX on this host), "
+                     f"H={H} I={I} k={k}, rotating over {nlayers} distinct layers of {E} experts, {threads} threads in {subpools} sub-pool(s) "
+                     f"(host NUMA nodes with CPUs: {numa_nodes}; sub-pools placed by the reference's libnuma calls, workers pinned to cores); "
+                     f"tok/s = 1/({Lm} MoE layers x t_layer) = the routed experts of the full-depth model alone; "
+                     f"weight quant took {t_load:.1f}s (untimed)"}
+    # ---- prompt leg (kt-kernel/bench/bench_moe_amx.py's loop at qlen > 1; forward_prefill, operators/amx/moe_base.hpp:208-436):
+    # T_PRE tokens over the sample's 32 experts = T_PRE * k / 32 rows per expert, the per-expert GEMM of a 2048-token chunk over
+    # the model's 256 experts; the chunk's layer time is the sample's times (E_model / 32).
+    try:
+        rows_per_expert = T_PRE * k // E
+        chunk = rows_per_expert * wl["E"] // k                                     # tokens of the chunk this sample stands for
+        xp = f32_to_bf16((rng.standard_normal((T_PRE, H), dtype=np.float32) / 100))
+        idp = np.stack([rng.permutation(E)[:k] for _ in range(T_PRE)]).astype(np.int64)
+        wp = rng.random((T_PRE, k), dtype=np.float32)
+        for i in range(2):
+            ref.moe_forward(moes[i % nlayers], idp, wp, xp)
+        m, t0 = 0, time.perf_counter()
+        while time.perf_counter() - t0 < prefill_budget_s and m < 2000:
+            ref.moe_forward(moes[m % nlayers], idp, wp, xp)
+            m += 1
+        tp = (time.perf_counter() - t0) / m
+        t_chunk_layer = tp * (wl["E"] / E)
+        flop = 2.0 * 3 * H * I * T_PRE * k
+        out["prefill"] = {"value": round(chunk / (Lm * t_chunk_layer), 2), "unit": "tok/s", "chunk_tokens": chunk,
+                          "ms_per_layer_chunk": round(t_chunk_layer * 1e3, 2), "int8_TOPs": round(flop / tp / 1e12, 2),
+                          "covers": "routed experts only",
+                          "sample": f"{m} forwards of {T_PRE} tokens over {E} experts ({rows_per_expert} rows per expert = a {chunk}-token chunk over "
+                                    f"{wl['E']} experts; layer time = sample x {wl['E'] // E}); tok/s = {chunk} / ({Lm} MoE layers x layer time)"}
+    except Exception as e:   # the decode leg stands without it
+        out["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:200]}
+    return out
 
 
 def cpu_baseline_subprocess(workload, timeout_s=300):
@@ -850,7 +914,44 @@ def box_info():
     return out
 
 
-def whole_model_prefill(mr, T, dev, reps=3):
+MFMA_PEAK_BF16, MFMA_PEAK_I8 = 2.5e15, 5.0e15      # dense peaks, MI355X_MICROARCH.md (never the 2:1-sparsity figures)
+
+
+def prefill_roofline(cfg, n_layers, T, wl, dt):
+    """Which roof bounds ONE T-token prompt chunk through the model as built, and how close the chunk came (the
+    grouped expert GEMM is HBM-bound below ~150 rows per expert — every touched expert's weights are read once — and MFMA-bound
+    beyond).  flops: every linear 2 T N K, the routed experts 2 * 3 H I k T per MoE layer, causal attention over qk 192 / v 128;
+    bytes: every weight of the resident layers once (all experts once T k >= 4 E) + the embedding rows."""
+    H, I, Im, E, k = cfg.hidden_size, cfg.intermediate_size, cfg.moe_intermediate_size, cfg.n_routed_experts, cfg.num_experts_per_tok
+    Hq, nope, rope, v, lora = cfg.num_attention_heads, cfg.qk_nope_head_dim, cfg.qk_rope_head_dim, cfg.v_head_dim, cfg.kv_lora_rank
+    wlin = LINEAR_BPW[wl.get("linear", "W4")]
+    q_params = (H * cfg.q_lora_rank + cfg.q_lora_rank * Hq * (nope + rope)) if cfg.q_lora_rank else H * Hq * (nope + rope)
+    attn_params = q_params + H * (lora + rope) + Hq * v * H + Hq * (nope + v) * lora            # + kv_b expansion of the chunk
+    n_dense = min(cfg.first_k_dense_replace, n_layers)
+    n_moe = n_layers - n_dense
+    shared_params = (cfg.n_shared_experts or 0) * 3 * H * Im
+    lin_flop = 2.0 * T * (n_layers * attn_params + n_dense * 3 * H * I + n_moe * (shared_params + E * H))
+    attn_flop = n_layers * 2.0 * Hq * (nope + rope + v) * T * (T + 1) / 2
+    exp_flop = n_moe * 2.0 * 3 * H * Im * k * T
+    gu, dn = expert_bpw(wl)
+    touched = E if T * k >= 4 * E else min(E, T * k)
+    nbytes = (n_layers * (attn_params - Hq * (nope + v) * lora) * wlin + n_layers * Hq * (nope + v) * lora * 2 + n_dense * 3 * H * I * wlin
+              + n_moe * (touched * (2 * H * Im * gu + H * Im * dn) + shared_params * wlin + E * H * 2) + T * H * 2)
+    int_experts = wl["method"] in ("AMXINT4", "AMXINT8", "RAWINT4", "GGUF")            # int8 MFMA paths; FP8 / BF16 experts multiply in bf16
+    t_mfma = (lin_flop + attn_flop) / MFMA_PEAK_BF16 + exp_flop / (MFMA_PEAK_I8 if int_experts else MFMA_PEAK_BF16)
+    t_hbm = nbytes / (HBM_PEAK_GBS * 1e9)
+    hbm = t_hbm >= t_mfma
+    flop = lin_flop + attn_flop + exp_flop
+    return {"bound": "hbm" if hbm else "mfma", "achieved": round(nbytes / dt / 1e9, 1) if hbm else round(flop / dt / 1e12, 1),
+            "peak": HBM_PEAK_GBS if hbm else round((flop / t_mfma) / 1e12, 1), "unit": "GB/s" if hbm else "TFLOP/s",
+            "frac": round(max(t_hbm, t_mfma) / dt, 4), "algorithmic_bytes": int(nbytes), "flop": int(flop),
+            "rows_per_expert": round(T * k / max(E, 1), 1) if n_moe else None,
+            "ms_at_hbm_roof": round(t_hbm * 1e3, 3), "ms_at_mfma_roof": round(t_mfma * 1e3, 3),
+            "note": "frac = the larger of the two roof times / the measured chunk time; the MFMA peak is the flop-weighted mix of the "
+                    "dense bf16 (2.5 PFLOP/s) and int8 (5 POP/s) peaks of the chunk's GEMMs"}
+
+
+def whole_model_prefill(mr, T, dev, reps=3, per_kernel_pass=True):
     """One T-token prompt chunk through the resident model's prefill path (every operator's T>1 kernels)."""
     from ktransformers_amd.util.generate import set_inference_mode
     from ktransformers_amd.util.utils import InferenceState
@@ -874,6 +975,8 @@ def whole_model_prefill(mr, T, dev, reps=3):
     from ktransformers_amd import _native
     per_kernel, lib_ms = [], None
     try:
+        if not per_kernel_pass:
+            raise StopIteration
         _native.timing_enable(1)
         with torch.no_grad():
             mr.cache.past_tokens = [0] * mr.cfg.num_hidden_layers
@@ -888,6 +991,8 @@ def whole_model_prefill(mr, T, dev, reps=3):
         lib_ms = tot / 1e3
         per_kernel = [{"kernel": k2, "launches": v[0], "total_ms": round(v[1] / 1e3, 3), "share": round(v[1] / tot, 4)}
                       for k2, v in sorted(agg.items(), key=lambda kv: -kv[1][1])][:12]
+    except StopIteration:
+        pass
     finally:
         _native.timing_enable(0)
     set_inference_mode(mr.model, InferenceState.GENERATE)
@@ -896,7 +1001,8 @@ def whole_model_prefill(mr, T, dev, reps=3):
     n_moe = cfg.num_hidden_layers - min(cfg.first_k_dense_replace, cfg.num_hidden_layers)
     moe_flop = 2 * 3 * cfg.hidden_size * cfg.moe_intermediate_size * cfg.num_experts_per_tok * T * n_moe
     return {"value": round(T / dt, 1), "unit": "tok/s", "tokens": T, "ms_per_chunk": round(dt * 1e3, 3),
-            "layers": cfg.num_hidden_layers, "routed_expert_TOPs_share": round(moe_flop / dt / 1e12, 1), "per_kernel": per_kernel,
+            "layers": cfg.num_hidden_layers, "roofline": prefill_roofline(cfg, cfg.num_hidden_layers, T, mr.wl, dt),
+            "routed_expert_TOPs_share": round(moe_flop / dt / 1e12, 1), "per_kernel": per_kernel,
             # every launch of libktx_hip.so is event-bracketed in that extra pass; the rest of the chunk is torch glue
             # (elementwise adds, the GLU row permutation, copies, index ops) and launch gaps — no vendor GEMM is called
             "library_kernel_ms": None if lib_ms is None else round(lib_ms, 3),
@@ -971,6 +1077,43 @@ def run_experts_decode(name, args, dev, steps):
     gc.collect()
     torch.cuda.empty_cache()
     return res
+
+
+def run_experts_prefill(name, dev, T=2048, reps=2):
+    """`kind: experts` workloads: one T-token chunk through the routed experts of every layer (grouped prompt kernels), uniform routing."""
+    wl = WORKLOADS[name]
+    layers = build_layers(wl, dev, max_len=T)
+    g = torch.Generator(device=dev)
+    g.manual_seed(5)
+    x = (torch.randn((T, wl["H"]), generator=g, device=dev) / 10).to(torch.bfloat16)
+    ids = torch.stack([torch.randperm(wl["E"], generator=g, device=dev)[:wl["k"]] for _ in range(T)]).to(torch.int64)
+    w = torch.rand((T, wl["k"]), generator=g, device=dev)
+    y = torch.empty_like(x)
+    times = []
+    for r in range(reps + 1):
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for h in layers:
+            h.forward(x, ids, w, out=y)
+        torch.cuda.synchronize(dev)
+        if r:
+            times.append(time.perf_counter() - t0)
+    dt = sum(times) / len(times)
+    gu, dn = expert_bpw(wl)
+    nbytes = wl["L"] * wl["E"] * (2 * wl["H"] * wl["I"] * gu + wl["H"] * wl["I"] * dn)
+    flop = wl["L"] * 2.0 * 3 * wl["H"] * wl["I"] * wl["k"] * T
+    t_hbm, t_mfma = nbytes / (HBM_PEAK_GBS * 1e9), flop / MFMA_PEAK_I8
+    hbm = t_hbm >= t_mfma
+    for h in layers:
+        h.close()
+    del layers
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"value": round(T / dt, 1), "unit": "tok/s (routed experts of all layers only)", "tokens": T, "ms_per_chunk": round(dt * 1e3, 3),
+            "layers": wl["L"],
+            "roofline": {"bound": "hbm" if hbm else "mfma", "achieved": round(nbytes / dt / 1e9, 1) if hbm else round(flop / dt / 1e12, 1),
+                         "peak": HBM_PEAK_GBS if hbm else MFMA_PEAK_I8 / 1e12, "unit": "GB/s" if hbm else "TOP/s",
+                         "frac": round(max(t_hbm, t_mfma) / dt, 4), "rows_per_expert": round(T * wl["k"] / wl["E"], 1)}}
 
 
 def llamafile_cpu_leg(wl, budget_s=10.0):
@@ -1244,6 +1387,9 @@ def main():
             t_sec = time.perf_counter()
             out["cpu_baseline"] = cpu_baseline_subprocess(args.workload)
             lap("cpu_baseline", t_sec)
+            if isinstance(out.get("prefill"), dict) and isinstance(out["cpu_baseline"].get("prefill"), dict):
+                out["prefill"]["cpu_baseline"] = dict(out["cpu_baseline"]["prefill"], cores=out["cpu_baseline"].get("cores"),
+                                                      kind=out["cpu_baseline"].get("kind"))
         # ---------------- the other BASELINE.json configurations, as secondary fields -------------------------------------------
         if args.workload == "v3-int4" and not args.no_secondary:
             for name in [x for x in args.secondary.split(",") if x]:
@@ -1258,10 +1404,22 @@ def main():
                     n2 = max(30, min(args.steps, 100))
                     if w2.get("kind") == "experts":
                         r2 = run_experts_decode(name, args, dev, n2)
+                        if not args.no_prefill:
+                            try:
+                                r2["prefill"] = run_experts_prefill(name, dev, args.prefill_tokens)
+                            except Exception as e:
+                                r2["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                                torch.cuda.synchronize(dev)
                         if not args.no_cpu_baseline:
                             r2["cpu_llamafile"] = llamafile_cpu_leg(w2)
                     else:
                         r2, m2 = run_model_decode(name, args, dev, n2, 10)
+                        if not args.no_prefill:
+                            try:   # the same resident model, one prompt chunk (no per-launch pass: the headline workload carries that table)
+                                r2["prefill"] = whole_model_prefill(m2, args.prefill_tokens, dev, reps=1, per_kernel_pass=False)
+                            except Exception as e:
+                                r2["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                                torch.cuda.synchronize(dev)
                         m2.close()
                         del m2
                         if name == "r1-iq1s":     # BASELINE.json configs[4] names a 128K context: the same model again at 131072 cached tokens

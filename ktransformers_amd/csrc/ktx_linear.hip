@@ -1365,7 +1365,7 @@ hipError_t gate_granules_for(int dev) {
   if (e == hipSuccess) e = hipMemset(g_gate_granules[dev], 0, nb);
   return e;
 }
-struct LinSlab { char* base; size_t cap, used; int live; int dev; };
+struct LinSlab { char* base; size_t cap, used, last; int live; int dev; };   // last = offset of the most recently carved piece
 std::mutex g_arena_mu;
 std::vector<LinSlab> g_slabs;
 bool arena_on() {
@@ -1373,16 +1373,25 @@ bool arena_on() {
   if (on < 0) { const char* e = getenv("KTX_ARENA"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
+// (1) a slab that cannot be had (less than 1 GiB free on a device full of experts) is retried at exactly the
+// piece's size — a plain hipMalloc would have placed it; (2) freeing the most recently carved piece of a slab gives its bytes
+// back (`used` rewinds), so the re-allocation of a bias or an unload / load cycle of one linear re-uses its space instead of
+// growing the slab until every other piece in it has gone too.
 hipError_t lin_alloc(void** out, size_t bytes, int dev) {
   if (!arena_on()) return hipMalloc(out, bytes);
   const size_t need = (bytes + 4095) & ~(size_t)4095;
   std::lock_guard<std::mutex> lk(g_arena_mu);
   for (auto& s : g_slabs)
-    if (s.dev == dev && s.cap - s.used >= need) { *out = s.base + s.used; s.used += need; s.live++; return hipSuccess; }
+    if (s.dev == dev && s.cap - s.used >= need) { *out = s.base + s.used; s.last = s.used; s.used += need; s.live++; return hipSuccess; }
   static size_t slab_bytes = 0;
   if (!slab_bytes) { const char* e = getenv("KTX_ARENA_MB"); slab_bytes = (size_t)(e ? atol(e) : 1024) << 20; }
-  LinSlab s{nullptr, std::max(need, slab_bytes), need, 1, dev};
-  const hipError_t e = hipMalloc((void**)&s.base, s.cap);
+  LinSlab s{nullptr, std::max(need, slab_bytes), need, 0, 1, dev};
+  hipError_t e = hipMalloc((void**)&s.base, s.cap);
+  if (e != hipSuccess && s.cap > need) {   // not a whole slab's worth of free memory left: a slab of just this piece
+    (void)hipGetLastError();
+    s.cap = need;
+    e = hipMalloc((void**)&s.base, s.cap);
+  }
   if (e != hipSuccess) return e;
   g_slabs.push_back(s);
   *out = s.base;
@@ -1395,6 +1404,7 @@ void lin_free(void* p) {
     for (size_t i = 0; i < g_slabs.size(); i++) {
       LinSlab& s = g_slabs[i];
       if ((char*)p >= s.base && (char*)p < s.base + s.cap) {
+        if ((size_t)((char*)p - s.base) == s.last && s.used > s.last) s.used = s.last;   // the newest piece: its bytes are free again
         if (--s.live == 0) { (void)hipFree(s.base); g_slabs.erase(g_slabs.begin() + i); }
         return;
       }
@@ -2001,6 +2011,7 @@ extern "C" int ktx_linear_forward_fused_gate(ktx_linear_t h, const int32_t* d_bs
     ga.granules = (h->cfg.device >= 0 && h->cfg.device < 64 && T <= KTX_GRAN_T) ? g_gate_granules[h->cfg.device] : nullptr;
     ga.tickets = ga.granules ? reinterpret_cast<int*>(ga.granules + (size_t)KTX_GRAN_T * KTX_GATE_MAX_E) : nullptr;
     if (ktx_debug_get(21) == 1 && ktx_debug_get(19) == 0) ga.granules = nullptr;   // A/B: the round-2 store-ack hand-off in the router
+    ga.wg_select = ktx_debug_get(28) == 1 ? 0 : 1;   // A/B: 1 = the last arriver's eight wavefronts share the selection (round 4)
     const int rc = linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion, nullptr, &ga);
     if (rc != KTX_LIN_NOT_FUSED) return rc;
   }

@@ -5,7 +5,7 @@
  * load this library; the product path (ktransformers_amd/) never does and fails loudly without its HIP
  * extension.
  *
- * Pinning: tests/test_oracle_vs_reference.py drives this file and the reference's own unmodified kernels
+ * Pinning: tests/test_oracle_cpu.py drives this file and the reference's own unmodified kernels
  * (oracle/_ref/libkt_ref.so, built by oracle/Makefile from /root/reference) on the same seeded inputs and
  * requires BIT-EXACT bf16 outputs; tests/golden/ holds vectors generated from the reference build so the
  * same check travels to machines without /root/reference.
