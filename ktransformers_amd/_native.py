@@ -61,7 +61,10 @@ class _AttnDecodeArgs(C.Structure):   # include/ktx_attn.h: ktx_attn_decode_args
                 ("d_position", C.c_void_p), ("d_inv_freq", C.c_void_p), ("mscale", C.c_float),
                 ("d_ckv", C.c_void_p), ("d_k_pe", C.c_void_p), ("ckv_token_stride", C.c_int64), ("kpe_token_stride", C.c_int64),
                 ("page_size", C.c_int32), ("d_kv_indptr", C.c_void_p), ("d_kv_indices", C.c_void_p), ("d_kv_len", C.c_void_p),
-                ("kv_len_hint", C.c_int32), ("sm_scale", C.c_float), ("phases", C.c_int32), ("last", C.c_int32)]
+                ("kv_len_hint", C.c_int32), ("sm_scale", C.c_float), ("phases", C.c_int32), ("last", C.c_int32),
+                ("moe_shared_gate_up", C.c_void_p), ("moe_gate", C.c_void_p), ("d_moe_gate_w", C.c_void_p), ("d_moe_gate_bias", C.c_void_p),
+                ("d_post_norm_w", C.c_void_p), ("post_norm_eps", C.c_float), ("d_xn_out", C.c_void_p), ("d_shared_act_out", C.c_void_p),
+                ("d_topk_idx", C.c_void_p), ("d_topk_w", C.c_void_p)]
 
 
 class _MoeLayerArgs(C.Structure):   # include/ktx_moe.h: ktx_moe_layer_args
@@ -882,7 +885,7 @@ def attn_decode_args(qkv_a: "LinearHandle", q_b: "LinearHandle", qabs: "LinearHa
                      inv_freq: torch.Tensor, mscale: float, num_heads: int, nope: int, rope: int, kv_lora: int, v_dim: int,
                      ckv_pages: torch.Tensor, kpe_pages: torch.Tensor, page_size: int, kv_indptr: torch.Tensor,
                      kv_indices: torch.Tensor | None, kv_len: torch.Tensor, kv_len_hint: int, sm_scale: float,
-                     phases: int = ATTN_PHASE_ALL, last: bool = True) -> _AttnDecodeArgs:
+                     phases: int = ATTN_PHASE_ALL, last: bool = True, moe_front: dict | None = None) -> _AttnDecodeArgs:
     """Arguments of the one-launch MLA decode step (include/ktx_attn.h).  x / out: bf16 [hidden] rows; the norm tuples are
     (bf16 weight, eps); position int64 [1]; kv_len int32 [1] = context length including the new token; the cache views as in
     MLAWrapper.run.  The caller keeps every tensor alive until the launch is enqueued."""
@@ -896,12 +899,32 @@ def attn_decode_args(qkv_a: "LinearHandle", q_b: "LinearHandle", qabs: "LinearHa
     ckv_ts, kpe_ts = ckv_pages.stride(-2), kpe_pages.stride(-2)
     if ckv_pages.stride(0) != ckv_ts * page_size or kpe_pages.stride(0) != kpe_ts * page_size:
         raise KtxError("attn_decode: pages must be contiguous runs of page_size tokens")
-    return _AttnDecodeArgs(qkv_a._h, q_b._h, qabs._h, oabs._h, o_proj._h, num_heads, nope, rope, kv_lora, v_dim, q_b.K, x.numel(),
-                           x.data_ptr(), out.data_ptr(), in_norm[0].data_ptr(), float(in_norm[1]), qa_norm[0].data_ptr(),
-                           float(qa_norm[1]), kv_norm[0].data_ptr(), float(kv_norm[1]), position.data_ptr(), inv_freq.data_ptr(),
-                           float(mscale), ckv_pages.data_ptr(), kpe_pages.data_ptr(), ckv_ts, kpe_ts, page_size, kv_indptr.data_ptr(),
-                           kv_indices.data_ptr() if kv_indices is not None else None, kv_len.data_ptr(), int(kv_len_hint),
-                           float(sm_scale), int(phases), 1 if last else 0)
+    a = _AttnDecodeArgs(qkv_a._h, q_b._h, qabs._h, oabs._h, o_proj._h, num_heads, nope, rope, kv_lora, v_dim, q_b.K, x.numel(),
+                        x.data_ptr(), out.data_ptr(), in_norm[0].data_ptr(), float(in_norm[1]), qa_norm[0].data_ptr(),
+                        float(qa_norm[1]), kv_norm[0].data_ptr(), float(kv_norm[1]), position.data_ptr(), inv_freq.data_ptr(),
+                        float(mscale), ckv_pages.data_ptr(), kpe_pages.data_ptr(), ckv_ts, kpe_ts, page_size, kv_indptr.data_ptr(),
+                        kv_indices.data_ptr() if kv_indices is not None else None, kv_len.data_ptr(), int(kv_len_hint),
+                        float(sm_scale), int(phases), 1 if last else 0)
+    if moe_front is not None:
+        # the MoE block's front rides in this launch (KTX_ATTN_PHASE_MOE_FRONT): shared gate|up LinearHandle, GateHandle, router weight
+        # bf16 [E, hidden] (+ fp32 bias), post_attention_layernorm (weight bf16, eps), and the four output tensors
+        f = moe_front
+        for t, what in ((f["gate_weight"], "router weight"), (f["norm"][0], "post-attention norm"), (f["xn"], "xn"), (f["shared_act"], "shared_act")):
+            if t.dtype != torch.bfloat16 or not t.is_contiguous():
+                raise KtxError(f"attn_decode: MoE front: {what} must be contiguous bf16")
+        if f["topk_idx"].dtype != torch.int64 or f["topk_w"].dtype != torch.float32:
+            raise KtxError("attn_decode: MoE front: topk_idx int64, topk_w fp32")
+        b = f.get("gate_bias")
+        if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
+            raise KtxError("attn_decode: MoE front: the router bias must be contiguous fp32")
+        a.moe_shared_gate_up = f["shared_gate_up"]._h
+        a.moe_gate = C.cast(C.pointer(f["gate"].cfg), C.c_void_p)
+        a.d_moe_gate_w, a.d_moe_gate_bias = f["gate_weight"].data_ptr(), (b.data_ptr() if b is not None else None)
+        a.d_post_norm_w, a.post_norm_eps = f["norm"][0].data_ptr(), float(f["norm"][1])
+        a.d_xn_out, a.d_shared_act_out = f["xn"].data_ptr(), f["shared_act"].data_ptr()
+        a.d_topk_idx, a.d_topk_w = f["topk_idx"].data_ptr(), f["topk_w"].data_ptr()
+        a.phases = int(phases) | 32
+    return a
 
 
 def attn_decode_eligible(args: _AttnDecodeArgs) -> bool:

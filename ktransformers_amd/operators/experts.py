@@ -319,11 +319,43 @@ class _KMoEBlock(BaseInjectedModule):
     def moe_kexperts(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weight: torch.Tensor) -> torch.Tensor:
         return self.experts(x, topk_ids, topk_weight)
 
-    def forward(self, hidden_states, residual=None, pre_norm=None):
+    def forward(self, hidden_states, residual=None, pre_norm=None, front=None):
         """Fusion hooks of the decoder-layer glue: `residual` -> returns residual + mlp(hidden_states), the two adds riding
         in the shared experts' down_proj epilogue; `pre_norm` (the layer's post_attention_layernorm module) ->
-        hidden_states is the un-normalised residual stream and the norm runs inside the router launch."""
-        return self._forward(hidden_states, residual, pre_norm)
+        hidden_states is the un-normalised residual stream and the norm runs inside the router launch; `front` (a request from
+        front_request() that the attention's one-launch decode step has fulfilled): router and shared gate|up are done already."""
+        return self._forward(hidden_states, residual, pre_norm, front)
+
+    def front_request(self, hidden_states, pre_norm):
+        """What the attention operator's one-launch decode step needs to run THIS block's front (post-attention norm, router, shared
+        experts' gate|up) inside its launch (include/ktx_attn.h, KTX_ATTN_PHASE_MOE_FRONT), or None when the block does not have the
+        covered shape.  The outputs are allocated here; `done` is set by the attention operator when its launch carried the front."""
+        # OPT-IN (KTX_MOE_FRONT_FUSED=1): inside the whole-model graph the attention launch with this sixth phase measured 4.03 against
+        # 3.82 ms per step on a fast box and 4.89 against 4.87 on a slow one (profiles/r04_f_ab_moe_front.txt): the stand-alone launch
+        # overlaps the router's chain with the shared GEMV on different CUs, the phase runs them one after the other behind a hand-off
+        if not os.environ.get("KTX_MOE_FRONT_FUSED") or os.environ.get("KTX_MOE_FRONT_SEPARATE") or hidden_states.numel() != hidden_states.shape[-1]:
+            return None
+        side = self._router_side_linear(hidden_states, pre_norm)
+        if side is None or getattr(self.config, "n_routed_experts", 0) != 256 or side.K != 7168 or side.N != 4096:
+            return None
+        gate = self.gate
+        w = gate.orig_module.weight
+        if not w.is_contiguous():
+            return None
+        bias = getattr(gate.orig_module, "e_score_correction_bias", None)
+        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
+            cached = getattr(self, "_fused_bias", None)
+            if cached is None or cached[0] is not bias:
+                cached = (bias, bias.detach().to(torch.float32).contiguous())
+                object.__setattr__(self, "_fused_bias", cached)
+            bias = cached[1]
+        dev, H, k = hidden_states.device, hidden_states.shape[-1], gate._handle().k
+        nw = pre_norm.weight if pre_norm.weight.dtype == torch.bfloat16 else pre_norm.weight.to(torch.bfloat16)
+        return {"shared_gate_up": side, "gate": gate._handle(), "gate_weight": w, "gate_bias": bias, "norm": (nw, pre_norm.variance_epsilon),
+                "xn": torch.empty((1, H), dtype=torch.bfloat16, device=dev),
+                "shared_act": torch.empty((1, side.N // 2), dtype=torch.bfloat16, device=dev),
+                "topk_idx": torch.empty((1, k), dtype=torch.int64, device=dev), "topk_w": torch.empty((1, k), dtype=torch.float32, device=dev),
+                "done": False}
 
     def _finish(self, y, identity, residual, orig_shape, shared_act=None):
         shared = getattr(self.config, "n_shared_experts", None) is not None
@@ -384,16 +416,22 @@ class _KMoEBlock(BaseInjectedModule):
         N.moe_layer_decode(args, hidden_states.device)
         return out
 
-    def _forward(self, hidden_states, residual=None, pre_norm=None):
+    def _forward(self, hidden_states, residual=None, pre_norm=None, front=None):
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
         shared_act = None
-        if sequence_length == 1 and orig_shape[0] == 1:
-            fused = self._fused_decode(hidden_states, residual, pre_norm)
-            if fused is not None:
-                return fused
-        side = self._router_side_linear(hidden_states, pre_norm)
-        if side is not None:
+        if front is not None and front.get("done"):
+            # the attention's launch ran the norm, the router and the shared experts' gate|up on this very row
+            topk_idx, topk_weight, shared_act = front["topk_idx"], front["topk_w"], front["shared_act"]
+            hidden_states = front["xn"].view(*orig_shape)
+            side = None
+        elif sequence_length == 1 and orig_shape[0] == 1 and (fused := self._fused_decode(hidden_states, residual, pre_norm)) is not None:
+            return fused
+        else:
+            side = self._router_side_linear(hidden_states, pre_norm)
+        if front is not None and front.get("done"):
+            pass
+        elif side is not None:
             # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)
             topk_idx, topk_weight, xn, shared_act = self.gate.forward_with_linear(
                 hidden_states, (pre_norm.weight, pre_norm.variance_epsilon), side)

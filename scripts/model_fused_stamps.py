@@ -35,6 +35,9 @@ print("attention launch of the last layer, workgroup 0 (us from entry):")
 for i, nme in enumerate(an):
     if ta[i]:
         print(f"  {nme:24s} {(ta[i] - ta[0]) * 0.01:7.2f}")
+for i, nme in ((28, "F: output row polled"), (29, "F done")):
+    if ta[i]:
+        print(f"  {nme:24s} {(ta[i] - ta[0]) * 0.01:7.2f}")
 mn = ["entry", "row normalised", "F: logit / slice done", "F: shared strip published", "selection done", "G done", "H: activations polled", "H done"]
 if tm[0]:
     print("MoE launch of the last layer, workgroup 0 (us from entry):")

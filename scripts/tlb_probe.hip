@@ -88,6 +88,40 @@ __global__ __launch_bounds__(64) void cold_kernel(const unsigned* arena, size_t 
   if (v == 0x9abcdef0u) sink[2] = v;
 }
 
+// Part 3: the in-model situation the two parts above do not reproduce — a small DEPENDENT load issued while the same kernel's bulk
+// weight requests are in flight chip-wide.  Wavefronts 0..6 of every workgroup request `bulk_kb` KiB of never-touched memory (nt),
+// wavefront 7 (no bulk of its own: a wavefront's replies come back in order) times one load of
+//   kind 0  a line another workgroup (another XCD) wrote with a plain store in the PREVIOUS kernel   (an activation row)
+//   kind 1  a read-only line every workgroup reads in every kernel                                   (norm weights)
+// and then a returning device-scope atomic on a word of its own (a ticket).
+__global__ __launch_bounds__(512) void mix_kernel(const u4v* __restrict__ bulk, size_t bulk_stride16, int bulk_loads, unsigned* hot,
+                                                  unsigned long long* out, int round, unsigned* sink) {
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  unsigned acc = 0;
+  if (wave < 7) {
+    const u4v* p = bulk + (size_t)blockIdx.x * bulk_stride16 + (size_t)wave * 64 * bulk_loads + lane;
+    for (int i = 0; i < bulk_loads; i++) { const u4v v = __builtin_nontemporal_load(p + (size_t)i * 64); acc += v.x ^ v.w; }
+  } else if (lane == 0) {
+    unsigned* h2 = hot + ((size_t)6 << 20) / 4;                       // peer-written lines
+    unsigned* tick = hot + ((size_t)7 << 20) / 4 + blockIdx.x * 64;   // this workgroup's ticket word
+    const unsigned long long t0 = wall_clock64();
+    unsigned v = *(volatile const unsigned*)(h2 + (size_t)((blockIdx.x + 1) % gridDim.x) * 64);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t1 = wall_clock64();
+    v += *(volatile const unsigned*)(hot + (size_t)(blockIdx.x & 15) * 64 + (v & 1));
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t2 = wall_clock64();
+    v += __hip_atomic_fetch_add(tick, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    const unsigned long long t3 = wall_clock64();
+    h2[(size_t)blockIdx.x * 64] = (unsigned)round + v * 0;
+    unsigned long long* o = out + ((size_t)round * gridDim.x + blockIdx.x) * 4;
+    o[0] = t1 - t0; o[1] = t2 - t1; o[2] = t3 - t2;
+    acc = v;
+  }
+  if (acc == 0x12345678u) sink[3] = acc;
+}
+
 static double med(std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() / 2]; }
 
 int main(int argc, char** argv) {
@@ -182,6 +216,35 @@ int main(int argc, char** argv) {
       (void)hipGraphExecDestroy(ge);
       (void)hipGraphDestroy(g);
     }
+  }
+  // ---- part 3: dependent loads under the kernel's own bulk requests
+  printf("\nwavefront 7's loads while wavefronts 0..6 of all 256 workgroups request bulk:   peer-written line   read-only line   returning atomic | us, median (p90)\n");
+  for (int kb : {0, 32, 128, 448}) {
+    const int loads = kb * 1024 / (7 * 64 * 16);   // 16-byte loads per thread of the seven streaming wavefronts
+    hipGraph_t g;
+    hipGraphExec_t ge;
+    CK(hipStreamBeginCapture(st, hipStreamCaptureModeGlobal));
+    for (int r = 0; r < N; r++) {
+      const char* base = chunks[(r * 5 + 1) % chunks.size()];
+      hipLaunchKernelGGL(mix_kernel, dim3(NWG), dim3(512), 0, st, (const u4v*)base, (size_t)(1 << 20) / 16 * 2, loads, hot, out, r, sink);
+    }
+    CK(hipStreamEndCapture(st, &g));
+    CK(hipGraphInstantiate(&ge, g, nullptr, nullptr, 0));
+    CK(hipGraphLaunch(ge, st));
+    CK(hipStreamSynchronize(st));
+    std::vector<unsigned long long> h((size_t)N * NWG * 4);
+    CK(hipMemcpy(h.data(), out, h.size() * 8, hipMemcpyDeviceToHost));
+    std::vector<double> a, b, c;
+    for (int r = 4; r < N; r++)
+      for (int w = 0; w < NWG; w++) {
+        const unsigned long long* o = &h[((size_t)r * NWG + w) * 4];
+        a.push_back(o[0] * 0.01); b.push_back(o[1] * 0.01); c.push_back(o[2] * 0.01);
+      }
+    auto p90 = [](std::vector<double> v) { std::sort(v.begin(), v.end()); return v[v.size() * 9 / 10]; };
+    printf("bulk %3d KiB per workgroup (%5.1f MB per kernel) %8.2f (%5.2f) %8.2f (%5.2f) %8.2f (%5.2f)\n", kb, kb * NWG / 1024.0, med(a), p90(a),
+           med(b), p90(b), med(c), p90(c));
+    (void)hipGraphExecDestroy(ge);
+    (void)hipGraphDestroy(g);
   }
   return 0;
 }
