@@ -692,6 +692,9 @@ def pmc_traffic(args, label, timeout_s=300):
                                               for lab, row in zip(labels, rows)):
                 return None, "pmc: the dispatch sequence does not line up with the library's launch log"
             vals = [float(row["Counter_Value"]) for lab, row in zip(labels, rows) if lab == label]
+            if not vals:      # the child's shorter cache can change a launch-time choice the label carries (the KV split count)
+                stem = label.split(" nsplit=")[0]
+                vals = [float(row["Counter_Value"]) for lab, row in zip(labels, rows) if lab.split(" nsplit=")[0] == stem]
             if not vals:
                 return None, f"pmc: no dispatch of {label!r} in the child"
             res[counter] = sum(vals) / len(vals)
@@ -727,6 +730,11 @@ def host_numa_nodes():
 def host_cpu_info():
     """What the CPU leg ran on: logical CPUs this process may use, sockets, hardware threads per core, model name."""
     info = {"logical_cpus": len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)}
+    try:                                      # the container's CFS allowance: "quota period" in us, or "max"
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        info["cpu_quota"] = None if q == "max" else round(int(q) / int(per), 2)
+    except (OSError, ValueError):
+        info["cpu_quota"] = None
     try:
         sib = open("/sys/devices/system/cpu/cpu0/topology/thread_siblings_list").read().strip()
         n = 0
@@ -757,7 +765,7 @@ def host_cpu_info():
     return info
 
 
-def cpu_baseline(wl, budget_s=16.0, prefill_budget_s=8.0):
+def cpu_baseline(wl, budget_s=16.0, prefill_budget_s=8.0, threads=None):
     """The reference's own AVX512 MoE kernels (oracle/_ref) on this box's host cores, same expert shape: a bs=1 decode leg and a
     prompt leg.  Threads: ONE per physical core the process may use, pinned by the reference's own worker pool (its hwloc calls are
     served from sysfs by oracle/shim/hwloc.h), one sub-pool per NUMA node — the placement kt-kernel/README.md asks for.
@@ -778,27 +786,58 @@ def cpu_baseline(wl, budget_s=16.0, prefill_budget_s=8.0):
     Lm = wl["full_layers"] - wl["dense"]
     host = host_cpu_info()
     numa_nodes = host_numa_nodes()
-    threads = max(1, host["logical_cpus"] // host["threads_per_core"])      # physical cores (reference guidance)
+    phys = max(1, host["logical_cpus"] // host["threads_per_core"])          # physical cores (reference guidance: one worker each)
     subpools = numa_nodes if (numa_nodes > 1 and I % (numa_nodes * 32) == 0) else 1
-    threads -= threads % subpools
-    threads = max(threads, subpools)
+    rng = np.random.default_rng(0)
+    base = f32_to_bf16((rng.standard_normal((E, I, H), dtype=np.float32) / 10))
+    x = f32_to_bf16((rng.standard_normal((1, H), dtype=np.float32) / 100))
+    sets = [(np.stack([rng.permutation(E)[:k]]).astype(np.int64), rng.random((1, k), dtype=np.float32)) for _ in range(64)]
+
+    def fit(n):
+        n = max(subpools, min(int(n), phys))
+        return n - n % subpools
+
+    # The reference's workers busy-wait, so a container with a CFS quota below its CPU count (measured on the pool's boxes: 16 CPUs of
+    # quota on 256 logical CPUs, profiles/r04_i_cpu_leg_probe.txt) throttles a one-worker-per-core pool to a fraction of what fewer
+    # workers reach (128 -> 3.4, 64 -> 6.8, 32 -> 8.8 tok/s).  Placement sweep: the candidates are timed for ~1.5 s each on one layer
+    # and the best one runs the legs.
+    sweep = None
+    if threads:
+        threads = fit(threads)
+    else:
+        quota = host.get("cpu_quota")
+        cands = sorted({fit(phys)} | ({fit(quota), fit(2 * quota), fit(4 * quota)} if quota and quota < phys else set()))
+        if len(cands) == 1:
+            threads = cands[0]
+        else:
+            sweep = {}
+            for c in cands:
+                r = Reference(threads=c // subpools, subpools=subpools)
+                m0 = r.make_moe(FMT_AMXINT4, base, np.roll(base, 1, axis=0), np.roll(base, 2, axis=0).reshape(E, H, I), k=k, max_len=8)
+                for i in range(10):
+                    r.moe_forward(m0, sets[i][0], sets[i][1], x)
+                n0, t0 = 0, time.perf_counter()
+                while time.perf_counter() - t0 < 1.5:
+                    r.moe_forward(m0, sets[n0 % 64][0], sets[n0 % 64][1], x)
+                    n0 += 1
+                sweep[c] = round((time.perf_counter() - t0) / n0 * 1e6, 1)
+                r.free_moe(m0)
+                r.close()
+            threads = min(sweep, key=sweep.get)
     ref = Reference(threads=threads // subpools, subpools=subpools)
     rng = np.random.default_rng(0)
     nlayers = 3
     T_PRE = 256
     moes = []
     t_load = time.perf_counter()
-    # one block of randn/10 bf16 values, re-used with cheap permutations so that every matrix of every layer is
+    # one block of randn/10 bf16 values (`base`), re-used with cheap permutations so that every matrix of every layer is
     # distinct in memory (what matters for a bandwidth-bound baseline) without minutes of single-threaded numpy RNG
-    base = f32_to_bf16((rng.standard_normal((E, I, H), dtype=np.float32) / 10))
     for li in range(nlayers):
         gate = np.roll(base, li + 1, axis=0)
         up = np.ascontiguousarray(base[::-1]) if li % 2 == 0 else np.roll(base, -(li + 2), axis=0)
         down = np.roll(base, li + 3, axis=0).reshape(E, H, I)
         moes.append(ref.make_moe(FMT_AMXINT4, gate, up, down, k=k, max_len=T_PRE))
     t_load = time.perf_counter() - t_load
-    x = f32_to_bf16((rng.standard_normal((1, H), dtype=np.float32) / 100))
-    sets = [(np.stack([rng.permutation(E)[:k]]).astype(np.int64), rng.random((1, k), dtype=np.float32)) for _ in range(64)]
     for i in range(30):
         ref.moe_forward(moes[i % nlayers], sets[i % 64][0], sets[i % 64][1], x)
     n, t0 = 0, time.perf_counter()
@@ -810,7 +849,9 @@ def cpu_baseline(wl, budget_s=16.0, prefill_budget_s=8.0):
     t_layer = dt / n
     layer_bytes = k * (3 * H * I * 0.5 + (2 * I + H) * 4)                     # int4 weights + per-row fp32 scales of the k experts
     out = {"value": round(1.0 / (Lm * t_layer), 3), "unit": "tok/s", "cores": threads, "kind": "reference", "numa_nodes": numa_nodes,
-           "subpools": subpools, "host": host, "pinned": "one worker per physical core, bound by the reference's worker pool (sysfs-backed hwloc shim)",
+           "subpools": subpools, "host": host, "physical_cores": phys, "thread_sweep_us_per_layer": sweep,
+           "pinned": "workers bound to distinct physical cores by the reference's worker pool (sysfs-backed hwloc shim); thread count = the best of "
+                     "the placement sweep when the container's CFS quota is below its core count, else one per physical core",
            "us_per_layer": round(t_layer * 1e6, 1), "GBs": round(layer_bytes / t_layer / 1e9, 1),
            "covers": "routed experts only (the part the reference runs on the CPU)",
            "sample": f"{n} bs=1 forwards of TP_MOE<AMX_MOE_TP<GemmKernel224Int4>> (AVX512-VNNI path, no AMX on this host), "
@@ -1187,6 +1228,8 @@ def main():
     ap.add_argument("--strong", action="store_true", help="N > 1: ONE token stream (every rank decodes the same token; routed experts "
                                                             "E/N per rank) instead of one stream per rank")
     ap.add_argument("--cpu-baseline-only", action="store_true")
+    ap.add_argument("--cpu-threads", type=int, default=0, help="CPU leg: total worker threads (0 = one per physical core)")
+    ap.add_argument("--cpu-budget", type=float, default=16.0, help="CPU leg: seconds of bs=1 forwards")
     ap.add_argument("--force-dist", action="store_true",
                     help="dev / test aid: take the N > 1 code path (process group, expert parallelism, exchange transport) "
                          "even with WORLD_SIZE=1, so that path can be run on a one-GPU box")
@@ -1195,7 +1238,7 @@ def main():
     args = ap.parse_args()
     wl = WORKLOADS[args.workload]
     if args.cpu_baseline_only:
-        print(json.dumps(cpu_baseline(wl)), flush=True)
+        print(json.dumps(cpu_baseline(wl, budget_s=args.cpu_budget, prefill_budget_s=args.cpu_budget / 2, threads=args.cpu_threads or None)), flush=True)
         return
 
     clock = RunClock(args.time_budget)

@@ -239,6 +239,13 @@ class Reference:
         if rc != 0:
             raise RuntimeError(self.lib.ktref_last_error().decode())
 
+    def close(self):
+        """Join and free the worker pool (its threads busy-wait between jobs: a pool that is no longer used must not stay)."""
+        if self.pool:
+            self.lib.ktref_pool_destroy.argtypes = [C.c_void_p]
+            self.lib.ktref_pool_destroy(self.pool)
+            self.pool = None
+
     def make_moe(self, fmt: int, gate, up, down, k: int, max_len: int = 64, group_size: int = 0,
                  gate_scale=None, up_scale=None, down_scale=None):
         E, I, H = gate.shape[0], (gate.shape[1] if fmt != FMT_RAWINT4 else gate.shape[1]), None

@@ -119,6 +119,8 @@ static inline hwloc_obj_t hwloc_get_obj_inside_cpuset_by_type(hwloc_topology_t t
 }
 static inline int hwloc_set_thread_cpubind(hwloc_topology_t t, pthread_t th, hwloc_const_bitmap_t s, int f) {
   (void)t; (void)f;
+  const char* nobind = getenv("KTX_HWLOC_NOBIND");       /* bench.py's placement sweep: the same pool, threads left to the scheduler */
+  if (nobind && nobind[0] == '1') return 0;
   cpu_set_t* cs = CPU_ALLOC(KTX_HWLOC_MAXCPU);
   if (!cs) return -1;
   const size_t sz = CPU_ALLOC_SIZE(KTX_HWLOC_MAXCPU);
