@@ -813,7 +813,7 @@ def cpu_baseline(wl, budget_s=16.0, prefill_budget_s=8.0, threads=None):
             sweep = {}
             for c in cands:
                 r = Reference(threads=c // subpools, subpools=subpools)
-                m0 = r.make_moe(FMT_AMXINT4, base, np.roll(base, 1, axis=0), np.roll(base, 2, axis=0).reshape(E, H, I), k=k, max_len=8)
+                m0 = r.make_moe(FMT_AMXINT4, base, np.roll(base, 1, axis=0), np.roll(base, 2, axis=0).reshape(E, H, I), k=k, max_len=64)
                 for i in range(10):
                     r.moe_forward(m0, sets[i][0], sets[i][1], x)
                 n0, t0 = 0, time.perf_counter()
@@ -1459,7 +1459,7 @@ def main():
                         r2, m2 = run_model_decode(name, args, dev, n2, 10)
                         if not args.no_prefill:
                             try:   # the same resident model, one prompt chunk (no per-launch pass: the headline workload carries that table)
-                                r2["prefill"] = whole_model_prefill(m2, args.prefill_tokens, dev, reps=1, per_kernel_pass=False)
+                                r2["prefill"] = whole_model_prefill(m2, args.prefill_tokens, dev, reps=1, per_kernel_pass=True)
                             except Exception as e:
                                 r2["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
                                 torch.cuda.synchronize(dev)

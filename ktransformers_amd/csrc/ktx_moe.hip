@@ -1879,6 +1879,202 @@ __global__ __launch_bounds__(256) void moe_rawint4_gemm_kernel(RawGemmParams p) 
   }
 }
 
+// =====================================================================================================
+// RAWINT4 prompt chunks: the same products on the 16x16x32 int8 MFMA, one MFMA per (32-k group) x (16 rows) x (16 tokens).
+//
+// The exact kernel above keeps the reference's SIXTEEN fp32 lane accumulators per output, i.e. one convert + multiply + fma per
+// FOUR int8 products (4x4x4 MFMA blocks, four tokens per tile, every weight byte re-read and re-unpacked per four tokens): 38 ms
+// per Kimi-K2 layer at a 2048-token chunk against 1.4 ms for the AMXINT4 format (profiles/r04_final).  A prompt chunk does not
+// need that association: the terms of an output are the per-group sums  (as[t][g] * bs[n][g]) * float(sum_{k in g} a[t][k] * 16 q[n][k])
+// — the reference adds them as 16 interleaved chains + a tree, this kernel as ONE chain over the groups in k order (the
+// integer group sum is exact either way, so only the association of <= K/32 fp32 additions differs: <= a few fp32 ulps before the
+// one bf16 rounding; tests/test_moe_gpu.py::test_rawint4_prompt_chunks holds it to the bound of the FP8 / BF16 formats, whose
+// prompt kernels re-associate in the same way).  Decode and short batches (qlen < 64) keep the exact kernels; dev knob 29 = 1
+// forces them for every size.
+//
+// No second copy of the weights: the RAW tiles are read as they lie in HBM.  MFMA lane (i = lane & 15, kc = lane >> 4) needs
+// row i's eight nibbles k = 64 kb + 32 h + 8 kc + [0, 8) of group (kb, h): those are the pieces (L, j) = (8h + 2kc + o, i & 3),
+// o = 0 / 1, of RAW tile rg = i >> 2 — so the lane loads exactly its four pieces q = (h, o) of the strip's four tiles (16 bytes
+// each, every 128-byte line of the 4 KiB used by one wave instruction pair) and nothing moves between lanes.
+//   workgroup = 4 wavefronts = 4 strips of 16 weight rows x (gate, up) x 64 tokens; K walks in the RAW step of 512 (16 groups):
+//   activations + their group scales of the step are double-buffered in LDS, the step's weights + scales in registers.
+// =====================================================================================================
+template <bool GATE_UP>
+__global__ __launch_bounds__(256, 2) void moe_rawint4_chunk_kernel(RawGemmParams p) {
+  constexpr int NU = 2;                             // B operands per wavefront that share one activation fragment: (gate, up) of a
+                                                    // strip, or two strips of down (one fragment + scale read per two MFMAs: LDS port)
+  constexpr int TOK = 64, MT = 4;
+  constexpr int CS = TOK * 16 + 16;                 // bytes between 16-byte activation columns (+16: staging writes spread over banks)
+  constexpr int XB = 32 * CS;                       // one step of activations: 32 columns x 64 tokens x 16 B
+  constexpr int AB = 16 * TOK * 4;                  // one step of activation scales: [16 groups][64 tokens] fp32
+  extern __shared__ __attribute__((aligned(16))) uint8_t smem[];   // [2][XB] | [2][AB]
+  __shared__ int s_src[TOK];
+  uint8_t* xs = smem;
+  float* as_l = reinterpret_cast<float*>(smem + 2 * XB);
+
+  const int tile_idx = blockIdx.y;
+  if (tile_idx >= p.counters[0]) return;
+  const Tile tile = p.tiles[tile_idx];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nstrips = p.N / 16;
+  const int NS = p.K / 512, G = p.K / 32;
+  const int i = lane & 15, kc = lane >> 4, rg = i >> 2, j = i & 3;
+  int ustrip[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) ustrip[u] = GATE_UP ? blockIdx.x * 4 + wave : (blockIdx.x * 4 + wave) * 2 + u;
+  const bool wave_ok = ustrip[0] < nstrips;
+
+  if (tid < TOK) s_src[tid] = tid < tile.nrows ? (p.row_src ? p.row_src[tile.row0 + tid] : tile.row0 + tid) : -1;
+  __syncthreads();
+
+  // ---- this lane's four pieces of each unit's four RAW tiles, and its row's scales (a strip past N aliases strip 0, not stored)
+  const uint8_t* wb[NU];
+  const bf16_t* sb[NU];
+#pragma unroll
+  for (int u = 0; u < NU; u++) {
+    const int st = ustrip[u] < nstrips ? ustrip[u] : 0;
+    const uint8_t* w = (GATE_UP && u) ? p.w1 : p.w0;
+    const bf16_t* sc = (GATE_UP && u) ? p.s1 : p.s0;
+    wb[u] = w + (size_t)tile.expert * p.expert_stride + ((size_t)(st * 4 + rg) * NS) * 1024 + (size_t)((2 * kc) * 4 + j) * 16;
+    sb[u] = sc + (size_t)tile.expert * p.scale_stride + ((size_t)(st * 4 + rg) * NS) * 64 + (size_t)(j * 2) * 8;
+  }
+  struct WStep { uint4 w[NU][4]; uint4 s[NU][2]; };   // w[u][h * 2 + o]: piece L = 8h + 2kc + o; s[u][h]: 8 bf16 scales (kb = 0..7)
+  auto load_w = [&](WStep& d, int st) {
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+        d.w[u][q] = *reinterpret_cast<const uint4*>(wb[u] + (size_t)st * 1024 + ((q >> 1) * 8 + (q & 1)) * 64);
+#pragma unroll
+      for (int h = 0; h < 2; h++) d.s[u][h] = *reinterpret_cast<const uint4*>(sb[u] + (size_t)st * 64 + h * 8);
+    }
+  };
+
+  // ---- staging: thread -> 8 x (token, 16-byte piece) of the step's 64 x 512 activation bytes + one float4 of group scales
+  auto stage = [&](int st, int buf) {
+    uint4 xr[8];
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = it * 256 + tid, tok = idx >> 5, piece = idx & 31;
+      const int src = s_src[tok];
+      xr[it] = src >= 0 ? *reinterpret_cast<const uint4*>(p.act_q + (size_t)src * p.K + (size_t)st * 512 + piece * 16) : make_uint4(0, 0, 0, 0);
+    }
+    const int tok4 = tid >> 2, src4 = s_src[tok4];
+    const float4 ar = src4 >= 0 ? *reinterpret_cast<const float4*>(p.act_d + (size_t)src4 * G + (size_t)st * 16 + (tid & 3) * 4)
+                                : make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+    for (int it = 0; it < 8; it++) {
+      const int idx = it * 256 + tid, tok = idx >> 5, piece = idx & 31;
+      *reinterpret_cast<uint4*>(xs + buf * XB + piece * CS + tok * 16) = xr[it];
+    }
+    float* ab = as_l + buf * (AB / 4) + ((tid & 3) * 4) * TOK + tok4;
+    ab[0] = ar.x; ab[TOK] = ar.y; ab[2 * TOK] = ar.z; ab[3 * TOK] = ar.w;
+  };
+
+  float acc[NU][MT][4];
+#pragma unroll
+  for (int u = 0; u < NU; u++)
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) acc[u][t][r] = 0.0f;
+
+  // One step = 4 dword positions p4 of the lane's pieces, each = 2 nibble halves (kb8 = 2 p4 + par) x 2 group halves h.  The p4 loop
+  // is NOT unrolled (fully unrolled, the compiler unpacked a whole step's operands up front and spilled 460 registers): the body
+  // always uses component .x and the pieces rotate by one dword per iteration.
+  auto compute = [&](WStep& w, int buf) {
+    if (!wave_ok) return;
+    const uint8_t* xb = xs + buf * XB + (kc >> 1) * CS + i * 16 + (kc & 1) * 8;
+    const float* ab = as_l + buf * (AB / 4) + kc * 4;
+#pragma unroll 1
+    for (int p4 = 0; p4 < 4; p4++) {
+#pragma unroll 1
+      for (int par = 0; par < 2; par++) {
+        const int nsh = 4 - 4 * par, ssh = 16 - 16 * par;     // low nibbles / low bf16 first (kb8 = 2 p4), then the high halves
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          long bop[NU];
+          float bs[NU];
+#pragma unroll
+          for (int u = 0; u < NU; u++) {
+            const uint32_t b0 = (w.w[u][h * 2].x << nsh) & 0xF0F0F0F0u, b1 = (w.w[u][h * 2 + 1].x << nsh) & 0xF0F0F0F0u;
+            bop[u] = (long)(((unsigned long long)b1 << 32) | b0);
+            bs[u] = __uint_as_float((w.s[u][h].x << ssh) & 0xffff0000u);
+          }
+          const int col = (p4 * 2 + par) * 4 + h * 2, g = (p4 * 2 + par) * 2 + h;
+#pragma unroll
+          for (int t = 0; t < MT; t++) {
+            const long aop = *reinterpret_cast<const long*>(xb + (size_t)col * CS + t * 256);
+            const float4 as4 = *reinterpret_cast<const float4*>(ab + g * TOK + t * 16);
+            const float asv[4] = {as4.x, as4.y, as4.z, as4.w};
+#pragma unroll
+            for (int u = 0; u < NU; u++) {
+              const v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop[u], v4i{0, 0, 0, 0}, 0, 0, 0);
+#pragma unroll
+              for (int r = 0; r < 4; r++) acc[u][t][r] = fmaf(asv[r] * bs[u], (float)d[r], acc[u][t][r]);
+            }
+          }
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < NU; u++) {
+#pragma unroll
+        for (int q = 0; q < 4; q++) w.w[u][q] = make_uint4(w.w[u][q].y, w.w[u][q].z, w.w[u][q].w, w.w[u][q].x);
+#pragma unroll
+        for (int h = 0; h < 2; h++) w.s[u][h] = make_uint4(w.s[u][h].y, w.s[u][h].z, w.s[u][h].w, w.s[u][h].x);
+      }
+    }
+  };
+
+  // The next step's weights are requested before the current step's MFMAs (registers), its activations AFTER them (staging
+  // registers live across the MFMAs of a step cost more than they hide); the CU's second workgroup computes while this one stages.
+  WStep wa, wb2;
+  load_w(wa, 0);
+  stage(0, 0);
+  __syncthreads();
+  for (int st = 0; st < NS; st += 2) {
+    if (st + 1 < NS) load_w(wb2, st + 1);
+    compute(wa, 0);
+    if (st + 1 < NS) stage(st + 1, 1);
+    __syncthreads();
+    if (st + 1 < NS) {
+      if (st + 2 < NS) load_w(wa, st + 2);
+      compute(wb2, 1);
+      if (st + 2 < NS) stage(st + 2, 0);
+      __syncthreads();
+    }
+  }
+
+  if (!wave_ok) return;
+  if constexpr (GATE_UP) {
+    const int n = ustrip[0] * 16 + i;
+#pragma unroll
+    for (int t = 0; t < MT; t++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const int row = t * 16 + kc * 4 + r;
+        if (row < tile.nrows) {
+          const bf16_t gv = f32_to_bf16(acc[0][t][r] / 16.0f), uv = f32_to_bf16(acc[1][t][r] / 16.0f);
+          p.out[(size_t)(tile.row0 + row) * p.N + n] = f32_to_bf16(act_fn(bf16_to_f32(gv), bf16_to_f32(uv)));
+        }
+      }
+  } else {
+#pragma unroll
+    for (int u = 0; u < NU; u++) {
+      if (ustrip[u] >= nstrips) continue;
+      const int n = ustrip[u] * 16 + i;
+#pragma unroll
+      for (int t = 0; t < MT; t++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          const int row = t * 16 + kc * 4 + r;
+          if (row < tile.nrows) p.out[(size_t)(tile.row0 + row) * p.N + n] = f32_to_bf16(acc[u][t][r] / 16.0f);
+        }
+    }
+  }
+}
+
 // per-(row, 32-group) int8 quantisation (BufferASmallKGroupImpl::from_mat, amx_buffers.hpp:431-495): one block per row,
 // 8 elements per thread, a group = 4 adjacent lanes
 __device__ __forceinline__ void quant_row_kgroup_block(const bf16_t* __restrict__ src, int K, int8_t* __restrict__ dst,
@@ -3096,6 +3292,18 @@ static int launch_rawint4(const RawGemmParams& p, int max_tiles, hipStream_t st)
   return 0;
 }
 
+template <bool GATE_UP>
+static int launch_rawint4_chunk(const RawGemmParams& p, int max_tiles, hipStream_t st) {
+  constexpr size_t lds = 2 * (32 * (64 * 16 + 16) + 16 * 64 * 4);
+  static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_rawint4_chunk_kernel<GATE_UP>),
+                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  KTX_HIP(err);
+  const int per_wg = GATE_UP ? 4 : 8;       // strips per workgroup (down: two strips per wavefront)
+  hipLaunchKernelGGL((moe_rawint4_chunk_kernel<GATE_UP>), dim3((p.N / 16 + per_wg - 1) / per_wg, max_tiles), dim3(256), lds, st, p);
+  KTX_HIP(hipGetLastError());
+  return 0;
+}
+
 // RAWINT4: bucket (4-row tiles) -> per-group activation quant -> gate/up -> per-group requant -> down -> combine
 static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const int64_t* d_expert_ids,
                            const float* d_weights, const void* d_input, void* d_output, int flags, hipStream_t st) {
@@ -3139,9 +3347,12 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
     return 0;
   }
 
+  // prompt chunks: 64-row tiles through the group-scaled 16x16x32 kernel (moe_rawint4_chunk_kernel: same terms, one fp32 chain per
+  // output instead of the reference's sixteen); short batches and dev knob 29 = 1 keep the exact 4-row kernel
+  const bool chunk = qlen >= 64 && g_dbg[29] != 1 && H % 512 == 0 && I % 512 == 0;
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
-  pp.rows_per_tile = 4; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
+  pp.rows_per_tile = chunk ? 64 : 4; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
   pp.x_q = ws->x_q; pp.x_d = ws->x_d; pp.row_of_pair = ws->row_of_pair; pp.src_of_row = ws->src_of_row;
   pp.tiles = ws->tiles; pp.counters = ws->counters;
   {
@@ -3158,7 +3369,8 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
   int rc;
   {
     ProfScope ps(1, st);
-    rc = qlen == 1 ? launch_rawint4<1, true>(g1, max_tiles, st) : launch_rawint4<4, true>(g1, max_tiles, st);
+    rc = chunk ? launch_rawint4_chunk<true>(g1, std::min(npairs, E) + npairs / 64, st)
+               : qlen == 1 ? launch_rawint4<1, true>(g1, max_tiles, st) : launch_rawint4<4, true>(g1, max_tiles, st);
   }
   if (rc) return rc;
   {
@@ -3173,7 +3385,8 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
   g2.tiles = ws->tiles; g2.counters = ws->counters; g2.out = ws->dn_buf;
   {
     ProfScope ps(3, st);
-    rc = qlen == 1 ? launch_rawint4<1, false>(g2, max_tiles, st) : launch_rawint4<4, false>(g2, max_tiles, st);
+    rc = chunk ? launch_rawint4_chunk<false>(g2, std::min(npairs, E) + npairs / 64, st)
+               : qlen == 1 ? launch_rawint4<1, false>(g2, max_tiles, st) : launch_rawint4<4, false>(g2, max_tiles, st);
   }
   if (rc) return rc;
   CombineParams cp{};

@@ -442,13 +442,49 @@ def test_rawint4_bit_exact(oracle, dev, shape):
     try:
         h.load_rawint4(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch_bf16(x[1], dev) for x in q])
         want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+        _native.lib.ktx_debug_set(29, 1)  # the exact kernels at every size (prompt chunks of >= 64 tokens otherwise take the
+        #                                   re-associating chunk kernel: test_rawint4_prompt_chunks)
         for generic in (False, True):     # T*k <= 64: the two-launch decode kernels, then the grouped path on the same input
             _native.force_generic_path(generic)
             got = run(h, c, dev)
             assert np.array_equal(got, want), f"{int((got != want).sum())} of {want.size} bf16 outputs differ (generic={generic})"
             assert np.array_equal(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
     finally:
+        _native.lib.ktx_debug_set(29, 0)
         _native.force_generic_path(False)
+        h.close()
+
+
+@pytest.mark.parametrize("shape", [(4, 2, 512, 512, 300), (8, 3, 1024, 512, 130), (16, 8, 7168, 2048, 64), (6, 2, 1536, 1024, 257)])
+def test_rawint4_prompt_chunks(oracle, dev, shape):
+    """Prompt chunks (qlen >= 64) of the RAWINT4 format go through moe_rawint4_chunk_kernel: the same int8 x int4 products and the
+    same per-group scale products as the reference's GemmKernel224Int4SmallKGroup, summed as ONE fp32 chain over the 32-k groups
+    instead of sixteen interleaved chains + a tree (csrc/ktx_moe.hip).  Bound: that of the FP8 / BF16 formats, whose prompt kernels
+    re-associate the same way (element-wise 2^-7 |ref| + 2^-9 max|ref|, < 5 % of the bf16 outputs different at all, mean error
+    < 1e-3 of the mean magnitude); and against the exact kernels of this library on the same input (dev knob 29), Kimi-K2's
+    expert shape included, ragged tiles and invalid ids included."""
+    from helpers import rawint4_quantize
+    from ktransformers_amd import _native
+    from ktransformers_amd._native import MoEHandle
+    E, k, H, I, T = shape
+    c = make_case(21, E, k, H, I, T, invalid_ids=True)
+    q = [rawint4_quantize(bf16_to_f32(c[n])) for n in ("gate", "up", "down")]
+    mo = oracle.make_moe_rawint4(q[0][0], q[1][0], q[2][0], q[0][1], q[1][1], q[2][1])
+    want = oracle.moe_forward(mo, c["ids"], c["w"], c["x"])
+    h = MoEHandle(E, k, H, I, max_len=T, method="RAWINT4", device=0, group_size=32)
+    try:
+        h.load_rawint4(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch_bf16(x[1], dev) for x in q])
+        got = run(h, c, dev)
+        _check_fp(got, want)
+        _native.lib.ktx_debug_set(29, 1)
+        exact = run(h, c, dev)
+        assert np.array_equal(exact, want)
+        assert (got != exact).mean() < 0.05
+        _native.lib.ktx_debug_set(29, 0)
+        want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+        _check_fp(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
+    finally:
+        _native.lib.ktx_debug_set(29, 0)
         h.close()
 
 
