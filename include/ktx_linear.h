@@ -153,6 +153,17 @@ int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_absorb, int T,
  * the weight bytes are expanded once per call instead of once per 64-token tile, and the arithmetic is the reference's. */
 int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_out, ktx_stream_t stream);
 
+/* Prompt-sized calls of an FP8 handle (KLinearFP8.forward, archive/ktransformers/operators/linear.py:388-436: act_quant +
+ * fp8_gemm of ktransformers_ext/triton/fp8gemm.py) in two launches:
+ *   ktx_fp8_act_quant  — act_quant (fp8gemm.py:10-31) of x bf16 [T][ldx]: d_q = e4m3 bytes [T][K]; d_scales_t[kb * s_ld + t] =
+ *                        amax(x[t][128 kb .. 128 kb + 127]) / 448 (block-major, so a tile's scales of one k-step are contiguous);
+ *   ktx_linear_gemm_fp8 — y bf16 [T][ldy] = fp8_gemm(d_q, scales, W, scale_inv) (+ bias): 128 x 128 output tiles, k-step = one
+ *                        128-block, accumulator += dot * a_s * b_s (fp8gemm.py:156).  s_ld >= ceil(T / 128) * 128, a multiple of 4.
+ * Same arithmetic as ktx_linear_forward on the same handle (bit for bit); the decode layout of the weights is read in place. */
+int ktx_fp8_act_quant(const void* d_x, int64_t ldx, int T, int K, void* d_q, float* d_scales_t, int64_t s_ld, ktx_stream_t stream);
+int ktx_linear_gemm_fp8(ktx_linear_t h, const void* d_q, const float* d_scales_t, int64_t s_ld, int T, void* d_y, int64_t ldy,
+                        ktx_stream_t stream);
+
 /* The merge of the MLA KV splits and the per-head un-absorb products (torch.matmul(attn_output, out_absorb.mT),
  * archive/ktransformers/operators/attention.py:465-468) of a decode step (T <= 4) in ONE launch: h = the batched BF16 W_UV
  * handle (batch = heads, kv_lora 512 -> v_head_dim 128); d_part_o / d_part_ml / nsplit = what ktx_mla_decode_partials

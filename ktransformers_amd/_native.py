@@ -137,6 +137,8 @@ def _load() -> C.CDLL:
                                              C.c_void_p]
     lib.ktx_linear_decode_eligible.argtypes = [C.c_void_p, C.c_int]
     lib.ktx_linear_dequant_bf16.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ktx_fp8_act_quant.argtypes = [C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    lib.ktx_linear_gemm_fp8.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]
     lib.ktx_mla_decode_partials.argtypes = [C.POINTER(_MlaConfig)] + [C.c_void_p] * 4 + [C.c_int64, C.c_int64] + [C.c_void_p] * 5 + [
         C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_size_t, C.POINTER(C.c_int), C.c_void_p]
     lib.ktx_linear_merge_eligible.argtypes = [C.c_void_p, C.c_int, C.c_int, C.c_int]
@@ -205,7 +207,7 @@ STREAM_CALLS = frozenset((
     "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
     "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_mla_prefill", "ktx_linear_forward",
     "ktx_linear_forward_batched", "ktx_linear_forward_batched_prep", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
-    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt", "ktx_attn_decode", "ktx_moe_layer_decode"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
+    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt", "ktx_attn_decode", "ktx_moe_layer_decode", "ktx_fp8_act_quant", "ktx_linear_gemm_fp8"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
 TRACE: list | None = None
 HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
 
@@ -698,6 +700,29 @@ class LinearHandle:
             return out
         return y
 
+    # ---- prompt-sized FP8 calls: act_quant once per call + the block-scaled fp8 GEMM on the handle's own tiles
+    # (csrc/ktx_linear_fp8gemm.inc; bit-identical to ktx_linear_forward; KTX_FP8_PROMPT_KERNEL=1 keeps the strip kernel for A/B) ----
+    FP8_PROMPT_MIN_T = 128
+
+    def _prompt_forward_fp8(self, x2: torch.Tensor, out, add1, add2, glu: bool) -> torch.Tensor:
+        T = x2.shape[0]
+        tp = (T + 127) // 128 * 128
+        q = torch.empty((T, self.K), dtype=torch.uint8, device=self.device)
+        st = torch.empty((self.K // 128, tp), dtype=torch.float32, device=self.device)
+        y = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device)
+        sp = _stream_ptr(self.device)
+        check(lib.ktx_fp8_act_quant(x2.data_ptr(), x2.stride(0), T, self.K, q.data_ptr(), st.data_ptr(), tp, sp))
+        check(lib.ktx_linear_gemm_fp8(self._h, q.data_ptr(), st.data_ptr(), tp, T, y.data_ptr(), self.N, sp))
+        if glu:   # rows are interleaved per 16-row strip as [8 gate | 8 up]
+            y = silu_mul(y.view(T, self.N // 16, 2, 8).permute(0, 2, 1, 3).reshape(T, self.N))
+        for a in (add1, add2):   # the epilogue adds of the decoder layer, torch's bf16 tensor arithmetic
+            if a is not None:
+                y = a.reshape(y.shape) + y
+        if out is not None:
+            out.copy_(y)
+            return out
+        return y
+
     def load_bf16(self, weight: torch.Tensor, bias: torch.Tensor | None = None) -> None:
         """weight: bf16 [out, in] (nn.Linear layout). W4 handles quantise with quantize_weights' arithmetic."""
         shape = (self.N, self.K) if self.batch == 1 else (self.batch, self.N, self.K)
@@ -757,6 +782,11 @@ class LinearHandle:
             if norm is not None:
                 x2 = rmsnorm(x2.contiguous(), norm[0], norm[1], native_rounding=True)
             return self._prompt_forward(x2, out, add1, add2, glu).reshape(*x.shape[:-1], n_out)
+        if (self.fmt == "FP8" and self.batch == 1 and T >= self.FP8_PROMPT_MIN_T and bsz_tensor is None and self.N % 8 == 0
+                and not os.environ.get("KTX_FP8_PROMPT_KERNEL") and not torch.cuda.is_current_stream_capturing()):
+            if norm is not None:
+                x2 = rmsnorm(x2.contiguous(), norm[0], norm[1], native_rounding=True)
+            return self._prompt_forward_fp8(x2, out, add1, add2, glu).reshape(*x.shape[:-1], n_out)
         if out is None:
             out = torch.empty((T, n_out), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
                 torch.zeros((T, n_out), dtype=torch.bfloat16, device=self.device)

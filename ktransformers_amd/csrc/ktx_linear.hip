@@ -2149,6 +2149,8 @@ extern "C" int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_o
   return 0;
 }
 
+#include "ktx_linear_fp8gemm.inc"
+
 extern "C" size_t ktx_linear_weight_bytes(ktx_linear_t h) { return h ? h->w_bytes + h->sc_bytes : 0; }
 
 extern "C" int ktx_linear_debug_get_w4(ktx_linear_t h, uint8_t* q, uint16_t* s) {

@@ -1896,11 +1896,11 @@ __global__ __launch_bounds__(256) void moe_rawint4_gemm_kernel(RawGemmParams p) 
 // row i's eight nibbles k = 64 kb + 32 h + 8 kc + [0, 8) of group (kb, h): those are the pieces (L, j) = (8h + 2kc + o, i & 3),
 // o = 0 / 1, of RAW tile rg = i >> 2 — so the lane loads exactly its four pieces q = (h, o) of the strip's four tiles (16 bytes
 // each, every 128-byte line of the 4 KiB used by one wave instruction pair) and nothing moves between lanes.
-//   workgroup = 4 wavefronts = 4 strips of 16 weight rows x (gate, up) x 64 tokens; K walks in the RAW step of 512 (16 groups):
+//   workgroup = 8 wavefronts = 8 strips of 16 weight rows x (gate, up) x 64 tokens; K walks in the RAW step of 512 (16 groups):
 //   activations + their group scales of the step are double-buffered in LDS, the step's weights + scales in registers.
 // =====================================================================================================
 template <bool GATE_UP>
-__global__ __launch_bounds__(256, 2) void moe_rawint4_chunk_kernel(RawGemmParams p) {
+__global__ __launch_bounds__(512) void moe_rawint4_chunk_kernel(RawGemmParams p) {
   constexpr int NU = 2;                             // B operands per wavefront that share one activation fragment: (gate, up) of a
                                                     // strip, or two strips of down (one fragment + scale read per two MFMAs: LDS port)
   constexpr int TOK = 64, MT = 4;
@@ -1922,7 +1922,7 @@ __global__ __launch_bounds__(256, 2) void moe_rawint4_chunk_kernel(RawGemmParams
   const int i = lane & 15, kc = lane >> 4, rg = i >> 2, j = i & 3;
   int ustrip[NU];
 #pragma unroll
-  for (int u = 0; u < NU; u++) ustrip[u] = GATE_UP ? blockIdx.x * 4 + wave : (blockIdx.x * 4 + wave) * 2 + u;
+  for (int u = 0; u < NU; u++) ustrip[u] = GATE_UP ? blockIdx.x * 8 + wave : (blockIdx.x * 8 + wave) * 2 + u;
   const bool wave_ok = ustrip[0] < nstrips;
 
   if (tid < TOK) s_src[tid] = tid < tile.nrows ? (p.row_src ? p.row_src[tile.row0 + tid] : tile.row0 + tid) : -1;
@@ -1951,25 +1951,35 @@ __global__ __launch_bounds__(256, 2) void moe_rawint4_chunk_kernel(RawGemmParams
     }
   };
 
-  // ---- staging: thread -> 8 x (token, 16-byte piece) of the step's 64 x 512 activation bytes + one float4 of group scales
-  auto stage = [&](int st, int buf) {
-    uint4 xr[8];
+  // ---- staging: thread -> 4 x (token, 16-byte piece) of the step's 64 x 512 activation bytes + (256 threads) one float4 of group
+  // scales.  The requests go out BEFORE the step's MFMAs, the LDS writes after them (20 registers across the step buy the overlap:
+  // with one workgroup per CU nobody else keeps the memory pipe busy while this one computes).
+  struct XStage { uint4 x0, x1, x2, x3; float4 a; };
+  auto load_x = [&](XStage& xg, int st) {
+    uint4 xr[4];
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int idx = it * 256 + tid, tok = idx >> 5, piece = idx & 31;
-      const int src = s_src[tok];
-      xr[it] = src >= 0 ? *reinterpret_cast<const uint4*>(p.act_q + (size_t)src * p.K + (size_t)st * 512 + piece * 16) : make_uint4(0, 0, 0, 0);
+    for (int it = 0; it < 4; it++) {
+      const int idx = it * 512 + tid, tok = idx >> 5, piece = idx & 31;
+      const int src = s_src[tok];      // unconditional loads from a clamped row (a branch per load serialises the requests)
+      xr[it] = *reinterpret_cast<const uint4*>(p.act_q + (size_t)(src >= 0 ? src : 0) * p.K + (size_t)st * 512 + piece * 16);
     }
-    const int tok4 = tid >> 2, src4 = s_src[tok4];
-    const float4 ar = src4 >= 0 ? *reinterpret_cast<const float4*>(p.act_d + (size_t)src4 * G + (size_t)st * 16 + (tid & 3) * 4)
-                                : make_float4(0.f, 0.f, 0.f, 0.f);
+    const int tok4 = (tid & 255) >> 2, src4 = s_src[tok4];
+    const float4 av = *reinterpret_cast<const float4*>(p.act_d + (size_t)(src4 >= 0 ? src4 : 0) * G + (size_t)st * 16 + (tid & 3) * 4);
+    const float keep = src4 >= 0 ? 1.0f : 0.0f;              // rows past the tile: scale 0 (their int8 values are then irrelevant)
+    xg.x0 = xr[0]; xg.x1 = xr[1]; xg.x2 = xr[2]; xg.x3 = xr[3];
+    xg.a = make_float4(av.x * keep, av.y * keep, av.z * keep, av.w * keep);
+  };
+  auto store_x = [&](const XStage& xg, int buf) {
+    const uint4 xr[4] = {xg.x0, xg.x1, xg.x2, xg.x3};
 #pragma unroll
-    for (int it = 0; it < 8; it++) {
-      const int idx = it * 256 + tid, tok = idx >> 5, piece = idx & 31;
+    for (int it = 0; it < 4; it++) {
+      const int idx = it * 512 + tid, tok = idx >> 5, piece = idx & 31;
       *reinterpret_cast<uint4*>(xs + buf * XB + piece * CS + tok * 16) = xr[it];
     }
-    float* ab = as_l + buf * (AB / 4) + ((tid & 3) * 4) * TOK + tok4;
-    ab[0] = ar.x; ab[TOK] = ar.y; ab[2 * TOK] = ar.z; ab[3 * TOK] = ar.w;
+    if (tid < 256) {
+      float* ab = as_l + buf * (AB / 4) + ((tid & 3) * 4) * TOK + (tid >> 2);
+      ab[0] = xg.a.x; ab[TOK] = xg.a.y; ab[2 * TOK] = xg.a.z; ab[3 * TOK] = xg.a.w;
+    }
   };
 
   float acc[NU][MT][4];
@@ -1980,68 +1990,78 @@ __global__ __launch_bounds__(256, 2) void moe_rawint4_chunk_kernel(RawGemmParams
 #pragma unroll
       for (int r = 0; r < 4; r++) acc[u][t][r] = 0.0f;
 
-  // One step = 4 dword positions p4 of the lane's pieces, each = 2 nibble halves (kb8 = 2 p4 + par) x 2 group halves h.  The p4 loop
-  // is NOT unrolled (fully unrolled, the compiler unpacked a whole step's operands up front and spilled 460 registers): the body
-  // always uses component .x and the pieces rotate by one dword per iteration.
-  auto compute = [&](WStep& w, int buf) {
+  // One step = 4 dword positions p4 of the lane's pieces x 2 nibble halves (kb8 = 2 p4 + par) x 2 group halves h = 16 groups.
+  // Two things the compiler does to this loop when left alone, both measured (profiles/r04_j_*): (1) fully unrolled, it unpacks a
+  // whole step's operands up front and spills 460 registers — every group's operand words therefore pass an empty volatile asm
+  // right before their use, which pins the unpack behind the previous group; (2) it SLP-packs the four scale products and fmas of
+  // a fragment into v_pk_mul_f32 / v_pk_fma_f32 plus ~6 register-pair moves per MFMA — slower than the scalar forms beside MFMAs
+  // (MI355X_MICROARCH.md, per-instruction constants) — so the two operations are spelled as single instructions.
+  auto mul1 = [](float a, float b) { float d; asm("v_mul_f32 %0, %1, %2" : "=v"(d) : "v"(a), "v"(b)); return d; };
+  auto fma1 = [](float a, float b, float c) { float d; asm("v_fma_f32 %0, %1, %2, %3" : "=v"(d) : "v"(a), "v"(b), "v"(c)); return d; };
+  // MTL = 16-token groups of the tile that hold rows (a Kimi-K2 chunk of 2048 tokens leaves ~43 rows per expert: three groups,
+  // not four, for most tiles); one instantiation per count, chosen once per workgroup
+  auto compute_n = [&](auto mtl, const WStep& w, int buf) __attribute__((always_inline)) {
+    constexpr int MTL = decltype(mtl)::value;
     if (!wave_ok) return;
     const uint8_t* xb = xs + buf * XB + (kc >> 1) * CS + i * 16 + (kc & 1) * 8;
     const float* ab = as_l + buf * (AB / 4) + kc * 4;
-#pragma unroll 1
-    for (int p4 = 0; p4 < 4; p4++) {
-#pragma unroll 1
-      for (int par = 0; par < 2; par++) {
-        const int nsh = 4 - 4 * par, ssh = 16 - 16 * par;     // low nibbles / low bf16 first (kb8 = 2 p4), then the high halves
 #pragma unroll
-        for (int h = 0; h < 2; h++) {
-          long bop[NU];
-          float bs[NU];
+    for (int kb8 = 0; kb8 < 8; kb8++) {
+#pragma unroll
+      for (int h = 0; h < 2; h++) {
+        long bop[NU];
+        float bs[NU];
+#pragma unroll
+        for (int u = 0; u < NU; u++) {
+          const uint4 &w0 = w.w[u][h * 2], &w1 = w.w[u][h * 2 + 1], &sv = w.s[u][h];
+          uint32_t P0 = kb8 < 2 ? w0.x : kb8 < 4 ? w0.y : kb8 < 6 ? w0.z : w0.w;
+          uint32_t P1 = kb8 < 2 ? w1.x : kb8 < 4 ? w1.y : kb8 < 6 ? w1.z : w1.w;
+          uint32_t S = kb8 < 2 ? sv.x : kb8 < 4 ? sv.y : kb8 < 6 ? sv.z : sv.w;
+          asm volatile("" : "+v"(P0), "+v"(P1), "+v"(S));
+          const uint32_t b0 = (kb8 & 1) ? (P0 & 0xF0F0F0F0u) : ((P0 << 4) & 0xF0F0F0F0u);
+          const uint32_t b1 = (kb8 & 1) ? (P1 & 0xF0F0F0F0u) : ((P1 << 4) & 0xF0F0F0F0u);
+          bop[u] = (long)(((unsigned long long)b1 << 32) | b0);
+          bs[u] = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
+        }
+        const int col = kb8 * 4 + h * 2, g = kb8 * 2 + h;
+#pragma unroll
+        for (int t = 0; t < MTL; t++) {
+          const long aop = *reinterpret_cast<const long*>(xb + (size_t)col * CS + t * 256);
+          const float4 as4 = *reinterpret_cast<const float4*>(ab + g * TOK + t * 16);
+          const float asv[4] = {as4.x, as4.y, as4.z, as4.w};
 #pragma unroll
           for (int u = 0; u < NU; u++) {
-            const uint32_t b0 = (w.w[u][h * 2].x << nsh) & 0xF0F0F0F0u, b1 = (w.w[u][h * 2 + 1].x << nsh) & 0xF0F0F0F0u;
-            bop[u] = (long)(((unsigned long long)b1 << 32) | b0);
-            bs[u] = __uint_as_float((w.s[u][h].x << ssh) & 0xffff0000u);
-          }
-          const int col = (p4 * 2 + par) * 4 + h * 2, g = (p4 * 2 + par) * 2 + h;
+            const v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop[u], v4i{0, 0, 0, 0}, 0, 0, 0);
 #pragma unroll
-          for (int t = 0; t < MT; t++) {
-            const long aop = *reinterpret_cast<const long*>(xb + (size_t)col * CS + t * 256);
-            const float4 as4 = *reinterpret_cast<const float4*>(ab + g * TOK + t * 16);
-            const float asv[4] = {as4.x, as4.y, as4.z, as4.w};
-#pragma unroll
-            for (int u = 0; u < NU; u++) {
-              const v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop[u], v4i{0, 0, 0, 0}, 0, 0, 0);
-#pragma unroll
-              for (int r = 0; r < 4; r++) acc[u][t][r] = fmaf(asv[r] * bs[u], (float)d[r], acc[u][t][r]);
-            }
+            for (int r = 0; r < 4; r++) acc[u][t][r] = fma1(mul1(asv[r], bs[u]), (float)d[r], acc[u][t][r]);
           }
         }
       }
-#pragma unroll
-      for (int u = 0; u < NU; u++) {
-#pragma unroll
-        for (int q = 0; q < 4; q++) w.w[u][q] = make_uint4(w.w[u][q].y, w.w[u][q].z, w.w[u][q].w, w.w[u][q].x);
-#pragma unroll
-        for (int h = 0; h < 2; h++) w.s[u][h] = make_uint4(w.s[u][h].y, w.s[u][h].z, w.s[u][h].w, w.s[u][h].x);
-      }
     }
   };
+  const int mt_live = (tile.nrows + 15) >> 4;
+  auto compute = [&](const WStep& w, int buf) __attribute__((always_inline)) {
+    if (mt_live >= 4) compute_n(std::integral_constant<int, 4>{}, w, buf);
+    else if (mt_live == 3) compute_n(std::integral_constant<int, 3>{}, w, buf);
+    else if (mt_live == 2) compute_n(std::integral_constant<int, 2>{}, w, buf);
+    else compute_n(std::integral_constant<int, 1>{}, w, buf);
+  };
 
-  // The next step's weights are requested before the current step's MFMAs (registers), its activations AFTER them (staging
-  // registers live across the MFMAs of a step cost more than they hide); the CU's second workgroup computes while this one stages.
   WStep wa, wb2;
+  XStage xg;
   load_w(wa, 0);
-  stage(0, 0);
+  load_x(xg, 0);
+  store_x(xg, 0);
   __syncthreads();
   for (int st = 0; st < NS; st += 2) {
-    if (st + 1 < NS) load_w(wb2, st + 1);
+    if (st + 1 < NS) { load_w(wb2, st + 1); load_x(xg, st + 1); }
     compute(wa, 0);
-    if (st + 1 < NS) stage(st + 1, 1);
+    if (st + 1 < NS) store_x(xg, 1);     // buffer 1 was last read in step st - 1: every wavefront is past that step's barrier
     __syncthreads();
     if (st + 1 < NS) {
-      if (st + 2 < NS) load_w(wa, st + 2);
+      if (st + 2 < NS) { load_w(wa, st + 2); load_x(xg, st + 2); }
       compute(wb2, 1);
-      if (st + 2 < NS) stage(st + 2, 0);
+      if (st + 2 < NS) store_x(xg, 0);
       __syncthreads();
     }
   }
@@ -3298,8 +3318,8 @@ static int launch_rawint4_chunk(const RawGemmParams& p, int max_tiles, hipStream
   static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_rawint4_chunk_kernel<GATE_UP>),
                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   KTX_HIP(err);
-  const int per_wg = GATE_UP ? 4 : 8;       // strips per workgroup (down: two strips per wavefront)
-  hipLaunchKernelGGL((moe_rawint4_chunk_kernel<GATE_UP>), dim3((p.N / 16 + per_wg - 1) / per_wg, max_tiles), dim3(256), lds, st, p);
+  const int per_wg = GATE_UP ? 8 : 16;      // strips per workgroup of 8 wavefronts (down: two strips per wavefront)
+  hipLaunchKernelGGL((moe_rawint4_chunk_kernel<GATE_UP>), dim3((p.N / 16 + per_wg - 1) / per_wg, max_tiles), dim3(512), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

@@ -107,6 +107,36 @@ def test_fp8_forward(K, N, T):
     close(y, linear_fp8_ref(x, w, sc, bias), rel=2e-3)
 
 
+@pytest.mark.parametrize("K,N,T", [(256, 64, 128), (1536, 200, 300), (2048, 576, 513), (7168, 2112, 2048), (512, 4096, 1000)])
+def test_fp8_prompt_gemm_is_the_strip_kernel_bit_for_bit(K, N, T, monkeypatch):
+    """Prompt-sized FP8 calls (T >= 128) run act_quant once + lin_fp8_gemm_kernel (csrc/ktx_linear_fp8gemm.inc): the same four MFMAs
+    per 128-block in the same order, the same (dot * a_s) * b_s accumulation and the same output rounding as the strip kernel every
+    other test of this file pins to the reference (lin_gemm_kernel<FP8>) — so the two paths must agree bit for bit: ragged T and N
+    (partial 128-tiles), bias, the GLU epilogue, the decoder layer's adds, a fused input norm, strided rows; and against
+    oracle/linear_ref.py at the file's FP8 bound."""
+    n = native()
+    torch.manual_seed(K + N + T)
+    w = (torch.randn(N, K) / 4).to(torch.float8_e4m3fn)
+    sc = (torch.rand((N + 127) // 128, K // 128) + 0.5) / 32
+    x = (torch.randn(T, K) / 10).to(torch.bfloat16).cuda()
+    bias = (torch.randn(N) / 10).to(torch.bfloat16) if N % 3 == 0 else None
+    h = n.LinearHandle(K, N, "FP8", 128, T)
+    h.load_fp8(w.cuda(), sc.cuda(), bias.cuda() if bias is not None else None)
+    add1 = (torch.randn(T, N) / 10).to(torch.bfloat16).cuda()
+    nw = (1 + torch.randn(K) / 10).to(torch.bfloat16).cuda()
+    xs = torch.zeros(T, K + 64, dtype=torch.bfloat16, device="cuda")[:, :K]
+    xs.copy_(x)
+    calls = [dict(), dict(add1=add1), dict(norm=(nw, 1e-6)), dict(add1=add1, add2=add1)]
+    if N % 16 == 0 and bias is None:
+        calls.append(dict(glu=True))
+    got = [h.forward(x, **kw) for kw in calls] + [h.forward(xs)]
+    monkeypatch.setenv("KTX_FP8_PROMPT_KERNEL", "1")
+    want = [h.forward(x, **kw) for kw in calls] + [h.forward(xs)]
+    for a, b, kw in zip(got, want, calls + [dict(strided=True)]):
+        assert a.shape == b.shape and torch.equal(a, b), f"{kw.keys()}: {(a != b).sum().item()} of {a.numel()} outputs differ"
+    close(got[0], linear_fp8_ref(x.cpu(), w, sc, bias), rel=2e-3)
+
+
 def test_bsz_tensor_and_graph_capture():
     n = native()
     torch.manual_seed(0)
