@@ -2005,36 +2005,67 @@ __global__ __launch_bounds__(512) void moe_rawint4_chunk_kernel(RawGemmParams p)
     if (!wave_ok) return;
     const uint8_t* xb = xs + buf * XB + (kc >> 1) * CS + i * 16 + (kc & 1) * 8;
     const float* ab = as_l + buf * (AB / 4) + kc * 4;
+    // PMC of the first version (profiles/r04_j_rawint4_chunk_pmc.txt): 48 % of the wave cycles parked on s_waitcnt (every group
+    // read its activation fragments and scales from LDS and waited for them), 24 % in issue stalls (a fragment converted right
+    // behind its MFMA).  So: the fragments of group g + 1 are requested before the MFMAs of group g, and a group's eight MFMAs are
+    // issued back to back before the first result is touched.
+    struct Frag { long a[MTL]; float4 s[MTL]; };
+    auto load_frag = [&](Frag& f, int g) __attribute__((always_inline)) {      // g = kb8 * 2 + h: column 2 g, scale row g
 #pragma unroll
-    for (int kb8 = 0; kb8 < 8; kb8++) {
+      for (int t = 0; t < MTL; t++) {
+        f.a[t] = *reinterpret_cast<const long*>(xb + (size_t)(2 * g) * CS + t * 256);
+        f.s[t] = *reinterpret_cast<const float4*>(ab + g * TOK + t * 16);
+      }
+    };
+    Frag fr[2];
+    load_frag(fr[0], 0);
 #pragma unroll
-      for (int h = 0; h < 2; h++) {
-        long bop[NU];
-        float bs[NU];
+    for (int g = 0; g < 16; g++) {
+      const int kb8 = g >> 1, h = g & 1;
+      const Frag& cur = fr[g & 1];
+      long bop[NU];
+      float bs[NU];
 #pragma unroll
-        for (int u = 0; u < NU; u++) {
-          const uint4 &w0 = w.w[u][h * 2], &w1 = w.w[u][h * 2 + 1], &sv = w.s[u][h];
-          uint32_t P0 = kb8 < 2 ? w0.x : kb8 < 4 ? w0.y : kb8 < 6 ? w0.z : w0.w;
-          uint32_t P1 = kb8 < 2 ? w1.x : kb8 < 4 ? w1.y : kb8 < 6 ? w1.z : w1.w;
-          uint32_t S = kb8 < 2 ? sv.x : kb8 < 4 ? sv.y : kb8 < 6 ? sv.z : sv.w;
-          asm volatile("" : "+v"(P0), "+v"(P1), "+v"(S));
-          const uint32_t b0 = (kb8 & 1) ? (P0 & 0xF0F0F0F0u) : ((P0 << 4) & 0xF0F0F0F0u);
-          const uint32_t b1 = (kb8 & 1) ? (P1 & 0xF0F0F0F0u) : ((P1 << 4) & 0xF0F0F0F0u);
-          bop[u] = (long)(((unsigned long long)b1 << 32) | b0);
-          bs[u] = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
-        }
-        const int col = kb8 * 4 + h * 2, g = kb8 * 2 + h;
+      for (int u = 0; u < NU; u++) {
+        const uint4 &w0 = w.w[u][h * 2], &w1 = w.w[u][h * 2 + 1], &sv = w.s[u][h];
+        uint32_t P0 = kb8 < 2 ? w0.x : kb8 < 4 ? w0.y : kb8 < 6 ? w0.z : w0.w;
+        uint32_t P1 = kb8 < 2 ? w1.x : kb8 < 4 ? w1.y : kb8 < 6 ? w1.z : w1.w;
+        const uint32_t S = kb8 < 2 ? sv.x : kb8 < 4 ? sv.y : kb8 < 6 ? sv.z : sv.w;
+        asm volatile("" : "+v"(P0), "+v"(P1));
+        const uint32_t b0 = (kb8 & 1) ? (P0 & 0xF0F0F0F0u) : ((P0 << 4) & 0xF0F0F0F0u);
+        const uint32_t b1 = (kb8 & 1) ? (P1 & 0xF0F0F0F0u) : ((P1 << 4) & 0xF0F0F0F0u);
+        bop[u] = (long)(((unsigned long long)b1 << 32) | b0);
+        bs[u] = __uint_as_float((kb8 & 1) ? (S & 0xffff0000u) : (S << 16));
+      }
+      if (g + 1 < 16) load_frag(fr[(g + 1) & 1], g + 1);
 #pragma unroll
-        for (int t = 0; t < MTL; t++) {
-          const long aop = *reinterpret_cast<const long*>(xb + (size_t)col * CS + t * 256);
-          const float4 as4 = *reinterpret_cast<const float4*>(ab + g * TOK + t * 16);
-          const float asv[4] = {as4.x, as4.y, as4.z, as4.w};
+      for (int t0 = 0; t0 < MTL; t0 += 2) {          // four MFMAs in flight (two token groups x two operands), then their 16 results
+        v4i d[2][NU];
 #pragma unroll
-          for (int u = 0; u < NU; u++) {
-            const v4i d = __builtin_amdgcn_mfma_i32_16x16x32_i8(aop, bop[u], v4i{0, 0, 0, 0}, 0, 0, 0);
+        for (int tt = 0; tt < 2; tt++)
 #pragma unroll
-            for (int r = 0; r < 4; r++) acc[u][t][r] = fma1(mul1(asv[r], bs[u]), (float)d[r], acc[u][t][r]);
-          }
+          for (int u = 0; u < NU; u++)
+            if (t0 + tt < MTL) d[tt][u] = __builtin_amdgcn_mfma_i32_16x16x32_i8(cur.a[t0 + tt], bop[u], v4i{0, 0, 0, 0}, 0, 0, 0);
+        // products, conversions, then the fmas: a dependent pair of VALU instructions back to back stalls the issue (the first
+        // version's `mul -> fma` / `cvt -> fma` chains showed as 30 % SQ_WAIT_INST_ANY)
+#pragma unroll
+        for (int tt = 0; tt < 2; tt++) {
+          if (t0 + tt >= MTL) continue;
+          const int t = t0 + tt;
+          const float asv[4] = {cur.s[t].x, cur.s[t].y, cur.s[t].z, cur.s[t].w};
+          float pm[NU][4], cf[NU][4];
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) pm[u][r] = mul1(asv[r], bs[u]);
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) cf[u][r] = (float)d[tt][u][r];
+#pragma unroll
+          for (int u = 0; u < NU; u++)
+#pragma unroll
+            for (int r = 0; r < 4; r++) acc[u][t][r] = fma1(pm[u][r], cf[u][r], acc[u][t][r]);
         }
       }
     }
