@@ -3508,7 +3508,7 @@ extern "C" int ktx_moe_merge_partials(int nparts, int qlen, int hidden, const fl
 template <int WT, int MT, bool GATE_UP>
 static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = gg_nbs(WT);
-  const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4 + (WT == GG_IQ1S ? 2048 * 8 : 0);
+  const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4 + (WT == GG_IQ1S ? 4096 * 8 : 0);
   hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
@@ -3550,9 +3550,9 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   {
     const int tg = h->gg_type[0], td = h->gg_type[2];
     const int nkb1 = H / 256, nkb2 = I / 256;
-    const size_t lds_gu = (size_t)H + (size_t)nkb1 * (gg_nbs(tg) + 1) * 4 + 8 + (tg == GG_IQ1S ? 2048 * 8 : 0);
+    const size_t lds_gu = (size_t)H + (size_t)nkb1 * (gg_nbs(tg) + 1) * 4 + 8 + (tg == GG_IQ1S ? 4096 * 8 : 0);
     const size_t lds_dn = (size_t)k * I + (size_t)k * nkb2 * (gg_nbs(td) + 1) * 4 + (size_t)k * (16 + 2) * 4 + 8 +
-                          (td == GG_IQ1S ? 2048 * 8 : 0);
+                          (td == GG_IQ1S ? 4096 * 8 : 0);
     if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && lds_gu <= 64 * 1024 && lds_dn <= 64 * 1024 && !g_force_generic) {
       GgDecParams dp;
       dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
