@@ -1276,14 +1276,20 @@ struct FpGemmParams {
   bf16_t* out;                // [sorted rows][N]
 };
 
-template <bool FP8, int MT, bool GATE_UP>
-__global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
-  constexpr int NMAT = GATE_UP ? 2 : 1;
+// WIDE (round 4, the prompt configuration MT = 4): 8 wavefronts per workgroup and two B operands per wavefront for BOTH GEMMs (gate and up
+// of a strip; two strips of down).  At 64 rows per expert every weight byte is read once, but every workgroup re-reads the tile's
+// bf16 activations — with 4 strips per workgroup that was as many bytes as the fp8 weights themselves (7.5 GB against 6.4 GB per
+// DeepSeek-V3 gate|up layer; 3.5x the weights for down) and the kernel ran at the CUs' ingest rate, not HBM's (profiles/r04_bench2).
+// Per output the arithmetic is unchanged (same MFMA chain per 128-k group, same scale fma): bit-identical results.
+template <bool FP8, int MT, bool GATE_UP, bool WIDE = false>
+__global__ __launch_bounds__(WIDE ? 512 : 256) void moe_gemm_fp_kernel(FpGemmParams p) {
+  constexpr int NMAT = (GATE_UP || WIDE) ? 2 : 1;      // B operands (units) per wavefront
+  constexpr int NWV = WIDE ? 8 : 4;
   constexpr int SPC = 2;                      // k-steps per chunk
   constexpr int COLS = SPC * 16;              // 16-byte columns per chunk (128 bf16 = 256 B per step)
   constexpr int BUF_BYTES = MT * COLS * 256;
   constexpr int GROUPS = MT * COLS / 4;       // staging groups of (16 tok x 4 cols)
-  constexpr int UPT = (GROUPS + 3) / 4;
+  constexpr int UPT = (GROUPS + NWV - 1) / NWV;
   constexpr int TILE_BYTES = FP8 ? 2048 : 4096;
   constexpr int NQ = FP8 ? 2 : 4;             // uint4 per lane per k-step per matrix
 
@@ -1296,21 +1302,29 @@ __global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
   const Tile tile = p.tiles[tile_idx];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int strip = blockIdx.x * 4 + wave;
   const int NKS = p.K / 128;
   const int NC = (NKS + SPC - 1) / SPC;
-  const bool strip_ok = strip * 16 < p.N;
+  int ustrip[NMAT];
+  bool uok[NMAT];
+#pragma unroll
+  for (int m = 0; m < NMAT; m++) {
+    ustrip[m] = GATE_UP ? blockIdx.x * NWV + wave : (WIDE ? (blockIdx.x * NWV + wave) * 2 + m : blockIdx.x * NWV + wave);
+    uok[m] = ustrip[m] * 16 < p.N;
+  }
+  const bool strip_ok = uok[0];      // (a wavefront's second strip of down can only be missing when the first is present)
 
   if (tid < MT * 16) s_src[tid] = tid < tile.nrows ? (p.row_src ? p.row_src[tile.row0 + tid] : tile.row0 + tid) : -1;
   __syncthreads();
 
   const uint8_t* wbase[NMAT];
   const float* sbase[NMAT];
-  wbase[0] = p.w0 + (size_t)tile.expert * p.expert_stride + (size_t)strip * NKS * TILE_BYTES;
-  sbase[0] = FP8 ? p.s0 + (size_t)tile.expert * p.scale_stride + (size_t)(strip * 16 / 128) * NKS : nullptr;
-  if constexpr (GATE_UP) {
-    wbase[1] = p.w1 + (size_t)tile.expert * p.expert_stride + (size_t)strip * NKS * TILE_BYTES;
-    sbase[1] = FP8 ? p.s1 + (size_t)tile.expert * p.scale_stride + (size_t)(strip * 16 / 128) * NKS : nullptr;
+#pragma unroll
+  for (int m = 0; m < NMAT; m++) {
+    const int st = uok[m] ? ustrip[m] : 0;                  // a strip past N aliases strip 0 and is not stored
+    const uint8_t* w = (GATE_UP && m) ? p.w1 : p.w0;
+    const float* sc = (GATE_UP && m) ? p.s1 : p.s0;
+    wbase[m] = w + (size_t)tile.expert * p.expert_stride + (size_t)st * NKS * TILE_BYTES;
+    sbase[m] = FP8 ? sc + (size_t)tile.expert * p.scale_stride + (size_t)(st * 16 / 128) * NKS : nullptr;
   }
 
   v4f acc[NMAT][MT];
@@ -1338,7 +1352,7 @@ __global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
   auto load_b = [&](int c) {
 #pragma unroll
     for (int it = 0; it < UPT; it++) {
-      const int g = it * 4 + wave;
+      const int g = it * NWV + wave;
       uint4 v = make_uint4(0, 0, 0, 0);
       if (g < GROUPS) {
         const int mt = g / (COLS / 4), col = (g % (COLS / 4)) * 4 + (lane >> 4);
@@ -1352,7 +1366,7 @@ __global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
   auto store_b = [&](int buf) {
 #pragma unroll
     for (int it = 0; it < UPT; it++) {
-      const int g = it * 4 + wave;
+      const int g = it * NWV + wave;
       if (g < GROUPS) {
         const int mt = g / (COLS / 4), col = (g % (COLS / 4)) * 4 + (lane >> 4);
         *reinterpret_cast<uint4*>(Bs + buf * BUF_BYTES + ((mt * COLS + col) * 16 + (lane & 15)) * 16) = breg[it];
@@ -1430,28 +1444,32 @@ __global__ __launch_bounds__(256) void moe_gemm_fp_kernel(FpGemmParams p) {
 
   if (!strip_ok) return;
   const int tok = lane & 15;
-  const int n0 = strip * 16 + (lane >> 4) * 4;
 #pragma unroll
-  for (int t = 0; t < MT; t++) {
-    const int row = t * 16 + tok;
-    if (row < tile.nrows) {
-      bf16_t o[4];
+  for (int m = 0; m < (GATE_UP ? 1 : NMAT); m++) {       // gate|up: one output per wavefront (both units); down: one per unit
+    if (!uok[m]) continue;
+    const int n0 = ustrip[m] * 16 + (lane >> 4) * 4;
 #pragma unroll
-      for (int r = 0; r < 4; r++) {
-        // FP8_PERCHANNEL: the whole-K sum times the row's scale (apply_scale_perchannel, amx_raw_kernels.hpp:686-700); x * 1.0f
-        // is exact, so the other formats are untouched
-        const float rs0 = p.r0 ? p.r0[(size_t)tile.expert * p.N + n0 + r] : 1.0f;
-        const bf16_t g = f32_to_bf16(acc[0][t][r] * rs0);
-        if constexpr (GATE_UP) {
-          const float rs1 = p.r1 ? p.r1[(size_t)tile.expert * p.N + n0 + r] : 1.0f;
-          const bf16_t u = f32_to_bf16(acc[1][t][r] * rs1);
-          o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
-        } else {
-          o[r] = g;
+    for (int t = 0; t < MT; t++) {
+      const int row = t * 16 + tok;
+      if (row < tile.nrows) {
+        bf16_t o[4];
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+          // FP8_PERCHANNEL: the whole-K sum times the row's scale (apply_scale_perchannel, amx_raw_kernels.hpp:686-700); x * 1.0f
+          // is exact, so the other formats are untouched
+          const float rs0 = p.r0 ? p.r0[(size_t)tile.expert * p.N + n0 + r] : 1.0f;
+          const bf16_t g = f32_to_bf16(acc[m][t][r] * rs0);
+          if constexpr (GATE_UP) {
+            const float rs1 = p.r1 ? p.r1[(size_t)tile.expert * p.N + n0 + r] : 1.0f;
+            const bf16_t u = f32_to_bf16(acc[1][t][r] * rs1);
+            o[r] = f32_to_bf16(act_fn(bf16_to_f32(g), bf16_to_f32(u)));
+          } else {
+            o[r] = g;
+          }
         }
+        *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * p.N + n0) =
+            make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
       }
-      *reinterpret_cast<uint2*>(p.out + (size_t)(tile.row0 + row) * p.N + n0) =
-          make_uint2((uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16));
     }
   }
 }
@@ -2907,18 +2925,20 @@ static int launch_gemm_mt(int mt, const GemmParams& p, int max_tiles, hipStream_
 
 template <bool FP8, bool GATE_UP>
 static int launch_gemm_fp(int mt, const FpGemmParams& p, int max_tiles, hipStream_t st) {
-  const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
-#define KTX_FP_LAUNCH(MT)                                                                                              \
-  do {                                                                                                                 \
-    constexpr size_t lds = 2 * (MT * 32 * 256) + MT * 16 * sizeof(int);                                                \
-    static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp_kernel<FP8, MT, GATE_UP>),   \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                 \
-    KTX_HIP(err);                                                                                                      \
-    hipLaunchKernelGGL((moe_gemm_fp_kernel<FP8, MT, GATE_UP>), grid, dim3(256), lds, st, p);                           \
+  const int nstrips = (p.N + 15) / 16;
+#define KTX_FP_LAUNCH(MT, WIDE, PER_WG, NTH)                                                                                  \
+  do {                                                                                                                        \
+    constexpr size_t lds = 2 * (MT * 32 * 256) + MT * 16 * sizeof(int);                                                       \
+    static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp_kernel<FP8, MT, GATE_UP, WIDE>),    \
+                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    KTX_HIP(err);                                                                                                             \
+    hipLaunchKernelGGL((moe_gemm_fp_kernel<FP8, MT, GATE_UP, WIDE>), dim3((nstrips + PER_WG - 1) / PER_WG, max_tiles), dim3(NTH), lds, st, p); \
   } while (0)
-  if (mt == 1) KTX_FP_LAUNCH(1);
-  else if (mt == 2) KTX_FP_LAUNCH(2);
-  else KTX_FP_LAUNCH(4);
+  if (mt == 1) KTX_FP_LAUNCH(1, false, 4, 256);
+  else if (mt == 2) KTX_FP_LAUNCH(2, false, 4, 256);
+  else if (g_dbg[30] == 1) KTX_FP_LAUNCH(4, false, 4, 256);          // A/B: the round-3 configuration (4 strips per workgroup)
+  else if (GATE_UP) KTX_FP_LAUNCH(4, true, 8, 512);
+  else KTX_FP_LAUNCH(4, true, 16, 512);
 #undef KTX_FP_LAUNCH
   KTX_HIP(hipGetLastError());
   return 0;
