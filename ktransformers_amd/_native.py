@@ -777,13 +777,15 @@ class LinearHandle:
             strided = False
         T = x2.shape[0]
         n_out = self.N // 2 if glu else self.N
-        if (self.fmt == "W4" and self.batch == 1 and T >= self.PROMPT_MIN_T and bsz_tensor is None
-                and not os.environ.get("KTX_W4_PROMPT_KERNEL") and not torch.cuda.is_current_stream_capturing()):
+        # (the GEMM behind the prompt paths wants K % 64 == 0, N % 8 == 0 and 16-byte aligned rows: other shapes stay on the strip
+        # kernels, which take any out_features — ADVICE r3)
+        gemm_ok = (self.batch == 1 and bsz_tensor is None and self.N % 8 == 0 and self.K % 64 == 0 and x2.data_ptr() % 16 == 0
+                   and (x2.stride(0) * 2) % 16 == 0 and not torch.cuda.is_current_stream_capturing())
+        if (self.fmt == "W4" and gemm_ok and T >= self.PROMPT_MIN_T and not os.environ.get("KTX_W4_PROMPT_KERNEL")):
             if norm is not None:
                 x2 = rmsnorm(x2.contiguous(), norm[0], norm[1], native_rounding=True)
             return self._prompt_forward(x2, out, add1, add2, glu).reshape(*x.shape[:-1], n_out)
-        if (self.fmt == "FP8" and self.batch == 1 and T >= self.FP8_PROMPT_MIN_T and bsz_tensor is None and self.N % 8 == 0
-                and not os.environ.get("KTX_FP8_PROMPT_KERNEL") and not torch.cuda.is_current_stream_capturing()):
+        if (self.fmt == "FP8" and gemm_ok and T >= self.FP8_PROMPT_MIN_T and not os.environ.get("KTX_FP8_PROMPT_KERNEL")):
             if norm is not None:
                 x2 = rmsnorm(x2.contiguous(), norm[0], norm[1], native_rounding=True)
             return self._prompt_forward_fp8(x2, out, add1, add2, glu).reshape(*x.shape[:-1], n_out)
@@ -1067,7 +1069,11 @@ class GateHandle:
         [3E, H] (split once per weight tensor and version)."""
         if weight.dtype == torch.bfloat16:
             return weight.contiguous()
-        key = (weight.data_ptr(), weight._version, weight.device)
+        try:
+            ver = weight._version
+        except RuntimeError:      # inference-mode tensors do not track a version: the storage address has to do
+            ver = -1
+        key = (weight.data_ptr(), ver, weight.device)
         hit = getattr(self, "_planes", None)
         if hit is None or hit[0] != key:
             hit = self._planes = (key, split_f32_bf16x3(weight.to(torch.float32)))
@@ -1123,7 +1129,10 @@ class GateHandle:
         if (x.dtype == torch.bfloat16 and weight.dim() == 2 and weight.dtype in (torch.bfloat16, torch.float32)
                 and weight.shape[1] % 64 == 0 and weight.shape[0] % 4 == 0 and not os.environ.get("KTX_VENDOR_GEMM")):
             planes = self._planes_of(weight)
-            l3 = gemm_bf16_nt(x.reshape(T, -1), planes, out_f32=True)
+            xg = x.reshape(T, -1)
+            if xg.stride(1) != 1 or xg.stride(0) % 8 or xg.data_ptr() % 16:      # the GEMM reads 16-byte pieces of whole rows
+                xg = xg.contiguous()
+            l3 = gemm_bf16_nt(xg, planes, out_f32=True)
             E_ = weight.shape[0]
             logits = l3 if planes.shape[0] == E_ else ((l3[:, 2 * E_:] + l3[:, E_:2 * E_]) + l3[:, :E_]).contiguous()
         if logits is None:
