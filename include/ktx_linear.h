@@ -40,6 +40,9 @@ enum ktx_linear_format {
   KTX_LIN_BF16 = 0, /* dense bf16 weights (KLinearTorch) */
   KTX_LIN_W4 = 1,   /* Marlin/GPTQ symmetric uint4, zero point 8, bf16 scale per (group of `group_size` inputs, output) */
   KTX_LIN_FP8 = 2,  /* e4m3 weights + fp32 scale_inv per 128x128 block; activations quantised to e4m3 per 128 inputs */
+  KTX_LIN_W8 = 3,   /* Marlin/GPTQ symmetric uint8, zero point 128, bf16 scale per (group of `group_size` inputs, output): one byte per
+                       weight in HBM; the kernels multiply bf16 activations with Marlin's own multiplicand bf16((q - 128) * s),
+                       formed in registers (KLinearMarlin num_bits = 8, archive/ktransformers/operators/linear.py:608-666) */
 };
 
 typedef struct ktx_linear_config {
@@ -151,6 +154,10 @@ int ktx_linear_forward_qb_absorb(ktx_linear_t q_b, ktx_linear_t q_absorb, int T,
  * gptq_marlin_gemm multiplies bf16 activations with (custom_marlin/gptq_marlin).  For prompt-sized calls (hundreds of tokens)
  * the operator de-quantises into a scratch buffer with this call and runs a plain library GEMM on it (F.linear -> hipBLASLt):
  * the weight bytes are expanded once per call instead of once per 64-token tile, and the arithmetic is the reference's. */
+/* KTX_LIN_W8 handles: q uint8 [in][out] in 0..255, s bf16 [in / group][out] — the (q_w, s) of quantize_weights(w, 8, group)
+ * (custom_marlin/quantize/utils/quant_utils.py:36-98), the orientation of ktx_linear_load_w4. */
+int ktx_linear_load_w8(ktx_linear_t h, const uint8_t* d_q, const void* d_s, const void* d_bias);
+
 int ktx_linear_dequant_bf16(ktx_linear_t h, void* d_out, int64_t ld_out, ktx_stream_t stream);
 
 /* Prompt-sized calls of an FP8 handle (KLinearFP8.forward, archive/ktransformers/operators/linear.py:388-436: act_quant +

@@ -125,6 +125,7 @@ def _load() -> C.CDLL:
     lib.ktx_linear_destroy.argtypes = [C.c_void_p]
     lib.ktx_linear_load_bf16.argtypes = [C.c_void_p] * 3
     lib.ktx_linear_load_w4.argtypes = [C.c_void_p] * 4
+    lib.ktx_linear_load_w8.argtypes = [C.c_void_p] * 4
     lib.ktx_linear_load_fp8.argtypes = [C.c_void_p] * 4
     lib.ktx_linear_forward.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
     lib.ktx_linear_forward_batched.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p,
@@ -621,7 +622,7 @@ def moe_combine(rows: torch.Tensor, row_of_pair: torch.Tensor, weights: torch.Te
     return out
 
 
-LIN_FMT = {"BF16": 0, "W4": 1, "FP8": 2}
+LIN_FMT = {"BF16": 0, "W4": 1, "FP8": 2, "W8": 3}
 
 
 class LinearHandle:
@@ -738,6 +739,14 @@ class LinearHandle:
         b = self._bias(bias)
         torch.cuda.synchronize(self.device)
         check(lib.ktx_linear_load_w4(self._h, q.data_ptr(), s.data_ptr(), b.data_ptr() if b is not None else None))
+
+    def load_w8(self, q: torch.Tensor, s: torch.Tensor, bias: torch.Tensor | None = None) -> None:
+        """q: uint8 [in, out] in 0..255, s: bf16 [in/group, out] — the (q_w, s) of quantize_weights(w, 8, group)."""
+        q = self._chk(q, torch.uint8, (self.K, self.N), "load_w8 q")
+        s = self._chk(s, torch.bfloat16, (self.K // self.group_size, self.N), "load_w8 s")
+        b = self._bias(bias)
+        torch.cuda.synchronize(self.device)
+        check(lib.ktx_linear_load_w8(self._h, q.data_ptr(), s.data_ptr(), b.data_ptr() if b is not None else None))
 
     def load_fp8(self, weight: torch.Tensor, scale_inv: torch.Tensor, bias: torch.Tensor | None = None) -> None:
         """weight: float8_e4m3fn (or its uint8 bytes) [out, in]; scale_inv fp32 [ceil(out/128), ceil(in/128)]."""

@@ -43,7 +43,9 @@ namespace {
 
 #include "ktx_w4_step.inc"
 
-constexpr int F_BF16 = KTX_LIN_BF16, F_W4 = KTX_LIN_W4, F_FP8 = KTX_LIN_FP8;
+constexpr int F_BF16 = KTX_LIN_BF16, F_W4 = KTX_LIN_W4, F_FP8 = KTX_LIN_FP8, F_W8 = KTX_LIN_W8;
+constexpr bool lin_group_scaled(int f) { return f == F_W4 || f == F_W8; }   // bf16 scale per (group, output): [tile][16][GPK]
+constexpr const char* lin_fmt_name(int f) { return f == F_W4 ? "W4" : f == F_FP8 ? "FP8" : f == F_W8 ? "W8" : "BF16"; }
 
 __device__ __forceinline__ lv8bf as_v8bf(const uint4& u) {
   union { uint4 u; lv8bf v; } c;
@@ -125,9 +127,9 @@ __device__ __forceinline__ void lin_select_batch(LinParams& p, int b) {
 
 template <int FMT, int G>
 struct Fmt {
-  static constexpr int NQ = FMT == F_W4 ? 1 : FMT == F_FP8 ? 2 : 4;
+  static constexpr int NQ = FMT == F_W4 ? 1 : (FMT == F_FP8 || FMT == F_W8) ? 2 : 4;
   static constexpr int TILE = NQ * 1024;
-  static constexpr int GPK = FMT == F_W4 ? 128 / G : 1;   // scale groups per k-step
+  static constexpr int GPK = lin_group_scaled(FMT) ? 128 / G : 1;   // scale groups per k-step
   static constexpr int JPG = 4 / GPK;                     // MFMAs per group
 };
 
@@ -153,6 +155,23 @@ __device__ __forceinline__ void lin_step(const uint4 (&w)[Fmt<FMT, G>::NQ], cons
     acc[1] = fmaf(tmp[1] * as.y, bs, acc[1]);
     acc[2] = fmaf(tmp[2] * as.z, bs, acc[2]);
     acc[3] = fmaf(tmp[3] * as.w, bs, acc[3]);
+  } else if constexpr (FMT == F_W8) {
+    // The BF16 format's k-step with the weights formed in registers: the lane's 32 bytes are its row's 32 inputs k = kc * 32 + [0, 32)
+    // of the step (one scale group for G >= 32), each expanded to Marlin's multiplicand bf16((q - 128) * s): q * s and 128 * s are
+    // exact in fp32 (8 x 8 significant bits), so fma(q, s, -128 s) IS (q - 128) * s and the pack rounds it once — bit for bit the
+    // matrix KLinearMarlin's 8-bit mode held as a BF16 handle before round 4, at half the bytes.
+    const float s = w4_scale(sc, (((int)threadIdx.x & 63) >> 4) * 32 / G), ms = -128.0f * s;
+#pragma unroll
+    for (int j = 0; j < 4; j++) {
+      const uint32_t d0 = (j & 1) ? w[j >> 1].z : w[j >> 1].x, d1 = (j & 1) ? w[j >> 1].w : w[j >> 1].y;
+      uint4 f;
+      f.x = ktx_pk_bf16(fmaf((float)(d0 & 0xffu), s, ms), fmaf((float)((d0 >> 8) & 0xffu), s, ms));
+      f.y = ktx_pk_bf16(fmaf((float)((d0 >> 16) & 0xffu), s, ms), fmaf((float)(d0 >> 24), s, ms));
+      f.z = ktx_pk_bf16(fmaf((float)(d1 & 0xffu), s, ms), fmaf((float)((d1 >> 8) & 0xffu), s, ms));
+      f.w = ktx_pk_bf16(fmaf((float)((d1 >> 16) & 0xffu), s, ms), fmaf((float)(d1 >> 24), s, ms));
+      const uint4 xa = *reinterpret_cast<const uint4*>(xb + j * cs);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(as_v8bf(xa), as_v8bf(f), acc, 0, 0, 0);
+    }
   } else {
 #pragma unroll
     for (int j = 0; j < 4; j++) {
@@ -320,7 +339,7 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
       const u4v v = __builtin_nontemporal_load(reinterpret_cast<const u4v*>(wp + (size_t)ks * F::TILE + q * 1024));
       wr[d][q] = make_uint4(v.x, v.y, v.z, v.w);
     }
-    if constexpr (FMT == F_W4) sr[d] = load_w4_scales<F::GPK>(sp4 + (size_t)ks * 16 * F::GPK);
+    if constexpr (lin_group_scaled(FMT)) sr[d] = load_w4_scales<F::GPK>(sp4 + (size_t)ks * 16 * F::GPK);
     else if constexpr (FMT == F_FP8) sr[d] = make_uint2(__float_as_uint(sp8[ks]), 0);
     else sr[d] = make_uint2(0, 0);
   };
@@ -923,7 +942,7 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(LinParams p) {
 #pragma unroll
         for (int q = 0; q < F::NQ; q++)
           dst[s][q] = *reinterpret_cast<const uint4*>(wp + (size_t)ks * F::TILE + q * 1024);
-        if constexpr (FMT == F_W4) sdst[s] = load_w4_scales<F::GPK>(sp4 + (size_t)ks * 16 * F::GPK);
+        if constexpr (lin_group_scaled(FMT)) sdst[s] = load_w4_scales<F::GPK>(sp4 + (size_t)ks * 16 * F::GPK);
         else if constexpr (FMT == F_FP8) sdst[s] = make_uint2(__float_as_uint(sp8[ks]), 0);
         else sdst[s] = make_uint2(0, 0);
       }
@@ -1316,6 +1335,38 @@ __global__ __launch_bounds__(64) void lin_pack_w4_kernel(const uint8_t* __restri
   }
 }
 
+// W8, pre-quantised: q uint8 [Kx][N], s bf16 [Kx/G][N] -> tiles in the fp8 / bf16 element order (lane (i, kc): row i's 32 inputs
+// k = ks * 128 + kc * 32 + [0, 32); plane 0 = the first 16, plane 1 = the rest) + group scales in the W4 layout [tile][16][GPK]
+template <int G>
+__global__ __launch_bounds__(64) void lin_pack_w8_kernel(const uint8_t* __restrict__ q, const bf16_t* __restrict__ s, int N, int Kx,
+                                                         int NKS, uint4* __restrict__ tiles, bf16_t* __restrict__ scales) {
+  constexpr int GPK = 128 / G;
+  const int tile = blockIdx.x, strip = tile / NKS, ks = tile % NKS;
+  const int lane = threadIdx.x, n = strip * 16 + (lane & 15), kc = lane >> 4;
+#pragma unroll
+  for (int pl = 0; pl < 2; pl++) {
+    uint32_t d[4];
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+      d[u] = 0;
+#pragma unroll
+      for (int b = 0; b < 4; b++) {
+        const int k = ks * 128 + kc * 32 + pl * 16 + u * 4 + b;
+        const uint32_t v = (n < N && k < Kx) ? q[(size_t)k * N + n] : 128u;      // padding: (128 - 128) * s = 0
+        d[u] |= v << (8 * b);
+      }
+    }
+    tiles[((size_t)tile * 2 + pl) * 64 + lane] = make_uint4(d[0], d[1], d[2], d[3]);
+  }
+  if (kc == 0) {
+#pragma unroll
+    for (int gi = 0; gi < GPK; gi++) {
+      const int k = ks * 128 + gi * G;
+      scales[((size_t)tile * 16 + (lane & 15)) * GPK + gi] = (n < N && k < Kx) ? s[(size_t)(k / G) * N + n] : (bf16_t)0;
+    }
+  }
+}
+
 // fp8 / bf16 row-major [N][Kx] -> tiles: plane q of a tile holds the lane's elements [q*16/esz, +16/esz) of its 32-k run
 __global__ __launch_bounds__(64) void lin_pack_plain_kernel(const uint8_t* __restrict__ src, int N, int Kx, int NKS, int esz,
                                                             uint4* __restrict__ tiles) {
@@ -1416,7 +1467,7 @@ void lin_free(void* p) {
 
 namespace {
 
-int tile_bytes(int fmt) { return fmt == F_W4 ? 1024 : fmt == F_FP8 ? 2048 : 4096; }
+int tile_bytes(int fmt) { return fmt == F_W4 ? 1024 : (fmt == F_FP8 || fmt == F_W8) ? 2048 : 4096; }
 
 int set_bias(ktx_linear_s* h, const void* d_bias) {
   if (h->d_bias) { lin_free(h->d_bias); h->d_bias = nullptr; }
@@ -1581,7 +1632,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
     hipDeviceProp_t prop;
     ncu = (hipGetDeviceProperties(&prop, h->cfg.device) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 256;
   }
-  const double strip_bytes = (double)NKS * (F::TILE + (FMT == F_W4 ? 16 * F::GPK * 2 : 0));
+  const double strip_bytes = (double)NKS * (F::TILE + (lin_group_scaled(FMT) ? 16 * F::GPK * 2 : 0));
   const double x_bytes = (double)NKS * 128 * 2 * p.TP + 30.0 * 1024;
   int SW = 1;
   double best = 1e30;
@@ -1676,7 +1727,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
   };
   constexpr int DMAX = FMT == F_BF16 ? 4 : 8;   // ring depth bound by registers: a BF16 k-step is 4 KiB per wave
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
-            "lin_dec_kernel<%s> %d->%d%s%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", p.Kx, p.N,
+            "lin_dec_kernel<%s> %d->%d%s%s", lin_fmt_name(FMT), p.Kx, p.N,
             h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "", p.prep_on ? " +mla_prep" : "");
   if constexpr (FMT == F_W4) {
     switch (dma_depth) {
@@ -1715,7 +1766,7 @@ int launch_gemm(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
   const dim3 grid((h->nstrips + 3) / 4, (p.T + TOK - 1) / TOK, h->batch);
   auto kern = lin_gemm_kernel<FMT, G, MT>;
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
-            "lin_gemm_kernel<%s,MT%d> T=%d %d->%d%s", FMT == F_W4 ? "W4" : FMT == F_FP8 ? "FP8" : "BF16", MT, p.T, p.Kx, p.N,
+            "lin_gemm_kernel<%s,MT%d> T=%d %d->%d%s", lin_fmt_name(FMT), MT, p.T, p.Kx, p.N,
             h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
   static bool attr_set = false;
   if (!attr_set) {
@@ -1793,10 +1844,11 @@ extern "C" int ktx_linear_create(const ktx_linear_config* cfg, ktx_linear_t* out
   KTX_REQUIRE(cfg && out, "ktx_linear_create: null argument");
   KTX_REQUIRE(cfg->in_features > 0 && cfg->out_features > 0, "ktx_linear_create: bad shape");
   KTX_REQUIRE(cfg->in_features % 8 == 0, "ktx_linear_create: in_features must be a multiple of 8");
-  KTX_REQUIRE(cfg->format >= KTX_LIN_BF16 && cfg->format <= KTX_LIN_FP8, "ktx_linear_create: unknown format");
-  if (cfg->format == KTX_LIN_W4)
+  KTX_REQUIRE(cfg->format >= KTX_LIN_BF16 && cfg->format <= KTX_LIN_W8, "ktx_linear_create: unknown format");
+  if (cfg->format == KTX_LIN_W4 || cfg->format == KTX_LIN_W8)
     KTX_REQUIRE(cfg->group_size == 32 || cfg->group_size == 64 || cfg->group_size == 128,
-                "ktx_linear_create: W4 group_size must be 32, 64 or 128");
+                "ktx_linear_create: W4 / W8 group_size must be 32, 64 or 128");
+  KTX_REQUIRE(cfg->format != KTX_LIN_W8 || cfg->batch <= 1, "ktx_linear_create: W8 handles are not batched");
   if (cfg->format == KTX_LIN_FP8) {
     KTX_REQUIRE(cfg->group_size == 128, "ktx_linear_create: FP8 block size must be 128");
     KTX_REQUIRE(cfg->in_features % 128 == 0, "ktx_linear_create: FP8 needs in_features % 128 == 0 (act_quant, fp8gemm.py:47)");
@@ -1816,7 +1868,7 @@ extern "C" int ktx_linear_create(const ktx_linear_config* cfg, ktx_linear_t* out
   h->NKS = (cfg->in_features + 127) / 128;
   h->batch = cfg->batch > 1 ? cfg->batch : 1;
   h->w_bytes = (size_t)h->batch * h->nstrips * h->NKS * tile_bytes(cfg->format);
-  if (cfg->format == KTX_LIN_W4) h->sc_bytes = (size_t)h->batch * h->nstrips * h->NKS * 16 * (128 / cfg->group_size) * 2;
+  if (cfg->format == KTX_LIN_W4 || cfg->format == KTX_LIN_W8) h->sc_bytes = (size_t)h->batch * h->nstrips * h->NKS * 16 * (128 / cfg->group_size) * 2;
   else if (cfg->format == KTX_LIN_FP8) h->sc_bytes = (size_t)h->batch * ((h->nstrips + 7) / 8) * h->NKS * 4;
   hipError_t e = lin_alloc((void**)&h->d_w, h->w_bytes, cfg->device);
   if (e == hipSuccess && h->sc_bytes) e = lin_alloc(&h->d_sc, h->sc_bytes, cfg->device);
@@ -1852,6 +1904,7 @@ extern "C" int ktx_linear_destroy(ktx_linear_t h) {
 extern "C" int ktx_linear_load_bf16(ktx_linear_t h, const void* d_w, const void* d_bias) {
   KTX_REQUIRE(h && d_w, "ktx_linear_load_bf16: null argument");
   KTX_REQUIRE(h->cfg.format != KTX_LIN_FP8, "ktx_linear_load_bf16: FP8 handles load e4m3 weights (ktx_linear_load_fp8)");
+  KTX_REQUIRE(h->cfg.format != KTX_LIN_W8, "ktx_linear_load_bf16: W8 handles load quantised weights (ktx_linear_load_w8)");
   KTX_HIP(hipSetDevice(h->cfg.device));
   // a batched handle is loaded as one tall [batch*N][K] matrix (N % 16 == 0, so strips never straddle batches)
   const int N = h->cfg.out_features * h->batch, Kx = h->cfg.in_features, ntiles = h->nstrips * h->batch * h->NKS;
@@ -1892,6 +1945,24 @@ extern "C" int ktx_linear_load_w4(ktx_linear_t h, const uint8_t* d_q, const void
   return 0;
 }
 
+extern "C" int ktx_linear_load_w8(ktx_linear_t h, const uint8_t* d_q, const void* d_s, const void* d_bias) {
+  KTX_REQUIRE(h && d_q && d_s, "ktx_linear_load_w8: null argument");
+  KTX_REQUIRE(h->cfg.format == KTX_LIN_W8, "ktx_linear_load_w8: handle is not W8");
+  KTX_HIP(hipSetDevice(h->cfg.device));
+  const int N = h->cfg.out_features, Kx = h->cfg.in_features, ntiles = h->nstrips * h->NKS;
+  const bf16_t* s = (const bf16_t*)d_s;
+  switch (h->cfg.group_size) {
+    case 32: hipLaunchKernelGGL(lin_pack_w8_kernel<32>, dim3(ntiles), dim3(64), 0, 0, d_q, s, N, Kx, h->NKS, (uint4*)h->d_w, (bf16_t*)h->d_sc); break;
+    case 64: hipLaunchKernelGGL(lin_pack_w8_kernel<64>, dim3(ntiles), dim3(64), 0, 0, d_q, s, N, Kx, h->NKS, (uint4*)h->d_w, (bf16_t*)h->d_sc); break;
+    default: hipLaunchKernelGGL(lin_pack_w8_kernel<128>, dim3(ntiles), dim3(64), 0, 0, d_q, s, N, Kx, h->NKS, (uint4*)h->d_w, (bf16_t*)h->d_sc); break;
+  }
+  KTX_HIP(hipGetLastError());
+  KTX_HIP(hipDeviceSynchronize());
+  if (int rc = set_bias(h, d_bias)) return rc;
+  h->loaded = true;
+  return 0;
+}
+
 extern "C" int ktx_linear_load_fp8(ktx_linear_t h, const void* d_w, const float* d_scale_inv, const void* d_bias) {
   KTX_REQUIRE(h && d_w && d_scale_inv, "ktx_linear_load_fp8: null argument");
   KTX_REQUIRE(h->cfg.format == KTX_LIN_FP8, "ktx_linear_load_fp8: handle is not FP8");
@@ -1913,7 +1984,7 @@ namespace {
 bool dec_fits(const ktx_linear_s* h, int T) {
   const int ncol16 = h->cfg.format == KTX_LIN_FP8 ? h->NKS * 8 : h->NKS * 16;
   const int TP = T <= 1 ? 1 : T <= 2 ? 2 : 4;
-  const int gpk = h->cfg.format == KTX_LIN_W4 ? 128 / h->cfg.group_size : 1;
+  const int gpk = (h->cfg.format == KTX_LIN_W4 || h->cfg.format == KTX_LIN_W8) ? 128 / h->cfg.group_size : 1;
   const size_t dec_smem = (size_t)ncol16 * TP * 16 + (size_t)h->NKS * gpk * 16 + 2048;
   return T <= 4 && dec_smem <= 160 * 1024 && !g_lin_force_gemm;
 }
@@ -1964,6 +2035,12 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   switch (h->cfg.format) {
     case KTX_LIN_BF16: return forward_fmt<F_BF16, 128>(h, p, st, gate);
     case KTX_LIN_FP8: return forward_fmt<F_FP8, 128>(h, p, st, gate);
+    case KTX_LIN_W8:
+      switch (h->cfg.group_size) {
+        case 32: return forward_fmt<F_W8, 32>(h, p, st, gate);
+        case 64: return forward_fmt<F_W8, 64>(h, p, st, gate);
+        default: return forward_fmt<F_W8, 128>(h, p, st, gate);
+      }
     default:
       switch (h->cfg.group_size) {
         case 32: return forward_fmt<F_W4, 32>(h, p, st, gate);

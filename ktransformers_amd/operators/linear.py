@@ -113,11 +113,10 @@ class KLinearTorch(KLinearBase):
         self.loaded = True
 
 
-def marlin_multiplicand(weight: torch.Tensor, num_bits: int, group_size: int) -> torch.Tensor:
-    """[N, K] bf16 weights -> the [N, K] bf16 matrix gptq_marlin_gemm multiplies activations with: quantize_weights on weight.T
-    (custom_marlin/quantize/utils/quant_utils.py:36-98 — s = max|w| * 2/(2^bits - 1) per group and output, q = clamp(round(w / s)
-    + 2^(bits-1), 0, 2^bits - 1), every step in the tensor's own bf16 arithmetic) and Marlin's in-register de-quantisation
-    bf16((q - 2^(bits-1)) * s) (kt-kernel/cuda/gptq_marlin/gptq_marlin.cu: dequant + scale).  torch ops on the weight's device."""
+def marlin_quantize(weight: torch.Tensor, num_bits: int, group_size: int):
+    """[N, K] bf16 weights -> (q [N, K/g, g] float, signed: quantised value minus 2^(bits-1); s [N, K/g, 1] bf16) = quantize_weights on
+    weight.T (custom_marlin/quantize/utils/quant_utils.py:36-98 — s = max|w| * 2/(2^bits - 1) per group and output, q = clamp(round(w / s)
+    + 2^(bits-1), 0, 2^bits - 1), every step in the tensor's own bf16 arithmetic).  torch ops on the weight's device."""
     n, k = weight.shape
     g = k if group_size == -1 else group_size
     if k % g:
@@ -130,7 +129,14 @@ def marlin_multiplicand(weight: torch.Tensor, num_bits: int, group_size: int) ->
     q = torch.round(w / sc)
     q = torch.where(sc == 0, torch.full_like(q, -half), q)          # int(NaN) + half clamps to 0 in the reference
     q = torch.clamp(q.float() + half, 0, qmax) - half
-    return (q * sc.float()).to(torch.bfloat16).view(n, k)
+    return q, sc
+
+
+def marlin_multiplicand(weight: torch.Tensor, num_bits: int, group_size: int) -> torch.Tensor:
+    """[N, K] bf16 weights -> the [N, K] bf16 matrix gptq_marlin_gemm multiplies activations with: marlin_quantize, then Marlin's
+    in-register de-quantisation bf16((q - 2^(bits-1)) * s) (kt-kernel/cuda/gptq_marlin/gptq_marlin.cu: dequant + scale)."""
+    q, sc = marlin_quantize(weight, num_bits, group_size)
+    return (q * sc.float()).to(torch.bfloat16).view(weight.shape)
 
 
 class KLinearMarlin(KLinearBase):
@@ -138,9 +144,10 @@ class KLinearMarlin(KLinearBase):
     reference.
       * num_bits = 4 (every rule file of the reference): the native W4 format — packed nibbles + bf16 group scales, the W4
         decode GEMVs and prompt GEMM of csrc/ktx_linear.hip.
-      * num_bits = 8: Marlin's own multiplicand bf16((q - 128) * s) is computed at load and held in the library's BF16 format
-        (2 bytes per weight instead of 1): the same products and fp32 accumulation as gptq_marlin_gemm's 8-bit path; no
-        byte-saving W8 kernel exists here because no rule file of the reference selects 8 bits.
+      * num_bits = 8: the native W8 format (round 4) — one byte per weight + bf16 group scales in HBM, Marlin's own multiplicand
+        bf16((q - 128) * s) formed in registers in front of the bf16 MFMA: the same products and fp32 accumulation as
+        gptq_marlin_gemm's 8-bit path, bit-identical to holding that matrix as a BF16 handle (which is what rounds 2-3 did, and what
+        still happens for group sizes the W8 tiles do not carry: anything but 32, 64 or a multiple of 128).
       * act_order: the reference "simulates" it by a random permutation of the K rows of the STORED q_w with g_idx / sort_indices
         undoing it inside the kernel (quant_utils.py:15-33,82-92) — scales and quantised values are computed before the permutation,
         so the product x @ dequant(w) is the same matrix product; this layout needs no such permutation and the flag is accepted."""
@@ -157,7 +164,8 @@ class KLinearMarlin(KLinearBase):
         self.num_bits, self.group_size, self.act_order, self.is_k_full = num_bits, group_size, act_order, is_k_full
         self.k, self.n = self.in_features, self.out_features
         if num_bits == 8:
-            self.FMT = "BF16"
+            g = self.in_features if group_size == -1 else group_size
+            self.FMT = "W8" if (g in (32, 64) or g % 128 == 0) and self.in_features % g == 0 else "BF16"
 
     def load(self, w=None, device: str | None = None):
         if self.loaded:
@@ -171,12 +179,20 @@ class KLinearMarlin(KLinearBase):
         weight = weight.data.to(self.device, torch.bfloat16).view(self.out_features, self.in_features).contiguous()
         self.has_bias = bias is not None
         g = self.in_features if self.group_size == -1 else self.group_size
-        if self.num_bits == 8:
-            weight = marlin_multiplicand(weight, 8, g).contiguous()
+        b = bias.data.to(self.device, torch.bfloat16) if bias is not None else None
+        if self.num_bits == 8 and self.FMT == "W8":
+            q, sc = marlin_quantize(weight, 8, g)                                   # [N, K/g, g] signed, [N, K/g, 1]
+            qu = (q + 128).to(torch.uint8).view(self.out_features, self.in_features).T.contiguous()          # [K, N]
+            hg = min(g, 128)                                                         # groups of a multiple of 128 inputs: one scale per 128
+            st = sc.view(self.out_features, -1).repeat_interleave(g // hg, dim=1).T.contiguous()            # [K/hg, N]
+            self._h = self._make_handle(hg)
+            self._h.load_w8(qu, st, b)
+        elif self.num_bits == 8:
             self._h = self._make_handle()
+            self._h.load_bf16(marlin_multiplicand(weight, 8, g).contiguous(), b)
         else:
             self._h = self._make_handle(g)
-        self._h.load_bf16(weight, bias.data.to(self.device, torch.bfloat16) if bias is not None else None)
+            self._h.load_bf16(weight, b)
         # the reference exposes marlin_q_w here and consumers only use it for shape/device: no bf16 copy is kept
         self.weight = torch.empty((self.in_features, self.out_features), dtype=torch.bfloat16, device="meta")
         self.loaded = True

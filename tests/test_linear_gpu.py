@@ -137,6 +137,37 @@ def test_fp8_prompt_gemm_is_the_strip_kernel_bit_for_bit(K, N, T, monkeypatch):
     close(got[0], linear_fp8_ref(x.cpu(), w, sc, bias), rel=2e-3)
 
 
+@pytest.mark.parametrize("K,N,G", [(2048, 576, 64), (1536, 200, 32), (7168, 2112, 128), (1024, 64, -1), (384, 48, 128)])
+def test_w8_format_is_the_bf16_kernel_on_marlins_multiplicand_bit_for_bit(K, N, G):
+    """The W8 format (include/ktx_linear.h: KTX_LIN_W8, round 4): one byte per weight in HBM, bf16((q - 128) * s) formed in registers
+    in front of the BF16 format's MFMAs — so a W8 handle and a BF16 handle loaded with that very matrix must agree bit for bit, for
+    decode rows, small and prompt-sized batches, with bias, fused norm, adds and the GLU epilogue; per-channel scales (G = -1) ride
+    as groups of 128.  (The multiplicand itself is pinned to the reference's quantize_weights in tests/test_linear_cpu.py.)"""
+    n = native()
+    from ktransformers_amd.operators.linear import marlin_multiplicand, marlin_quantize
+    torch.manual_seed(K + N + G)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16).cuda()
+    g = K if G == -1 else G
+    hg = min(g, 128)
+    bias = (torch.randn(N) / 10).to(torch.bfloat16).cuda() if N % 3 == 0 else None
+    q, sc = marlin_quantize(w, 8, g)
+    h8 = n.LinearHandle(K, N, "W8", hg, 512)
+    h8.load_w8((q + 128).to(torch.uint8).view(N, K).T.contiguous(), sc.view(N, -1).repeat_interleave(g // hg, dim=1).T.contiguous(), bias)
+    hb = n.LinearHandle(K, N, "BF16", 0, 512)
+    hb.load_bf16(marlin_multiplicand(w, 8, g).contiguous(), bias)
+    assert h8.weight_bytes() < 0.6 * hb.weight_bytes()
+    nw = (1 + torch.randn(K) / 10).to(torch.bfloat16).cuda()
+    for T in (1, 2, 4, 5, 33, 300):
+        x = (torch.randn(T, K) / 10).to(torch.bfloat16).cuda()
+        add1 = (torch.randn(T, N) / 10).to(torch.bfloat16).cuda()
+        calls = [dict(), dict(norm=(nw, 1e-6)), dict(add1=add1)]
+        if N % 16 == 0 and bias is None:
+            calls.append(dict(glu=True))
+        for kw in calls:
+            a, b = h8.forward(x, **kw), hb.forward(x, **kw)
+            assert torch.equal(a, b), f"T={T} {list(kw)}: {(a != b).sum().item()} of {a.numel()} outputs differ"
+
+
 def test_bsz_tensor_and_graph_capture():
     n = native()
     torch.manual_seed(0)
@@ -450,8 +481,8 @@ def test_all_cu_decode_gemv_under_a_replayed_graph_and_many_handles():
 @pytest.mark.parametrize("T", [1, 5, 70])
 def test_marlin_8bit_operator_multiplies_with_the_reference_multiplicand(T, act_order):
     """KLinearMarlin(num_bits=8) (linear.py:608-666): Marlin's 8-bit multiplicand bf16((q - 128) * s) — pinned to the reference's
-    own quantize_weights in tests/test_linear_cpu.py — held in the BF16 format; forward against fp64 math on that matrix, at
-    the bound of the BF16 kernels (one bf16 rounding of an fp32-accumulated sum)."""
+    own quantize_weights in tests/test_linear_cpu.py — now formed in registers from the W8 format (one byte per weight); forward
+    against fp64 math on that matrix, at the bound of the BF16 kernels (one bf16 rounding of an fp32-accumulated sum)."""
     from types import SimpleNamespace
     from ktransformers_amd.operators.linear import KLinearMarlin, marlin_multiplicand
     from ktransformers_amd.util.loader import DictLoader
@@ -462,7 +493,7 @@ def test_marlin_8bit_operator_multiplies_with_the_reference_multiplicand(T, act_
     op = KLinearMarlin("k", DictLoader({"k.weight": w}), SimpleNamespace(), torch.nn.Linear(K, N, bias=False, device="meta"),
                        device="cuda", num_bits=8, group_size=G, act_order=act_order)
     op.load()
-    assert op._h.fmt == "BF16" and op._h.weight_bytes() >= 2 * N * K
+    assert op._h.fmt == "W8" and N * K <= op._h.weight_bytes() < 1.1 * N * K
     y = op.forward(x.cuda())
     torch.cuda.synchronize()
     close(y.cpu(), linear_bf16_ref(x, marlin_multiplicand(w, 8, G)), rel=1e-3)
