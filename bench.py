@@ -1288,6 +1288,7 @@ def main():
     box = box_info() if rank == 0 else None     # before any work: `idle_power_w` is the idle socket power of this box
     if wl.get("kind") == "experts":
         out = {"metric": f"decode tokens/s ({wl['name']})", **run_experts_decode(args.workload, args, dev, args.steps),
+               **({} if args.no_prefill else {"prefill": run_experts_prefill(args.workload, dev, args.prefill_tokens)}),
                "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int8 x q4_k/q6_k -> int32 per block (fp32 out)", "data": "synthetic", "config": {"workload": wl["desc"]},
                "box": box}

@@ -227,8 +227,22 @@ def build_merged_linear(template: "KLinearBase", keys: list, loader, device: str
     gate_proj | up_proj): per-(group, output-row) quantisation is independent of the other rows, so the merged GEMV gives
     exactly the rows the separate operators would, in one launch.  `template` supplies the operator class and its options."""
     ws = [loader.load_tensor(k + ".weight", device=device) for k in keys]
-    if any(loader.has_tensor(k + ".weight_scale_inv") or loader.has_tensor(k + ".bias") for k in keys):
-        return None                                   # fp8 block scales / biases: keep the separate operators
+    if any(loader.has_tensor(k + ".bias") for k in keys):
+        return None                                   # biases: keep the separate operators
+    if any(loader.has_tensor(k + ".weight_scale_inv") for k in keys):
+        # block-fp8 (round 4): the 128-row scale blocks of the concatenation are the matrices' own blocks as long as every matrix but
+        # the last ends on a block boundary (q_a_proj's 1536 rows do: q_a | kv_a merge for DeepSeek-V3 / R1 fp8 checkpoints); a GLU
+        # interleave would mix two matrices inside one block and is not done
+        scs = [loader.load_tensor(k + ".weight_scale_inv", device=device) if loader.has_tensor(k + ".weight_scale_inv") else None for k in keys]
+        if (interleave8 or not isinstance(template, KLinearFP8) or any(sc is None for sc in scs)
+                or any(t.shape[0] % template.block_size for t in ws[:-1]) or len({t.shape[1] for t in ws}) != 1):
+            return None
+        w8 = torch.cat([t.view(torch.uint8) if t.dtype != torch.uint8 else t for t in ws], dim=0).contiguous()
+        sc = torch.cat([t.to(torch.float32) for t in scs], dim=0).contiguous()
+        holder = nn.Linear(w8.shape[1], w8.shape[0], bias=False, device="meta")
+        op = type(template)("+".join(keys), loader, template.config, holder, device, max_len=template.max_len, block_size=template.block_size)
+        op.load((nn.Parameter(w8.view(torch.float8_e4m3fn), requires_grad=False), nn.Parameter(sc, requires_grad=False)))
+        return op, [t.shape[0] for t in ws]
     if interleave8:   # [gate | up] -> per 16-row strip 8 gate rows then 8 up rows (the `glu` epilogue of ktx_linear_forward_fused)
         g, u = (t.to(torch.bfloat16) for t in ws)
         if g.shape != u.shape or g.shape[0] % 8 != 0:

@@ -168,6 +168,32 @@ def test_w8_format_is_the_bf16_kernel_on_marlins_multiplicand_bit_for_bit(K, N, 
             assert torch.equal(a, b), f"T={T} {list(kw)}: {(a != b).sum().item()} of {a.numel()} outputs differ"
 
 
+def test_fp8_linears_merge_on_block_boundaries():
+    """build_merged_linear for block-fp8 checkpoints (round 4): q_a_proj (1536 rows = 12 whole 128-row scale blocks) | kv_a_proj_with_mqa
+    (576 rows: the last block is partial) as ONE operator gives exactly the rows the two operators give, decode and prompt sized; a first
+    matrix that does not end on a block boundary is refused (None: the separate operators stay)."""
+    from types import SimpleNamespace
+    from ktransformers_amd.operators.linear import KLinearFP8, build_merged_linear
+    from ktransformers_amd.util.loader import DictLoader
+    torch.manual_seed(3)
+    K = 1024
+    def mk(N):
+        return (torch.randn(N, K) / 4).to(torch.float8_e4m3fn), (torch.rand((N + 127) // 128, K // 128) + 0.5) / 32
+    (wa, sa), (wb, sb), (wc, sc) = mk(1536), mk(576), mk(200)
+    ld = DictLoader({"a.weight": wa, "a.weight_scale_inv": sa, "b.weight": wb, "b.weight_scale_inv": sb, "c.weight": wc, "c.weight_scale_inv": sc})
+    ops = {}
+    for key, N in (("a", 1536), ("b", 576), ("c", 200)):
+        ops[key] = KLinearFP8(key, ld, SimpleNamespace(), torch.nn.Linear(K, N, bias=False, device="meta"), device="cuda")
+        ops[key].load()
+    merged = build_merged_linear(ops["a"], ["a", "b"], ld, "cuda")
+    assert merged is not None and merged[1] == [1536, 576]
+    assert build_merged_linear(ops["c"], ["c", "b"], ld, "cuda") is None          # 200 rows: not a block boundary
+    for T in (1, 3, 200):
+        x = (torch.randn(T, K) / 10).to(torch.bfloat16).cuda()
+        y = merged[0].forward(x)
+        assert torch.equal(y[:, :1536], ops["a"].forward(x)) and torch.equal(y[:, 1536:], ops["b"].forward(x))
+
+
 def test_bsz_tensor_and_graph_capture():
     n = native()
     torch.manual_seed(0)
