@@ -20,6 +20,7 @@ class KDeepseekV3MLP(BaseInjectedModule):
                  generate_device: str = "cuda", **kwargs):
         BaseInjectedModule.__init__(self, key, gguf_loader, config, orig_module, prefill_device, generate_device, **kwargs)
         object.__setattr__(self, "_gate_up", None)
+        object.__setattr__(self, "_gate_up_cat", None)
 
     def load(self):
         down, gate, up = self.orig_module.down_proj, self.orig_module.gate_proj, self.orig_module.up_proj
@@ -29,8 +30,17 @@ class KDeepseekV3MLP(BaseInjectedModule):
         if all(isinstance(m, KTransformersLinear) for m in (down, gate, up)) and down.generate_linear is not None:
             merged = build_merged_linear(down.generate_linear, [self.key + ".gate_proj", self.key + ".up_proj"],
                                          self.gguf_loader, down.generate_linear.device, interleave8=True)
-        if merged is not None:
-            object.__setattr__(self, "_gate_up", merged[0])
+        cat = None
+        if merged is None and all(isinstance(m, KTransformersLinear) for m in (down, gate, up)) and down.generate_linear is not None:
+            # block-fp8 (round 4): the strip-interleaved GLU layout would put gate and up rows into one 128-row scale block, the plain
+            # concatenation [gate ; up] keeps every block whole (intermediate sizes are multiples of 128): one GEMV (+ the fused input
+            # norm) and one SiLU * up launch instead of norm + two GEMVs + a concatenation + SiLU * up
+            cat = build_merged_linear(down.generate_linear, [self.key + ".gate_proj", self.key + ".up_proj"],
+                                      self.gguf_loader, down.generate_linear.device, interleave8=False)
+            if cat is not None and (len(cat[1]) != 2 or cat[1][0] != cat[1][1] or getattr(cat[0], "FMT", None) != "FP8"):
+                cat = None                             # (only the fp8 case is new; other formats keep their separate operators)
+        if merged is not None or cat is not None:
+            object.__setattr__(self, "_gate_up" if merged is not None else "_gate_up_cat", (merged or cat)[0])
             for m in (gate, up):                       # their rows live in the merged operator
                 for op in {id(m.generate_linear): m.generate_linear, id(m.prefill_linear): m.prefill_linear}.values():
                     if op is not None:
@@ -47,6 +57,8 @@ class KDeepseekV3MLP(BaseInjectedModule):
         x2 = x.reshape(-1, x.shape[-1])
         if self._gate_up is not None:       # merged GEMV with the SiLU * up epilogue
             return self._gate_up.forward(x2, norm=norm, glu=True)
+        if self._gate_up_cat is not None:   # [gate | up] rows of one GEMV, then SiLU * up
+            return silu_mul(self._gate_up_cat.forward(x2, norm=norm))
         if norm is not None:
             x2 = rmsnorm(x2, norm[0], norm[1], native_rounding=True)
         return silu_mul(torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1))

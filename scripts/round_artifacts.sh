@@ -4,7 +4,8 @@
 R=${GRAFT_REPO_ROOT:-/root/repo}; O=$R/gpurun_out/${1:-r03}; mkdir -p $O
 /opt/rocm/bin/rocm-smi --showuniqueid | grep Unique > $O/box.txt
 if [ "${2:-all}" = "all" ] || [ "$2" = "tests" ]; then
-  (cd $R && timeout 1500 python -m pytest tests -m gpu -q -rs 2>&1 | tail -15) > $O/pytest_gpu.log; tail -3 $O/pytest_gpu.log
+  # (the reference's worker pools print to the C stdout, which is flushed after pytest's own summary: keep every line that matters)
+  (cd $R && timeout 1500 python -m pytest tests -m gpu -q -rs > $O/pytest_gpu_full.log 2>&1); grep -E "^[.sFEx]+ *\[|passed|failed|error|SKIPPED|FAILED|ERROR" $O/pytest_gpu_full.log > $O/pytest_gpu.log; grep -E "passed|failed" $O/pytest_gpu.log | tail -2
 fi
 if [ "${2:-all}" = "all" ] || [ "$2" = "bench" ]; then
   (cd $R && python bench.py > $O/bench.json 2> $O/bench.err); python -c "

@@ -194,6 +194,45 @@ def test_fp8_linears_merge_on_block_boundaries():
         assert torch.equal(y[:, :1536], ops["a"].forward(x)) and torch.equal(y[:, 1536:], ops["b"].forward(x))
 
 
+def test_fp8_mlp_runs_gate_and_up_as_one_operator():
+    """KDeepseekV3MLP on a block-fp8 checkpoint (round 4): gate_proj and up_proj are loaded as ONE operator over the concatenation
+    [gate ; up] (whole 128-row scale blocks; the W4 GLU interleave would split blocks) — the SiLU * up input, and so the block's
+    output, must be bit for bit what the separate operators give, with and without the fused input norm, decode and prompt sized."""
+    from types import SimpleNamespace
+    from ktransformers_amd._native import rmsnorm, silu_mul
+    from ktransformers_amd.operators.linear import KLinearFP8, KTransformersLinear
+    from ktransformers_amd.operators.mlp import KDeepseekV3MLP
+    from ktransformers_amd.util.loader import DictLoader
+    torch.manual_seed(5)
+    H, I = 1024, 512
+    def mk(N, K):
+        return (torch.randn(N, K) / 4).to(torch.float8_e4m3fn), (torch.rand((N + 127) // 128, K // 128) + 0.5) / 32
+    st = {}
+    for nm, (N, K) in (("gate_proj", (I, H)), ("up_proj", (I, H)), ("down_proj", (H, I))):
+        w, sc = mk(N, K)
+        st[f"mlp.{nm}.weight"], st[f"mlp.{nm}.weight_scale_inv"] = w, sc
+    ld, cfg = DictLoader(st), SimpleNamespace()
+    class Orig(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            for nm, (N, K) in (("gate_proj", (I, H)), ("up_proj", (I, H)), ("down_proj", (H, I))):
+                setattr(self, nm, KTransformersLinear(f"mlp.{nm}", ld, cfg, torch.nn.Linear(K, N, bias=False, device="meta"), "cuda",
+                                                      "KLinearFP8", "cuda", "KLinearFP8"))
+    mlp = KDeepseekV3MLP("mlp", ld, cfg, Orig(), "cuda", "cuda")
+    mlp.load()
+    assert mlp._gate_up is None and mlp._gate_up_cat is not None and mlp._gate_up_cat._h.N == 2 * I
+    ops = {nm: KLinearFP8(f"mlp.{nm}", ld, cfg, torch.nn.Linear(H, I, bias=False, device="meta"), device="cuda") for nm in ("gate_proj", "up_proj")}
+    for op in ops.values():
+        op.load()
+    nw = (1 + torch.randn(H) / 10).to(torch.bfloat16).cuda()
+    for T in (1, 3, 130):
+        x = (torch.randn(T, H) / 10).to(torch.bfloat16).cuda()
+        for norm in (None, (nw, 1e-6)):
+            xn = x if norm is None else rmsnorm(x, norm[0], norm[1], native_rounding=True)
+            want = silu_mul(torch.cat([ops["gate_proj"].forward(xn), ops["up_proj"].forward(xn)], dim=-1))
+            assert torch.equal(mlp.gate_up(x, norm), want), f"T={T} norm={norm is not None}"
+
+
 def test_bsz_tensor_and_graph_capture():
     n = native()
     torch.manual_seed(0)
