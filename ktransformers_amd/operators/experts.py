@@ -420,17 +420,18 @@ class _KMoEBlock(BaseInjectedModule):
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
         shared_act = None
-        if front is not None and front.get("done"):
+        routed = front is not None and front.get("done")
+        side = None
+        if routed:
             # the attention's launch ran the norm, the router and the shared experts' gate|up on this very row
             topk_idx, topk_weight, shared_act = front["topk_idx"], front["topk_w"], front["shared_act"]
             hidden_states = front["xn"].view(*orig_shape)
-            side = None
         elif sequence_length == 1 and orig_shape[0] == 1 and (fused := self._fused_decode(hidden_states, residual, pre_norm)) is not None:
             return fused
         else:
             side = self._router_side_linear(hidden_states, pre_norm)
-        if front is not None and front.get("done"):
-            pass
+        if routed:
+            pass                                              # ids, weights and the normalised row are already here
         elif side is not None:
             # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)
             topk_idx, topk_weight, xn, shared_act = self.gate.forward_with_linear(
