@@ -75,3 +75,9 @@ def test_marlin_8bit_multiplicand_matches_the_reference_quantiser(name, G, act):
     assert torch.equal(got.view(torch.uint16)[live], want.contiguous().view(torch.uint16)[live])
     assert float(got.float()[~live].abs().max() if (~live).any() else 0.0) == 0.0                 # an all-zero group stays zero
     assert float((got.float() - w.float()).abs().max()) < float(w.float().abs().max()) / 100      # 8-bit grid: < 1 % of full scale
+    # round 4: the W8 handle is loaded with (q, s) themselves (ktx_linear_load_w8): marlin_quantize must hand out the reference's
+    from ktransformers_amd.operators.linear import marlin_quantize
+    qs, sc = marlin_quantize(w, 8, G)                                                              # [N, K/G, G] signed, [N, K/G, 1]
+    q8 = (qs + 128).to(torch.int32).view(w.shape[0], -1).T                                         # [K, N] like quantize_weights' q_w
+    assert torch.equal(sc.view(w.shape[0], -1).T.contiguous().view(torch.uint16), s.view(torch.uint16))
+    assert torch.equal(q8[live.T], q[live.T])
