@@ -481,8 +481,9 @@ def test_rawint4_prompt_chunks(oracle, dev, shape):
         assert np.array_equal(exact, want)
         assert (got != exact).mean() < 0.05
         _native.lib.ktx_debug_set(29, 0)
-        want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
-        _check_fp(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
+        if H * I <= (1 << 22):            # (the oracle's second pass over the Kimi-K2 shape would cost another ~15 s of CPU)
+            want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
+            _check_fp(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
     finally:
         _native.lib.ktx_debug_set(29, 0)
         h.close()
