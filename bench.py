@@ -1204,6 +1204,123 @@ def truncated_line(out: dict, clock: RunClock, signum: int) -> dict:
     return line
 
 
+LINE_LIMIT = 4096      # bytes: the driver parses the LAST stdout line; round 4's 25 KB line was recorded as `parsed: null`
+
+
+def _pick(d, keys):
+    return {k: d[k] for k in keys if isinstance(d, dict) and k in d and d[k] is not None}
+
+
+def compact_line(out: dict) -> dict:
+    """The ONE stdout line of a run: the driver contract's fields + `roofline` + `cpu_baseline` + one (decode, prefill) number
+    pair per secondary workload — numbers only, under LINE_LIMIT bytes.  Everything else (per-kernel tables, prose, windows,
+    box, sample descriptions) is the detail record written next to it (`write_detail`)."""
+    cfg = out.get("config") or {}
+    line = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                    "scaling", "vs_baseline", "dtype", "data")}
+    line["metric"] = str(line["metric"])[:160]
+    line["config"] = dict(_pick(cfg, ("hidden", "intermediate", "experts", "top_k", "heads", "layers", "dense_layers", "moe_layers",
+                                      "vocab", "ctx", "batch_per_gpu", "parallelism", "rccl_ranks", "hip_graph", "ep_transport_status")),
+                          workload=str(cfg.get("workload", ""))[:200])
+    if cfg.get("ep_transport"):
+        line["config"]["ep_transport"] = str(cfg["ep_transport"])[:40]
+    for k in ("error", "truncated"):
+        if out.get(k):
+            line[k] = str(out[k])[:160]
+    rf = out.get("roofline") or {}
+    line["roofline"] = dict({k: rf.get(k) for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")},
+                            **_pick(rf, ("algorithmic_bytes_per_launch", "avg_launch_us", "launches_per_step", "share_of_step")),
+                            kernel=str(rf.get("kernel", ""))[:64])
+    ws = out.get("whole_step") or {}
+    line["whole_step"] = _pick(ws, ("GBs", "frac_of_hbm_peak", "moe_layer_kernel_us", "moe_layer_frac_of_hbm_peak"))
+    if out.get("median_tok_s") is not None:
+        line["median_tok_s"] = out["median_tok_s"]
+    fd = out.get("full_depth_extrapolation") or {}
+    if fd.get("tok_s") is not None:
+        line["full_depth_extrapolation"] = _pick(fd, ("layers", "tok_s", "ms_per_step"))
+    cb = out.get("cpu_baseline")
+    if isinstance(cb, dict):
+        c = _pick(cb, ("value", "unit", "cores", "kind", "us_per_layer", "GBs", "physical_cores", "error"))
+        c["sample"] = str(cb.get("sample", ""))[:150]
+        quota = (cb.get("host") or {}).get("cpu_quota")
+        if quota is not None:
+            c["cpu_quota"] = quota
+        if isinstance(cb.get("prefill"), dict):
+            c["prefill"] = _pick(cb["prefill"], ("value", "unit", "chunk_tokens", "error"))
+        line["cpu_baseline"] = c
+
+    def _prefill(p):
+        if not isinstance(p, dict):
+            return None
+        r = _pick(p, ("value", "unit", "tokens", "ms_per_chunk", "error"))
+        prf = p.get("roofline")
+        if isinstance(prf, dict):
+            r["roofline"] = _pick(prf, ("bound", "achieved", "peak", "unit", "frac"))
+        if "error" in r:
+            r["error"] = str(r["error"])[:100]
+        return r
+
+    if out.get("prefill") is not None:
+        line["prefill"] = _prefill(out["prefill"])
+    sec = {}
+    for name in SECONDARY:
+        key = name.replace("-", "_")
+        r2 = out.get(key)
+        if not isinstance(r2, dict):
+            continue
+        s = _pick(r2, ("value", "ms_per_step", "layers"))
+        if r2.get("value") is None:
+            s["value"] = None
+            s["why"] = str(r2.get("error") or r2.get("skipped") or "")[:100]
+        if isinstance(r2.get("whole_step"), dict):
+            s["frac_of_hbm_peak"] = r2["whole_step"].get("frac_of_hbm_peak")
+        pf = r2.get("prefill")
+        if isinstance(pf, dict):
+            s["prefill"] = pf.get("value")
+            if isinstance(pf.get("roofline"), dict):
+                s["prefill_frac"] = pf["roofline"].get("frac")
+                s["prefill_bound"] = pf["roofline"].get("bound")
+        if isinstance(r2.get("ctx_131072"), dict):
+            s["ctx_131072"] = r2["ctx_131072"].get("value")
+        if isinstance(r2.get("cpu_llamafile"), dict):
+            s["cpu_llamafile"] = _pick(r2["cpu_llamafile"], ("value", "cores"))
+        sec[key] = s
+    if sec:
+        line["secondary"] = sec
+    if out.get("timing_s"):
+        line["timing_s"] = {"total": out["timing_s"].get("total")}
+    line["detail"] = DETAIL_FILE
+    # last resort (a pathological error string, a future field): drop optional blocks until the line fits
+    for k in ("timing_s", "full_depth_extrapolation", "median_tok_s", "whole_step", "secondary", "prefill"):
+        if len(json.dumps(line)) < LINE_LIMIT:
+            break
+        line.pop(k, None)
+    return line
+
+
+DETAIL_FILE = "bench_detail.json"
+
+
+def write_detail(out: dict) -> None:
+    """The full record of the run (what round 1-4 printed as one line), beside the compact line: `bench_detail.json` in the
+    working directory and, when it exists, under gpurun_out/ (the directory gpurun merges back)."""
+    text = json.dumps(out)
+    for d in (".", "gpurun_out"):
+        try:
+            if d == "." or os.path.isdir(d):
+                with open(os.path.join(d, DETAIL_FILE), "w") as f:
+                    f.write(text + "\n")
+        except OSError as e:
+            log(f"[bench] could not write {d}/{DETAIL_FILE}: {e}")
+
+
+def emit(out: dict) -> None:
+    """Detail to the side file, then the compact line as the LAST (and only) stdout line."""
+    write_detail(out)
+    sys.stdout.flush()
+    print(json.dumps(compact_line(out)), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1292,7 +1409,7 @@ def main():
                "n_gpus": 1, "steps": args.steps, "warmup": args.warmup, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
                "dtype": "int8 x q4_k/q6_k -> int32 per block (fp32 out)", "data": "synthetic", "config": {"workload": wl["desc"]},
                "box": box}
-        print(json.dumps(out), flush=True)
+        emit(out)
         return
 
     # N >= 2: the experts are sharded E/N per rank, so the WHOLE model fits from two GPUs on (327 GB of int4 experts / N)
@@ -1346,7 +1463,7 @@ def main():
 
     def _salvage(signum, frame):
         if rank == 0:
-            print(json.dumps(truncated_line(out, clock, signum)), flush=True)
+            emit(truncated_line(out, clock, signum))
         os._exit(0)
 
     try:
@@ -1501,7 +1618,7 @@ def main():
     except (ValueError, OSError):
         pass
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if dist_on:
         dist.destroy_process_group()
 

@@ -139,3 +139,70 @@ def test_time_budget_clock_and_the_truncated_line():
     assert "truncated" not in out and "roofline" not in out                      # the run's own dict is not touched
     out["roofline"] = {"kernel": "measured"}
     assert b.truncated_line(out, clock, 15)["roofline"] == {"kernel": "measured"}
+
+
+def _synthetic_full_record():
+    """A full record shaped like a real run's (`profiles/r04_z_bench.json`, the 25 KB line the driver could not parse), with
+    every prose field stretched further."""
+    rec = json.loads(open(os.path.join(ROOT, "profiles", "r04_z_bench.json")).read().strip().splitlines()[-1])
+    rec["config"]["step"] = "x" * 4000
+    rec["cpu_baseline"]["sample"] = "y" * 3000
+    rec["per_kernel"] = rec["per_kernel"] * 4
+    for k in ("v2lite_int4", "r1_iq1s", "v3_fp8", "k2_rawint4"):
+        rec[k]["prefill"]["what"] = "z" * 2000
+    rec["r1_iq1s"] = {"value": None, "error": "RuntimeError: " + "e" * 5000}
+    return rec
+
+
+def test_the_stdout_line_is_compact_and_round_trips():
+    """Round 4's headline was lost (`BENCH_r04.parsed = null`) because bench.py printed one 25 KB line.  The LAST stdout line
+    is now `compact_line(record)`: under 4 KB whatever the record holds, every contract field + roofline + cpu_baseline +
+    one number pair per secondary workload; the full record goes to bench_detail.json."""
+    import io
+    import contextlib
+    b = _bench()
+    rec = _synthetic_full_record()
+    assert len(json.dumps(rec)) > 30000
+    line = b.compact_line(rec)
+    text = json.dumps(line)
+    assert len(text) < b.LINE_LIMIT == 4096 and "\n" not in text
+    back = json.loads(text)
+    for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+              "dtype", "data", "config", "roofline", "cpu_baseline", "prefill", "secondary"):
+        assert k in back, k
+    assert back["value"] == rec["value"] and back["ms_per_step"] == rec["ms_per_step"]
+    assert isinstance(back["config"]["workload"], str) and "model" not in back["config"]
+    rf = back["roofline"]
+    for k in ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "algorithmic_bytes_per_launch", "avg_launch_us"):
+        assert k in rf, k
+    assert rf == {**rf, **{k: rec["roofline"][k] for k in ("bound", "achieved", "peak", "unit", "frac", "traffic")}}
+    cb = back["cpu_baseline"]
+    assert cb["value"] == rec["cpu_baseline"]["value"] and cb["cores"] == 16 and cb["kind"] == "reference" and len(cb["sample"]) <= 150
+    assert cb["prefill"]["value"] == rec["cpu_baseline"]["prefill"]["value"]
+    assert back["prefill"]["value"] == rec["prefill"]["value"] and back["prefill"]["roofline"]["frac"] == rec["prefill"]["roofline"]["frac"]
+    sec = back["secondary"]
+    assert set(sec) == {"v2lite_int4", "r1_iq1s", "v3_fp8", "k2_rawint4", "mixtral_q4km"}
+    assert sec["k2_rawint4"]["value"] == rec["k2_rawint4"]["value"] and sec["k2_rawint4"]["prefill"] == rec["k2_rawint4"]["prefill"]["value"]
+    assert sec["r1_iq1s"]["value"] is None and len(sec["r1_iq1s"]["why"]) <= 100            # a failed section stays visible, short
+    # what emit() prints: the detail file, then exactly one stdout line that parses on its own
+    cwd = os.getcwd()
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        os.chdir(tmp)
+        try:
+            buf = io.StringIO()
+            with contextlib.redirect_stdout(buf):
+                b.emit(rec)
+            lines = buf.getvalue().splitlines()
+            assert len(lines) == 1 and json.loads(lines[-1]) == back
+            assert json.loads(open(os.path.join(tmp, b.DETAIL_FILE)).read()) == rec
+        finally:
+            os.chdir(cwd)
+
+
+def test_compact_line_of_a_truncated_and_of_an_experts_only_record():
+    b = _bench()
+    line = b.compact_line({"metric": "m", "value": 1.0, "unit": "tok/s", "n_gpus": 1, "steps": 2, "warmup": 1, "ms_per_step": 1000.0,
+                           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8", "data": "synthetic",
+                           "config": {"workload": "w"}, "truncated": "signal 15", "whole_step": {"GBs": 1.0, "frac_of_hbm_peak": 0.1}})
+    assert line["truncated"] == "signal 15" and line["roofline"]["frac"] is None and len(json.dumps(line)) < 4096
