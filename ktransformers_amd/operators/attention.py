@@ -349,11 +349,11 @@ class KDeepseekV2Attention(BaseInjectedModule):
                                   pos, inv_freq, mscale, H, nope, rope, lora, self.v_head_dim, cache[:, :, 0, :lora], cache[:, :, 0, lora:],
                                   past_key_value.page_size, kv_indptr, None if identity else kv_indices, kv_len, hint, self.softmax_scale,
                                   moe_front=front)
-        if ok is None:
-            ok = N.attn_decode_eligible(args)
-            object.__setattr__(self, "_fused_ok", ok)
-            if not ok:
-                return None
+        # eligibility depends on the per-call context bound (`hint` picks the split shape), so it is asked on every call — a
+        # host-only check; only the handle formats above are memoised.  A context that leaves the covered range mid-generation
+        # falls back to the five launches (same arithmetic), and comes back when a later request is short again.
+        if not N.attn_decode_eligible(args):
+            return None
         N.attn_decode(args, dev)
         if front is not None:
             front["done"] = True
