@@ -442,6 +442,11 @@ def timed(fn, steps, warmup, dev, dist_on):
         dist.barrier()
     torch.cuda.synchronize(dev)
     dt = time.perf_counter() - t0
+    # a bounded hand-off inside the one-launch attention step that gave up leaves undefined results and a status word: no number then
+    from ktransformers_amd import _native
+    bad_dev, st = _native.attn_status_any()
+    if st != 0:
+        raise RuntimeError(f"one-launch attention step on cuda:{bad_dev}: a hand-off timed out during the timed region (status {st:#x})")
     if dist_on:
         t = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

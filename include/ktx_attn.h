@@ -74,15 +74,25 @@ typedef struct ktx_attn_decode_args {
   float* d_topk_w;                   /* [top_k] */
 } ktx_attn_decode_args;
 
-/* 1 when ktx_attn_decode covers this configuration on the current device (DeepSeek-V3 / R1 attention dimensions, W4 g64
- * projections without bias, as many CUs as 2 x heads), else 0 with the reason in ktx_last_error(). */
+/* 1 when ktx_attn_decode covers this configuration on the current device (nope 128 / rope 64 / kv_lora 512 / v 128, hidden 7168 and
+ * q_lora 1536 — the DeepSeek-V3 / R1 and Kimi-K2 attention — with 128 or 64 heads, W4 g64 projections without bias, at least 256
+ * CUs, a context whose KV split count fits one head group's workgroups), else 0 with the reason in ktx_last_error().  The answer
+ * depends on kv_len_hint (it picks the split shape): ask per call, not once per layer. */
 int ktx_attn_decode_eligible(const ktx_attn_decode_args* a);
 
+/* The launch is PERSISTENT: 256 workgroups that wait for each other.  All of them must be resident at once, so (1) at most one such
+ * launch may be in flight per device — launches of one stream are ordered; launches issued from a second stream are ordered behind the
+ * device's previous one by an event the library records (eager mode; inside a stream capture the caller keeps one capture per
+ * device) — and (2) a foreign kernel occupying CUs for longer than the poll bound (0.2 s) makes a hand-off give up: the launch then
+ * ends with undefined results and the status word below is set. */
 int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t stream);
 
-/* Status word of the device's workspace: 0, or the code of the first hand-off that timed out (the launch then finished
- * with undefined results instead of hanging).  The caller checks it once per generated token batch. */
+/* Status word of a device: 0, or the code of the first hand-off that timed out (the launch then finished with undefined results
+ * instead of hanging).  The device writes the word into pinned host memory at the moment a poll gives up, so these calls are plain
+ * host loads — no synchronisation — and a decode loop checks after EVERY token.  ktx_attn_status_any: the first device with a
+ * non-zero word (device_out = -1 if none).  ktx_attn_reset synchronises the device, clears the word and re-arms the workspaces. */
 int ktx_attn_status(int device, uint32_t* status_out);
+int ktx_attn_status_any(int* device_out, uint32_t* status_out);
 int ktx_attn_reset(int device);
 
 /* tests: copy a workspace array of the last launch (0 q_a|kv_a row, 1 ckv_new, 2 kpe_new, 3 q_lat, 4 q_pe, 5 merged rows, 6 attn_out,

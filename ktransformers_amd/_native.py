@@ -194,6 +194,7 @@ def _load() -> C.CDLL:
     lib.ktx_attn_decode.argtypes = [C.POINTER(_AttnDecodeArgs), C.c_void_p]
     lib.ktx_attn_status.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
     lib.ktx_attn_reset.argtypes = [C.c_int]
+    lib.ktx_attn_status_any.argtypes = [C.POINTER(C.c_int), C.POINTER(C.c_uint32)]
     lib.ktx_attn_debug_read.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
     lib.ktx_attn_debug_stamps.argtypes = [C.c_void_p]
     return lib
@@ -987,6 +988,20 @@ def attn_status(device) -> int:
     st = C.c_uint32(0)
     check(lib.ktx_attn_status(dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(st)))
     return int(st.value)
+
+
+def attn_status_any() -> tuple[int, int]:
+    """(device, status) of the first device whose one-launch attention step saw a hand-off give up, (-1, 0) if none.  A host load
+    of a pinned word the device writes: cheap enough to call after every decode step."""
+    dev, st = C.c_int(-1), C.c_uint32(0)
+    check(lib.ktx_attn_status_any(C.byref(dev), C.byref(st)))
+    return int(dev.value), int(st.value)
+
+
+def attn_reset(device) -> None:
+    """Synchronise `device`, clear its status word and re-arm the workspaces after a timed-out hand-off."""
+    dev = torch.device(device)
+    check(lib.ktx_attn_reset(dev.index if dev.index is not None else torch.cuda.current_device()))
 
 
 def attn_debug_read(device, name: str, shape, dtype=torch.bfloat16) -> torch.Tensor:

@@ -27,6 +27,7 @@
 // workspace status word and the launch runs to its end with undefined results instead of hanging the GPU.
 #include "ktx_common.h"
 
+#include <cstring>
 #include <mutex>
 
 #include "../../include/ktx_attn.h"
@@ -51,7 +52,8 @@ constexpr int DA = 7;                   // phase A: k-steps per wavefront (hidde
 constexpr int NK2 = 6;                  // phase B: k-steps per k-half of q_b (q_lora = 2 * 6 * 128)
 constexpr int NOPE = 128, ROPE = 64, LORA = 512, VDIM = 128, QW = NOPE + ROPE;
 constexpr int SPH = QW / 16;            // q_b strips per head (12)
-constexpr int MAXS = 64;                // KV splits (one flag lane each)
+constexpr int GRID = 256;               // workgroups of the launch: one per CU, all resident
+constexpr int MAXS = 128;               // KV splits at most (64 heads: 2 head groups x 128; 128 heads: 4 x 64)
 constexpr int KROW = LORA + ROPE + 8;   // staged latent row: 584 elements (ktx_mla.hip)
 constexpr int TILE = 32;
 constexpr unsigned long long SPIN_TICKS = 20000000ull;   // 0.2 s of the 100 MHz wall clock
@@ -69,12 +71,12 @@ __host__ __device__ inline WsLayout ws_layout(int H, int nA) {
   WsLayout L;
   unsigned o = 256;
   auto take = [&](unsigned bytes) { const unsigned r = o; o += (bytes + 255u) & ~255u; return r; };
-  const int NWG = 2 * H;
+  const int NWG = GRID, SPG = GRID / (H / 32);   // splits per head group
   L.fA = take(4 * (nA > NWG ? nA : NWG)); L.fKV = take(4); L.fB = take(4 * NWG); L.fX = take(4 * NWG); L.fC = take(4 * NWG);
   L.fM = take(4 * NWG); L.fD = take(4 * NWG); L.fE = take(4 * NWG); L.gran = take(8 * NWG);
   L.qkv = take(2 * 16 * nA); L.ckv_new = take(2 * LORA); L.kpe_new = take(2 * ROPE);
   L.qx = take(2 * H * NOPE); L.q_lat = take(2 * H * LORA); L.q_pe = take(2 * H * ROPE); L.om = take(2 * H * LORA);
-  L.attn_out = take(2 * H * VDIM); L.part_ml = take(4 * H * MAXS * 2); L.part_o = take(4u * H * MAXS * LORA);
+  L.attn_out = take(2 * H * VDIM); L.part_ml = take(4 * H * SPG * 2); L.part_o = take(4u * H * SPG * LORA);
   L.total = o;
   return L;
 }
@@ -97,7 +99,7 @@ struct AttnParams {
   // phase D
   const uint8_t* wUV; size_t wbsUV;
   // phase E
-  const uint8_t* wE; const bf16_t* scE; int nksE, nE, eQ, eR;
+  const uint8_t* wE; const bf16_t* scE; int nksE, nksE_sh, nE, eQ, eR;
   bf16_t* y;
   // phase F (the MoE block's front: post_attention_layernorm + router + shared experts' gate|up on the row phase E produces)
   const bf16_t* post_norm_w; float post_eps;
@@ -106,6 +108,7 @@ struct AttnParams {
   bf16_t* xn_out; bf16_t* shared_act_out; int64_t* topk_idx; float* topk_w;
   // workspace
   uint8_t* ws; unsigned ws_bytes;
+  unsigned* hstatus;   // host-mapped copy of the status word (pinned): the host reads it every step without touching the device
   int last;
   unsigned long long* stamps;
 };
@@ -144,7 +147,10 @@ __device__ __forceinline__ void poll_flags(const AttnParams& p, const unsigned* 
     if (__all(ok)) return;
     if (ld_word(hdr + W_STATUS) != 0) return;
     if (wall_clock64() - t0 > SPIN_TICKS) {
-      if (lane == 0) st_word(hdr + W_STATUS, (unsigned)code);
+      if (lane == 0) {
+        st_word(hdr + W_STATUS, (unsigned)code);
+        if (p.hstatus) __hip_atomic_store(p.hstatus, (unsigned)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
       return;
     }
     __builtin_amdgcn_s_sleep(2);
@@ -167,6 +173,43 @@ __device__ __forceinline__ void w4_kstep1(const uint4& w, const uint2& sc, const
     const float s = w4_scale(sc, gi);
     acc = fmaf(s, fmaf(-136.f, aux[gi * 4], tmp[0]), acc);
   }
+}
+// Block-FP8 (e4m3 weights, fp32 scale per 128 x 128 block; activations quantised per 128-k block as act_quant does), one token row:
+// lin_step<F_FP8>'s arithmetic (ktx_linear.hip) for row 0 — acc += dot_128 * a_s * b_s (fp8gemm.py:156)
+__device__ __forceinline__ long at_lo64(const uint4& u) { return (long)(((uint64_t)u.y << 32) | u.x); }
+__device__ __forceinline__ long at_hi64(const uint4& u) { return (long)(((uint64_t)u.w << 32) | u.z); }
+__device__ __forceinline__ void fp8_kstep1(const uint4& w0, const uint4& w1, float bs, const uint8_t* xb, float as, float& acc) {
+  const uint4 xa0 = *reinterpret_cast<const uint4*>(xb), xa1 = *reinterpret_cast<const uint4*>(xb + 16);
+  v4f tmp = {0.f, 0.f, 0.f, 0.f};
+  tmp = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(at_lo64(xa0), at_lo64(w0), tmp, 0, 0, 0);
+  tmp = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(at_hi64(xa0), at_hi64(w0), tmp, 0, 0, 0);
+  tmp = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(at_lo64(xa1), at_lo64(w1), tmp, 0, 0, 0);
+  tmp = __builtin_amdgcn_mfma_f32_16x16x32_fp8_fp8(at_hi64(xa1), at_hi64(w1), tmp, 0, 0, 0);
+  acc = fmaf(tmp[0] * as, bs, acc);
+}
+// act_quant of one 16-byte piece (8 bf16) of a 128-k block held by 16 consecutive lanes: returns the 8 e4m3 bytes, `s` = amax / 448
+// of the block (lin_dec_body's stage_piece: same expressions)
+__device__ __forceinline__ uint2 fp8_quant_piece(const uint4& v, float& s) {
+  const uint32_t d[4] = {v.x, v.y, v.z, v.w};
+  float am = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; i++) am = fmaxf(am, fmaxf(fabsf(__uint_as_float(d[i] << 16)), fabsf(__uint_as_float(d[i] & 0xffff0000u))));
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1) am = fmaxf(am, __shfl_xor(am, o, 64));
+  s = am / 448.f;
+  float f[8];
+#pragma unroll
+  for (int i = 0; i < 4; i++) {
+    const float a = __uint_as_float(d[i] << 16), b = __uint_as_float(d[i] & 0xffff0000u);
+    f[2 * i] = s > 0.f ? a / s : 0.f;
+    f[2 * i + 1] = s > 0.f ? b / s : 0.f;
+  }
+  uint32_t o0, o1;
+  o0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+  o0 = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], o0, true);
+  o1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+  o1 = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], o1, true);
+  return make_uint2(o0, o1);
 }
 // BF16 tile of four 1 KiB planes, one k-step of 128: plane j contracts k = kc * 32 + j * 8 + e
 __device__ __forceinline__ void bf16_kstep(const uint4 (&w)[4], const uint8_t* xb, v4f& acc) {
@@ -246,15 +289,24 @@ __device__ __forceinline__ bf16_t glu_bf16(float g, float u) {
 }
 
 // =====================================================================================================================================
-template <int MASK>
+// FMT = the format of the three quantised projections (q_a|kv_a, q_b, o_proj): KTX_LIN_W4 (g64) or KTX_LIN_FP8 (128 x 128 blocks)
+template <int MASK, int FMT>
 __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   static_assert((MASK & PH_F) == 0 || (MASK & PH_E) != 0, "the MoE front runs in the launch that produces its input row");
+  static_assert(FMT == KTX_LIN_W4 || FMT == KTX_LIN_FP8, "W4 g64 or block-FP8 projections");
+  static_assert((MASK & PH_F) == 0 || FMT == KTX_LIN_W4, "the MoE front is built for the W4 shared experts");
+  constexpr bool F8 = FMT == KTX_LIN_FP8;
+  constexpr int NQ = F8 ? 2 : 1, TB = NQ * 1024;   // 1 KiB planes per weight tile, bytes per tile
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const uint32_t smem_lds = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;   // LDS byte address of the dynamic region
-  const int w = blockIdx.x, H = p.H, NWG = 2 * H;
-  const int h = w & (H - 1), part = w / H;           // phases B and D: head and which half (H is a power of two times ... see eligibility)
+  const int w = blockIdx.x, H = p.H, NWG = GRID, NWB = 2 * H;
+  // phases B and D: two workgroups per head — (head, half) = (w % H, w / H) for w < 2 H (H = 64 or 128: the other workgroups of a
+  // 64-head model sit those two phases out and take part in A, C and E)
+  const int h = w & (H - 1), part = w / H;
+  const bool doBD = w < NWB;
+  const int SPG = GRID / (H >> 5), SPG_SH = H == 128 ? 6 : 7;   // KV splits per head group of 32 heads (64 / 128), its log2
   unsigned* hdr = reinterpret_cast<unsigned*>(p.ws);
   const WsLayout L = ws_layout(H, p.nA);
   const __amdgpu_buffer_rsrc_t rs = ws_rsrc(p);
@@ -276,7 +328,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   const int npieceA = p.hidden >> 3;
   const bool doA = (MASK & PH_A) && w < p.nA;
   uint4 xrA[XRA], nwA[XRA];
-  uint4 wrA[DA];
+  uint4 wrA[DA][NQ];
   uint2 srA[DA];
   if constexpr ((MASK & PH_A) != 0) {
 #pragma unroll
@@ -292,8 +344,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     const long tile0 = (long)sA * p.nksA + wave * DA;
 #pragma unroll
     for (int d = 0; d < DA; d++) {
-      wrA[d] = nt_load16(p.wA + (tile0 + d) * 1024 + lane * 16);
-      srA[d] = load_w4_scales<2>(p.scA + ((tile0 + d) * 16 + (lane & 15)) * 2);
+#pragma unroll
+      for (int q = 0; q < NQ; q++) wrA[d][q] = nt_load16(p.wA + (tile0 + d) * TB + q * 1024 + lane * 16);
+      if constexpr (F8) srA[d] = make_uint2(__float_as_uint(reinterpret_cast<const float*>(p.scA)[(size_t)(sA >> 3) * p.nksA + wave * DA + d]), 0);
+      else srA[d] = load_w4_scales<2>(p.scA + ((tile0 + d) * 16 + (lane & 15)) * 2);
     }
   }
   // ---- phase B: q_a_layernorm weights, rope table inputs, the head's q_b tiles (waves 0..5: one strip, both k-halves) and
@@ -302,7 +356,8 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   float ropePos = 0.f, ropeIf = 0.f;
   // one register file for both wave roles: waves 0..5 hold rb[0..11] = their q_b strip (k-half kh, step s_ at kh * 6 + s_) and
   // rb[12..15] = their absorb strip; waves 6..7 hold rb[4 i .. 4 i + 3] = absorb strip i of their five
-  uint4 rb[20];
+  constexpr int ABS0 = 2 * NK2 * NQ;               // first absorb register of waves 0..5 (behind their q_b tiles)
+  uint4 rb[ABS0 + 4 > 20 ? ABS0 + 4 : 20];
   uint2 sb[2 * NK2];
   auto prefetch_B = [&]() {
     nwB = *reinterpret_cast<const uint4*>(p.qa_norm_w + min(tid, (p.q_lora >> 3) - 1) * 8);
@@ -312,17 +367,20 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       const size_t strip = (size_t)h * SPH + part * 6 + wave;
 #pragma unroll
       for (int kh = 0; kh < 2; kh++) {
-        const uint8_t* wp = p.wB + (strip * p.nksB + (size_t)kh * NK2) * 1024 + lane * 16;
+        const uint8_t* wp = p.wB + (strip * p.nksB + (size_t)kh * NK2) * TB + lane * 16;
         const bf16_t* sp = p.scB + ((strip * p.nksB + (size_t)kh * NK2) * 16 + (lane & 15)) * 2;
+        const float* sp8 = reinterpret_cast<const float*>(p.scB) + (strip >> 3) * p.nksB + kh * NK2;
 #pragma unroll
         for (int s_ = 0; s_ < NK2; s_++) {
-          rb[kh * NK2 + s_] = nt_load16(wp + (size_t)s_ * 1024);
-          sb[kh * NK2 + s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
+#pragma unroll
+          for (int q = 0; q < NQ; q++) rb[(kh * NK2 + s_) * NQ + q] = nt_load16(wp + (size_t)s_ * TB + q * 1024);
+          if constexpr (F8) sb[kh * NK2 + s_] = make_uint2(__float_as_uint(sp8[s_]), 0);
+          else sb[kh * NK2 + s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
         }
       }
       const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + wave) * 4096 + lane * 16;
 #pragma unroll
-      for (int q = 0; q < 4; q++) rb[12 + q] = nt_load16(wp2 + q * 1024);
+      for (int q = 0; q < 4; q++) rb[ABS0 + q] = nt_load16(wp2 + q * 1024);
     } else {
 #pragma unroll
       for (int i = 0; i < 5; i++) {
@@ -337,7 +395,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // whole queue (vmcnt(0)) at the first consumer behind them (measured with the stamps: the input row was staged 6.4 us after
   // entry with the requests in front, 2.9 us behind; phase A's k-steps ended at 7.0 us with the requests in front of them).
   if constexpr ((MASK & PH_B) != 0) {
-    if (!doA) {
+    if (!doA && doBD) {
       // (workgroups without a strip of phase A: their 136 KiB each would compete chip-wide with the 7 MB of phase A tiles the step
       // is waiting for — measured: those tiles took 6 us to arrive — so they start ~1.5 us late)
       if constexpr ((MASK & PH_A) != 0) __builtin_amdgcn_s_sleep(56);
@@ -376,27 +434,37 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         const int pc = tid + i * NT;
         if (pc < p.nksA * 16) {
           const uint4 v = norm8(xrA[i], rnorm, nwA[i]);
-          *reinterpret_cast<uint4*>(xs + (size_t)pc * 16) = v;
-          const float s = group_sum64(v);
-          if ((pc & 7) == 0) {
+          if constexpr (F8) {   // act_quant per 128-k block: 8 e4m3 bytes per piece, the block's scale in aux[k-step]
+            float sq;
+            const uint2 q8 = fp8_quant_piece(v, sq);
+            *reinterpret_cast<uint2*>(xs + (size_t)pc * 8) = q8;
+            if ((pc & 15) == 0) aux[pc >> 4] = sq;
+          } else {
+            *reinterpret_cast<uint4*>(xs + (size_t)pc * 16) = v;
+            const float s = group_sum64(v);
+            if ((pc & 7) == 0) {
 #pragma unroll
-            for (int r = 0; r < 4; r++) aux[(pc >> 3) * 4 + r] = s;
+              for (int r = 0; r < 4; r++) aux[(pc >> 3) * 4 + r] = s;
+            }
           }
         }
       }
       __syncthreads();
       AT_STAMP(1);
       const int kc = lane >> 4;
-      const uint8_t* xb0 = xs + kc * 16;
-      {   // (the host admits at most one strip per workgroup: nA <= 2 x heads)
+      const uint8_t* xb0 = xs + kc * (F8 ? 32 : 16);
+      {   // (the host admits at most one strip per workgroup: nA <= the grid)
         const int s = w;
         float acc = 0.f;
         const int ks0 = wave * DA;
 #pragma unroll
-        for (int d = 0; d < DA; d++) w4_kstep1(wrA[d], srA[d], xb0 + (size_t)(ks0 + d) * 256, aux + (ks0 + d) * 8, acc);
+        for (int d = 0; d < DA; d++) {
+          if constexpr (F8) fp8_kstep1(wrA[d][0], wrA[d][NQ - 1], __uint_as_float(srA[d].x), xb0 + (size_t)(ks0 + d) * 128, aux[ks0 + d], acc);
+          else w4_kstep1(wrA[d][0], srA[d], xb0 + (size_t)(ks0 + d) * 256, aux + (ks0 + d) * 8, acc);
+        }
         // phase B's requests go out HERE: nothing older is pending any more, so the wave-role branches inside (whose request counts
         // the compiler cannot line up: it drains the queue at their join) cost nothing, and the replies fly during the hand-off
-        if constexpr ((MASK & PH_B) != 0) prefetch_B();
+        if constexpr ((MASK & PH_B) != 0) { if (doBD) prefetch_B(); }
         if (lane < 16) table[wave * 64 + lane] = acc;
         AT_STAMP(19);
         AT_STAMP7(26);
@@ -422,6 +490,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // =========================== phase B ===================================================================================
   // LDS of phase B (the phase A region is dead for this workgroup once its strip is published; a barrier separates them)
   if constexpr ((MASK & PH_B) != 0) {
+   if (doBD) {
     __syncthreads();
     bf16_t* kvraw = reinterpret_cast<bf16_t*>(smem);                              // [576]
     uint8_t* xsB = smem + 1280;                                                   // [q_lora / 8][16 B]
@@ -461,13 +530,20 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         uint4 v = xp;
         if (tid < npq) v = norm8(xp, rn, nwB);
         else v = make_uint4(0, 0, 0, 0);
-        *reinterpret_cast<uint4*>(xsB + (size_t)tid * 16) = v;
-        const float sm = group_sum64(v);
-        if ((tid & 7) == 0) auxB[(tid >> 3) * 4] = sm;
+        if constexpr (F8) {
+          float sq;
+          const uint2 q8 = fp8_quant_piece(v, sq);
+          *reinterpret_cast<uint2*>(xsB + (size_t)tid * 8) = q8;
+          if ((tid & 15) == 0) auxB[tid >> 4] = sq;
+        } else {
+          *reinterpret_cast<uint4*>(xsB + (size_t)tid * 16) = v;
+          const float sm = group_sum64(v);
+          if ((tid & 7) == 0) auxB[(tid >> 3) * 4] = sm;
+        }
       }
     }
     // ---- one workgroup: kv_a_layernorm + k_pe RoPE (mla_prep_token_block's arithmetic) -> workspace + cache append
-    if (w == NWG - 1) {
+    if (w == NWB - 1) {
       float v8[8];
       float ss = 0.f;
       if (tid < LORA / 8) {
@@ -524,16 +600,25 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     // ---- q_b rows of this half: waves 0..5 = one strip each, two k-halves summed in order (lin_qb_absorb_kernel)
     const int kc = lane >> 4;
     if (wave < 6) {
-      const uint8_t* xb0 = xsB + kc * 16;
-#pragma unroll
-      for (int kh = 0; kh < 2; kh++) {
+      if constexpr (F8) {   // lin_dec_kernel<FP8> runs q_b's 12 k-steps as ONE k-slice per strip (8 strips per workgroup): one chain
+        const uint8_t* xb0 = xsB + kc * 32;
         float acc = 0.f;
 #pragma unroll
-        for (int s_ = 0; s_ < NK2; s_++) {
-          const int ks = kh * NK2 + s_;
-          w4_kstep1(rb[ks], sb[ks], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
+        for (int ks = 0; ks < 2 * NK2; ks++)
+          fp8_kstep1(rb[ks * NQ], rb[ks * NQ + NQ - 1], __uint_as_float(sb[ks].x), xb0 + (size_t)ks * 128, auxB[ks], acc);
+        if (lane < 16) { red1[(wave * 2 + 0) * 16 + lane] = acc; red1[(wave * 2 + 1) * 16 + lane] = 0.f; }
+      } else {
+        const uint8_t* xb0 = xsB + kc * 16;
+#pragma unroll
+        for (int kh = 0; kh < 2; kh++) {
+          float acc = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < NK2; s_++) {
+            const int ks = kh * NK2 + s_;
+            w4_kstep1(rb[ks], sb[ks], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
+          }
+          if (lane < 16) red1[(wave * 2 + kh) * 16 + lane] = acc;
         }
-        if (lane < 16) red1[(wave * 2 + kh) * 16 + lane] = acc;
       }
     }
     AT_STAMP(20);
@@ -571,7 +656,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       const uint8_t* xb2 = xs2 + kc * 4 * 16;
       if (wave < 6) {
         v4f acc = {0.f, 0.f, 0.f, 0.f};
-        const uint4 wt[4] = {rb[12], rb[13], rb[14], rb[15]};
+        const uint4 wt[4] = {rb[ABS0], rb[ABS0 + 1], rb[ABS0 + 2], rb[ABS0 + 3]};
         bf16_kstep(wt, xb2, acc);
         if (lane < 16) stage[wave * 16 + lane] = f32_to_bf16(0.f + acc[0]);
       } else {
@@ -590,12 +675,13 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     drain_stores();
     __syncthreads();
     if (tid == 0) st_word(fB + w, epoch);
+   }
     AT_STAMP(6);
   }
 
   // =========================== phase C: split-KV attention ===========================================================================
   // workgroup (hg, split): hg = w / 64 (32 heads), split = w % 64 < nsplit; XCD = w % 8 is the same for the four head groups of a split
-  const int hg = w >> 6, split = w & 63;
+  const int hg = w >> SPG_SH, split = w & (SPG - 1);
   const bool doC = (MASK & PH_C) && split < p.nsplit && hg < H / 32;
   // phase D's weights (waves 0..3: one strip of W_UV[h], 4 k-steps x 4 planes) are requested before phase C starts waiting
   // (measured, profiles/r04_a_*: spreading these 64 KiB over the KV tiles of phase C — one k-step per tile, behind the tile's own
@@ -605,7 +691,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   const uint8_t* wpD = p.wUV + (size_t)h * p.wbsUV + (size_t)(part * 4 + (wave & 3)) * 4 * 4096 + lane * 16;
 #define KTX_PF_D(KS)                                                                                   \
   do {                                                                                                 \
-    if (wave < 4) {                                                                                    \
+    if (wave < 4 && doBD) {                                                                            \
       _Pragma("unroll") for (int q = 0; q < 4; q++) wrD[KS][q] = nt_load16(wpD + (KS) * 4096 + q * 1024); \
     }                                                                                                  \
   } while (0)
@@ -805,11 +891,17 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // phase E's first ring tiles are requested before phase D starts waiting
   const int GPS_E = p.nksE >> 3;
   int Gb = 0, Ge = 0, gbE = 0, geE = 0;
-  uint4 wrE[8];
+  uint4 wrE[8][NQ];
   uint2 srE[8];
   auto load_E = [&](int d, long tile) {
-    wrE[d] = nt_load16(p.wE + tile * 1024 + lane * 16);
-    srE[d] = load_w4_scales<2>(p.scE + (tile * 16 + (lane & 15)) * 2);
+#pragma unroll
+    for (int q = 0; q < NQ; q++) wrE[d][q] = nt_load16(p.wE + tile * TB + q * 1024 + lane * 16);
+    if constexpr (F8) {   // fp32 scale of (128-row block, k-step): tile = strip * nksE + ks, nksE a power of two
+      const long strip = tile >> p.nksE_sh, ks = tile & (p.nksE - 1);
+      srE[d] = make_uint2(__float_as_uint(reinterpret_cast<const float*>(p.scE)[(strip >> 3) * p.nksE + ks]), 0);
+    } else {
+      srE[d] = load_w4_scales<2>(p.scE + (tile * 16 + (lane & 15)) * 2);
+    }
   };
   auto prefetch_E = [&]() {
     const int nwgE = min(NWG, p.nE);
@@ -841,15 +933,16 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   };
   if constexpr ((MASK & PH_E) != 0) prefetch_E();
   if constexpr ((MASK & PH_D) != 0) {
+   if (doBD) {
     __syncthreads();
     const int S = p.nsplit;
-    float* s_w = reinterpret_cast<float*>(smem);              // [64]
-    float* s_red = s_w + 64;                                  // [16]
+    float* s_w = reinterpret_cast<float*>(smem);              // [MAXS]
+    float* s_red = s_w + MAXS;                                // [16]
     float* s_acc = s_red + 16;                                // [8][256]
     bf16_t* stageD = reinterpret_cast<bf16_t*>(s_acc + 8 * 256);   // [256]
     uint8_t* xsD = reinterpret_cast<uint8_t*>(stageD + 256);       // [64][16 B]
     const int hgD = h >> 5;
-    if (wave == 7) poll_flags(p, fC, S, epoch, 0xD1, [=](int k) { return hgD * 64 + k; });
+    if (wave == 7) poll_flags(p, fC, S, epoch, 0xD1, [=](int k) { return hgD * SPG + k; });
     __syncthreads();
     AT_STAMP(10);
     const int sl = wave, dg = lane;   // split lane, dim group (8 dims) — lanes 0..31 cover this half's 256 dims
@@ -894,6 +987,25 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
           acc[4] += __uint_as_float(fb[u].x) * wv; acc[5] += __uint_as_float(fb[u].y) * wv; acc[6] += __uint_as_float(fb[u].z) * wv; acc[7] += __uint_as_float(fb[u].w) * wv;
         }
       }
+      for (int s0 = sl + 64; s0 < S; s0 += 32) {   // more than 64 splits (64-head models): lin_merge_unabsorb_kernel's continuation, same order
+        uint4 va[4], vb[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int sidx = min(s0 + 8 * u, S - 1);
+          const unsigned off = L.part_o + (unsigned)(((base + sidx) * LORA + part * 256 + dg * 8) * 4);
+          va[u] = ws_load16(rs, off);
+          vb[u] = ws_load16(rs, off + 16);
+        }
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+          const int sidx = s0 + 8 * u;
+          const float wv = sidx < S ? s_w[sidx] : 0.f;
+          if (wv > 0.f) {
+            acc[0] += __uint_as_float(va[u].x) * wv; acc[1] += __uint_as_float(va[u].y) * wv; acc[2] += __uint_as_float(va[u].z) * wv; acc[3] += __uint_as_float(va[u].w) * wv;
+            acc[4] += __uint_as_float(vb[u].x) * wv; acc[5] += __uint_as_float(vb[u].y) * wv; acc[6] += __uint_as_float(vb[u].z) * wv; acc[7] += __uint_as_float(vb[u].w) * wv;
+          }
+        }
+      }
 #pragma unroll
       for (int q = 0; q < 8; q++) s_acc[sl * 256 + dg * 8 + q] = acc[q];
     }
@@ -932,6 +1044,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     drain_stores();
     __syncthreads();
     if (tid == 0) st_word(fD + w, epoch);
+   }
     AT_STAMP(12);
   }
 
@@ -942,18 +1055,25 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     uint8_t* xsE = smem;                                                          // [nksE * 16][16 B]
     float* auxE = reinterpret_cast<float*>(smem + (size_t)nksE * 16 * 16);        // [nksE * 2][4]
     float* tableE = auxE + (size_t)nksE * 2 * 4;                                  // [strips of this workgroup][8][64]
-    if (wave == 7) poll_flags(p, fD, NWG, epoch, 0xE1, [](int k) { return k; });
+    if (wave == 7) poll_flags(p, fD, NWB, epoch, 0xE1, [](int k) { return k; });
     __syncthreads();
     AT_STAMP(13);
     {
       const int np = nksE * 16;
       for (int pc = tid; pc < np; pc += NT) {   // (whole wavefronts: np is a multiple of 64)
         const uint4 v = ws_load16(rs, L.attn_out + (unsigned)pc * 16);
-        *reinterpret_cast<uint4*>(xsE + (size_t)pc * 16) = v;
-        const float s = group_sum64(v);
-        if ((pc & 7) == 0) {
+        if constexpr (F8) {
+          float sq;
+          const uint2 q8 = fp8_quant_piece(v, sq);
+          *reinterpret_cast<uint2*>(xsE + (size_t)pc * 8) = q8;
+          if ((pc & 15) == 0) auxE[pc >> 4] = sq;
+        } else {
+          *reinterpret_cast<uint4*>(xsE + (size_t)pc * 16) = v;
+          const float s = group_sum64(v);
+          if ((pc & 7) == 0) {
 #pragma unroll
-          for (int r = 0; r < 4; r++) auxE[(pc >> 3) * 4 + r] = s;
+            for (int r = 0; r < 4; r++) auxE[(pc >> 3) * 4 + r] = s;
+          }
         }
       }
     }
@@ -961,7 +1081,11 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     const int s_first = Gb / GPS_E;
     if (geE > gbE) {
       const int kc = lane >> 4;
-      const uint8_t* xb0 = xsE + kc * 16;
+      const uint8_t* xb0 = xsE + kc * (F8 ? 32 : 16);
+      auto stepE = [&](int d, int ks, float& a) {
+        if constexpr (F8) fp8_kstep1(wrE[d][0], wrE[d][NQ - 1], __uint_as_float(srE[d].x), xb0 + (size_t)ks * 128, auxE[ks], a);
+        else w4_kstep1(wrE[d][0], srE[d], xb0 + (size_t)ks * 256, auxE + ks * 8, a);
+      };
       int strip = gbE / GPS_E, kg = gbE - strip * GPS_E;
       float acc = 0.f;
       auto flush = [&]() {
@@ -976,7 +1100,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
           const int ks0 = kg * 8;
 #pragma unroll
           for (int d = 0; d < 8; d++) {
-            w4_kstep1(wrE[d], srE[d], xb0 + (size_t)(ks0 + d) * 256, auxE + (ks0 + d) * 8, acc);
+            stepE(d, ks0 + d, acc);
             load_E(d, (long)(g + 1) * 8 + d);
             __builtin_amdgcn_sched_barrier(0);
           }
@@ -984,7 +1108,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         if (last_seg) {
           const int ks0 = kg * 8;
 #pragma unroll
-          for (int d = 0; d < 8; d++) w4_kstep1(wrE[d], srE[d], xb0 + (size_t)(ks0 + d) * 256, auxE + (ks0 + d) * 8, acc);
+          for (int d = 0; d < 8; d++) stepE(d, ks0 + d, acc);
           flush();
           break;
         }
@@ -1133,7 +1257,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
           }
           if (__all(ok)) break;
           if (wall_clock64() - t0 > SPIN_TICKS) {
-            if (lane == 0) st_word(hdr + W_STATUS, 0xF2u);
+            if (lane == 0) {
+              st_word(hdr + W_STATUS, 0xF2u);
+              if (p.hstatus) __hip_atomic_store(p.hstatus, 0xF2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+            }
             break;
           }
           __builtin_amdgcn_s_sleep(1);
@@ -1169,24 +1296,79 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
 // =====================================================================================================================================
 // host
 // =====================================================================================================================================
+// One workspace per (device, attention geometry): the layers of a model share it (launches of one stream are ordered), two models of
+// different geometry on one device each get their own.  `last` = the geometry of the device's most recent launch (debug reads).
 struct DevWs { uint8_t* base = nullptr; size_t bytes = 0; int H = 0, nA = 0; };
+constexpr int MAX_DEV = 64, MAX_GEO = 4;
 std::mutex g_mu;
-DevWs g_ws[64];
+DevWs g_ws[MAX_DEV][MAX_GEO];
+int g_last[MAX_DEV];
+bool g_attr_set[MAX_DEV][128];          // hipFuncSetAttribute is per device (and per instantiation: indexed by the phase mask)
 unsigned long long* g_stamps = nullptr;
+// Status words the DEVICE writes into pinned host memory when a hand-off gives up (one per device): ktx_attn_status reads them with a
+// plain load — no device synchronisation — so a decode loop can afford the check after every token.
+unsigned* g_hstatus = nullptr;       // host address of [MAX_DEV] words
+unsigned* g_hstatus_dev = nullptr;   // the same memory as the devices see it
+
+// One persistent launch in flight per device: a launch issued on another stream than the device's previous one first waits for an event
+// recorded behind that one (eager mode only: inside a stream capture the caller keeps one capture per device).
+struct DevOrder { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
+DevOrder g_order[MAX_DEV];
+
+int order_before_launch(int dev, hipStream_t st, bool* eager) {
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  *eager = cs == hipStreamCaptureStatusNone;
+  if (!*eager) return 0;
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevOrder& o = g_order[dev];
+  if (o.valid && o.last != st) KTX_HIP(hipStreamWaitEvent(st, o.ev, 0));
+  return 0;
+}
+int order_after_launch(int dev, hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  DevOrder& o = g_order[dev];
+  if (!o.ev) KTX_HIP(hipEventCreateWithFlags(&o.ev, hipEventDisableTiming));
+  KTX_HIP(hipEventRecord(o.ev, st));
+  o.last = st;
+  o.valid = true;
+  return 0;
+}
+
+int hstatus_for(int dev, unsigned** out) {
+  std::lock_guard<std::mutex> lk(g_mu);
+  if (!g_hstatus) {
+    void* h = nullptr;
+    KTX_HIP(hipHostMalloc(&h, MAX_DEV * sizeof(unsigned), hipHostMallocMapped | hipHostMallocPortable));
+    std::memset(h, 0, MAX_DEV * sizeof(unsigned));
+    void* d = nullptr;
+    KTX_HIP(hipHostGetDevicePointer(&d, h, 0));
+    g_hstatus = (unsigned*)h;
+    g_hstatus_dev = (unsigned*)d;
+  }
+  *out = g_hstatus_dev + dev;
+  return 0;
+}
 
 int ws_for(int dev, int H, int nA, uint8_t** out, unsigned* bytes) {
   std::lock_guard<std::mutex> lk(g_mu);
-  KTX_REQUIRE(dev >= 0 && dev < 64, "ktx_attn: device index out of range");
-  DevWs& d = g_ws[dev];
-  const WsLayout L = ws_layout(H, nA);
-  if (d.base && (d.H != H || d.nA != nA)) return ktx_fail("ktx_attn: one attention geometry per device (the workspace is shared by the layers of a model)");
+  KTX_REQUIRE(dev >= 0 && dev < MAX_DEV, "ktx_attn: device index out of range");
+  int slot = -1;
+  for (int i = 0; i < MAX_GEO; i++) {
+    if (g_ws[dev][i].base && g_ws[dev][i].H == H && g_ws[dev][i].nA == nA) { slot = i; break; }
+    if (!g_ws[dev][i].base && slot < 0) slot = i;
+  }
+  KTX_REQUIRE(slot >= 0, "ktx_attn: more attention geometries on one device than workspaces (4)");
+  DevWs& d = g_ws[dev][slot];
   if (!d.base) {
+    const WsLayout L = ws_layout(H, nA);
     KTX_HIP(hipMalloc((void**)&d.base, L.total));
     KTX_HIP(hipMemset(d.base, 0, L.total));
     const unsigned one = 1;
     KTX_HIP(hipMemcpy(d.base + 4 * W_EPOCH, &one, 4, hipMemcpyHostToDevice));
     d.bytes = L.total; d.H = H; d.nA = nA;
   }
+  g_last[dev] = slot;
   *out = d.base;
   *bytes = (unsigned)d.bytes;
   return 0;
@@ -1210,38 +1392,44 @@ int check_args(const ktx_attn_decode_args* a, KtxLinearRaw (&r)[5], int* nsplit_
   }
   const int H = a->num_heads;
   KTX_REQUIRE(a->nope_dim == NOPE && a->rope_dim == ROPE && a->kv_lora == LORA && a->v_dim == VDIM, "ktx_attn_decode: nope 128 / rope 64 / kv_lora 512 / v 128 only");
-  KTX_REQUIRE(H == 128, "ktx_attn_decode: 128 heads only (two workgroups per head on 256 CUs)");
+  KTX_REQUIRE(H == 128 || H == 64, "ktx_attn_decode: 64 or 128 heads (two workgroups per head, head groups of 32 over 256 workgroups)");
   KTX_REQUIRE(a->hidden == DA * 8 * 128 && a->q_lora == NK2 * 2 * 128, "ktx_attn_decode: hidden 7168 / q_lora 1536 only");
-  const int W4 = KTX_LIN_W4, BF = KTX_LIN_BF16;
-  KTX_REQUIRE(r[0].format == W4 && r[0].group_size == 64 && r[0].batch == 1 && r[0].in_features == a->hidden &&
-                  r[0].out_features == a->q_lora + LORA + ROPE, "ktx_attn_decode: qkv_a must be the merged W4 g64 q_a|kv_a linear");
-  KTX_REQUIRE(r[1].format == W4 && r[1].group_size == 64 && r[1].batch == 1 && r[1].in_features == a->q_lora &&
-                  r[1].out_features == H * QW, "ktx_attn_decode: q_b must be W4 g64 [heads * 192, q_lora]");
+  const int BF = KTX_LIN_BF16, QF = r[0].format, QG = QF == KTX_LIN_FP8 ? 128 : 64;   // the three quantised projections share one format
+  KTX_REQUIRE(QF == KTX_LIN_W4 || QF == KTX_LIN_FP8, "ktx_attn_decode: the projections must be W4 g64 or block-FP8 linears");
+  KTX_REQUIRE(r[0].group_size == QG && r[0].batch == 1 && r[0].in_features == a->hidden &&
+                  r[0].out_features == a->q_lora + LORA + ROPE, "ktx_attn_decode: qkv_a must be the merged W4 g64 / FP8 q_a|kv_a linear");
+  KTX_REQUIRE(r[1].format == QF && r[1].group_size == QG && r[1].batch == 1 && r[1].in_features == a->q_lora &&
+                  r[1].out_features == H * QW, "ktx_attn_decode: q_b must be W4 g64 / FP8 [heads * 192, q_lora] like qkv_a");
   KTX_REQUIRE(r[2].format == BF && r[2].batch == H && r[2].in_features == NOPE && r[2].out_features == LORA, "ktx_attn_decode: q_absorb must be BF16 [heads][512, 128]");
   KTX_REQUIRE(r[3].format == BF && r[3].batch == H && r[3].in_features == LORA && r[3].out_features == VDIM, "ktx_attn_decode: out_absorb must be BF16 [heads][128, 512]");
-  KTX_REQUIRE(r[4].format == W4 && r[4].group_size == 64 && r[4].batch == 1 && r[4].in_features == H * VDIM &&
-                  r[4].out_features == a->hidden && r[4].NKS % 8 == 0, "ktx_attn_decode: o_proj must be W4 g64 [hidden, heads * 128]");
+  KTX_REQUIRE(r[4].format == QF && r[4].group_size == QG && r[4].batch == 1 && r[4].in_features == H * VDIM &&
+                  r[4].out_features == a->hidden && r[4].NKS % 8 == 0 && (r[4].NKS & (r[4].NKS - 1)) == 0,
+              "ktx_attn_decode: o_proj must be W4 g64 / FP8 [hidden, heads * 128] like qkv_a");
+  KTX_REQUIRE(QF == KTX_LIN_W4 || !(a->phases & PH_F), "ktx_attn_decode: the MoE front rides only with W4 projections");
   KTX_REQUIRE(a->page_size > 0 && a->page_size % TILE == 0 && a->ckv_token_stride % 8 == 0 && a->kpe_token_stride % 8 == 0,
               "ktx_attn_decode: page_size must be a multiple of 32 and the token strides multiples of 8 elements");
   int ncu = 0;
   KTX_HIP(hipDeviceGetAttribute(&ncu, hipDeviceAttributeMultiprocessorCount, r[0].device));
-  KTX_REQUIRE(ncu >= 2 * H, "ktx_attn_decode: fewer CUs than workgroups (every workgroup must be resident)");
+  KTX_REQUIRE(ncu >= GRID, "ktx_attn_decode: fewer CUs than workgroups (every workgroup must be resident)");
   ktx_mla_config mc{H, LORA, ROPE, a->page_size, a->sm_scale, 256, a->kv_len_hint};
   const int ns = ktx_mla_decode_nsplit(&mc, 1, (size_t)1 << 40);
-  KTX_REQUIRE(ns >= 1 && ns <= MAXS, "ktx_attn_decode: the KV split rule asks for a split count this launch does not cover (context too long)");
+  KTX_REQUIRE(ns >= 1 && ns <= GRID / (H / 32), "ktx_attn_decode: the KV split rule asks for a split count this launch does not cover (context too long)");
   *nsplit_out = ns;
   return 0;
 }
 
-template <int MASK>
-int launch(const AttnParams& p, int nwg, hipStream_t st) {
-  static bool attr_set = false;
+template <int MASK, int FMT = KTX_LIN_W4>
+int launch(const AttnParams& p, int dev, int nwg, hipStream_t st) {
   constexpr size_t LDS = 108 * 1024;
-  if (!attr_set) {
-    KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<MASK>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
-    attr_set = true;
+  constexpr int SLOT = MASK + (FMT == KTX_LIN_FP8 ? 64 : 0);
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    if (!g_attr_set[dev][SLOT]) {
+      KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(attn_decode_kernel<MASK, FMT>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)LDS));
+      g_attr_set[dev][SLOT] = true;
+    }
   }
-  hipLaunchKernelGGL(attn_decode_kernel<MASK>, dim3(nwg), dim3(NT), LDS, st, p);
+  hipLaunchKernelGGL((attn_decode_kernel<MASK, FMT>), dim3(nwg), dim3(NT), LDS, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }
@@ -1267,7 +1455,7 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   KTX_REQUIRE(a->d_x && a->d_y && a->d_in_norm_w && a->d_qa_norm_w && a->d_kv_norm_w && a->d_position && a->d_inv_freq && a->d_ckv &&
                   a->d_k_pe && a->d_kv_indptr && a->d_kv_len, "ktx_attn_decode: null pointer");
   KTX_REQUIRE(a->phases > 0 && a->phases <= (KTX_ATTN_PHASE_ALL | KTX_ATTN_PHASE_MOE_FRONT), "ktx_attn_decode: bad phase mask");
-  const int dev = r[0].device, H = a->num_heads, NWG = 2 * H;
+  const int dev = r[0].device, H = a->num_heads, NWG = GRID;
   DeviceGuard guard(dev);
   AttnParams p{};
   p.wA = r[0].w; p.scA = (const bf16_t*)r[0].sc; p.nksA = r[0].NKS; p.nA = r[0].nstrips;
@@ -1283,6 +1471,7 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   p.page_size = a->page_size; p.nsplit = nsplit; p.sm_scale = a->sm_scale;
   p.wUV = r[3].w; p.wbsUV = (size_t)r[3].nstrips * r[3].NKS * 4096;
   p.wE = r[4].w; p.scE = (const bf16_t*)r[4].sc; p.nksE = r[4].NKS; p.nE = r[4].nstrips;
+  for (p.nksE_sh = 0; (1 << p.nksE_sh) < p.nksE; p.nksE_sh++) {}
   {
     const int nwgE = std::min(NWG, p.nE);
     p.eQ = p.nE / nwgE; p.eR = p.nE % nwgE;
@@ -1291,6 +1480,7 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   p.y = (bf16_t*)a->d_y;
   KTX_REQUIRE(p.nksA == DA * 8 && p.nksB == 2 * NK2 && p.nA <= NWG, "ktx_attn_decode: unexpected tile counts");
   if (ws_for(dev, H, p.nA, &p.ws, &p.ws_bytes) != 0) return -1;
+  if (hstatus_for(dev, &p.hstatus) != 0) return -1;
   p.last = a->last ? 1 : 0;
   p.stamps = g_stamps;
   KtxLinearRaw rf{};
@@ -1313,8 +1503,9 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   // algorithmic bytes of the phases in this launch (weights as stored + the context's latent rows)
   double bytes = 0;
   auto lin_bytes = [](const KtxLinearRaw& q) {
-    const double tile = q.format == KTX_LIN_W4 ? 1024.0 : 4096.0;
-    const double sc = q.format == KTX_LIN_W4 ? (double)q.nstrips * q.NKS * 16 * (128 / q.group_size) * 2 : 0.0;
+    const double tile = q.format == KTX_LIN_W4 ? 1024.0 : q.format == KTX_LIN_FP8 ? 2048.0 : 4096.0;
+    const double sc = q.format == KTX_LIN_W4 ? (double)q.nstrips * q.NKS * 16 * (128 / q.group_size) * 2
+                      : q.format == KTX_LIN_FP8 ? (double)((q.nstrips + 7) / 8) * q.NKS * 4 : 0.0;
     return ((double)q.nstrips * q.NKS * tile + sc) * q.batch;
   };
   if (a->phases & PH_A) bytes += lin_bytes(r[0]);
@@ -1323,37 +1514,53 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   if (a->phases & PH_D) bytes += lin_bytes(r[3]);
   if (a->phases & PH_E) bytes += lin_bytes(r[4]);
   if (a->phases & PH_F) bytes += lin_bytes(rf) + (double)NWG * a->hidden * 2.0;
-  KTX_TIMED(st, bytes, "attn_decode_kernel<%d> H=%d nsplit=%d", a->phases, H, nsplit);
+  const bool f8 = r[0].format == KTX_LIN_FP8;
+  KTX_TIMED(st, bytes, "attn_decode_kernel<%d%s> H=%d nsplit=%d", a->phases, f8 ? ",FP8" : "", H, nsplit);
+  bool eager = false;
+  if (order_before_launch(dev, st, &eager) != 0) return -1;
+  int rc = -1;
   switch (a->phases) {
 #ifdef KTX_ATTN_ONLY_MASK
-    case KTX_ATTN_ONLY_MASK: return launch<KTX_ATTN_ONLY_MASK>(p, NWG, st);
+    case KTX_ATTN_ONLY_MASK: rc = launch<KTX_ATTN_ONLY_MASK>(p, dev, NWG, st); break;
     default: return -1;
-  }
-}
 #else
-    case 31: return launch<31>(p, NWG, st);
-    case 63: return launch<63>(p, NWG, st);
-    case 48: return launch<48>(p, NWG, st);
-    case 1: return launch<1>(p, NWG, st);
-    case 2: return launch<2>(p, NWG, st);
-    case 4: return launch<4>(p, NWG, st);
-    case 8: return launch<8>(p, NWG, st);
-    case 16: return launch<16>(p, NWG, st);
-    case 3: return launch<3>(p, NWG, st);
-    case 24: return launch<24>(p, NWG, st);
-    case 28: return launch<28>(p, NWG, st);
+    case 31: rc = f8 ? launch<31, KTX_LIN_FP8>(p, dev, NWG, st) : launch<31>(p, dev, NWG, st); break;
+    case 63: rc = f8 ? -2 : launch<63>(p, dev, NWG, st); break;
+    case 48: rc = f8 ? -2 : launch<48>(p, dev, NWG, st); break;
+    case 1: rc = f8 ? launch<1, KTX_LIN_FP8>(p, dev, NWG, st) : launch<1>(p, dev, NWG, st); break;
+    case 2: rc = f8 ? launch<2, KTX_LIN_FP8>(p, dev, NWG, st) : launch<2>(p, dev, NWG, st); break;
+    case 4: rc = f8 ? launch<4, KTX_LIN_FP8>(p, dev, NWG, st) : launch<4>(p, dev, NWG, st); break;
+    case 8: rc = f8 ? launch<8, KTX_LIN_FP8>(p, dev, NWG, st) : launch<8>(p, dev, NWG, st); break;
+    case 16: rc = f8 ? launch<16, KTX_LIN_FP8>(p, dev, NWG, st) : launch<16>(p, dev, NWG, st); break;
+    case 3: rc = f8 ? -2 : launch<3>(p, dev, NWG, st); break;
+    case 24: rc = f8 ? -2 : launch<24>(p, dev, NWG, st); break;
+    case 28: rc = f8 ? -2 : launch<28>(p, dev, NWG, st); break;
     default: return ktx_fail("ktx_attn_decode: this phase subset is not instantiated (31, 63, 48, single phases 1..16, 3, 24, 28)");
-  }
-}
 #endif
+  }
+  if (rc == -2) return ktx_fail("ktx_attn_decode: this phase subset is not instantiated for FP8 projections (31 and the single phases are)");
+  if (rc == 0 && eager) rc = order_after_launch(dev, st);
+  return rc;
+}
 
 extern "C" int ktx_attn_status(int device, uint32_t* status_out) {
-  KTX_REQUIRE(status_out && device >= 0 && device < 64, "ktx_attn_status: bad arguments");
-  *status_out = 0;
+  KTX_REQUIRE(status_out && device >= 0 && device < MAX_DEV, "ktx_attn_status: bad arguments");
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ws[device].base) return 0;
-  DeviceGuard guard(device);
-  KTX_HIP(hipMemcpy(status_out, g_ws[device].base + 4 * W_STATUS, 4, hipMemcpyDeviceToHost));
+  // the host-mapped word: written by the device at the moment a poll gives up; read here without any device call
+  *status_out = g_hstatus ? __atomic_load_n(g_hstatus + device, __ATOMIC_RELAXED) : 0u;
+  return 0;
+}
+
+extern "C" int ktx_attn_status_any(int* device_out, uint32_t* status_out) {
+  KTX_REQUIRE(status_out, "ktx_attn_status_any: bad arguments");
+  std::lock_guard<std::mutex> lk(g_mu);
+  *status_out = 0;
+  if (device_out) *device_out = -1;
+  if (!g_hstatus) return 0;
+  for (int d = 0; d < MAX_DEV; d++) {
+    const unsigned v = __atomic_load_n(g_hstatus + d, __ATOMIC_RELAXED);
+    if (v) { *status_out = v; if (device_out) *device_out = d; break; }
+  }
   return 0;
 }
 
@@ -1363,7 +1570,7 @@ extern "C" int ktx_attn_status(int device, uint32_t* status_out) {
 extern "C" int ktx_attn_debug_read(int device, int which, void* d_dst, size_t bytes) {
   KTX_REQUIRE(device >= 0 && device < 64 && d_dst, "ktx_attn_debug_read: bad arguments");
   std::lock_guard<std::mutex> lk(g_mu);
-  const DevWs& d = g_ws[device];
+  const DevWs& d = g_ws[device][g_last[device]];
   KTX_REQUIRE(d.base, "ktx_attn_debug_read: no workspace on this device yet");
   const WsLayout L = ws_layout(d.H, d.nA);
   const unsigned offs[10] = {L.qkv, L.ckv_new, L.kpe_new, L.q_lat, L.q_pe, L.om, L.attn_out, L.part_ml, L.part_o, L.qx};
@@ -1374,12 +1581,15 @@ extern "C" int ktx_attn_debug_read(int device, int which, void* d_dst, size_t by
 }
 
 extern "C" int ktx_attn_reset(int device) {
-  KTX_REQUIRE(device >= 0 && device < 64, "ktx_attn_reset: bad device");
+  KTX_REQUIRE(device >= 0 && device < MAX_DEV, "ktx_attn_reset: bad device");
   std::lock_guard<std::mutex> lk(g_mu);
-  if (!g_ws[device].base) return 0;
   DeviceGuard guard(device);
-  KTX_HIP(hipDeviceSynchronize());
+  bool any = false;
+  for (int i = 0; i < MAX_GEO; i++) any = any || g_ws[device][i].base;
+  if (any) KTX_HIP(hipDeviceSynchronize());
   const unsigned z[2] = {0, 0};
-  KTX_HIP(hipMemcpy(g_ws[device].base + 4 * W_EXIT, z, 8, hipMemcpyHostToDevice));   // exit counter + status
+  for (int i = 0; i < MAX_GEO; i++)
+    if (g_ws[device][i].base) KTX_HIP(hipMemcpy(g_ws[device][i].base + 4 * W_EXIT, z, 8, hipMemcpyHostToDevice));   // exit counter + status
+  if (g_hstatus) __atomic_store_n(g_hstatus + device, 0u, __ATOMIC_RELAXED);
   return 0;
 }

@@ -293,12 +293,12 @@ class KDeepseekV2Attention(BaseInjectedModule):
     # ---- the whole decode step as ONE launch (csrc/ktx_attn.hip) -------------------------------------------------------------
     @staticmethod
     def _gen_handle(mod):
-        """The W4 LinearHandle a KTransformersLinear (or a merged operator) decodes with, or None."""
+        """The W4 / block-FP8 LinearHandle a KTransformersLinear (or a merged operator) decodes with, or None."""
         lin = mod
         if hasattr(mod, "generate_linear"):
             lin = mod.generate_linear if getattr(mod, "mode", None) == InferenceState.GENERATE else getattr(mod, "prefill_linear", None)
         h = getattr(lin, "_h", None)
-        return h if h is not None and getattr(h, "fmt", None) == "W4" else None
+        return h if h is not None and getattr(h, "fmt", None) in ("W4", "FP8") else None
 
     def _kv_len_of(self, position_ids, past_key_value):
         """kv_len = positions + 1 on the device, derived once per step (every layer sees the same position tensor)."""
@@ -313,8 +313,9 @@ class KDeepseekV2Attention(BaseInjectedModule):
 
     def _fused_decode(self, hidden_states, pre_norm, residual, position_ids, past_key_value, moe_front=None):
         """q_a|kv_a -> q_b + absorb + RoPE + latent norm + cache append -> split-KV attention -> merge + un-absorb -> o_proj +
-        residual as ONE persistent launch (include/ktx_attn.h) when this layer has the covered geometry (DeepSeek-V3 / R1 attention
-        dimensions, W4 g64 projections, the identity / paged single-request cache); None otherwise — the caller then takes the
+        residual as ONE persistent launch (include/ktx_attn.h) when this layer has the covered geometry (DeepSeek-V3 / R1 / Kimi-K2
+        attention dimensions: 128 or 64 heads; W4 g64 or block-FP8 projections, all three alike; the identity / paged single-request
+        cache); None otherwise — the caller then takes the
         five-launch path, whose kernels this launch restates bit for bit.  KTX_ATTN_SEPARATE=1 forces the five launches (A/B)."""
         ok = getattr(self, "_fused_ok", None)
         if ok is False or os.environ.get("KTX_ATTN_SEPARATE") or self.q_lora_rank is None or self._qkv is None:

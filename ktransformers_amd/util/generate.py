@@ -12,18 +12,30 @@ import torch
 from ktransformers_amd.util.utils import InferenceState
 
 
-def _check_ep() -> None:
-    """Bounded in-launch hand-offs must not fail silently: the expert-parallel peer-write transport (parallel.py) and the
-    one-launch attention step (include/ktx_attn.h) only set a status word when a poll gives up."""
+def check_handoffs(full: bool = True) -> None:
+    """Bounded in-launch hand-offs must not fail silently.  The one-launch attention step (include/ktx_attn.h) writes its status word
+    into pinned host memory when a poll gives up: reading it is a host load, so it is checked after EVERY token, for every device
+    (`full=False`: only that).  The expert-parallel peer-write transport (parallel.py) and the opt-in one-launch MoE half keep their
+    status words on the device (a small copy): checked with `full=True` — every 64 tokens and at the end of a generation."""
     from ktransformers_amd import _native, parallel
+    dev, st = _native.attn_status_any()
+    if st != 0:
+        raise RuntimeError(f"one-launch attention step on cuda:{dev}: a hand-off inside the launch timed out (status {st:#x}); the "
+                           "outputs since the previous token are not valid.  Another kernel held CUs for longer than the poll bound, or "
+                           "two persistent launches overlapped; ktransformers_amd._native.attn_reset(device) re-arms the workspace")
+    if not full:
+        return
     if parallel.EP_STATE.get("exchange") is not None:
         parallel.check_exchange_status()
     if torch.cuda.is_available():
-        dev = torch.device("cuda", torch.cuda.current_device())
-        for what, st in (("attention", _native.attn_status(dev)), ("MoE", _native.moe_layer_status(dev))):
+        for i in range(torch.cuda.device_count()):
+            st = _native.moe_layer_status(torch.device("cuda", i))
             if st != 0:
-                raise RuntimeError(f"one-launch {what} step: a hand-off inside the launch timed out (status {st:#x}); "
+                raise RuntimeError(f"one-launch MoE step on cuda:{i}: a hand-off inside the launch timed out (status {st:#x}); "
                                    "outputs since the previous check are not valid")
+
+
+_check_ep = check_handoffs      # (the name rounds 2-4 used)
 
 
 def set_inference_mode(model: torch.nn.Module, mode: InferenceState) -> None:
@@ -151,8 +163,7 @@ def prefill_and_generate(model, input_ids: torch.Tensor, past_key_values, max_ne
         else:
             logits = model(cur, pos, past_key_values, pos[0])
         nxt = pick(logits)
-        if (i & 63) == 63:
-            _check_ep()
-    _check_ep()
+        check_handoffs(full=(i & 63) == 63)
+    check_handoffs()
     out = torch.stack(tokens)
     return (out, torch.stack(all_logits)) if return_logits else out
