@@ -318,6 +318,9 @@ def test_one_launch_against_the_oracle(layer, ctx, pages, permute):
          "o_proj": layer["o_proj"].dequant_bf16().cpu(), "q_a_layernorm": layer["qa_norm"].cpu(), "kv_a_layernorm": layer["kv_norm"].cpu(),
          "kv_b_proj": torch.cat([layer["w_uk"].transpose(1, 2), layer["w_uv"]], dim=1).reshape(H * (NOPE + VDIM), LORA).cpu()}
     c = _case(layer, ctx, pages, permute)
+    # a small residual row (the layer's input passes through RMSNorm, so its scale does not matter to the attention): with |x| ~ 1 the
+    # bf16 rounding of `x + attn` (half an ulp of ~1) would be several per cent of the attention part this test looks at
+    c["x"].mul_(2.0 ** -6)
     x = c["x"].cpu()
     hidden = rmsnorm_ref(x, layer["in_norm"].cpu(), 1e-6)                       # input_layernorm (modeling_deepseek_v3.py:1200-1205)
     out_ref, new_row = mla_attention_ref(cfg, w, hidden, torch.tensor([ctx - 1]), c["rows"].cpu())
