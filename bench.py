@@ -1225,7 +1225,7 @@ def compact_line(out: dict) -> dict:
                                     "scaling", "vs_baseline", "dtype", "data")}
     line["metric"] = str(line["metric"])[:160]
     line["config"] = dict(_pick(cfg, ("hidden", "intermediate", "experts", "top_k", "heads", "layers", "dense_layers", "moe_layers",
-                                      "vocab", "ctx", "batch_per_gpu", "parallelism", "rccl_ranks", "hip_graph", "ep_transport_status")),
+                                      "vocab", "ctx", "batch_per_gpu", "parallelism", "rccl_ranks", "dist_backend", "hip_graph", "ep_transport_status")),
                           workload=str(cfg.get("workload", ""))[:200])
     if cfg.get("ep_transport"):
         line["config"]["ep_transport"] = str(cfg["ep_transport"])[:40]
@@ -1355,6 +1355,10 @@ def main():
     ap.add_argument("--force-dist", action="store_true",
                     help="dev / test aid: take the N > 1 code path (process group, expert parallelism, exchange transport) "
                          "even with WORLD_SIZE=1, so that path can be run on a one-GPU box")
+    ap.add_argument("--dist-backend", default="nccl", choices=("nccl", "gloo"),
+                    help="process-group backend of the N > 1 path.  nccl (= RCCL over xGMI) is the product path; gloo exists for the "
+                         "one-GPU smoke of the N-process code path (ranks share cuda:0, the decode exchange still runs through the "
+                         "peer-write transport over inter-process handles; RCCL refuses several ranks on one device)")
     ap.add_argument("--pmc-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--trace-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
@@ -1371,7 +1375,8 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     dist_on = world > 1 or args.force_dist
     assert torch.cuda.is_available(), "bench.py needs a HIP device (no CPU fallback)"
-    dev = torch.device("cuda", local_rank)
+    shared_gpu = dist_on and args.dist_backend == "gloo" and local_rank >= torch.cuda.device_count()
+    dev = torch.device("cuda", local_rank % torch.cuda.device_count() if shared_gpu else local_rank)
     torch.cuda.set_device(dev)
     if args.pmc_child:
         pmc_child(args, wl, dev)
@@ -1384,7 +1389,10 @@ def main():
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.dist_backend == "gloo":
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
         assert wl["E"] % world == 0
         from ktransformers_amd.parallel import enable_expert_parallel, enable_peer_exchange
@@ -1448,7 +1456,8 @@ def main():
                    "hidden": H, "intermediate": I, "experts": E, "top_k": k, "heads": wl["heads"], "layers": n_layers,
                    "dense_layers": n_dense, "moe_layers": n_layers - n_dense, "vocab": cfg.vocab_size, "ctx": args.ctx,
                    "batch_per_gpu": 1, "parallelism": f"ep{world}" if dist_on else "single",
-                   "rccl_ranks": world if dist_on else 0, "ep_transport": ep_transport if dist_on else None,
+                   "rccl_ranks": world if (dist_on and args.dist_backend == "nccl") else 0, "dist_backend": args.dist_backend if dist_on else None,
+                   "ep_transport": ep_transport if dist_on else None,
                    "hip_graph": res["hip_graph"], "graph_error": res["graph_error"], "prewarm_steps": res["prewarm_steps"],
                    "step": "one greedy token through the YAML-injected model: embedding, per layer [RMSNorm, MLA attention operator "
                            "(q_a|kv_a, q_b, o projections, YaRN RoPE, absorb, paged MQA over the cached context, cache append), "

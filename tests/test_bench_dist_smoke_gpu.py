@@ -1,0 +1,39 @@
+"""GPU: the N > 1 code path of bench.py — process group, experts sharded E/N per rank, the peer-write decode exchange, max-over-ranks
+timing, rank 0's compact line — run as EIGHT processes on the ONE GPU of the test box (`--dist-backend gloo`: the ranks share
+cuda:0 and map each other's exchange buffers through inter-process handles exactly as on an 8-GPU node; RCCL itself refuses
+several ranks on one device, so the rendezvous / status reductions go through gloo).  It de-risks the first real
+`torchrun --nproc-per-node 8 bench.py --gpus 8`: launch line, env handling, sharding arithmetic, exchange tags
+over many steps and layers, graph capture per rank, the final line.  Five layers (3 dense + 2 MoE: the exchange runs twice per step); the one-launch attention is switched off
+(`KTX_ATTN_SEPARATE=1`): a persistent launch needs every CU, and eight of them on one GPU would wait for each other."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.mark.parametrize("world", [8])
+def test_bench_runs_as_n_processes_on_one_gpu(world, tmp_path):
+    port = 29900 + os.getpid() % 1500
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KTX_ATTN_SEPARATE="1", OMP_NUM_THREADS="1")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
+           "--layers", "5", "--ctx", "256", "--windows", "0", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-prefill",
+           "--no-kernels", "--no-secondary"]
+    out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
+    tail = (out.stdout[-1500:] + "\n--- stderr ---\n" + out.stderr[-3000:])
+    assert out.returncode == 0, tail
+    lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
+    assert lines, tail
+    line = json.loads(lines[-1])
+    assert len(lines[-1]) < 4096
+    assert line["n_gpus"] == world and line["steps"] == 6 and line["warmup"] == 2 and line["scaling"] == "weak"
+    assert line["value"] and line["value"] > 0 and abs(line["value"] - world * 1e3 / line["ms_per_step"]) / line["value"] < 1e-2
+    cfg = line["config"]
+    assert cfg["parallelism"] == f"ep{world}" and cfg["dist_backend"] == "gloo" and cfg["rccl_ranks"] == 0
+    assert cfg.get("ep_transport_status") == 0, cfg                       # no poll of the peer-write exchange gave up
+    assert str(cfg.get("ep_transport", "")).startswith("peer writes"), cfg   # the transport an 8-GPU node takes, not the collective fallback
