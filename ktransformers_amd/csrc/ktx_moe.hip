@@ -2458,6 +2458,7 @@ __global__ void pack_rawint4_scales_kernel(const bf16_t* __restrict__ src, int N
 }
 
 #include "ktx_moe_gguf.inc"
+#include "ktx_moe_legacy.inc"
 
 // =====================================================================================================
 // host side
@@ -2583,11 +2584,11 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
     const bool raw = cfg->format == KTX_FMT_RAWINT4;
     size_t need[12] = {0};
     need[0] = (size_t)cfg->max_len * H;
-    need[1] = (size_t)cfg->max_len * sizeof(float) * (raw ? H / 32 : gguf ? H / 256 : 1);
+    need[1] = (size_t)cfg->max_len * sizeof(float) * (raw || gguf ? H / 32 : 1);   // (GGUF: Q8_K has a scale per 256, Q8_0 per 32)
     // int formats: the grouped gate/up GEMM stores g | u (2*I bf16 per row); GGUF: fp32 intermediates
     need[2] = (size_t)h->max_pairs * I * (gguf ? sizeof(float) : 2 * sizeof(bf16_t));
     need[3] = (size_t)h->max_pairs * I;
-    need[4] = (size_t)h->max_pairs * sizeof(float) * (raw ? I / 32 : gguf ? I / 256 : 1);
+    need[4] = (size_t)h->max_pairs * sizeof(float) * (raw || gguf ? I / 32 : 1);
     need[5] = (size_t)h->max_pairs * H * (gguf ? sizeof(float) : sizeof(bf16_t));
     need[6] = need[7] = (size_t)h->max_pairs * sizeof(int32_t);
     need[8] = (size_t)h->max_tiles * sizeof(Tile);
@@ -2647,8 +2648,13 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
   KTX_REQUIRE(h && d_gate && d_up && d_down, "ktx_moe_load_gguf: null argument");
   KTX_REQUIRE(h->cfg.format == KTX_FMT_GGUF, "ktx_moe_load_gguf: handle was not created with KTX_FMT_GGUF");
   const int types[3] = {gate_type, up_type, down_type};
+  // two families, by the activation format ggml pairs them with (vec_dot_type): Q8_K for the k- / i-quants, Q8_0 for the legacy types.
+  // One expert set stays inside one family (the intermediate is quantised once, to the down matrix's partner: moe.hpp:388).
+  const bool legacy = gl_known(types[0]);
   for (int t : types)
-    KTX_REQUIRE(gg_known(t), "ktx_moe_load_gguf: supported ggml types are Q2_K (10), Q3_K (11), Q4_K (12), Q5_K (13), Q6_K (14), IQ1_S (19) and IQ4_XS (23)");
+    KTX_REQUIRE(legacy ? gl_known(t) : gg_known(t),
+                "ktx_moe_load_gguf: supported ggml types are Q2_K (10), Q3_K (11), Q4_K (12), Q5_K (13), Q6_K (14), IQ1_S (19), IQ4_XS (23) "
+                "— or Q4_0 (2), Q5_0 (6), Q8_0 (8) for all three matrices");
   KTX_ON_DEVICE(h->cfg.device);
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
   const int Ns[3] = {I, I, H}, Ks[3] = {H, H, I};
@@ -2657,14 +2663,17 @@ extern "C" int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_
   for (int m = 0; m < 3; m++) {
     if (*dst[m]) { KTX_HIP(hipFree(*dst[m])); *dst[m] = nullptr; }
     h->gg_type[m] = types[m];
-    h->gg_stride[m] = gg_matrix_bytes(types[m], Ns[m], Ks[m]);
+    h->gg_stride[m] = legacy ? gl_matrix_bytes(types[m], Ns[m], Ks[m]) : gg_matrix_bytes(types[m], Ns[m], Ks[m]);
     KTX_HIP(hipMalloc(dst[m], (size_t)E * h->gg_stride[m]));
-    const size_t src_stride = (size_t)Ns[m] * gg_src_row_bytes(types[m], Ks[m]);
-    const int ntiles = (Ns[m] / 16) * (Ks[m] / 256);
+    const size_t src_stride = (size_t)Ns[m] * (legacy ? gl_src_row_bytes(types[m], Ks[m]) : gg_src_row_bytes(types[m], Ks[m]));
+    const int ntiles = (Ns[m] / 16) * (Ks[m] / (legacy ? 32 : 256));
     for (int e = 0; e < E; e++) {
       const uint8_t* sp = src[m] + e * src_stride;
       uint8_t* dp = *dst[m] + e * h->gg_stride[m];
-      if (types[m] == GG_Q4K) hipLaunchKernelGGL(gg_pack_q4k_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      if (types[m] == GG_Q4_0) hipLaunchKernelGGL(gl_pack_kernel<GG_Q4_0>, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_Q5_0) hipLaunchKernelGGL(gl_pack_kernel<GG_Q5_0>, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_Q8_0) hipLaunchKernelGGL(gl_pack_kernel<GG_Q8_0>, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
+      else if (types[m] == GG_Q4K) hipLaunchKernelGGL(gg_pack_q4k_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
       else if (types[m] == GG_IQ1S) hipLaunchKernelGGL(gg_pack_iq1s_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
       else if (types[m] == GG_Q5K) hipLaunchKernelGGL(gg_pack_q5k_kernel, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
       else if (types[m] == GG_Q2K) hipLaunchKernelGGL(gg_pack_q23k_kernel<GG_Q2K>, dim3(ntiles), dim3(64), 0, 0, sp, Ns[m], Ks[m], dp);
@@ -3562,8 +3571,47 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   KTX_REQUIRE(h->gg_type[0] == h->gg_type[1], "ktx_moe_forward: gate and up must share one ggml type (one Q8_K input, moe.hpp:284-288)");
   Workspace* ws = h->ws;
   const int E = h->cfg.expert_num, H = h->cfg.hidden_size, I = h->cfg.intermediate_size;
-  const int mt = std::min(4, pick_mt(qlen, k, E));
   const int npairs = qlen * k;
+  if (gl_known(h->gg_type[0])) {
+    // ---- legacy types (ktx_moe_legacy.inc): bucket -> Q8_0(x) -> gate/up (+ act, fp32) -> Q8_0(a) -> down (fp32) -> combine -------------
+    const int max_tiles = std::min(npairs, E) + npairs / 16;
+    PrepParams pp;
+    pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
+    pp.rows_per_tile = 16; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
+    pp.x_q = ws->x_q; pp.x_d = ws->x_d; pp.row_of_pair = ws->row_of_pair; pp.src_of_row = ws->src_of_row;
+    pp.tiles = ws->tiles; pp.counters = ws->counters;
+    KTX_HIP(launch_moe_prep(pp, 1, st));
+    hipLaunchKernelGGL(q80_quant_kernel<false>, dim3(qlen), dim3(256), 0, st, d_input, H, ws->x_q, ws->x_d, d_bsz, 1, qlen);
+    KTX_HIP(hipGetLastError());
+    GlGemmParams g1{};
+    g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.stride0 = h->gg_stride[0]; g1.stride1 = h->gg_stride[1]; g1.N = I; g1.K = H;
+    g1.act_q = ws->x_q; g1.act_d = ws->x_d; g1.row_src = ws->src_of_row; g1.tiles = ws->tiles; g1.counters = ws->counters;
+    g1.out = reinterpret_cast<float*>(ws->a_buf);
+    {
+      KTX_TIMED(st, (double)std::min(npairs, E) * (h->gg_stride[0] + h->gg_stride[1]) + (double)npairs * I * 4.0 + qlen * H * 2.0,
+                "moe_legacy_gemm_kernel<%s,gate|up> T=%d k=%d H=%d I=%d", gl_type_name(h->gg_type[0]), qlen, k, H, I);
+      if (int rc = launch_legacy_type<true>(h->gg_type[0], g1, max_tiles, st)) return rc;
+    }
+    hipLaunchKernelGGL(q80_quant_kernel<true>, dim3(npairs), dim3(256), 0, st, (const void*)ws->a_buf, I, ws->a_q, ws->a_d, ws->counters, 0, npairs);
+    KTX_HIP(hipGetLastError());
+    GlGemmParams g2{};
+    g2.w0 = h->down_w; g2.w1 = nullptr; g2.stride0 = h->gg_stride[2]; g2.stride1 = 0; g2.N = H; g2.K = I;
+    g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.row_src = nullptr; g2.tiles = ws->tiles; g2.counters = ws->counters;
+    g2.out = reinterpret_cast<float*>(ws->dn_buf);
+    {
+      KTX_TIMED(st, (double)std::min(npairs, E) * h->gg_stride[2] + (double)npairs * (I + H) * 4.0,
+                "moe_legacy_gemm_kernel<%s,down> T=%d k=%d H=%d I=%d", gl_type_name(h->gg_type[2]), qlen, k, H, I);
+      if (int rc = launch_legacy_type<false>(h->gg_type[2], g2, max_tiles, st)) return rc;
+    }
+    CombineParams cp{};
+    cp.d_bsz = d_bsz; cp.qlen = qlen; cp.k = k; cp.H = H; cp.dn = ws->dn_buf; cp.row_of_pair = ws->row_of_pair;
+    cp.weights = d_weights; cp.y = (bf16_t*)d_output; cp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0;
+    cp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0; cp.dn_f32 = 1;
+    hipLaunchKernelGGL(moe_combine_kernel, dim3((H / 4 + 255) / 256, qlen), dim3(256), 0, st, cp);
+    KTX_HIP(hipGetLastError());
+    return 0;
+  }
+  const int mt = std::min(4, pick_mt(qlen, k, E));
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
 
   // ---- decode fast path: two launches (ktx_moe_gguf.inc, moe_dec_gguf_gateup_kernel) --------------------------------------

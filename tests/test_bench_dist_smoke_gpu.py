@@ -3,7 +3,8 @@ timing, rank 0's compact line — run as EIGHT processes on the ONE GPU of the t
 cuda:0 and map each other's exchange buffers through inter-process handles exactly as on an 8-GPU node; RCCL itself refuses
 several ranks on one device, so the rendezvous / status reductions go through gloo).  It de-risks the first real
 `torchrun --nproc-per-node 8 bench.py --gpus 8`: launch line, env handling, sharding arithmetic, exchange tags
-over many steps and layers, graph capture per rank, the final line.  Five layers (3 dense + 2 MoE: the exchange runs twice per step); the one-launch attention is switched off
+over many steps and layers, graph capture per rank, the final line.  DeepSeek-V2-Lite dimensions, three layers (1 dense + 2 MoE: the exchange runs twice per step; 64 experts = 8 per rank) — the eight
+ranks share ONE GPU's memory, and the synthetic weight source builds every expert before a rank keeps its share; the one-launch attention is switched off
 (`KTX_ATTN_SEPARATE=1`): a persistent launch needs every CU, and eight of them on one GPU would wait for each other."""
 import json
 import os
@@ -22,10 +23,17 @@ def test_bench_runs_as_n_processes_on_one_gpu(world, tmp_path):
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", KTX_ATTN_SEPARATE="1", OMP_NUM_THREADS="1")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "6", "--warmup", "2",
-           "--layers", "5", "--ctx", "256", "--windows", "0", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-prefill",
+           "--workload", "v2lite-int4", "--layers", "3", "--ctx", "256", "--windows", "0", "--dist-backend", "gloo", "--no-cpu-baseline", "--no-prefill",
            "--no-kernels", "--no-secondary"]
     out = subprocess.run(cmd, cwd=str(tmp_path), env=env, capture_output=True, text=True, timeout=900)
-    tail = (out.stdout[-1500:] + "\n--- stderr ---\n" + out.stderr[-3000:])
+    # the ranks' own tracebacks come first in stderr, torchrun's summary last: show the head of the first one and the tail
+    first = out.stderr.find("Traceback (most recent call last)")
+    tail = (out.stdout[-1500:] + "\n--- stderr (first traceback) ---\n" + (out.stderr[first:first + 4000] if first >= 0 else "")
+            + "\n--- stderr (tail) ---\n" + out.stderr[-1500:])
+    log_dir = os.path.join(ROOT, "gpurun_out")
+    if os.path.isdir(log_dir):
+        with open(os.path.join(log_dir, f"bench_dist_smoke_{world}.stderr"), "w") as f:
+            f.write(out.stderr)
     assert out.returncode == 0, tail
     lines = [ln for ln in out.stdout.strip().splitlines() if ln.startswith("{")]
     assert lines, tail
