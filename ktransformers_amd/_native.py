@@ -16,7 +16,13 @@ LIB_PATH = os.path.join(_HERE, "lib", "libktx_hip.so")
 
 FMT = {"AMXINT4": 0, "AMXINT8": 1, "RAWINT4": 2, "FP8": 3, "BF16": 4, "GGUF": 5, "FP8_PERCHANNEL": 6}
 GGML_TYPE_Q4_K, GGML_TYPE_Q6_K, GGML_TYPE_IQ1_S = 12, 14, 19
-GGML_BLOCK_BYTES = {10: 84, 11: 110, 12: 144, 13: 176, 14: 210, 19: 50, 23: 136}   # Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ1_S, IQ4_XS
+GGML_BLOCK_BYTES = {10: 84, 11: 110, 12: 144, 13: 176, 14: 210, 19: 50, 23: 136,   # Q2_K, Q3_K, Q4_K, Q5_K, Q6_K, IQ1_S, IQ4_XS (256 weights per block)
+                    2: 18, 6: 22, 8: 34}                                            # Q4_0, Q5_0, Q8_0 (32 weights per block; Q8_0 activations)
+GGML_LEGACY_TYPES = (2, 6, 8)
+
+
+def ggml_block_elems(ty: int) -> int:
+    return 32 if ty in GGML_LEGACY_TYPES else 256
 MAT_GATE, MAT_UP, MAT_DOWN = 0, 1, 2
 
 
@@ -384,11 +390,17 @@ class MoEHandle:
 
     def load_gguf(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_type: int, up_type: int,
                   down_type: int) -> None:
-        """Raw GGUF blocks (uint8 device tensors): gate/up [E, I, H/256*blk], down [E, H, I/256*blk]; ggml type ids."""
+        """Raw GGUF blocks (uint8 device tensors): gate/up [E, I, H/blk_elems*blk_bytes], down [E, H, I/blk_elems*blk_bytes]; ggml type
+        ids.  The three matrices come from one family: k- / i-quants (Q8_K activations) or the legacy Q4_0 / Q5_0 / Q8_0 (Q8_0)."""
+        fam = {ty in GGML_LEGACY_TYPES for ty in (gate_type, up_type, down_type)}
+        if len(fam) != 1:
+            raise KtxError("load_gguf: gate / up / down must all be k- / i-quants or all be legacy types (Q4_0, Q5_0, Q8_0): the "
+                           "intermediate is quantised once, to the format ggml pairs the down matrix with")
         for t, n, kdim, ty in ((gate, self.I, self.H, gate_type), (up, self.I, self.H, up_type), (down, self.H, self.I, down_type)):
             if ty not in GGML_BLOCK_BYTES:
-                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q2_K=10, Q3_K=11, Q4_K=12, Q5_K=13, Q6_K=14, IQ1_S=19, IQ4_XS=23)")
-            shape = (self.E, n, kdim // 256 * GGML_BLOCK_BYTES[ty])
+                raise KtxError(f"load_gguf: unsupported ggml type {ty} (Q2_K=10, Q3_K=11, Q4_K=12, Q5_K=13, Q6_K=14, IQ1_S=19, IQ4_XS=23; "
+                               "Q4_0=2, Q5_0=6, Q8_0=8)")
+            shape = (self.E, n, kdim // ggml_block_elems(ty) * GGML_BLOCK_BYTES[ty])
             if t.dtype != torch.uint8 or tuple(t.shape) != shape or not t.is_contiguous() or t.device != self.device:
                 raise KtxError(f"load_gguf: expected contiguous uint8 {shape} on {self.device}, got {t.dtype} {tuple(t.shape)} on {t.device}")
         torch.cuda.synchronize(self.device)

@@ -190,9 +190,10 @@ class LlamafileMoEWrapper(BaseMoEWrapper):
             name = f"blk.{self.layer_idx}.ffn_{fam}_exps.weight"
             ty = self.gguf_loader.get_ggml_type(name)
             if ty not in _native.GGML_BLOCK_BYTES:
-                raise NotImplementedError(f"{name}: ggml type {ty} is not supported (Q2_K=10, Q3_K=11, Q4_K=12, Q5_K=13, Q6_K=14, IQ1_S=19, IQ4_XS=23)")
+                raise NotImplementedError(f"{name}: ggml type {ty} is not supported (Q2_K=10, Q3_K=11, Q4_K=12, Q5_K=13, Q6_K=14, IQ1_S=19, IQ4_XS=23; "
+                                          "Q4_0=2, Q5_0=6, Q8_0=8)")
             raw = torch.from_numpy(self.gguf_loader.get_mmap_tensor(name).copy()).view(torch.uint8)
-            raw = raw.reshape(self.num_experts, n, k // 256 * _native.GGML_BLOCK_BYTES[ty])
+            raw = raw.reshape(self.num_experts, n, k // _native.ggml_block_elems(ty) * _native.GGML_BLOCK_BYTES[ty])
             if order != list(range(self.num_experts)):
                 raw = raw[torch.tensor(order)]
             mats.append(raw.to(self.device).contiguous())

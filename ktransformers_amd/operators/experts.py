@@ -128,17 +128,21 @@ class KExpertsHIP(KExpertsBase):
             raise ValueError(f"{self.key}: backend {self.method} quantises bf16 weights online, but the loader holds ggml type "
                              f"{int(w['gate_type'])} blocks; use backend 'llamafile' for GGUF k-quant experts")
         elif method == "GGUF":
-            from ktransformers_amd._native import GGML_BLOCK_BYTES
+            from ktransformers_amd._native import GGML_BLOCK_BYTES, GGML_LEGACY_TYPES
             types = {n: int(w[f"{n}_type"]) for n in ("gate", "up", "down")}
-            if not all(t in GGML_BLOCK_BYTES for t in types.values()):
-                # a ggml type the expert kernels do not read natively (they read Q2_K..Q6_K, IQ1_S, IQ4_XS; not Q4_0/Q5_0/Q8_0): the blocks are
+            native = all(t in GGML_BLOCK_BYTES for t in types.values()) and len({t in GGML_LEGACY_TYPES for t in types.values()}) == 1
+            if os.environ.get("KTX_GGUF_BF16_FALLBACK") == "1" and any(t in GGML_LEGACY_TYPES for t in types.values()):
+                native = False      # opt-in (rounds 2-4 served Q4_0 / Q5_0 / Q8_0 experts this way): exact weights, un-quantised activations
+            if not native:
+                # a ggml type (or a mix of the two families) the expert kernels do not read natively — they read Q2_K..Q6_K, IQ1_S, IQ4_XS
+                # with Q8_K activations and Q4_0 / Q5_0 / Q8_0 with Q8_0 activations, llamafile's arithmetic both: the blocks are
                 # de-quantised on the host with the loader's (reference-pinned) codecs and served as BF16 experts — exact
-                # weights, un-quantised activations; NOT the llamafile arithmetic (Q8_K activations), and 2 bytes per weight.
+                # weights, un-quantised activations; NOT the llamafile arithmetic, and 2 bytes per weight.
                 import warnings
 
                 from ktransformers_amd.util.gguf_loader import GGML_NAMES, GGML_QUANT_SIZES, dequantize_expert_blocks
-                warnings.warn(f"{self.key}: GGUF expert types {[GGML_NAMES.get(t, t) for t in types.values()]} have no native "
-                              "expert kernel; de-quantising to BF16 experts", RuntimeWarning, stacklevel=2)
+                warnings.warn(f"{self.key}: GGUF expert types {[GGML_NAMES.get(t, t) for t in types.values()]} have no native expert kernel "
+                              "(as this combination / by request); de-quantising to BF16 experts", RuntimeWarning, stacklevel=2)
                 E_all, e0, en = self.n_routed_experts, self.expert_begin, self.expert_count
 
                 def local(name, rows, cols):   # only THIS rank's experts are de-quantised; the others stay zero rows the slice below drops

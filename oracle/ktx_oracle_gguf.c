@@ -23,6 +23,12 @@
  *     fca1caafea7de9fbd7efc733b9818f9cf2da3050, archive/ktransformers/util/custom_gguf.py:326).  Restated from ggml's
  *     published quantize_row_q8_K_ref; no in-tree code or vector pins it.  The reference's only numeric test for this path
  *     is `diff < 0.5` against torch (kt-kernel/examples/test_moe.py:203-206), which needs the built extension.
+ *   * legacy types Q4_0 / Q5_0 / Q8_0 (round 5): ggml pairs them with Q8_0 activations (vec_dot_type).  The products the reference
+ *     reaches are iqk's mul_mat_qX_0_q8_0_T (iqk_mul_mat.inc:2201-2213 — Q4_0, Q5_0: pinned through libiqk_ref like the k-quants) and,
+ *     for Q8_0 weights (iqk declines Q8_0 x Q8_0, :3228-3236), tinyBLAS_Q0_AVX2 (tinyblas_cpu.h:828-1010; restated from the in-tree
+ *     source, not compiled here).  Both keep 8 AVX lanes of per-block terms and add them at the end; here one fma per 32-block in k
+ *     order — same integers, another fp32 association (the k-quants' bound).  quantize_row_q8_0 (activations) is ggml's x86
+ *     arithmetic (d = fp16(amax/127), q = rne(x * (127/amax))) restated from the published source: *** unpinned *** like q8_K.
  */
 #include <math.h>
 #include <stdint.h>
@@ -37,6 +43,9 @@
 #define GGML_TYPE_IQ4_XS 23
 #define GGML_TYPE_Q6_K 14
 #define GGML_TYPE_IQ1_S 19
+#define GGML_TYPE_Q4_0 2
+#define GGML_TYPE_Q5_0 6
+#define GGML_TYPE_Q8_0 8
 
 /* IQ1_S codebook (format constant), packed 2 bits per weight: see tests/golden/make_iq1s_grid.py */
 static const uint16_t iq1s_grid_packed[2048] = {
@@ -80,6 +89,85 @@ void ktxo_quantize_row_q8_K(const float* x, int K, int8_t* q, float* d, int16_t*
     for (int j = 0; j < 16; j++) { int s = 0; for (int i = 0; i < 16; i++) s += q[j * 16 + i]; bsums[j] = (int16_t)s; }
     d[b] = 1 / iscale;
   }
+}
+
+/* fp32 -> fp16, round to nearest even (what GGML_FP32_TO_FP16 = _cvtss_sh(x, 0) does on the reference's x86 hosts) */
+static uint16_t f32_to_fp16(float f) {
+  uint32_t x; memcpy(&x, &f, 4);
+  const uint32_t sign = (x >> 16) & 0x8000u;
+  x &= 0x7fffffffu;
+  if (x >= 0x7f800000u) return (uint16_t)(sign | 0x7c00u | (x > 0x7f800000u ? 0x200u : 0));   /* inf / nan */
+  if (x >= 0x477ff000u) return (uint16_t)(sign | 0x7c00u);                                      /* rounds to inf (>= 65520) */
+  if (x < 0x33000001u) return (uint16_t)sign;                                                   /* <= 2^-25: rounds to zero */
+  int e = (int)(x >> 23) - 127;
+  uint32_t m = (x & 0x7fffffu) | 0x800000u;
+  int shift = e < -14 ? 13 + (-14 - e) : 13;          /* subnormal halves lose more bits */
+  const uint32_t half = 1u << (shift - 1), rest = m & ((1u << shift) - 1);
+  uint32_t r = m >> shift;
+  if (rest > half || (rest == half && (r & 1))) r++;
+  if (e < -14) return (uint16_t)(sign | r);           /* (a carry into bit 10 lands on the smallest normal: correct) */
+  return (uint16_t)(sign | (((uint32_t)(e + 15) << 10) + (r - 0x400u)));   /* a mantissa carry bumps the exponent */
+}
+
+/* ggml-quants.c quantize_row_q8_0 (x86 AVX2 arithmetic): per 32: d = amax / 127 stored as fp16; id = amax ? 127 / amax : 0;
+ * q = round-to-nearest-even(x * id).  d[] receives the fp32 VALUE of the stored fp16 (what the dot products multiply with). */
+void ktxo_quantize_row_q8_0(const float* x, int K, int8_t* q, float* d) {
+  for (int b = 0; b < K / 32; b++, x += 32, q += 32) {
+    float amax = 0;
+    for (int j = 0; j < 32; j++) { const float ax = fabsf(x[j]); if (ax > amax) amax = ax; }
+    const float dd = amax / 127.f;
+    const float id = amax != 0.0f ? 127.f / amax : 0.0f;
+    d[b] = fp16_to_f32(f32_to_fp16(dd));
+    for (int j = 0; j < 32; j++) q[j] = (int8_t)nearest_int(x[j] * id);
+  }
+}
+
+/* block_q4_0 { fp16 d; uint8 qs[16] } (18 B): element j = (qs[j] & 15) - 8, element j + 16 = (qs[j] >> 4) - 8.
+ * One fma per block in k order: acc = fma(d_w * d_x, float(exact int dot), acc). */
+float ktxo_vec_dot_q4_0(const uint8_t* wrow, int K, const int8_t* q8, const float* d8) {
+  float acc = 0;
+  for (int b = 0; b < K / 32; b++, wrow += 18, q8 += 32) {
+    uint16_t dh; memcpy(&dh, wrow, 2);
+    const uint8_t* qs = wrow + 2;
+    int s = 0;
+    for (int j = 0; j < 16; j++) s += ((qs[j] & 15) - 8) * q8[j] + ((qs[j] >> 4) - 8) * q8[j + 16];
+    acc = fmaf(fp16_to_f32(dh) * d8[b], (float)s, acc);
+  }
+  return acc;
+}
+/* block_q5_0 { fp16 d; uint8 qh[4]; uint8 qs[16] } (22 B): element e = ((nibble_e) | (bit e of qh) << 4) - 16 */
+float ktxo_vec_dot_q5_0(const uint8_t* wrow, int K, const int8_t* q8, const float* d8) {
+  float acc = 0;
+  for (int b = 0; b < K / 32; b++, wrow += 22, q8 += 32) {
+    uint16_t dh; memcpy(&dh, wrow, 2);
+    uint32_t qh; memcpy(&qh, wrow + 2, 4);
+    const uint8_t* qs = wrow + 6;
+    int s = 0;
+    for (int j = 0; j < 16; j++) {
+      const int lo = ((qs[j] & 15) | (((qh >> j) & 1) << 4)) - 16, hi = ((qs[j] >> 4) | (((qh >> (j + 16)) & 1) << 4)) - 16;
+      s += lo * q8[j] + hi * q8[j + 16];
+    }
+    acc = fmaf(fp16_to_f32(dh) * d8[b], (float)s, acc);
+  }
+  return acc;
+}
+/* block_q8_0 { fp16 d; int8 qs[32] } (34 B) */
+float ktxo_vec_dot_q8_0(const uint8_t* wrow, int K, const int8_t* q8, const float* d8) {
+  float acc = 0;
+  for (int b = 0; b < K / 32; b++, wrow += 34, q8 += 32) {
+    uint16_t dh; memcpy(&dh, wrow, 2);
+    const int8_t* qs = (const int8_t*)(wrow + 2);
+    int s = 0;
+    for (int j = 0; j < 32; j++) s += qs[j] * q8[j];
+    acc = fmaf(fp16_to_f32(dh) * d8[b], (float)s, acc);
+  }
+  return acc;
+}
+static int is_legacy(int t) { return t == GGML_TYPE_Q4_0 || t == GGML_TYPE_Q5_0 || t == GGML_TYPE_Q8_0; }
+static size_t legacy_row_bytes(int type, int K) { return (size_t)(K / 32) * (type == GGML_TYPE_Q4_0 ? 18 : type == GGML_TYPE_Q5_0 ? 22 : 34); }
+static float legacy_vec_dot(int type, const uint8_t* wrow, int K, const int8_t* q8, const float* d8) {
+  return type == GGML_TYPE_Q4_0 ? ktxo_vec_dot_q4_0(wrow, K, q8, d8) : type == GGML_TYPE_Q5_0 ? ktxo_vec_dot_q5_0(wrow, K, q8, d8)
+                                                                                             : ktxo_vec_dot_q8_0(wrow, K, q8, d8);
 }
 
 /* ggml-quants.c get_scale_min_k4 */
@@ -318,6 +406,39 @@ int ktxo_moe_forward_gguf(const ktxo_gguf_moe* m, int T, int k, const int64_t* i
                           uint16_t* y, float* inter_out) {
   const int H = m->H, I = m->I;
   const int types[3] = {m->gate_type, m->up_type, m->down_type};
+  if (is_legacy(types[0]) && is_legacy(types[1]) && is_legacy(types[2])) {
+    /* the same control flow with ggml's partner format of the legacy types: Q8_0 (scale per 32) */
+    float* xf = malloc(sizeof(float) * H);
+    int8_t* xq = malloc(H); float* xd = malloc(sizeof(float) * (H / 32));
+    float* inter = malloc(sizeof(float) * I);
+    int8_t* aq = malloc(I); float* ad = malloc(sizeof(float) * (I / 32));
+    float* out = malloc(sizeof(float) * H);
+    for (int t = 0; t < T; t++) {
+      for (int i = 0; i < H; i++) xf[i] = ktxo_bf16_to_f32(x[(size_t)t * H + i]);
+      ktxo_quantize_row_q8_0(xf, H, xq, xd);
+      for (int i = 0; i < H; i++) out[i] = 0;
+      for (int j = 0; j < k; j++) {
+        const int64_t e = ids[(size_t)t * k + j];
+        if (e < 0 || e >= m->E || (m->gpu_experts_mask && m->gpu_experts_mask[e])) continue;
+        const size_t rg = legacy_row_bytes(m->gate_type, H), ru = legacy_row_bytes(m->up_type, H), rd = legacy_row_bytes(m->down_type, I);
+        const uint8_t* g = m->gate + (size_t)e * I * rg;
+        const uint8_t* u = m->up + (size_t)e * I * ru;
+        const uint8_t* dn = m->down + (size_t)e * H * rd;
+        for (int i = 0; i < I; i++) {
+          const float gv = legacy_vec_dot(m->gate_type, g + (size_t)i * rg, H, xq, xd);
+          const float uv = legacy_vec_dot(m->up_type, u + (size_t)i * ru, H, xq, xd);
+          inter[i] = (gv / (1.0f + expf(-gv))) * uv;
+        }
+        if (inter_out && t == 0) memcpy(inter_out + (size_t)j * I, inter, sizeof(float) * I);
+        ktxo_quantize_row_q8_0(inter, I, aq, ad);
+        const float ew = w[(size_t)t * k + j];
+        for (int i = 0; i < H; i++) out[i] += legacy_vec_dot(m->down_type, dn + (size_t)i * rd, I, aq, ad) * ew;
+      }
+      for (int i = 0; i < H; i++) y[(size_t)t * H + i] = ktxo_f32_to_bf16(out[i]);
+    }
+    free(xf); free(xq); free(xd); free(inter); free(aq); free(ad); free(out);
+    return 0;
+  }
   for (int i = 0; i < 3; i++) if (types[i] != GGML_TYPE_Q4_K && types[i] != GGML_TYPE_Q5_K && types[i] != GGML_TYPE_Q6_K && types[i] != GGML_TYPE_IQ1_S &&
                                   types[i] != GGML_TYPE_Q2_K && types[i] != GGML_TYPE_Q3_K && types[i] != GGML_TYPE_IQ4_XS) return -1;
   float* xf = malloc(sizeof(float) * H);

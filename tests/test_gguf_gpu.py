@@ -35,16 +35,19 @@ def random_iq1s(E, N, K, rng):
 
 
 Q2, Q3, Q5, IQ4 = 10, 11, 13, 23          # round 3: native kernels for Q2_K, Q3_K, Q5_K, IQ4_XS as well
-BLOCK_BYTES = {Q2: 84, Q3: 110, Q4: 144, Q5: 176, Q6: 210, IQ1: 50, IQ4: 136}
-F16_FIELDS = {Q2: (80, 82), Q3: (108,), Q4: (0, 2), Q5: (0, 2), Q6: (208,), IQ1: (0,), IQ4: (0,)}     # byte offsets of the fp16 super-scales
-F16_RANGE = {Q2: (1e-3, 4e-3), Q3: (1e-4, 4e-4), Q4: (1e-4, 2e-4), Q5: (1e-4, 2e-4), Q6: (1e-5, 2e-5), IQ1: (1e-3, 4e-3), IQ4: (2e-5, 4e-5)}
+Q40, Q50, Q80 = 2, 6, 8                   # round 5: the legacy 32-element types, Q8_0 activations (csrc/ktx_moe_legacy.inc)
+BLOCK_BYTES = {Q2: 84, Q3: 110, Q4: 144, Q5: 176, Q6: 210, IQ1: 50, IQ4: 136, Q40: 18, Q50: 22, Q80: 34}
+BLOCK_ELEMS = {Q40: 32, Q50: 32, Q80: 32}
+F16_FIELDS = {Q2: (80, 82), Q3: (108,), Q4: (0, 2), Q5: (0, 2), Q6: (208,), IQ1: (0,), IQ4: (0,), Q40: (0,), Q50: (0,), Q80: (0,)}     # byte offsets of the fp16 scales
+F16_RANGE = {Q2: (1e-3, 4e-3), Q3: (1e-4, 4e-4), Q4: (1e-4, 2e-4), Q5: (1e-4, 2e-4), Q6: (1e-5, 2e-5), IQ1: (1e-3, 4e-3), IQ4: (2e-5, 4e-5),
+             Q40: (1e-3, 4e-3), Q50: (5e-4, 2e-3), Q80: (6e-5, 2.4e-4)}
 
 
 def random_kquant(t, E, N, K, rng):
     """Random but valid blocks of any native type (every byte pattern is a legal block; the fp16 super-scales are kept small and
     positive) for shapes where quantising real matrices in numpy would take minutes, and for the types the oracle has no
     quantiser for (Q2_K, Q3_K, IQ4_XS)."""
-    nb = K // 256
+    nb = K // BLOCK_ELEMS.get(t, 256)
     b = rng.integers(0, 256, (E, N, nb, BLOCK_BYTES[t]), dtype=np.uint8)
     lo, span = F16_RANGE[t]
     for c in F16_FIELDS[t]:
@@ -115,6 +118,31 @@ def test_small_round3_types(types, T):
     run_case(4, 2, 256, 512, T, types, seed=40 + T)
 
 
+@pytest.mark.parametrize("types", [(Q40, Q40, Q40), (Q50, Q50, Q50), (Q80, Q80, Q80), (Q40, Q40, Q80), (Q50, Q50, Q40)])
+@pytest.mark.parametrize("T", [1, 3, 19, 130])
+def test_legacy_types(types, T):
+    """Q4_0 / Q5_0 / Q8_0 experts with llamafile's arithmetic: Q8_0 activations (ggml's partner format of these
+    types), one exact int8 MFMA per 32-block, one fma per block in k order — the oracle's restatement (pinned to the reference's
+    compiled iqk kernels for Q4_0 / Q5_0 by tests/test_gguf_ref_pin_cpu.py), so the outputs agree to the last bit except where the
+    device expf and glibc's differ in SiLU's final ulp; held to the k-quants' bound.  Ragged expert tiles at T = 19 / 130."""
+    h = run_case(6, 3, 512, 256, T, types, seed=5 + T, invalid=(T == 19))
+    assert h.weight_bytes == 6 * (2 * 256 * 512 // 32 * BLOCK_BYTES[types[0]] + 512 * 256 // 32 * BLOCK_BYTES[types[2]])   # the file's bytes, re-tiled
+
+
+@pytest.mark.parametrize("types", [(Q40, Q40, Q40), (Q80, Q80, Q80)])
+def test_legacy_types_v3_expert_shape(types):
+    run_case(8, 8, 7168, 2048, 2, types, seed=9)
+
+
+def test_legacy_and_kquant_families_do_not_mix():
+    from ktransformers_amd import _native as n
+    h = n.MoEHandle(2, 1, 256, 256, 4, "GGUF", 0)
+    g = torch.zeros((2, 256, 256 // 32 * 18), dtype=torch.uint8, device="cuda")
+    d = torch.zeros((2, 256, 144), dtype=torch.uint8, device="cuda")
+    with pytest.raises(n.KtxError, match="all be k- / i-quants or all be legacy"):
+        h.load_gguf(g, g, d, Q40, Q40, Q4)
+
+
 @pytest.mark.parametrize("types", [(Q5, Q5, Q6), (Q2, Q2, Q3), (IQ4, IQ4, IQ4)])
 def test_round3_types_v3_expert_shape(types):
     """The DeepSeek-V3 / R1 expert shape (7168 x 2048, the decode kernels' 2-k-slice variants and deep rings) for the type mixes
@@ -157,7 +185,7 @@ def test_errors():
     g = torch.zeros(4, 512, 144, dtype=torch.uint8, device="cuda")
     d = torch.zeros(4, 256, 2 * 210, dtype=torch.uint8, device="cuda")
     with pytest.raises(n.KtxError):
-        h.load_gguf(g, g, d, 12, 12, 8)                                   # Q8_0 not supported
+        h.load_gguf(g, g, d, 12, 12, 8)                                   # Q8_0 down behind k-quant gate / up: the families do not mix
 
 
 def test_llamafile_backend_through_the_operator_and_gguf_file(tmp_path):
@@ -189,7 +217,8 @@ def test_llamafile_backend_through_the_operator_and_gguf_file(tmp_path):
 
 
 def test_expert_types_without_a_native_kernel_are_served_as_dequantised_bf16_experts(tmp_path):
-    """A GGUF file whose experts are Q5_K / Q8_0 (types the expert kernels do not read): the operator says so (RuntimeWarning),
+    """A GGUF file whose experts are Q5_K gate / up with a Q8_0 down (a mix of the two activation families the expert kernels do not
+    serve — Q8_K and Q8_0 inputs in one expert): the operator says so (RuntimeWarning),
     de-quantises the blocks with the loader's reference-pinned codecs and serves BF16 experts.  Checked against fp64 math on
     the same de-quantised weights (bf16 kernels: 2^-7 relative + a small absolute term), not against llamafile arithmetic."""
     from helpers import write_gguf
@@ -246,3 +275,49 @@ def test_expert_types_without_a_native_kernel_are_served_as_dequantised_bf16_exp
             g, u = G[e] @ xf[t], U[e] @ xf[t]
             ref[t] += w[t, j] * (D[e] @ (g / (1 + np.exp(-g)) * u))
     assert (np.abs(y - ref) <= 2.0 ** -6 * np.abs(ref) + 1e-2 * np.abs(ref).max()).all()
+
+
+def test_legacy_type_experts_through_the_operator_and_gguf_file(tmp_path, monkeypatch):
+    """A GGUF file whose routed experts are Q4_0 (gate / up) and Q8_0 (down): KTransformersExperts(backend="llamafile") serves them
+    NATIVELY (no warning, the file's bytes re-tiled, llamafile's arithmetic with Q8_0 activations) — against the oracle on the same
+    blocks; KTX_GGUF_BF16_FALLBACK=1 brings back the de-quantised BF16 experts of rounds 2-4 (opt-in, with the warning)."""
+    import warnings
+    from helpers import write_gguf
+    from toy_model import ToyConfig
+    from ktransformers_amd.operators.experts import KTransformersExperts
+    from ktransformers_amd.util.gguf_loader import GGUFLoader
+    from ktransformers_amd.util.utils import InferenceState
+
+    rng = np.random.default_rng(21)
+    E, H, I, k, T = 4, 256, 512, 2, 5
+    gate, up, down = random_kquant(Q40, E, I, H, rng), random_kquant(Q40, E, I, H, rng), random_kquant(Q80, E, H, I, rng)
+    write_gguf(str(tmp_path / "toy.gguf"), {"blk.1.ffn_gate_exps.weight": (Q40, [H, I, E], gate.tobytes()),
+                                            "blk.1.ffn_up_exps.weight": (Q40, [H, I, E], up.tobytes()),
+                                            "blk.1.ffn_down_exps.weight": (Q80, [I, H, E], down.tobytes())},
+               {"deepseek2.expert_count": E})
+    cfg = ToyConfig(hidden_size=H, moe_intermediate_size=I, intermediate_size=I, n_routed_experts=E, num_experts_per_tok=k)
+    orig = torch.nn.ModuleList([torch.nn.Identity() for _ in range(E)])
+
+    def build():
+        return KTransformersExperts("model.layers.1.mlp.experts", GGUFLoader(str(tmp_path)), cfg, orig, prefill_device="cuda",
+                                    prefill_op="KExpertsTorch", generate_device="cpu", generate_op="KExpertsCPU", out_device="cuda",
+                                    backend="llamafile", max_len=16)
+    ex = build()
+    with warnings.catch_warnings():
+        warnings.simplefilter("error", RuntimeWarning)
+        ex.load(mode=InferenceState.GENERATE)
+    assert ex.generate_experts.loaded_method == "GGUF"
+    x = f32_to_bf16((rng.standard_normal((T, H)) / 4).astype(np.float32))
+    ids = np.stack([rng.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
+    w = rng.random((T, k)).astype(np.float32)
+    args = (torch.from_numpy(x.view(np.int16)).view(torch.bfloat16).cuda(), torch.from_numpy(ids).cuda(), torch.from_numpy(w).cuda())
+    y = ex.forward(*args).float().cpu().numpy()
+    ref = bf16_to_f32(GgufOracle().moe_forward(gate, up, down, (Q40, Q40, Q80), E, H, I, ids, w, x))
+    assert (np.abs(y - ref) <= 2.0 ** -7 * np.abs(ref) + 2e-3 * np.abs(ref).max()).all() and float((y == ref).mean()) >= 0.99
+    monkeypatch.setenv("KTX_GGUF_BF16_FALLBACK", "1")
+    ex2 = build()
+    with pytest.warns(RuntimeWarning, match="no native expert kernel"):
+        ex2.load(mode=InferenceState.GENERATE)
+    assert ex2.generate_experts.loaded_method == "BF16"
+    y2 = ex2.forward(*args).float().cpu().numpy()
+    assert (np.abs(y2 - ref) <= 2.0 ** -5 * np.abs(ref) + 2e-2 * np.abs(ref).max()).all()      # same weights, un-quantised activations

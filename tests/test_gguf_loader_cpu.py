@@ -109,10 +109,13 @@ def test_every_type_the_reference_loader_reads_dequantises_bit_for_bit(t):
 
 
 def test_native_expert_types_use_the_loaders_block_sizes():
-    """The ggml types the expert kernels read natively (Q2_K..Q6_K, IQ1_S, IQ4_XS; csrc/ktx_moe_gguf.inc) and the loader's table of
-    block sizes (custom_gguf.py:72-100) name the same bytes per 256-block; Q4_0 / Q5_0 / Q8_0 experts stay on the de-quantised path."""
+    """The ggml types the expert kernels read natively — Q2_K..Q6_K, IQ1_S, IQ4_XS (csrc/ktx_moe_gguf.inc: 256-weight blocks, Q8_K
+    activations) and, round 5, Q4_0 / Q5_0 / Q8_0 (csrc/ktx_moe_legacy.inc: 32-weight blocks, Q8_0 activations) — and the loader's table
+    of block sizes (custom_gguf.py:72-100) name the same (weights, bytes) per block."""
     from ktransformers_amd import _native
     from ktransformers_amd.util.gguf_loader import GGML_QUANT_SIZES, GGML_TYPES
-    assert set(_native.GGML_BLOCK_BYTES) == {GGML_TYPES[n] for n in ("Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_XS")} | {19}
+    assert set(_native.GGML_BLOCK_BYTES) == ({GGML_TYPES[n] for n in ("Q2_K", "Q3_K", "Q4_K", "Q5_K", "Q6_K", "IQ4_XS")} | {19}
+                                             | {GGML_TYPES[n] for n in ("Q4_0", "Q5_0", "Q8_0")})
+    assert set(_native.GGML_LEGACY_TYPES) == {GGML_TYPES[n] for n in ("Q4_0", "Q5_0", "Q8_0")}
     for t, nbytes in _native.GGML_BLOCK_BYTES.items():
-        assert GGML_QUANT_SIZES[t] == (256, nbytes)
+        assert GGML_QUANT_SIZES[t] == (_native.ggml_block_elems(t), nbytes)
