@@ -100,12 +100,17 @@ int ktx_moe_load_fp8_perchannel(ktx_moe_t h, const void* d_gate, const void* d_u
 int ktx_moe_load_rawint4(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, const void* d_gate_scale,
                          const void* d_up_scale, const void* d_down_scale);
 
-/* GGUF k-quant experts (the llamafile backend: LLAMA_MOE_TP::load_weights, operators/llamafile/moe.hpp:104-176; the
+/* GGUF experts (the llamafile backend: LLAMA_MOE_TP::load_weights, operators/llamafile/moe.hpp:104-176; the
  * archive engine hands it mmap'ed `blk.N.ffn_{gate,up,down}_exps.weight`, archive/ktransformers/operators/experts.py:
- * 177-224): raw ggml blocks gate/up [expert_num][I][H/256 blocks], down [expert_num][H][I/256 blocks], DEVICE pointers,
- * with their ggml type ids (MOEConfig gate_type/up_type/down_type).  Supported: Q4_K (12), Q6_K (14) — the q4_k_m mix — and IQ1_S (19; its only in-tree definition is the reference's
- * mul_mat_iq1_s_q8_K, third_party/llamafile/iqk_mul_mat.inc:2689-2770);
- * gate and up must share a type.  The handle re-tiles into its own layout.  Synchronous. */
+ * 177-224): raw ggml blocks gate/up [expert_num][I][H/B blocks], down [expert_num][H][I/B blocks], DEVICE pointers,
+ * with their ggml type ids (MOEConfig gate_type/up_type/down_type).  Two families, by the activation format ggml pairs the
+ * weights with (type_traits.vec_dot_type, which is what moe.hpp:284-288,388 quantises the input / the intermediate to):
+ *   B = 256, Q8_K activations: Q2_K (10), Q3_K (11), Q4_K (12), Q5_K (13), Q6_K (14), IQ4_XS (23), IQ1_S (19; its only in-tree
+ *            definition is the reference's mul_mat_iq1_s_q8_K, third_party/llamafile/iqk_mul_mat.inc:2689-2770);
+ *   B = 32,  Q8_0 activations: Q4_0 (2), Q5_0 (6), Q8_0 (8) — iqk_mul_mat.inc:2201-2213 (mul_mat_qX_0_q8_0_T) for the first two,
+ *            tinyBLAS_Q0_AVX2 (tinyblas_cpu.h:828-1010) for Q8_0 weights.
+ * The three matrices of a handle come from ONE family (the intermediate is quantised once); gate and up must share a type.
+ * The handle re-tiles the blocks into its own layout (same bytes).  Synchronous. */
 int ktx_moe_load_gguf(ktx_moe_t h, const void* d_gate, const void* d_up, const void* d_down, int gate_type, int up_type,
                       int down_type);
 
@@ -118,6 +123,15 @@ int ktx_moe_combine(int qlen, int k, int hidden, const void* d_rows, const int32
 
 /* should_skip_expert mask (operators/common.hpp:241-258): mask[e] != 0 => expert e contributes nothing. HOST ptr, may be NULL. */
 int ktx_moe_set_expert_mask(ktx_moe_t h, const uint8_t* mask);
+
+/* Exact / fast switch of a handle (default 0 = fast).  Every decode-sized call, and every format but RAWINT4 at any size, reproduces
+ * the reference's fp32 summation order bit for bit either way.  RAWINT4 (Kimi-K2) prompt chunks of >= 64 tokens are the one place a
+ * faster kernel re-associates: moe_rawint4_chunk_kernel adds a row's K/32 group terms (d_a * d_w * int32 dot, the same terms) as ONE
+ * fp32 chain, the reference keeps sixteen interleaved chains and a final tree (la/amx_kernels.hpp:3385-3455).  Measured bound of the
+ * fast path against the reference on its own test's data (tests/test_moe_gpu.py): |y - ref| <= 2^-7 |ref| + 2^-9 max|ref| (two bf16
+ * ulp element-wise), < 5 % of the outputs different, mean error < 1e-3; ~6.7x the exact kernel's prompt rate (16 k vs 2.4 k tok/s at
+ * Kimi-K2 dimensions).  exact = 1 keeps the 4-row kernel whose sums are the reference's: bit-identical outputs at any size. */
+int ktx_moe_set_exact(ktx_moe_t h, int exact);
 
 /* y[t] = (incremental ? y[t] : 0) + sum_j w[t][j] * Expert_{ids[t][j]}(x[t])   — see DESIGN.md for the exact
  * rounding contract (= SURVEY.md Appendix A).  d_bsz may be NULL (then qlen is used); otherwise min(*d_bsz, qlen)

@@ -108,6 +108,7 @@ def _load() -> C.CDLL:
                                     C.c_void_p, C.c_int, C.c_void_p]
     lib.ktx_moe_forward_ex.argtypes = lib.ktx_moe_forward.argtypes
     lib.ktx_moe_forward_side.argtypes = [C.c_void_p, C.c_void_p, C.c_int, C.c_int] + [C.c_void_p] * 8
+    lib.ktx_moe_set_exact.argtypes = [C.c_void_p, C.c_int]
     lib.ktx_moe_weight_bytes.argtypes = [C.c_void_p]
     lib.ktx_moe_weight_bytes.restype = C.c_size_t
     lib.ktx_moe_debug_ptrs.argtypes = [C.c_void_p, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p)]
@@ -387,6 +388,11 @@ class MoEHandle:
         torch.cuda.synchronize(self.device)
         check(lib.ktx_moe_load_rawint4(self._h, gate.data_ptr(), up.data_ptr(), down.data_ptr(), gate_scale.data_ptr(),
                                        up_scale.data_ptr(), down_scale.data_ptr()))
+
+    def set_exact(self, exact: bool = True) -> None:
+        """ktx_moe_set_exact (include/ktx_moe.h): with exact=True no path of this handle re-associates the reference's fp32 sums — the
+        RAWINT4 prompt-chunk kernel (the one fast path that does, within 2 bf16 ulp) is replaced by the exact 4-row kernel."""
+        check(lib.ktx_moe_set_exact(self._h, 1 if exact else 0))
 
     def load_gguf(self, gate: torch.Tensor, up: torch.Tensor, down: torch.Tensor, gate_type: int, up_type: int,
                   down_type: int) -> None:

@@ -2522,6 +2522,7 @@ struct ktx_moe_s {
   int gg_type[3] = {0, 0, 0};     // GGUF: ggml type of gate / up / down
   size_t gg_stride[3] = {0, 0, 0};
   bool loaded_gguf = false;
+  bool exact = false;             // ktx_moe_set_exact: no path of this handle may re-associate the reference's fp32 sums
 };
 
 static int pick_mt(int qlen, int k, int E) {
@@ -2632,6 +2633,12 @@ extern "C" int ktx_moe_destroy(ktx_moe_t h) {
   for (void* p : ptrs)
     if (p) hipFree(p);
   delete h;
+  return 0;
+}
+
+extern "C" int ktx_moe_set_exact(ktx_moe_t h, int exact) {
+  KTX_REQUIRE(h, "ktx_moe_set_exact: null handle");
+  h->exact = exact != 0;
   return 0;
 }
 
@@ -3429,7 +3436,7 @@ static int forward_rawint4(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, 
 
   // prompt chunks: 64-row tiles through the group-scaled 16x16x32 kernel (moe_rawint4_chunk_kernel: same terms, one fp32 chain per
   // output instead of the reference's sixteen); short batches and dev knob 29 = 1 keep the exact 4-row kernel
-  const bool chunk = qlen >= 64 && g_dbg[29] != 1 && H % 512 == 0 && I % 512 == 0;
+  const bool chunk = qlen >= 64 && g_dbg[29] != 1 && !h->exact && H % 512 == 0 && I % 512 == 0;
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
   pp.rows_per_tile = chunk ? 64 : 4; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;

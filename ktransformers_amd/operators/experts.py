@@ -85,6 +85,7 @@ class KExpertsHIP(KExpertsBase):
             raise ValueError(f"KExpertsHIP: unsupported backend {backend!r} (have {sorted(_BACKEND_TO_METHOD)})")
         self.method = _BACKEND_TO_METHOD[backend]
         self.max_len = int(kwargs.get("max_len", kwargs.get("chunk_size", 8192)))
+        self.exact = bool(kwargs.get("exact", False))      # include/ktx_moe.h ktx_moe_set_exact (RAWINT4 prompt chunks: exact vs fast)
         self.expert_begin = int(kwargs.get("expert_begin", 0))
         self.expert_count = int(kwargs.get("expert_count", n_routed_experts))
         self.handle = None
@@ -185,6 +186,9 @@ class KExpertsHIP(KExpertsBase):
             h.load_rawint4(prep(w["gate"]).view(torch.uint8), prep(w["up"]).view(torch.uint8), prep(w["down"]).view(torch.uint8),
                            prep(w["gate_scale"], torch.bfloat16), prep(w["up_scale"], torch.bfloat16),
                            prep(w["down_scale"], torch.bfloat16))
+        # exact / fast switch (include/ktx_moe.h ktx_moe_set_exact): rule-file kwarg `exact: true` or KTX_MOE_EXACT=1
+        if bool(self.exact) or os.environ.get("KTX_MOE_EXACT") == "1":
+            h.set_exact(True)
         self.handle = h
         self.loaded_method = method          # the format this load actually built (the BF16 fallback of GGUF types without a kernel)
         if ep_on:

@@ -26,19 +26,21 @@ class KDeepseekV3MLP(BaseInjectedModule):
         down, gate, up = self.orig_module.down_proj, self.orig_module.gate_proj, self.orig_module.up_proj
         from ktransformers_amd.util.utils import load_weights
         load_weights(down, self.gguf_loader, self.key + ".down_proj.")
-        merged = None
+        merged = cat = None
         if all(isinstance(m, KTransformersLinear) for m in (down, gate, up)) and down.generate_linear is not None:
-            merged = build_merged_linear(down.generate_linear, [self.key + ".gate_proj", self.key + ".up_proj"],
-                                         self.gguf_loader, down.generate_linear.device, interleave8=True)
-        cat = None
-        if merged is None and all(isinstance(m, KTransformersLinear) for m in (down, gate, up)) and down.generate_linear is not None:
-            # block-fp8 (round 4): the strip-interleaved GLU layout would put gate and up rows into one 128-row scale block, the plain
-            # concatenation [gate ; up] keeps every block whole (intermediate sizes are multiples of 128): one GEMV (+ the fused input
-            # norm) and one SiLU * up launch instead of norm + two GEMVs + a concatenation + SiLU * up
-            cat = build_merged_linear(down.generate_linear, [self.key + ".gate_proj", self.key + ".up_proj"],
-                                      self.gguf_loader, down.generate_linear.device, interleave8=False)
-            if cat is not None and (len(cat[1]) != 2 or cat[1][0] != cat[1][1] or getattr(cat[0], "FMT", None) != "FP8"):
-                cat = None                             # (only the fp8 case is new; other formats keep their separate operators)
+            from ktransformers_amd.operators.linear import KLinearFP8
+            keys = [self.key + ".gate_proj", self.key + ".up_proj"]
+            # decided BEFORE anything is built (each build loads and quantises both matrices): block-fp8 sources take the plain
+            # concatenation [gate ; up] — the strip-interleaved GLU layout would put gate and up rows into one 128-row scale block, the
+            # concatenation keeps every block whole (intermediate sizes are multiples of 128): one GEMV (+ the fused input norm) and one
+            # SiLU * up launch — every other format takes the interleaved layout with the GLU epilogue
+            fp8 = isinstance(down.generate_linear, KLinearFP8) and all(self.gguf_loader.has_tensor(k + ".weight_scale_inv") for k in keys)
+            if fp8:
+                cat = build_merged_linear(down.generate_linear, keys, self.gguf_loader, down.generate_linear.device, interleave8=False)
+                if cat is not None and (len(cat[1]) != 2 or cat[1][0] != cat[1][1] or getattr(cat[0], "FMT", None) != "FP8"):
+                    cat = None
+            else:
+                merged = build_merged_linear(down.generate_linear, keys, self.gguf_loader, down.generate_linear.device, interleave8=True)
         if merged is not None or cat is not None:
             object.__setattr__(self, "_gate_up" if merged is not None else "_gate_up_cat", (merged or cat)[0])
             for m in (gate, up):                       # their rows live in the merged operator

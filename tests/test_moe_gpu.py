@@ -461,7 +461,7 @@ def test_rawint4_prompt_chunks(oracle, dev, shape):
     same per-group scale products as the reference's GemmKernel224Int4SmallKGroup, summed as ONE fp32 chain over the 32-k groups
     instead of sixteen interleaved chains + a tree (csrc/ktx_moe.hip).  Bound: that of the FP8 / BF16 formats, whose prompt kernels
     re-associate the same way (element-wise 2^-7 |ref| + 2^-9 max|ref|, < 5 % of the bf16 outputs different at all, mean error
-    < 1e-3 of the mean magnitude); and against the exact kernels of this library on the same input (dev knob 29), Kimi-K2's
+    < 1e-3 of the mean magnitude); and against the exact kernels of this library on the same input (MoEHandle.set_exact), Kimi-K2's
     expert shape included, ragged tiles and invalid ids included."""
     from helpers import rawint4_quantize
     from ktransformers_amd import _native
@@ -476,11 +476,12 @@ def test_rawint4_prompt_chunks(oracle, dev, shape):
         h.load_rawint4(*[torch.from_numpy(x[0]).to(dev) for x in q], *[torch_bf16(x[1], dev) for x in q])
         got = run(h, c, dev)
         _check_fp(got, want)
-        _native.lib.ktx_debug_set(29, 1)
+        h.set_exact(True)                 # the PUBLIC switch (include/ktx_moe.h ktx_moe_set_exact): bit-identical at any size
         exact = run(h, c, dev)
         assert np.array_equal(exact, want)
         assert (got != exact).mean() < 0.05
-        _native.lib.ktx_debug_set(29, 0)
+        h.set_exact(False)
+        assert np.array_equal(run(h, c, dev), got)        # ... and back to the fast kernel
         if H * I <= (1 << 22):            # (the oracle's second pass over the Kimi-K2 shape would cost another ~15 s of CPU)
             want_inc = oracle.moe_forward(mo, c["ids"], c["w"], c["x"], y_prev=want)
             _check_fp(run(h, c, dev, out=torch_bf16(want, dev), incremental=True), want_inc)
