@@ -728,7 +728,7 @@ class LinearHandle:
         T = x2.shape[0]
         tp = (T + 127) // 128 * 128
         q = torch.empty((T, self.K), dtype=torch.uint8, device=self.device)
-        st = torch.empty((self.K // 128, tp), dtype=torch.float32, device=self.device)
+        st = torch.zeros((self.K // 128, tp), dtype=torch.float32, device=self.device)   # (act_quant writes T columns: the pad rows' scales are 0, not garbage)
         y = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device)
         sp = _stream_ptr(self.device)
         check(lib.ktx_fp8_act_quant(x2.data_ptr(), x2.stride(0), T, self.K, q.data_ptr(), st.data_ptr(), tp, sp))

@@ -1395,6 +1395,7 @@ struct ktx_linear_s {
   size_t w_bytes = 0, sc_bytes = 0;
   bool loaded = false;
   unsigned long long* d_sk_words = nullptr;   // lin_sk_kernel: [nstrips][64] meeting words (zero between launches)
+  unsigned long long* d_granules = nullptr;   // this handle's {tag, logit} granules + tickets of the router that rides in its launches
   int sk_ncu = 0;
 };
 
@@ -1406,8 +1407,12 @@ struct ktx_linear_s {
 // fragment covers many of them, and a layer's matrices sit next to each other in launch order.  A slab is returned to the
 // driver when its last piece is freed.  KTX_ARENA=0 restores the plain hipMalloc / hipFree per piece (A/B).
 namespace {
-// {tag, logit} granules of the router riding in lin_sk_gate_kernel: one buffer per device, zero between launches
+// {tag, logit} granules of the router riding in lin_sk_gate_kernel, zero between launches.  Each handle that carries a router gets its
+// OWN buffer at its first such call (gate_granules_of: two models / two streams on one device must not sweep each other's logits —
+// VERDICT r4 #11); the per-device buffer below remains only as the fallback of a first call that arrives inside a stream capture,
+// where nothing may be allocated (every shipped flow warms up eagerly before it captures).
 constexpr int KTX_GRAN_T = 64;
+constexpr size_t KTX_GRAN_BYTES = (size_t)KTX_GRAN_T * KTX_GATE_MAX_E * sizeof(unsigned long long) + (size_t)KTX_GRAN_T * 16 * sizeof(int);
 unsigned long long* g_gate_granules[64] = {nullptr};
 hipError_t gate_granules_for(int dev) {
   if (dev < 0 || dev >= 64 || g_gate_granules[dev]) return hipSuccess;
@@ -1415,6 +1420,24 @@ hipError_t gate_granules_for(int dev) {
   hipError_t e = hipMalloc((void**)&g_gate_granules[dev], nb);
   if (e == hipSuccess) e = hipMemset(g_gate_granules[dev], 0, nb);
   return e;
+}
+unsigned long long* gate_granules_of(ktx_linear_s* h, hipStream_t st) {
+  if (h->d_granules) return h->d_granules;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cs) != hipSuccess) { (void)hipGetLastError(); cs = hipStreamCaptureStatusNone; }
+  if (cs != hipStreamCaptureStatusNone) return g_gate_granules[h->cfg.device];
+  static std::mutex mu;
+  std::lock_guard<std::mutex> lk(mu);
+  if (!h->d_granules) {
+    unsigned long long* p = nullptr;
+    if (hipMalloc((void**)&p, KTX_GRAN_BYTES) != hipSuccess || hipMemset(p, 0, KTX_GRAN_BYTES) != hipSuccess) {
+      (void)hipGetLastError();
+      if (p) (void)hipFree(p);
+      return g_gate_granules[h->cfg.device];
+    }
+    h->d_granules = p;
+  }
+  return h->d_granules;
 }
 struct LinSlab { char* base; size_t cap, used, last; int live; int dev; };   // last = offset of the most recently carved piece
 std::mutex g_arena_mu;
@@ -1897,6 +1920,7 @@ extern "C" int ktx_linear_destroy(ktx_linear_t h) {
   lin_free(h->d_sc);
   lin_free(h->d_bias);
   lin_free(h->d_sk_words);
+  if (h->d_granules) (void)hipFree(h->d_granules);
   delete h;
   return 0;
 }
@@ -2085,7 +2109,7 @@ extern "C" int ktx_linear_forward_fused_gate(ktx_linear_t h, const int32_t* d_bs
     ga.c = *gate_cfg; ga.d_bsz = d_bsz; ga.qlen = T; ga.x = (const bf16_t*)d_x; ga.w = (const bf16_t*)d_gate_w; ga.bias = d_gate_bias;
     ga.logits = d_logits; ga.counters = d_counters; ga.topk_idx = d_topk_idx; ga.topk_w = d_topk_weight;
     ga.norm_w = (const bf16_t*)fusion->norm_weight; ga.norm_eps = fusion->norm_eps; ga.xn_out = (bf16_t*)d_xn_out;
-    ga.granules = (h->cfg.device >= 0 && h->cfg.device < 64 && T <= KTX_GRAN_T) ? g_gate_granules[h->cfg.device] : nullptr;
+    ga.granules = (h->cfg.device >= 0 && h->cfg.device < 64 && T <= KTX_GRAN_T) ? gate_granules_of(const_cast<ktx_linear_s*>(h), (hipStream_t)stream) : nullptr;
     ga.tickets = ga.granules ? reinterpret_cast<int*>(ga.granules + (size_t)KTX_GRAN_T * KTX_GATE_MAX_E) : nullptr;
     if (ktx_debug_get(21) == 1 && ktx_debug_get(19) == 0) ga.granules = nullptr;   // A/B: the round-2 store-ack hand-off in the router
     ga.wg_select = ktx_debug_get(28) == 1 ? 0 : 1;   // A/B: 1 = the last arriver's eight wavefronts share the selection (round 4)

@@ -198,3 +198,40 @@ def test_router_riding_in_the_all_cu_gate_up_kernel(name, I_shared, T, mode):
             assert (y2.float() - y0.float()).abs().max().item() <= 2e-2 * y0.float().abs().max().item()
     finally:
         n.lib.ktx_debug_set(19, 0)
+
+
+def test_two_models_route_on_two_streams_of_one_device():
+    """the {tag, logit} granules of the router that rides in the shared gate|up launch were ONE buffer per device —
+    two models (or two streams) on one GPU could sweep each other's logits.  Every handle now owns its granules: two MoE fronts of
+    DeepSeek-V3 dimensions issued alternately on two streams, many times, give exactly what each gives alone."""
+    from ktransformers_amd import _native as n
+    cfg = dict(CONFIGS["deepseek_v3"])
+    E, H = cfg.pop("E"), cfg.pop("H")
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(5)
+    models = []
+    for m in range(2):
+        w = (torch.randn((E, H), generator=g) * H ** -0.5).to(torch.bfloat16).to(dev)
+        nw = (1 + 0.1 * torch.randn((H,), generator=g)).to(torch.bfloat16).to(dev)
+        bias = (torch.randn((E,), generator=g) * 0.1).to(dev)
+        wl = (torch.randn((4096, H), generator=g) / 10).to(torch.bfloat16).to(dev)
+        gh = n.GateHandle(E, H, cfg["top_k"], cfg["n_group"], cfg["topk_group"], cfg["scoring_func"], cfg["topk_method"],
+                          cfg["norm_topk_prob"], cfg["routed_scaling_factor"])
+        lin = n.LinearHandle(H, 4096, "W4", 64, 8, dev)
+        lin.load_bf16(wl)
+        xs = [torch.randn((1, H), generator=g).to(torch.bfloat16).to(dev) for _ in range(6)]
+        alone = [tuple(t.clone() for t in n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6))) for x in xs]
+        models.append((gh, lin, w, bias, nw, xs, alone))
+    torch.cuda.synchronize()
+    streams = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)]
+    for rnd in range(4):
+        got = [[], []]
+        for i in range(6):
+            for m, (gh, lin, w, bias, nw, xs, _) in enumerate(models):
+                with torch.cuda.stream(streams[m]):
+                    got[m].append(tuple(t.clone() for t in n.gate_with_linear(gh, lin, xs[i], w, bias, (nw, 1e-6))))
+        torch.cuda.synchronize()
+        for m in range(2):
+            for i in range(6):
+                for a, b in zip(got[m][i], models[m][6][i]):
+                    assert torch.equal(a, b), f"round {rnd}, model {m}, step {i}: differs from the model running alone"

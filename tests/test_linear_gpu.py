@@ -478,6 +478,33 @@ def test_all_cu_decode_gemv_both_deals_against_the_reference_math(K, N, T):
     assert bool((d <= y_strips.float().abs() * 2.0 ** -7 + 1e-6).all())
 
 
+@pytest.mark.parametrize("bad", [float("nan"), float("inf"), 3.0e38])
+def test_shared_strip_words_do_not_swallow_non_finite_parts(bad):
+    """ADVICE r3 / VERDICT r4 #11: a strip shared between workgroups meets through fixed-point words; a part that is NaN, Inf or
+    beyond the words' range used to be clamped into a NUMBER (fminf / fmaxf drop a NaN).  It now travels as a marker no sum of
+    in-range parts can reach and the finisher writes NaN: a poisoned input row gives non-finite outputs under BOTH deals, the
+    words are back at zero afterwards (a clean row right behind it is exact again)."""
+    n = native()
+    torch.manual_seed(11)
+    K, N = 7168, 2112
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16)
+    h = n.LinearHandle(K, N, "W4", 64, 16)
+    h.load_bf16(w.cuda())
+    x = (torch.randn(1, K) / 10).to(torch.bfloat16)
+    xb = x.clone()
+    xb[0, 5] = bad                      # (3e38 * a weight of ~0.1 over a 1 KiB tile stays finite in fp32 but leaves the words' +-2^18 range)
+    q, s = quantize_weights_ref(w.T.contiguous(), 64)
+    ref = linear_w4_ref(x, q, s, 64, None)
+    for knobs in ({}, {"k17": 1}):
+        with _knobs(n, **knobs):
+            y_bad = h.forward(xb.cuda())
+            y_ok = h.forward(x.cuda())
+        assert not bool(torch.isfinite(y_bad.float()).all()), f"deal {knobs or 'whole strips'}: the poisoned row came out finite"
+        if knobs:   # every output of the row depends on x[5] (one k-step of every strip): all of them must be flagged
+            assert float(torch.isfinite(y_bad.float()).float().mean()) < 0.01
+        close(y_ok, ref)
+
+
 @pytest.mark.parametrize("T", [1, 3])
 def test_all_cu_decode_gemv_epilogues(T):
     """Fused RMSNorm prologue, glu, bias and both addends through lin_sk_kernel == the same call through lin_dec_kernel up to
