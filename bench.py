@@ -1075,7 +1075,8 @@ def run_model_decode(name, args, dev, steps, warmup, dist_on=False, world=1, ran
     # runs its first replays at idle clocks).  N > 1: every step issues collectives, so all ranks run the SAME fixed number of
     # steps.  Declared in the JSON as `prewarm_steps`.
     n_pre, t_pre = 0, time.perf_counter()
-    while n_pre < 100 if dist_on else (time.perf_counter() - t_pre < 1.0 and n_pre < 300):
+    n_pre_dist = 20 if getattr(args, "dist_backend", "nccl") == "gloo" else 100     # (gloo = ranks time-slicing one GPU: a smoke, not a measurement)
+    while n_pre < n_pre_dist if dist_on else (time.perf_counter() - t_pre < 1.0 and n_pre < 300):
         for _ in range(10):
             mr.step()
             n_pre += 1
@@ -1406,7 +1407,8 @@ def main():
         if os.environ.get("KTX_EP_TRANSPORT", "peer") != "collectives":
             try:
                 ep_exchange = enable_peer_exchange(wl["H"], wl["k"], 16, dev)
-                ep_exchange.set_spin_seconds(120)    # ranks capture their graphs at their own pace; a dead peer still ends the wait
+                # ranks capture their graphs at their own pace; a dead peer still ends the wait (KTX_EP_SPIN_SECONDS: the bound)
+                ep_exchange.set_spin_seconds(float(os.environ.get("KTX_EP_SPIN_SECONDS", "120")))
                 ep_transport = ("peer writes: tagged 8-byte granules into the peers' buffers over xGMI, two launches per MoE "
                                 "layer (ktx_ep_gather / ktx_ep_reduce), partials added in rank order")
             except Exception as e:      # raised on every rank alike: all ranks fall back together, and the line says so

@@ -641,6 +641,7 @@ struct MlaPrefillParams {
   bf16_t* out;                   // [T][H][128]
   int T, H, kv_len, kv_pad;
   float sm_scale;
+  int no_skip;                   // dev knob 23 = 1: round 3's unconditional mask and rescale (A/B)
 };
 
 // one 64-key tile of one head in flight in registers: K_nope (64 keys x 16 pieces, contiguous), k_pe (64 keys x 8 pieces of the
@@ -755,19 +756,33 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
       }
     }
     // ---- online softmax, per query (lane & 15; the 4 key-chunk lanes g of a query agree after the two exchanges) ---------
+    // Round 5: the causal mask only exists on a query block's last two key tiles — a tile every query of the wavefront sees whole
+    // (wave-uniform test) skips the 32 compares + selects, and the 64 multiplies of `o *= alpha` are skipped whenever no lane's running
+    // maximum moved (alpha == 1 exactly: the common case once the first tiles are past).  Same bits either way.
+    const bool tile_full = !p.no_skip && j0 + PF_BN - 1 <= min(pos_off + min(q0, p.T - 1), p.kv_len - 1);
     uint4 pb[2][2];
 #pragma unroll
     for (int u = 0; u < 2; u++) {
       const int lim = min(pos_off + tq[u], p.kv_len - 1);       // last visible key of this lane's query
       float mx = -__builtin_inff();
+      if (tile_full) {
 #pragma unroll
-      for (int kt = 0; kt < 4; kt++)
+        for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          const int key = j0 + kt * 16 + g * 4 + r;
-          st[u][kt][r] = key <= lim ? st[u][kt][r] * p.sm_scale : -__builtin_inff();
-          mx = fmaxf(mx, st[u][kt][r]);
-        }
+          for (int r = 0; r < 4; r++) {
+            st[u][kt][r] = st[u][kt][r] * p.sm_scale;
+            mx = fmaxf(mx, st[u][kt][r]);
+          }
+      } else {
+#pragma unroll
+        for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const int key = j0 + kt * 16 + g * 4 + r;
+            st[u][kt][r] = key <= lim ? st[u][kt][r] * p.sm_scale : -__builtin_inff();
+            mx = fmaxf(mx, st[u][kt][r]);
+          }
+      }
       mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
       mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
       const float m_new = fmaxf(m_run[u], mx);                  // finite from tile 0 on: key 0 is visible to every query
@@ -785,10 +800,12 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
       sum += __shfl_xor(sum, 32, 64);
       l_run[u] = l_run[u] * alpha + sum;
       m_run[u] = m_new;
+      if (p.no_skip || !__all(alpha == 1.0f)) {
 #pragma unroll
-      for (int i = 0; i < 8; i++)
+        for (int i = 0; i < 8; i++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) o[u][i][r] *= alpha;
+          for (int r = 0; r < 4; r++) o[u][i][r] *= alpha;
+      }
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
         pb[u][ks] = make_uint4(ktx_pk_bf16(pv[2 * ks][0], pv[2 * ks][1]), ktx_pk_bf16(pv[2 * ks][2], pv[2 * ks][3]),
@@ -836,6 +853,7 @@ extern "C" int ktx_mla_prefill(int T, int num_heads, int kv_len, int kv_pad, flo
   p.k_nope = (const bf16_t*)d_k_nope; p.k_pe = (const bf16_t*)d_k_pe; p.kpe_ts = kpe_token_stride;
   p.v_t = (const bf16_t*)d_v_t; p.out = (bf16_t*)d_out;
   p.T = T; p.H = num_heads; p.kv_len = kv_len; p.kv_pad = kv_pad; p.sm_scale = sm_scale;
+  p.no_skip = ktx_debug_get(23) == 1 ? 1 : 0;
   const size_t lds = (size_t)(PF_BN * PF_KROW + 128 * PF_VROW) * sizeof(bf16_t);
   hipStream_t st = (hipStream_t)stream;
   // per (query, key, head): 2*(192 + 128) flop over the causal half

@@ -54,3 +54,11 @@ for knob, name in ((0, "two workgroups per CU (<= 256 registers)"), (1, "one wor
     print(f"T={T} kv={kv_len} H={H}  {name:44s} {ms:7.3f} ms  {flop / ms / 1e9:7.1f} TFLOP/s  ({flop / ms / 1e9 / 2500:.3f} of the bf16 MFMA peak)", flush=True)
 n.check(n.lib.ktx_debug_set(22, 0))
 print("outputs identical:", bool(torch.equal(outs[0], outs[1])))
+# round 5: mask / rescale skipped where they are the identity (default) against round 3's unconditional ones (knob 23 = 1)
+n.check(n.lib.ktx_debug_set(23, 1))
+ms_old = timed()
+old = run().clone()
+n.check(n.lib.ktx_debug_set(23, 0))
+ms_new = timed()
+print(f"mask + rescale unconditional (round 3) {ms_old:7.3f} ms   skipped where identity (default) {ms_new:7.3f} ms = "
+      f"{flop / ms_new / 1e9:7.1f} TFLOP/s ({flop / ms_new / 1e9 / 2500:.3f} of peak)   outputs identical: {bool(torch.equal(old, run()))}")

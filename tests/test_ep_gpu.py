@@ -121,21 +121,27 @@ def test_bench_takes_its_multi_gpu_branch_on_one_rank():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     env = dict(os.environ, RANK="0", LOCAL_RANK="0", WORLD_SIZE="1", MASTER_ADDR="127.0.0.1",
                MASTER_PORT=str(29900 + os.getpid() % 90), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    import tempfile
+    tmp = tempfile.mkdtemp()
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--workload", "v2lite-int4",
                         "--layers", "3", "--steps", "8", "--warmup", "2", "--no-prefill", "--no-secondary", "--no-cpu-baseline"],
-                       env=env, capture_output=True, text=True, timeout=280)
+                       env=env, capture_output=True, text=True, timeout=280, cwd=tmp)
     assert r.returncode == 0, r.stderr[-2000:]
-    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    out_lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(out_lines) == 1 and len(out_lines[0]) < 4096          # ONE compact stdout line (round 5) ...
+    line = json.loads(out_lines[-1])
+    detail = json.load(open(os.path.join(tmp, line["detail"])))      # ... the per-kernel table lives in the detail record beside it
+    assert detail["value"] == line["value"] and detail["config"]["ep_transport_status"] == 0
     cfg = line["config"]
     assert line["value"] and line["value"] > 0 and line["n_gpus"] == 1 and line["scaling"] == "weak"
     assert cfg["parallelism"] == "ep1" and cfg["rccl_ranks"] == 1 and cfg["hip_graph"] is True, cfg
     assert cfg["ep_transport"].startswith("peer writes") and cfg["ep_transport_status"] == 0, cfg
     # round 3: the N > 1 line carries the per-kernel table and a roofline too (HIP events on rank 0, all ranks stepping together)
-    assert line["roofline"]["bound"] == "hbm" and line["per_kernel"] and line["per_kernel"][0]["us_per_step"] > 0
+    assert line["roofline"]["bound"] == "hbm" and detail["per_kernel"] and detail["per_kernel"][0]["us_per_step"] > 0
     # ... and --strong is ONE token stream: the same rows on every rank, only the fp32 partials travel
     r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "1", "--force-dist", "--strong", "--workload",
                         "v2lite-int4", "--layers", "3", "--steps", "8", "--warmup", "2", "--no-prefill", "--no-secondary",
-                        "--no-cpu-baseline", "--no-kernels", "--windows", "0"], env=env, capture_output=True, text=True, timeout=280)
+                        "--no-cpu-baseline", "--no-kernels", "--windows", "0"], env=env, capture_output=True, text=True, timeout=280, cwd=tmp)
     assert r.returncode == 0, r.stderr[-2000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["scaling"] == "strong" and line["value"] > 0 and line["config"]["ep_transport_status"] == 0
