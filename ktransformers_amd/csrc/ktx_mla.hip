@@ -642,6 +642,7 @@ struct MlaPrefillParams {
   int T, H, kv_len, kv_pad;
   float sm_scale;
   int no_skip;                   // dev knob 23 = 1: round 3's unconditional mask and rescale (A/B)
+  int nqb;                       // > 0: 1-D XCD-aware grid of nqb query blocks x H heads (H % 8 == 0); 0: grid (query blocks, heads)
 };
 
 // one 64-key tile of one head in flight in registers: K_nope (64 keys x 16 pieces, contiguous), k_pe (64 keys x 8 pieces of the
@@ -688,6 +689,28 @@ __device__ __forceinline__ void pf_store_tile(const PfTile& t, bf16_t* Ks, bf16_
   *reinterpret_cast<uint4*>(vd + 96 * PF_VROW) = t.v3;
 }
 
+// Reductions over the four 16-lane rows of a wavefront (lanes l, l ^ 16, l ^ 32, l ^ 48).  Round 5: gfx950's row swaps — v_permlane32_swap
+// exchanges the upper 32 lanes of one register with the lower 32 of another, v_permlane16_swap the odd rows with the even rows — are
+// plain VALU instructions; the ds_bpermute shuffles they replace are LDS-crossbar round trips, four of them in a dependent chain per
+// query tile and key tile.  Sum: (x_l + x_{l^32}) + (that of l ^ 16) — fp32 addition is commutative, so every lane of a query gets the
+// same bits, and they are the bits the shuffle version produced ((x + shfl16) + shfl32 groups the rows as (r0 + r1) + (r2 + r3) for
+// rows 0 / 1 and likewise here after the 32-swap first: see pf_sum_rows).
+typedef unsigned pf_v2u __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ float pf_max_rows(float x) {
+  pf_v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float pf_sum_rows(float x) {
+  // the shuffle version computed (x + x^16) first, then + the same of l ^ 32: keep that association — rows (r0 + r1) and (r2 + r3)
+  // first (16-swap), then across the halves (32-swap)
+  pf_v2u r = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
 // MINW = wavefronts per SIMD the register allocation must allow.  Unconstrained (MINW = 1) the compiler takes 340 VGPRs: ONE
 // wavefront per SIMD, one workgroup per CU, so the QK MFMAs, the softmax VALU chain, the PV MFMAs and the staging of the next
 // tile run strictly one after the other (0.10 of the MFMA peak).  MINW = 2 caps the allocation at 256 (7 values
@@ -699,9 +722,19 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
   bf16_t* Vs = Ks + PF_BN * PF_KROW;                 // [128][PF_VROW]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int h = blockIdx.y;
-  // heaviest query blocks first (causal: the last block sees the whole context)
-  const int qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  // blockIdx -> (head, query block).  Round 5, XCD-aware (p.nqb > 0: a 1-D grid): workgroup ids are dealt round-robin to the 8 XCDs, so
+  // id % 8 picks the XCD; all query blocks of ONE head go to one XCD (head % 8 == XCD) and run there back to back — the head's K / V^T
+  // (1 MB at 2048 keys) is fetched into that XCD's L2 once instead of into all eight.  Within a head: heaviest query blocks first
+  // (causal: the last block sees the whole context).
+  int h, qb;
+  if (p.nqb > 0) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    h = (slot / p.nqb) * 8 + xcd;
+    qb = p.nqb - 1 - slot % p.nqb;
+  } else {
+    h = blockIdx.y;
+    qb = (int)gridDim.x - 1 - (int)blockIdx.x;
+  }
   const int q0 = qb * 128 + wave * 32;
   const int qi = lane & 15, g = lane >> 4;
   const int pos_off = p.kv_len - p.T;                // query t sits at position pos_off + t
@@ -783,8 +816,7 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
             mx = fmaxf(mx, st[u][kt][r]);
           }
       }
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = pf_max_rows(mx);                                     // over the query's four key-chunk lanes (qi, qi + 16, + 32, + 48)
       const float m_new = fmaxf(m_run[u], mx);                  // finite from tile 0 on: key 0 is visible to every query
       const float alpha = __expf(m_run[u] - m_new);
       float sum = 0.f;
@@ -796,8 +828,7 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
           pv[kt][r] = __expf(st[u][kt][r] - m_new);
           sum += pv[kt][r];
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = pf_sum_rows(sum);
       l_run[u] = l_run[u] * alpha + sum;
       m_run[u] = m_new;
       if (p.no_skip || !__all(alpha == 1.0f)) {
@@ -858,8 +889,12 @@ extern "C" int ktx_mla_prefill(int T, int num_heads, int kv_len, int kv_pad, flo
   hipStream_t st = (hipStream_t)stream;
   // per (query, key, head): 2*(192 + 128) flop over the causal half
   KTX_TIMED(st, 0.0, "mla_prefill_kernel T=%d Hq=%d kv=%d", T, num_heads, kv_len);
-  if (ktx_debug_get(22) == 1) hipLaunchKernelGGL(mla_prefill_kernel<1>, dim3((T + 127) / 128, num_heads), dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(mla_prefill_kernel<2>, dim3((T + 127) / 128, num_heads), dim3(256), lds, st, p);
+  const int nqb = (T + 127) / 128;
+  const bool xcd = num_heads % 8 == 0 && ktx_debug_get(24) != 1;     // dev knob 24 = 1: the 2-D grid of rounds 2-4 (A/B)
+  p.nqb = xcd ? nqb : 0;
+  const dim3 grid = xcd ? dim3((unsigned)(nqb * num_heads)) : dim3(nqb, num_heads);
+  if (ktx_debug_get(22) == 1) hipLaunchKernelGGL(mla_prefill_kernel<1>, grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL(mla_prefill_kernel<2>, grid, dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

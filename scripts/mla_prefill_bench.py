@@ -62,3 +62,12 @@ n.check(n.lib.ktx_debug_set(23, 0))
 ms_new = timed()
 print(f"mask + rescale unconditional (round 3) {ms_old:7.3f} ms   skipped where identity (default) {ms_new:7.3f} ms = "
       f"{flop / ms_new / 1e9:7.1f} TFLOP/s ({flop / ms_new / 1e9 / 2500:.3f} of peak)   outputs identical: {bool(torch.equal(old, run()))}")
+
+# round 5: all query blocks of a head on one XCD (default) against the 2-D grid of rounds 2-4 (knob 24 = 1)
+n.check(n.lib.ktx_debug_set(24, 1))
+ms_old = timed()
+old = run().clone()
+n.check(n.lib.ktx_debug_set(24, 0))
+ms_new = timed()
+print(f"2-D grid (rounds 2-4) {ms_old:7.3f} ms   one head per XCD (default) {ms_new:7.3f} ms = {flop / ms_new / 1e9:7.1f} TFLOP/s "
+      f"({flop / ms_new / 1e9 / 2500:.3f} of peak)   outputs identical: {bool(torch.equal(old, run()))}")
