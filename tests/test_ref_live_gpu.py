@@ -4,7 +4,7 @@ VERDICT r3 (weak 4): those pins are CPU tests that skip on hosts without AVX512-
 so the driver's `-m "not gpu"` run never executes them and only their goldens travel.  The GPU box's host cores do have the
 instructions and the prebuilt oracle/_ref libraries travel with the snapshot, so the same test functions are imported here and
 run by `pytest -m gpu`: the oracle restatement against the reference's AMX / RAWINT4 / FP8 / BF16 kernels bit for bit, the AMX
-weight packer, the packed-checkpoint loader leg, and the iqk (llamafile) GGUF kernels.  No GPU work happens in this module; the
+weight packer, the packed-checkpoint loader leg, and the iqk (llamafile) GGUF kernels — k- / i-quants x Q8_K and, round 5, Q4_0 / Q5_0 x Q8_0.  No GPU work happens in this module; the
 marker only chooses the machine.  A test that still has to skip (library missing) says so."""
 import pytest
 
@@ -13,6 +13,9 @@ from test_amx_packed_cpu import (test_row_sharded_parts_concatenate_and_k_sharde
 from test_oracle_cpu import golden  # noqa: F401  (fixture used by the imported tests' module)
 from test_oracle_cpu import (test_oracle_fp8_perchannel_matches_live_reference, test_oracle_fp_formats_match_live_reference,  # noqa: F401
                              test_oracle_matches_live_reference, test_oracle_rawint4_matches_live_reference)
+
+from test_gguf_ref_pin_cpu import (test_quantize_row_q8_0_is_ggml_x86_arithmetic, test_restated_legacy_vec_dot_against_reference_iqk_kernels,  # noqa: F401
+                                   test_restated_q8_0_vec_dot_is_the_exact_block_sum, test_restated_vec_dot_against_reference_iqk_kernels)
 
 pytestmark = pytest.mark.gpu
 
