@@ -715,7 +715,9 @@ __device__ __forceinline__ float pf_sum_rows(float x) {
 // wavefront per SIMD, one workgroup per CU, so the QK MFMAs, the softmax VALU chain, the PV MFMAs and the staging of the next
 // tile run strictly one after the other (0.10 of the MFMA peak).  MINW = 2 caps the allocation at 256 (7 values
 // spill to scratch) and two workgroups share a CU: one's softmax runs under the other's MFMAs.  Dev knob 22 = 1 selects MINW = 1.
-template <int MINW>
+// NU = query tiles of 16 per wavefront: 2 (default: 128 queries per workgroup, every K fragment read feeds two MFMAs) or 1 (dev knob 31:
+// 64 queries per workgroup, half the registers -> three wavefronts per SIMD; measured in DESIGN.md 4.2.4)
+template <int MINW, int NU>
 __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   bf16_t* Ks = reinterpret_cast<bf16_t*>(smem);      // [64][PF_KROW]
@@ -735,15 +737,15 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
     h = blockIdx.y;
     qb = (int)gridDim.x - 1 - (int)blockIdx.x;
   }
-  const int q0 = qb * 128 + wave * 32;
+  const int q0 = qb * (64 * NU) + wave * (16 * NU);
   const int qi = lane & 15, g = lane >> 4;
   const int pos_off = p.kv_len - p.T;                // query t sits at position pos_off + t
 
   // Q^T fragments: lane (query qi, k-chunk g)
-  v8bf qf[2][6];
-  int tq[2];
+  v8bf qf[NU][6];
+  int tq[NU];
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int u = 0; u < NU; u++) {
     tq[u] = min(q0 + u * 16 + qi, p.T - 1);
     const bf16_t* qn = p.q_nope + (size_t)tq[u] * p.qn_ts + (size_t)h * p.qn_hs + g * 8;
     const bf16_t* qr = p.q_pe + (size_t)tq[u] * p.qp_ts + (size_t)h * p.qp_hs + g * 8;
@@ -752,14 +754,17 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
 #pragma unroll
     for (int s = 0; s < 2; s++) qf[u][4 + s] = as_v8bf(*reinterpret_cast<const uint4*>(qr + s * 32));
   }
-  v4f o[2][8];
+  v4f o[NU][8];
+  float m_run[NU], l_run[NU];
 #pragma unroll
-  for (int u = 0; u < 2; u++)
+  for (int u = 0; u < NU; u++) {
 #pragma unroll
     for (int i = 0; i < 8; i++) o[u][i] = v4f{0.f, 0.f, 0.f, 0.f};
-  float m_run[2] = {-__builtin_inff(), -__builtin_inff()}, l_run[2] = {0.f, 0.f};
+    m_run[u] = -__builtin_inff();
+    l_run[u] = 0.f;
+  }
 
-  const int pos_max = pos_off + min(qb * 128 + 127, p.T - 1);
+  const int pos_max = pos_off + min(qb * (64 * NU) + 64 * NU - 1, p.T - 1);
   const int ntiles = min(pos_max, p.kv_len - 1) / PF_BN + 1;
   const bf16_t* kn = p.k_nope + (size_t)h * p.kv_pad * 128;
   const bf16_t* vt = p.v_t + (size_t)h * 128 * p.kv_pad;
@@ -773,9 +778,9 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
     nxt = pf_load_tile(p, kn, vt, min(tile + 1, ntiles - 1), tid);   // (unconditional: the last iteration re-reads its tile)
     const int j0 = tile * PF_BN;
     // ---- S^T = K Q^T: st[u][kt][r] = S[query qi of tile u][key j0 + 16*kt + 4*g + r] -------------------------------------
-    v4f st[2][4];
+    v4f st[NU][4];
 #pragma unroll
-    for (int u = 0; u < 2; u++)
+    for (int u = 0; u < NU; u++)
 #pragma unroll
       for (int kt = 0; kt < 4; kt++) st[u][kt] = v4f{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -784,8 +789,8 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
 #pragma unroll
       for (int s = 0; s < 6; s++) {
         const v8bf a = as_v8bf(*reinterpret_cast<const uint4*>(kb + s * 32));
-        st[0][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[0][s], st[0][kt], 0, 0, 0);
-        st[1][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[1][s], st[1][kt], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; u++) st[u][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][s], st[u][kt], 0, 0, 0);
       }
     }
     // ---- online softmax, per query (lane & 15; the 4 key-chunk lanes g of a query agree after the two exchanges) ---------
@@ -793,9 +798,9 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
     // (wave-uniform test) skips the 32 compares + selects, and the 64 multiplies of `o *= alpha` are skipped whenever no lane's running
     // maximum moved (alpha == 1 exactly: the common case once the first tiles are past).  Same bits either way.
     const bool tile_full = !p.no_skip && j0 + PF_BN - 1 <= min(pos_off + min(q0, p.T - 1), p.kv_len - 1);
-    uint4 pb[2][2];
+    uint4 pb[NU][2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) {
+    for (int u = 0; u < NU; u++) {
       const int lim = min(pos_off + tq[u], p.kv_len - 1);       // last visible key of this lane's query
       float mx = -__builtin_inff();
       if (tile_full) {
@@ -850,13 +855,13 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
       for (int ks = 0; ks < 2; ks++) {
         const uint2 lo = *reinterpret_cast<const uint2*>(vb + ks * 32), hi = *reinterpret_cast<const uint2*>(vb + ks * 32 + 16);
         const v8bf a = as_v8bf(make_uint4(lo.x, lo.y, hi.x, hi.y));
-        o[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_v8bf(pb[0][ks]), o[0][i], 0, 0, 0);
-        o[1][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_v8bf(pb[1][ks]), o[1][i], 0, 0, 0);
+#pragma unroll
+        for (int u = 0; u < NU; u++) o[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_v8bf(pb[u][ks]), o[u][i], 0, 0, 0);
       }
     }
   }
 #pragma unroll
-  for (int u = 0; u < 2; u++) {
+  for (int u = 0; u < NU; u++) {
     const int t = q0 + u * 16 + qi;
     if (t < p.T) {
       const float inv = l_run[u] > 0.f ? 1.0f / l_run[u] : 0.f;
@@ -889,12 +894,14 @@ extern "C" int ktx_mla_prefill(int T, int num_heads, int kv_len, int kv_pad, flo
   hipStream_t st = (hipStream_t)stream;
   // per (query, key, head): 2*(192 + 128) flop over the causal half
   KTX_TIMED(st, 0.0, "mla_prefill_kernel T=%d Hq=%d kv=%d", T, num_heads, kv_len);
-  const int nqb = (T + 127) / 128;
+  const bool one_tile = ktx_debug_get(31) == 1;                      // dev knob 31 = 1: one query tile per wavefront, three wavefronts per SIMD
+  const int nqb = one_tile ? (T + 63) / 64 : (T + 127) / 128;
   const bool xcd = num_heads % 8 == 0 && ktx_debug_get(24) != 1;     // dev knob 24 = 1: the 2-D grid of rounds 2-4 (A/B)
   p.nqb = xcd ? nqb : 0;
   const dim3 grid = xcd ? dim3((unsigned)(nqb * num_heads)) : dim3(nqb, num_heads);
-  if (ktx_debug_get(22) == 1) hipLaunchKernelGGL(mla_prefill_kernel<1>, grid, dim3(256), lds, st, p);
-  else hipLaunchKernelGGL(mla_prefill_kernel<2>, grid, dim3(256), lds, st, p);
+  if (one_tile) hipLaunchKernelGGL((mla_prefill_kernel<3, 1>), grid, dim3(256), lds, st, p);
+  else if (ktx_debug_get(22) == 1) hipLaunchKernelGGL((mla_prefill_kernel<1, 2>), grid, dim3(256), lds, st, p);
+  else hipLaunchKernelGGL((mla_prefill_kernel<2, 2>), grid, dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

@@ -71,3 +71,12 @@ n.check(n.lib.ktx_debug_set(24, 0))
 ms_new = timed()
 print(f"2-D grid (rounds 2-4) {ms_old:7.3f} ms   one head per XCD (default) {ms_new:7.3f} ms = {flop / ms_new / 1e9:7.1f} TFLOP/s "
       f"({flop / ms_new / 1e9 / 2500:.3f} of peak)   outputs identical: {bool(torch.equal(old, run()))}")
+
+# dev knob 31 = 1: one query tile per wavefront (64 queries per workgroup), three wavefronts per SIMD
+n.check(n.lib.ktx_debug_set(31, 1))
+ms_1 = timed()
+one = run().clone()
+n.check(n.lib.ktx_debug_set(31, 0))
+ref = run()
+print(f"one query tile per wavefront, 3 waves per SIMD (knob 31) {ms_1:7.3f} ms = {flop / ms_1 / 1e9:7.1f} TFLOP/s ({flop / ms_1 / 1e9 / 2500:.3f} of peak)"
+      f"   outputs identical to the default: {bool(torch.equal(one, ref))}")
