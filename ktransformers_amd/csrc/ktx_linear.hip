@@ -543,7 +543,7 @@ __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
 // the shared experts beside the routed ones), the router is a latency chain on E/8 workgroups and the GEMV a weight stream on
 // the rest of the chip.  Row blockIdx.y == 0 (dispatched first: the longer chain) = router workgroups, gate_epw (4 or 8) experts each, of
 // token blockIdx.x / gate_nwg; rows 1.. = the GEMV's grid.  Same device code as the stand-alone kernels.
-template <int G, int D, int EPL, int NJ>
+template <int FMT, int G, int D, int EPL, int NJ>
 __global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs ga, int gate_nwg, int gate_epw) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   if (blockIdx.y == 0) {
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(512) void lin_dec_gate_kernel(LinParams p, GateArgs
     if (t < ga.qlen) gate_fused_body<EPL, NJ, 8>(ga, blockIdx.x - t * gate_nwg, gate_nwg, t, smem, gate_epw);
     return;
   }
-  lin_dec_body<F_W4, G, D, M_EXACT>(p, blockIdx.x, blockIdx.y - 1, gridDim.x, smem);
+  lin_dec_body<FMT, G, D, M_EXACT>(p, blockIdx.x, blockIdx.y - 1, gridDim.x, smem);
 }
 
 #include "ktx_linear_sk.inc"
@@ -1697,8 +1697,8 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
       if (dma_depth) smem += 8 * (dma_depth * 1024 + scl_bytes);
     }
   }
-  if (gate) {   // the router rides in this launch (lin_dec_gate_kernel) — W4 g64, whole k-slices, router grid inside one row
-    if constexpr (FMT == F_W4 && G == 64) {
+  if (gate) {   // the router rides in this launch (lin_dec_gate_kernel) — W4 g64 or (round 5) block-FP8, whole k-slices, router grid inside one row
+    if constexpr ((FMT == F_W4 && G == 64) || FMT == F_FP8) {
       const int E = gate->c.n_routed_experts, H = gate->c.hidden_size;
       // router workgroups: 4 experts each where the router row of the grid has room for them (the 8 wavefronts of a workgroup
       // then stream half the router rows: the logits exist earlier on the launch's critical chain), else 8; dev knob 25 = 1: always 8
@@ -1713,7 +1713,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
       const size_t smem_g = std::max(smem, (size_t)H * 2);
       const dim3 grid_g(grid.x, grid.y + 1);
       KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0 + (double)E * H * 2.0,
-                "lin_dec_gate_kernel<W4> %d->%d + router E=%d", p.Kx, p.N, E);
+                "lin_dec_gate_kernel<%s> %d->%d + router E=%d", lin_fmt_name(FMT), p.Kx, p.N, E);
       auto go_g = [&](auto kern) -> int {
         static bool attr_set = false;   // one flag per kernel instantiation
         if (!attr_set) {
@@ -1726,10 +1726,10 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
       };
 #define KTX_GATE_D(EPLV, NJV)                                             \
       switch (d) {                                                        \
-        case 8: return go_g(lin_dec_gate_kernel<G, 8, EPLV, NJV>);        \
-        case 7: return go_g(lin_dec_gate_kernel<G, 7, EPLV, NJV>);        \
-        case 4: return go_g(lin_dec_gate_kernel<G, 4, EPLV, NJV>);        \
-        default: return go_g(lin_dec_gate_kernel<G, 2, EPLV, NJV>);       \
+        case 8: return go_g(lin_dec_gate_kernel<FMT, G, 8, EPLV, NJV>);   \
+        case 7: return go_g(lin_dec_gate_kernel<FMT, G, 7, EPLV, NJV>);   \
+        case 4: return go_g(lin_dec_gate_kernel<FMT, G, 4, EPLV, NJV>);   \
+        default: return go_g(lin_dec_gate_kernel<FMT, G, 2, EPLV, NJV>);  \
       }
       if (epl <= 1 && H <= 2048) { KTX_GATE_D(1, 4) }
       else if (epl <= 4) { KTX_GATE_D(4, 16) }

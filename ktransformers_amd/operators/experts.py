@@ -437,13 +437,17 @@ class _KMoEBlock(BaseInjectedModule):
         elif sequence_length == 1 and orig_shape[0] == 1 and (fused := self._fused_decode(hidden_states, residual, pre_norm)) is not None:
             return fused
         else:
-            side = self._router_side_linear(hidden_states, pre_norm)
+            side = self._router_side_linear(hidden_states, pre_norm, allow_cat=True)
         if routed:
             pass                                              # ids, weights and the normalised row are already here
         elif side is not None:
             # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)
+            glu = side.fmt == "W4"                           # block-FP8 shared experts: [gate | up] rows, SiLU * up after the launch
             topk_idx, topk_weight, xn, shared_act = self.gate.forward_with_linear(
-                hidden_states, (pre_norm.weight, pre_norm.variance_epsilon), side)
+                hidden_states, (pre_norm.weight, pre_norm.variance_epsilon), side, glu=glu)
+            if not glu:
+                from ktransformers_amd._native import silu_mul
+                shared_act = silu_mul(shared_act)
             hidden_states = xn.view(*orig_shape)
         elif pre_norm is not None and hasattr(self.gate, "_handle"):
             topk_idx, topk_weight, xn = self.gate(hidden_states, norm=(pre_norm.weight, pre_norm.variance_epsilon))
@@ -489,9 +493,10 @@ class _KMoEBlock(BaseInjectedModule):
         res = None if residual is None else residual.reshape(-1, residual.shape[-1])
         return (h, shared_act, res)
 
-    def _router_side_linear(self, hidden_states, pre_norm):
+    def _router_side_linear(self, hidden_states, pre_norm, allow_cat: bool = False):
         """The LinearHandle of the shared experts' merged gate|up operator when this call can use the combined launch: a decode
-        step (<= 4 rows) with the layer's post-attention norm handed in, a HIP router and merged bf16-activation shared experts."""
+        step (<= 4 rows) with the layer's post-attention norm handed in, a HIP router and merged shared experts (W4 GLU-interleaved
+        rows; with allow_cat also the block-FP8 [gate | up] rows, whose SiLU * up the caller runs)."""
         if pre_norm is None or not hasattr(self.gate, "forward_with_linear") or os.environ.get("KTX_MOE_SEPARATE_ROUTER"):
             return None
         if getattr(self.config, "n_shared_experts", None) is None or hidden_states.numel() // hidden_states.shape[-1] > 4:
@@ -503,7 +508,13 @@ class _KMoEBlock(BaseInjectedModule):
             return None
         gu = getattr(self.shared_experts, "_gate_up", None)
         h = getattr(gu, "_h", None)
-        if h is None or getattr(h, "fmt", None) != "W4" or not hasattr(self.shared_experts, "down"):
+        if h is None and allow_cat:
+            h = getattr(getattr(self.shared_experts, "_gate_up_cat", None), "_h", None)
+            if h is not None and getattr(h, "fmt", None) != "FP8":
+                h = None
+        elif getattr(h, "fmt", None) != "W4":
+            h = None
+        if h is None or not hasattr(self.shared_experts, "down"):
             return None
         return h
 

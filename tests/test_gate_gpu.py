@@ -161,6 +161,59 @@ def test_router_riding_in_the_shared_gate_up_launch(name, I_shared, T):
         n.lib.ktx_debug_set(25, 0)
 
 
+@pytest.mark.parametrize("T", [1, 3])
+def test_router_riding_in_the_fp8_shared_gate_up_launch(T):
+    """The same combined launch for block-FP8 shared experts (DeepSeek-V3 / R1 fp8 checkpoints: [gate ; up] rows of one GEMV, no
+    GLU epilogue — operators/mlp.py keeps every 128-row scale block whole): knob 13 = the two separate launches, bit-identical;
+    the combined kernel = same device code, possibly another k-slice split (fp32 summation order) — and the profile label shows
+    that it was the combined kernel that ran."""
+    from ktransformers_amd import _native as n
+    cfg = dict(CONFIGS["deepseek_v3"])
+    E, H = cfg.pop("E"), cfg.pop("H")
+    I_shared = 2048
+    dev = torch.device("cuda", 0)
+    g = torch.Generator().manual_seed(23 + T)
+    x = torch.randn((T, H), generator=g).to(torch.bfloat16).to(dev)
+    w = (torch.randn((E, H), generator=g) * H ** -0.5).to(torch.bfloat16).to(dev)
+    nw = (1 + 0.1 * torch.randn((H,), generator=g)).to(torch.bfloat16).to(dev)
+    bias = (torch.randn((E,), generator=g) * 0.1).to(dev)
+    wl = (torch.randn((2 * I_shared, H), generator=g) / 4).to(torch.float8_e4m3fn).to(dev)
+    sc = ((torch.rand((2 * I_shared // 128, H // 128), generator=g) + 0.5) / 32).to(dev)
+    gh = n.GateHandle(E, H, cfg["top_k"], cfg["n_group"], cfg["topk_group"], cfg["scoring_func"], cfg["topk_method"],
+                      cfg["norm_topk_prob"], cfg["routed_scaling_factor"])
+    lin = n.LinearHandle(H, 2 * I_shared, "FP8", 128, 64, dev)
+    lin.load_fp8(wl, sc)
+    idx0, wt0, xn0 = gh.forward(x, w, bias, norm=(nw, 1e-6))
+    y0 = lin.forward(x, norm=(nw, 1e-6))
+    try:
+        n.lib.ktx_debug_set(13, 1)
+        idx1, wt1, xn1, y1 = n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6), glu=False)
+    finally:
+        n.lib.ktx_debug_set(13, 0)
+    assert torch.equal(idx0, idx1) and torch.equal(wt0, wt1) and torch.equal(xn0, xn1) and torch.equal(y0, y1)
+    for rep in range(3):
+        idx2, wt2, xn2, y2 = n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6), glu=False)
+        torch.cuda.synchronize()
+        ulp = (xn2.float() - xn0.float()).abs() <= xn0.float().abs() * 2.0 ** -7 + 1e-30
+        assert bool(ulp.all()), "normalised row differs by more than one bf16 ulp"
+        for t in range(T):
+            assert set(idx2[t].tolist()) == set(idx0[t].tolist()), f"token {t}: routed expert set differs"
+            ref = dict(zip(idx0[t].tolist(), wt0[t].tolist()))
+            for e, v in zip(idx2[t].tolist(), wt2[t].tolist()):
+                assert abs(v - ref[e]) <= 2e-3 * abs(ref[e]) + 1e-9, (t, e, v, ref[e])
+        err = (y2.float() - y0.float()).abs().max().item()
+        assert err <= 2e-2 * y0.float().abs().max().item(), err
+    n.timing_collect()
+    n.timing_enable(2)
+    try:
+        n.gate_with_linear(gh, lin, x, w, bias, (nw, 1e-6), glu=False)
+        torch.cuda.synchronize()
+        names = [r[0] for r in n.timing_collect()]
+    finally:
+        n.timing_enable(0)
+    assert any(nm.startswith("lin_dec_gate_kernel<FP8>") for nm in names), names
+
+
 @pytest.mark.parametrize("mode", [2, 3])
 @pytest.mark.parametrize("name,I_shared", [("deepseek_v3", 2048), ("deepseek_v2_lite", 2816), ("kimi_k2", 2048)])
 @pytest.mark.parametrize("T", [1, 3])
