@@ -46,7 +46,8 @@ class _LinearConfig(C.Structure):
 
 class _LinearFusion(C.Structure):
     _fields_ = [("norm_weight", C.c_void_p), ("norm_eps", C.c_float), ("add1", C.c_void_p), ("add1_ld", C.c_int64),
-                ("add2", C.c_void_p), ("add2_ld", C.c_int64), ("x_ld", C.c_int64), ("y_ld", C.c_int64), ("glu", C.c_int32)]
+                ("add2", C.c_void_p), ("add2_ld", C.c_int64), ("x_ld", C.c_int64), ("y_ld", C.c_int64), ("glu", C.c_int32),
+                ("glu_in", C.c_int32)]
 
 
 class _GemmArgs(C.Structure):
@@ -792,10 +793,14 @@ class LinearHandle:
 
     def forward(self, x: torch.Tensor, bsz_tensor: torch.Tensor | None = None, out: torch.Tensor | None = None,
                 norm: tuple | None = None, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
-                glu: bool = False) -> torch.Tensor:
+                glu: bool = False, glu_in: bool = False) -> torch.Tensor:
         """x: bf16 [..., in] -> bf16 [..., out] on the current stream.  Optional fusions (include/ktx_linear.h,
         ktx_linear_fusion): norm = (weight bf16 [in], eps) applies RMSNorm to x inside the kernel (falls back to a separate
-        ktx_rmsnorm launch where the decode kernel does not run); add1 / add2 = bf16 [..., out] tensors added in that order."""
+        ktx_rmsnorm launch where the decode kernel does not run); add1 / add2 = bf16 [..., out] tensors added in that order;
+        glu_in: x is bf16 [..., 2 * in] = [gate | up] and the linear reads silu_mul(x) — inside the decode kernel where it
+        runs, as a separate ktx_silu_mul launch otherwise."""
+        if glu_in:
+            return self._forward_glu_in(x, bsz_tensor, out, norm, add1, add2, glu)
         if x.dtype != torch.bfloat16 or x.shape[-1] != self.K or x.device != self.device:
             raise KtxError(f"forward: expected bf16 [..., {self.K}] on {self.device}, got {x.dtype} {tuple(x.shape)} on {x.device}")
         x2 = x if x.dim() == 2 else x.reshape(-1, self.K)
@@ -848,6 +853,38 @@ class LinearHandle:
                 keep.append(a2)
         check(lib.ktx_linear_forward_fused(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), C.byref(fu), _stream_ptr(self.device)))
         return out.reshape(*x.shape[:-1], n_out)
+
+    def _forward_glu_in(self, x, bsz_tensor, out, norm, add1, add2, glu):
+        if norm is not None or glu:
+            raise KtxError("forward: glu_in does not combine with norm / glu")
+        if x.dtype != torch.bfloat16 or x.shape[-1] != 2 * self.K or x.device != self.device:
+            raise KtxError(f"forward: glu_in expects bf16 [..., {2 * self.K}] on {self.device}, got {x.dtype} {tuple(x.shape)} on {x.device}")
+        x2 = x.reshape(-1, 2 * self.K)
+        if not x2.is_contiguous():
+            x2 = x2.contiguous()
+        T = x2.shape[0]
+        if not self.decode_eligible(T) or self.batch != 1 or os.environ.get("KTX_LINEAR_SEPARATE_SILU_MUL"):
+            return self.forward(silu_mul(x2, bsz_tensor), bsz_tensor, out, None, add1, add2).reshape(*x.shape[:-1], self.N)
+        if out is None:
+            out = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \
+                torch.zeros((T, self.N), dtype=torch.bfloat16, device=self.device)
+        bsz = None
+        if bsz_tensor is not None:
+            if bsz_tensor.dtype != torch.int32 or bsz_tensor.device != self.device:
+                raise KtxError("forward: bsz_tensor must be int32 on the handle's device")
+            bsz = bsz_tensor.data_ptr()
+        fu = _LinearFusion(None, 0.0, None, 0, None, 0, 0, 0, 0, 1)
+        keep = []
+        for name, a in (("add1", add1), ("add2", add2)):
+            if a is not None:
+                a2 = a.reshape(-1, self.N)
+                if a2.dtype != torch.bfloat16 or a2.shape[0] != T or a2.stride(1) != 1 or a2.device != self.device:
+                    raise KtxError(f"forward: {name} must be bf16 [{T}, {self.N}] on {self.device}")
+                setattr(fu, name, a2.data_ptr())
+                setattr(fu, name + "_ld", a2.stride(0))
+                keep.append(a2)
+        check(lib.ktx_linear_forward_fused(self._h, bsz, T, x2.data_ptr(), out.data_ptr(), C.byref(fu), _stream_ptr(self.device)))
+        return out.reshape(*x.shape[:-1], self.N)
 
     def forward_batched(self, x: torch.Tensor, out: torch.Tensor | None = None, bsz_tensor: torch.Tensor | None = None) -> torch.Tensor:
         """x: bf16 [T, batch, in] (any row / batch strides that are multiples of 8, unit stride along `in`) ->

@@ -101,6 +101,7 @@ struct LinParams {
   const bf16_t *add1, *add2;
   long ld1, ld2;
   int glu;   // rows interleaved per strip as [8 gate | 8 up]: the epilogue writes act_fn(gate) * up, N/2 columns
+  int glu_in;   // x rows are [gate | up], 2 Kx elements: the prologue stages bf16(bf16(silu(gate)) * up) (decode kernel only, no norm)
   // ktx_linear_forward_batched_prep: one extra row of workgroups (blockIdx.y == 0, the products shift up by one) runs the MLA prep of the same decode
   // step (latent RMSNorm + RoPE) beside the per-head absorb products — independent work, one launch instead of two
   int prep_on;
@@ -206,6 +207,17 @@ __device__ __forceinline__ uint4 lin_norm8(const uint4& v, float r, const bf16_t
   return make_uint4(ktx_norm_pk(v.x, r, wv.x), ktx_norm_pk(v.y, r, wv.y), ktx_norm_pk(v.z, r, wv.z), ktx_norm_pk(v.w, r, wv.w));
 }
 
+// 8 gate values and their 8 up values -> act_fn(gate) * up as ktx_silu_mul (ktx_ops.hip) evaluates it, op for op: SiLU in fp32
+// rounded to bf16 (torch's SiLU on a bf16 tensor), then the bf16 product (DeepseekV3MLP.forward, modeling_deepseek_v3.py:396-398)
+__device__ __forceinline__ uint32_t lin_glu_pk(uint32_t g, uint32_t u) {
+  const float g0 = ktx_lo_f32(g), g1 = ktx_hi_f32(g);
+  const uint32_t a = ktx_pk_bf16(g0 / (1.0f + expf(-g0)), g1 / (1.0f + expf(-g1)));
+  return ktx_pk_bf16(ktx_lo_f32(a) * ktx_lo_f32(u), ktx_hi_f32(a) * ktx_hi_f32(u));
+}
+__device__ __forceinline__ uint4 lin_glu8(const uint4& g, const uint4& u) {
+  return make_uint4(lin_glu_pk(g.x, u.x), lin_glu_pk(g.y, u.y), lin_glu_pk(g.z, u.z), lin_glu_pk(g.w, u.w));
+}
+
 // =====================================================================================================
 // Decode kernel: T <= 4 token slots, the whole activation row block lives in LDS, a wavefront streams one strip over
 // one k-slice through a D-deep register ring; the 8 wavefronts of a workgroup are SW strips x 8/SW k-slices and meet in
@@ -307,14 +319,16 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   const int npiece = NKS * 16;   // 8-element pieces per token
   const int ntot = TP * npiece;
   const int kpieces = p.Kx >> 3;
-  const bf16_t* nwp = p.norm_w ? p.norm_w : p.x;
+  // (glu_in: the second operand slot carries the row's `up` half instead of the norm weights — the two prologues exclude each other)
+  const bf16_t* nwp = p.glu_in ? p.x + p.Kx : p.norm_w ? p.norm_w : p.x;
   uint4 xpre[XPRE], nwpre[XPRE];
 #pragma unroll
   for (int i = 0; i < XPRE; i++) {
     const int idx = min(tid + i * 512, ntot - 1);
     const int tok = TP == 1 ? 0 : idx / npiece, col = min(idx - tok * npiece, kpieces - 1);
-    xpre[i] = *reinterpret_cast<const uint4*>(p.x + (size_t)min(tok, max(bsz, 1) - 1) * p.ldx + col * 8);
-    nwpre[i] = *reinterpret_cast<const uint4*>(nwp + col * 8);
+    const size_t row = (size_t)min(tok, max(bsz, 1) - 1) * p.ldx;
+    xpre[i] = *reinterpret_cast<const uint4*>(p.x + row + col * 8);
+    nwpre[i] = *reinterpret_cast<const uint4*>(nwp + (p.glu_in ? row : 0) + col * 8);
   }
   auto piece = [&](int it, int idx) -> uint4 {   // piece `idx` of the block: register copy for the first XPRE rounds
     if (it < XPRE) return xpre[it < XPRE ? it : 0];
@@ -410,6 +424,8 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
         v = lin_norm8(v, r, p.norm_w + col * 8);
       }
     }
+    if (p.glu_in && tok < bsz && col * 8 < p.Kx)
+      v = lin_glu8(v, it < XPRE ? nwpre[it < XPRE ? it : 0] : *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + p.Kx + col * 8));
     if constexpr (FMT == F_FP8) {
       float am = amax8_bf16(v);
 #pragma unroll
@@ -1641,7 +1657,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
   using F = Fmt<FMT, G>;
   const int NKS = h->NKS;
   if constexpr (FMT == F_W4 && G == 64) {   // (the all-CU kernel is instantiated for Marlin's default group size)
-    const int rc = launch_sk<G>(h, p, st, gate);
+    const int rc = p.glu_in ? KTX_LIN_NOT_FUSED : launch_sk<G>(h, p, st, gate);   // (the SiLU * up prologue lives in lin_dec_body)
     if (rc != KTX_LIN_NOT_FUSED) return rc;
   }
   p.TP = p.T <= 1 ? 1 : p.T <= 2 ? 2 : 4;
@@ -2054,6 +2070,10 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
     p.glu = fu->glu ? 1 : 0;
     KTX_REQUIRE(!p.glu || (h->cfg.out_features % 16 == 0 && !h->d_bias && !p.add1 && !p.add2),
                 "ktx_linear_forward_fused: glu needs out_features % 16 == 0 and no bias / addends");
+    p.glu_in = fu->glu_in ? 1 : 0;
+    KTX_REQUIRE(!p.glu_in || (dec_fits(h, T) && !p.norm_w && !gate && !prep && ldx >= 2L * h->cfg.in_features),
+                "ktx_linear_forward_fused: glu_in exists in the decode kernel only (T <= 4), without the RMSNorm prologue, on rows of "
+                "2 * in_features elements; run ktx_silu_mul first");
   }
   hipStream_t st = (hipStream_t)stream;
   switch (h->cfg.format) {
@@ -2083,7 +2103,7 @@ extern "C" int ktx_linear_forward(ktx_linear_t h, const int32_t* d_bsz, int T, c
 extern "C" int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,
                                         const ktx_linear_fusion* fusion, ktx_stream_t stream) {
   KTX_REQUIRE(h, "ktx_linear_forward_fused: null handle");
-  const long ldx = fusion && fusion->x_ld ? (long)fusion->x_ld : (long)h->cfg.in_features;
+  const long ldx = fusion && fusion->x_ld ? (long)fusion->x_ld : (long)h->cfg.in_features * (fusion && fusion->glu_in ? 2 : 1);
   const long ldy = fusion && fusion->y_ld ? (long)fusion->y_ld : (long)(fusion && fusion->glu ? h->cfg.out_features / 2 : h->cfg.out_features);
   return linear_forward_impl(h, d_bsz, T, d_x, ldx, 0, d_y, ldy, 0, stream, fusion);
 }

@@ -365,11 +365,12 @@ class _KMoEBlock(BaseInjectedModule):
                 "topk_idx": torch.empty((1, k), dtype=torch.int64, device=dev), "topk_w": torch.empty((1, k), dtype=torch.float32, device=dev),
                 "done": False}
 
-    def _finish(self, y, identity, residual, orig_shape, shared_act=None):
+    def _finish(self, y, identity, residual, orig_shape, shared_act=None, shared_raw=False):
         shared = getattr(self.config, "n_shared_experts", None) is not None
         se = self.shared_experts if shared else None
         if shared_act is not None:                                         # gate|up of the shared experts already done (rode with the router)
-            return se.down(shared_act, orig_shape, add1=y.view(*orig_shape), add2=residual).view(*orig_shape)
+            # (shared_raw: the un-activated [gate | up] rows of a block-fp8 MLP — SiLU * up runs in down_proj's prologue)
+            return se.down(shared_act, orig_shape, add1=y.view(*orig_shape), add2=residual, glu_in=shared_raw).view(*orig_shape)
         # (running the shared experts' first GEMV on a side stream, forked from and joined to the captured stream so it
         # overlaps the routed launches like the reference overlaps its CPU experts, was measured: 325 vs 465 tok/s —
         # a cross-stream join inside the HIP graph costs more than the launch it hides.)
@@ -438,16 +439,15 @@ class _KMoEBlock(BaseInjectedModule):
             return fused
         else:
             side = self._router_side_linear(hidden_states, pre_norm, allow_cat=True)
+        shared_raw = False
         if routed:
             pass                                              # ids, weights and the normalised row are already here
         elif side is not None:
             # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)
-            glu = side.fmt == "W4"                           # block-FP8 shared experts: [gate | up] rows, SiLU * up after the launch
+            glu = side.fmt == "W4"                           # block-FP8 shared experts: [gate | up] rows, SiLU * up in down_proj's prologue
             topk_idx, topk_weight, xn, shared_act = self.gate.forward_with_linear(
                 hidden_states, (pre_norm.weight, pre_norm.variance_epsilon), side, glu=glu)
-            if not glu:
-                from ktransformers_amd._native import silu_mul
-                shared_act = silu_mul(shared_act)
+            shared_raw = not glu
             hidden_states = xn.view(*orig_shape)
         elif pre_norm is not None and hasattr(self.gate, "_handle"):
             topk_idx, topk_weight, xn = self.gate(hidden_states, norm=(pre_norm.weight, pre_norm.variance_epsilon))
@@ -463,19 +463,19 @@ class _KMoEBlock(BaseInjectedModule):
         gen = getattr(self.experts, "generate_experts", None)
         if (sequence_length == 1 and gen is not None and hasattr(gen, "submit_for_one_decode")
                 and torch.cuda.is_available() and torch.cuda.is_current_stream_capturing()):
-            tail = self._tail_side(shared_act, residual, gen)
+            tail = self._tail_side(None if shared_raw else shared_act, residual, gen)
             gen.submit_for_one_decode(hidden_states[0], topk_idx[0], topk_weight[0], **({"side": tail} if tail else {}))
             y = gen.sync_for_one_decode().unsqueeze(0)
-            return y.view(*orig_shape) if tail else self._finish(y, identity, residual, orig_shape, shared_act)
+            return y.view(*orig_shape) if tail else self._finish(y, identity, residual, orig_shape, shared_act, shared_raw)
 
         ex = self.experts
         op = getattr(ex, "generate_experts", None) if getattr(ex, "mode", None) == InferenceState.GENERATE else \
             getattr(ex, "prefill_experts", None)
-        tail = self._tail_side(shared_act, residual, op)
+        tail = self._tail_side(None if shared_raw else shared_act, residual, op)
         if tail:
             return op.forward(hidden_states, topk_idx, topk_weight, side=tail).view(*orig_shape).to(device=hidden_states.device)
         y = self.moe_kexperts(hidden_states, topk_idx, topk_weight).view(*orig_shape).to(device=hidden_states.device)
-        return self._finish(y, identity, residual, orig_shape, shared_act)
+        return self._finish(y, identity, residual, orig_shape, shared_act, shared_raw)
 
     def _tail_side(self, shared_act, residual, experts_op):
         """(down_proj handle, shared_act, residual) when the routed experts' call can carry the shared experts' down projection and

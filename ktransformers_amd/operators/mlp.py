@@ -11,6 +11,7 @@ from torch import nn
 
 from ktransformers_amd.operators.base_operator import BaseInjectedModule
 from ktransformers_amd.operators.linear import KTransformersLinear, build_merged_linear
+from ktransformers_amd.util.utils import InferenceState
 
 
 class KDeepseekV3MLP(BaseInjectedModule):
@@ -65,10 +66,21 @@ class KDeepseekV3MLP(BaseInjectedModule):
             x2 = rmsnorm(x2, norm[0], norm[1], native_rounding=True)
         return silu_mul(torch.cat([self.orig_module.gate_proj(x2), self.orig_module.up_proj(x2)], dim=-1))
 
-    def down(self, a: torch.Tensor, shape, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None) -> torch.Tensor:
-        """Second half: down_proj(a) (+ add1, + add2 in its epilogue)."""
+    def down(self, a: torch.Tensor, shape, add1: torch.Tensor | None = None, add2: torch.Tensor | None = None,
+             glu_in: bool = False) -> torch.Tensor:
+        """Second half: down_proj(a) (+ add1, + add2 in its epilogue).  glu_in: `a` is the un-activated [gate | up] block of the
+        first half (block-fp8: the concatenated GEMV has no GLU epilogue) and SiLU * up runs in down_proj's prologue
+        (LinearHandle.forward(glu_in=True): inside the decode kernel, a ktx_silu_mul launch in front of the prompt kernels)."""
         down = self.orig_module.down_proj
         fusion = {k: v.reshape(-1, shape[-1]) for k, v in (("add1", add1), ("add2", add2)) if v is not None}
+        if glu_in:
+            op = down.prefill_linear if isinstance(down, KTransformersLinear) and down.mode == InferenceState.PREFILL else \
+                getattr(down, "generate_linear", None)
+            if getattr(op, "_h", None) is not None and hasattr(op._h, "_forward_glu_in"):
+                fusion["glu_in"] = True
+            else:
+                from ktransformers_amd._native import silu_mul
+                a = silu_mul(a)
         if isinstance(down, KTransformersLinear):
             y = down(a, **fusion)
         else:
@@ -81,6 +93,8 @@ class KDeepseekV3MLP(BaseInjectedModule):
                 norm: tuple | None = None, pre_norm=None) -> torch.Tensor:
         if pre_norm is not None:
             norm = (pre_norm.weight, pre_norm.variance_epsilon)
+        if self._gate_up_cat is not None:   # block-fp8: [gate | up] rows of one GEMV; SiLU * up in down_proj's prologue
+            return self.down(self._gate_up_cat.forward(x.reshape(-1, x.shape[-1]), norm=norm), x.shape, add1, add2, glu_in=True)
         return self.down(self.gate_up(x, norm), x.shape, add1, add2)
 
 

@@ -231,6 +231,36 @@ def test_fp8_mlp_runs_gate_and_up_as_one_operator():
             xn = x if norm is None else rmsnorm(x, norm[0], norm[1], native_rounding=True)
             want = silu_mul(torch.cat([ops["gate_proj"].forward(xn), ops["up_proj"].forward(xn)], dim=-1))
             assert torch.equal(mlp.gate_up(x, norm), want), f"T={T} norm={norm is not None}"
+            # the whole block: SiLU * up rides in down_proj's prologue on decode-sized calls (glu_in) — same bits as the three launches
+            res = (torch.randn(T, H) / 10).to(torch.bfloat16).cuda()
+            assert torch.equal(mlp.forward(x, add1=res, norm=norm), mlp.down(want, x.shape, add1=res)), f"T={T} block"
+
+
+@pytest.mark.parametrize("fmt,K,N", [("FP8", 2048, 7168), ("FP8", 1536, 576), ("W4", 2048, 7168), ("W4", 1408, 2048), ("BF16", 512, 200)])
+def test_silu_mul_in_the_prologue_of_a_decode_linear(fmt, K, N):
+    """ktx_linear_fusion.glu_in (round 5): x rows are [gate | up] and the decode kernel stages silu(gate) * up itself — the same
+    roundings as ktx_silu_mul, so bit for bit the two-launch result, with the epilogue adds, the bsz tensor and for every decode
+    row count; a prompt-sized call takes the separate launch inside LinearHandle.forward."""
+    n = native()
+    torch.manual_seed(K + N)
+    h = n.LinearHandle(K, N, fmt, 128 if fmt == "FP8" else 64, 64)
+    if fmt == "FP8":
+        h.load_fp8((torch.randn(N, K) / 4).to(torch.float8_e4m3fn).cuda(), ((torch.rand((N + 127) // 128, K // 128) + 0.5) / 32).cuda())
+    else:
+        h.load_bf16((torch.randn(N, K) / 10).to(torch.bfloat16).cuda())
+    for T in (1, 2, 3, 4, 9):
+        gu = (torch.randn(T, 2 * K) * 2).to(torch.bfloat16).cuda()
+        a1 = torch.randn(T, N).to(torch.bfloat16).cuda()
+        a2 = torch.randn(T, N).to(torch.bfloat16).cuda()
+        act = n.silu_mul(gu)
+        assert torch.equal(h.forward(gu, glu_in=True), h.forward(act)), (fmt, T)
+        assert torch.equal(h.forward(gu, add1=a1, add2=a2, glu_in=True), h.forward(act, add1=a1, add2=a2)), (fmt, T, "adds")
+        if T == 3:
+            bsz = torch.tensor([2], dtype=torch.int32, device="cuda")
+            got, want = h.forward(gu, bsz, glu_in=True), h.forward(n.silu_mul(gu, bsz)[:T], bsz)
+            assert torch.equal(got[:2], want[:2]) and bool((got[2:] == 0).all())
+    with pytest.raises(n.KtxError):
+        h.forward(torch.zeros(1, 2 * K, dtype=torch.bfloat16, device="cuda"), norm=(torch.ones(K, dtype=torch.bfloat16, device="cuda"), 1e-6), glu_in=True)
 
 
 def test_bsz_tensor_and_graph_capture():
