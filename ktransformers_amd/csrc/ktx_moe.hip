@@ -2593,7 +2593,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
     need[5] = (size_t)h->max_pairs * H * (gguf ? sizeof(float) : sizeof(bf16_t));
     need[6] = need[7] = (size_t)h->max_pairs * sizeof(int32_t);
     need[8] = (size_t)h->max_tiles * sizeof(Tile);
-    need[9] = 4 * sizeof(int32_t);
+    need[9] = (4 + KTX_DEC_MAX_PAIRS * 64) * sizeof(int32_t);   // [4] bucket counters | arrival tickets of the GGUF decode launches
     if (gguf) {
       need[10] = (size_t)cfg->max_len * (H / 16) * sizeof(int16_t);
       need[11] = (size_t)h->max_pairs * (I / 16) * sizeof(int16_t);
@@ -2612,7 +2612,7 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
       alloc(w->x_q, 0); alloc(w->x_d, 1); alloc(w->a_buf, 2); alloc(w->a_q, 3); alloc(w->a_d, 4); alloc(w->dn_buf, 5);
       alloc(w->row_of_pair, 6); alloc(w->src_of_row, 7); alloc(w->tiles, 8); alloc(w->counters, 9);
       alloc(w->x_bs, 10); alloc(w->a_bs, 11);
-      if (e == hipSuccess) e = hipMemset(w->counters, 0, 4 * sizeof(int32_t));
+      if (e == hipSuccess) e = hipMemset(w->counters, 0, w->cap[9]);
       if (e != hipSuccess) {
         ktx_moe_destroy(h);
         return ktx_fail(std::string("ktx_moe_create: workspace: ") + hipGetErrorString(e));
@@ -3625,16 +3625,17 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   {
     const int tg = h->gg_type[0], td = h->gg_type[2];
     const int nkb1 = H / 256, nkb2 = I / 256;
-    const size_t lds_gu = (size_t)H + (size_t)nkb1 * (gg_nbs(tg) + 1) * 4 + 8 + (tg == GG_IQ1S ? 4096 * 8 : 0);
+    const size_t lds_gu = (size_t)H + (size_t)nkb1 * (gg_nbs(tg) + 1) * 4 + 32 + (tg == GG_IQ1S ? 4096 * 8 : 0);   // (+ the arrival flag)
     const size_t lds_dn = (size_t)k * I + (size_t)k * nkb2 * (gg_nbs(td) + 1) * 4 + (size_t)k * (16 + 2) * 4 + 8 +
                           (td == GG_IQ1S ? 4096 * 8 : 0);
-    if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && lds_gu <= 64 * 1024 && lds_dn <= 64 * 1024 && !g_force_generic) {
+    if (npairs <= KTX_DEC_MAX_PAIRS && k <= 8 && nkb2 <= 64 && lds_gu <= 64 * 1024 && lds_dn <= 64 * 1024 && !g_force_generic) {
       GgDecParams dp;
       dp.d_bsz = d_bsz; dp.qlen = qlen; dp.k = k; dp.E = E; dp.expert_begin = h->cfg.expert_begin; dp.H = H; dp.I = I;
       dp.ids = d_expert_ids; dp.mask = h->mask; dp.x = (const bf16_t*)d_input; dp.weights = d_weights;
       dp.gate_w = h->gate_w; dp.up_w = h->up_w; dp.down_w = h->down_w;
       dp.gate_stride = h->gg_stride[0]; dp.up_stride = h->gg_stride[1]; dp.down_stride = h->gg_stride[2];
       dp.a_buf = reinterpret_cast<float*>(ws->a_buf); dp.y = d_output;
+      dp.a_q = reinterpret_cast<uint8_t*>(ws->a_q); dp.a_bs = ws->a_bs; dp.a_d8 = ws->a_d; dp.tickets = ws->counters + 4;
       dp.incremental = (flags & KTX_FWD_INCREMENTAL) ? 1 : 0; dp.partial_f32 = (flags & KTX_FWD_PARTIAL_F32) ? 1 : 0;
       const dim3 g1((I / 16 + 3) / 4, npairs), g2(H / 16, qlen);
       int d1 = nkb1 % 4 == 0 ? 4 : nkb1 % 2 == 0 ? 2 : 1;
@@ -3645,6 +3646,12 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
       auto tname = [](int t) { return gg_type_name(t); };
 #define KTX_GG_GU(WT)                                                                                                \
       do {                                                                                                           \
+        if constexpr (WT == GG_IQ1S) {   /* 4 strips x 4 k-slices, a slice's tiles all in flight from the start: four wavefronts per SIMD (dev knob 20 = 2: two) */ \
+          const size_t lds4 = lds_gu + 4 * 4 * 2 * 16 * 4;                                                           \
+          if (nkb1 == 28 && g_dbg[20] == 0) { hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 3, 4, 4, 7>), g1, dim3(1024), lds4, st, dp); break; } \
+          if (nkb1 == 16 && g_dbg[20] == 0) { hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4, 4, 4>), g1, dim3(1024), lds4, st, dp); break; } \
+          if (nkb1 == 8 && g_dbg[20] == 0) { hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4, 4, 2>), g1, dim3(1024), lds4, st, dp); break; } \
+        }                                                                                                            \
         if (ks2) {   /* 4 strips x 2 k-slices per workgroup: two wavefronts per SIMD (dev knob 20 = 1: one) */       \
           if (nkb1 % 4 == 0) hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 2, 4, 2>), g1, dim3(512), lds_gu + 2 * 4 * 2 * 16 * 4, st, dp); \
           else hipLaunchKernelGGL((moe_dec_gguf_gateup_kernel<WT, 1, 4, 2>), g1, dim3(512), lds_gu + 2 * 4 * 2 * 16 * 4, st, dp); \

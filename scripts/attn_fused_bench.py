@@ -21,14 +21,31 @@ def u(shape, scale):
     return ((torch.rand(shape, generator=g, device=dev, dtype=torch.float32) * 2 - 1) * scale).to(torch.bfloat16)
 
 
+import os  # noqa: E402
+FMT = os.environ.get("KTX_ATTN_BENCH_FMT", "W4")      # "FP8": block-fp8 projections (DeepSeek fp8 checkpoints)
+
+
+def proj(K, Nout, scale):
+    w = u((Nout, K), scale)
+    if FMT == "FP8":
+        import bench
+        h = N.LinearHandle(K, Nout, "FP8", 128, 8, dev)
+        q, sc = bench.fp8_block_quant(w)
+        h.load_fp8(q, sc)
+    else:
+        h = N.LinearHandle(K, Nout, "W4", 64, 8, dev)
+        h.load_bf16(w)
+    return h
+
+
 layers = []
 for _ in range(L):
     o = {}
-    o["qkv_a"] = N.LinearHandle(HIDDEN, QLORA + LORA + ROPE, "W4", 64, 8, dev); o["qkv_a"].load_bf16(u((QLORA + LORA + ROPE, HIDDEN), 0.03))
-    o["q_b"] = N.LinearHandle(QLORA, H * (NOPE + ROPE), "W4", 64, 8, dev); o["q_b"].load_bf16(u((H * (NOPE + ROPE), QLORA), 0.05))
+    o["qkv_a"] = proj(HIDDEN, QLORA + LORA + ROPE, 0.03)
+    o["q_b"] = proj(QLORA, H * (NOPE + ROPE), 0.05)
     o["qabs"] = N.LinearHandle(NOPE, LORA, "BF16", 0, 8, dev, batch=H); o["qabs"].load_bf16(u((H, LORA, NOPE), 0.08))
     o["oabs"] = N.LinearHandle(LORA, VDIM, "BF16", 0, 8, dev, batch=H); o["oabs"].load_bf16(u((H, VDIM, LORA), 0.05))
-    o["o_proj"] = N.LinearHandle(H * VDIM, HIDDEN, "W4", 64, 8, dev); o["o_proj"].load_bf16(u((HIDDEN, H * VDIM), 0.02))
+    o["o_proj"] = proj(H * VDIM, HIDDEN, 0.02)
     o["in_norm"] = (1 + u((HIDDEN,), 0.2).float()).to(torch.bfloat16)
     o["qa_norm"] = (1 + u((QLORA,), 0.2).float()).to(torch.bfloat16)
     o["kv_norm"] = (1 + u((LORA,), 0.2).float()).to(torch.bfloat16)
@@ -105,6 +122,8 @@ import subprocess
 print(subprocess.run("/opt/rocm/bin/rocm-smi --showuniqueid | grep Unique", shell=True, capture_output=True, text=True).stdout.strip())
 if len(sys.argv) > 3:
     cfgs = [c for c in cfgs if c[0] in ("five launches", "one launch")]
+if FMT == "FP8":      # (the five-launch chain of this script uses the W4-only q_b + absorb launch: compare with the phases as launches)
+    cfgs = [c for c in cfgs if c[0] in ("one launch", "phases as 5 launches")]   # (the phase masks instantiated for FP8)
 graphs = [(name, capture(fn)) for name, fn in cfgs]
 ref_y = None
 for rnd in range(2):
