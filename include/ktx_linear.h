@@ -97,8 +97,8 @@ typedef struct ktx_linear_fusion {
                          out_features / 2 columns (DeepseekV3MLP, modeling_deepseek_v3.py:396-398) */
   int32_t glu_in;     /* the INPUT rows are [gate | up], 2 * in_features elements (x_ld defaults to that): the linear reads
                          act_fn(gate) * up with ktx_silu_mul's roundings (include/ktx_ops.h) — down_proj of a DeepseekV3MLP whose
-                         gate_proj / up_proj ran as one [gate ; up] GEMV (block-fp8 checkpoints).  Decode kernel only
-                         (ktx_linear_decode_eligible), not together with norm_weight; otherwise call ktx_silu_mul first.
+                         gate_proj / up_proj ran as one [gate ; up] GEMV (block-fp8 checkpoints).  KTX_LIN_FP8 handles, decode
+                         kernel only (ktx_linear_decode_eligible), not together with norm_weight; otherwise call ktx_silu_mul first.
                          (Occupies what was padding after `glu`: the struct's size and the other offsets are unchanged.) */
 } ktx_linear_fusion;
 int ktx_linear_forward_fused(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y,

@@ -797,8 +797,8 @@ class LinearHandle:
         """x: bf16 [..., in] -> bf16 [..., out] on the current stream.  Optional fusions (include/ktx_linear.h,
         ktx_linear_fusion): norm = (weight bf16 [in], eps) applies RMSNorm to x inside the kernel (falls back to a separate
         ktx_rmsnorm launch where the decode kernel does not run); add1 / add2 = bf16 [..., out] tensors added in that order;
-        glu_in: x is bf16 [..., 2 * in] = [gate | up] and the linear reads silu_mul(x) — inside the decode kernel where it
-        runs, as a separate ktx_silu_mul launch otherwise."""
+        glu_in: x is bf16 [..., 2 * in] = [gate | up] and the linear reads silu_mul(x) — inside the block-fp8 decode kernel,
+        as a separate ktx_silu_mul launch otherwise."""
         if glu_in:
             return self._forward_glu_in(x, bsz_tensor, out, norm, add1, add2, glu)
         if x.dtype != torch.bfloat16 or x.shape[-1] != self.K or x.device != self.device:
@@ -863,7 +863,7 @@ class LinearHandle:
         if not x2.is_contiguous():
             x2 = x2.contiguous()
         T = x2.shape[0]
-        if not self.decode_eligible(T) or self.batch != 1 or os.environ.get("KTX_LINEAR_SEPARATE_SILU_MUL"):
+        if self.fmt != "FP8" or not self.decode_eligible(T) or self.batch != 1 or os.environ.get("KTX_LINEAR_SEPARATE_SILU_MUL"):
             return self.forward(silu_mul(x2, bsz_tensor), bsz_tensor, out, None, add1, add2).reshape(*x.shape[:-1], self.N)
         if out is None:
             out = torch.empty((T, self.N), dtype=torch.bfloat16, device=self.device) if bsz_tensor is None else \

@@ -277,7 +277,10 @@ __device__ __forceinline__ void lin_vmcnt_rt(int n) {
 }
 
 // (bx, by) = the workgroup's place in the grid of products — a device function so that another kernel's launch can carry it
-template <int FMT, int G, int D, int MODE>
+// GLUIN (round 5, ktx_linear_fusion.glu_in): x rows are [gate | up] and the staging pass forms act_fn(gate) * up — a TEMPLATE
+// parameter, instantiated for block-fp8 only: as a run-time flag the eight expf expansions sat (skipped) in the prologue of
+// every decode kernel of the library, 1350 instructions each.
+template <int FMT, int G, int D, int MODE, bool GLUIN = false>
 __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const int by, const int nbx, uint8_t* smem) {
   constexpr bool EXACT = MODE != M_GUARD;
   static_assert(MODE != M_DMA || FMT == F_W4, "the LDS-DMA ring is built for the W4 format");
@@ -319,8 +322,8 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   const int npiece = NKS * 16;   // 8-element pieces per token
   const int ntot = TP * npiece;
   const int kpieces = p.Kx >> 3;
-  // (glu_in: the second operand slot carries the row's `up` half instead of the norm weights — the two prologues exclude each other)
-  const bf16_t* nwp = p.glu_in ? p.x + p.Kx : p.norm_w ? p.norm_w : p.x;
+  // (GLUIN: the second operand slot carries the row's `up` half instead of the norm weights — the two prologues exclude each other)
+  const bf16_t* nwp = GLUIN ? p.x + p.Kx : p.norm_w ? p.norm_w : p.x;
   uint4 xpre[XPRE], nwpre[XPRE];
 #pragma unroll
   for (int i = 0; i < XPRE; i++) {
@@ -328,7 +331,7 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
     const int tok = TP == 1 ? 0 : idx / npiece, col = min(idx - tok * npiece, kpieces - 1);
     const size_t row = (size_t)min(tok, max(bsz, 1) - 1) * p.ldx;
     xpre[i] = *reinterpret_cast<const uint4*>(p.x + row + col * 8);
-    nwpre[i] = *reinterpret_cast<const uint4*>(nwp + (p.glu_in ? row : 0) + col * 8);
+    nwpre[i] = *reinterpret_cast<const uint4*>(nwp + (GLUIN ? row : 0) + col * 8);
   }
   auto piece = [&](int it, int idx) -> uint4 {   // piece `idx` of the block: register copy for the first XPRE rounds
     if (it < XPRE) return xpre[it < XPRE ? it : 0];
@@ -424,8 +427,10 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
         v = lin_norm8(v, r, p.norm_w + col * 8);
       }
     }
-    if (p.glu_in && tok < bsz && col * 8 < p.Kx)
-      v = lin_glu8(v, it < XPRE ? nwpre[it < XPRE ? it : 0] : *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + p.Kx + col * 8));
+    if constexpr (GLUIN) {
+      if (tok < bsz && col * 8 < p.Kx)
+        v = lin_glu8(v, it < XPRE ? nwpre[it < XPRE ? it : 0] : *reinterpret_cast<const uint4*>(p.x + (size_t)tok * p.ldx + p.Kx + col * 8));
+    }
     if constexpr (FMT == F_FP8) {
       float am = amax8_bf16(v);
 #pragma unroll
@@ -548,10 +553,10 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   }
 }
 
-template <int FMT, int G, int D, int MODE>
+template <int FMT, int G, int D, int MODE, bool GLUIN = false>
 __global__ __launch_bounds__(512) void lin_dec_kernel(LinParams p) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
-  lin_dec_body<FMT, G, D, MODE>(p, blockIdx.x, blockIdx.y, gridDim.x, smem);
+  lin_dec_body<FMT, G, D, MODE, GLUIN>(p, blockIdx.x, blockIdx.y, gridDim.x, smem);
 }
 
 // The MoE router riding in the launch of the shared experts' gate|up GEMV (ktx_linear_forward_fused_gate): both read the same
@@ -1766,8 +1771,23 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
   };
   constexpr int DMAX = FMT == F_BF16 ? 4 : 8;   // ring depth bound by registers: a BF16 k-step is 4 KiB per wave
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
-            "lin_dec_kernel<%s> %d->%d%s%s", lin_fmt_name(FMT), p.Kx, p.N,
-            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "", p.prep_on ? " +mla_prep" : "");
+            "lin_dec_kernel<%s> %d->%d%s%s%s", lin_fmt_name(FMT), p.Kx, p.N,
+            h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "", p.prep_on ? " +mla_prep" : "", p.glu_in ? " silu*up in" : "");
+  if (p.glu_in) {   // SiLU * up in the staging pass: block-fp8 (the format whose MLPs have no GLU epilogue), a short list of ring depths
+    if constexpr (FMT == F_FP8) {
+      if (nsl * p.SPS == NKS) {
+        if (p.SPS % 8 == 0) return go(lin_dec_kernel<FMT, G, 8, M_EXACT, true>);
+        if (p.SPS % 6 == 0) return go(lin_dec_kernel<FMT, G, 6, M_EXACT, true>);
+        if (p.SPS % 4 == 0) return go(lin_dec_kernel<FMT, G, 4, M_EXACT, true>);
+        if (p.SPS % 2 == 0) return go(lin_dec_kernel<FMT, G, 2, M_EXACT, true>);
+      }
+      if (p.SPS >= 8) return go(lin_dec_kernel<FMT, G, 8, M_GUARD, true>);
+      if (p.SPS >= 4) return go(lin_dec_kernel<FMT, G, 4, M_GUARD, true>);
+      return go(lin_dec_kernel<FMT, G, 2, M_GUARD, true>);
+    } else {
+      return ktx_fail("ktx_linear_forward_fused: glu_in is built for block-fp8 handles (run ktx_silu_mul first)");
+    }
+  }
   if constexpr (FMT == F_W4) {
     switch (dma_depth) {
       case 16: return go(lin_dec_kernel<FMT, G, 16, M_DMA>);
@@ -2071,9 +2091,9 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
     KTX_REQUIRE(!p.glu || (h->cfg.out_features % 16 == 0 && !h->d_bias && !p.add1 && !p.add2),
                 "ktx_linear_forward_fused: glu needs out_features % 16 == 0 and no bias / addends");
     p.glu_in = fu->glu_in ? 1 : 0;
-    KTX_REQUIRE(!p.glu_in || (dec_fits(h, T) && !p.norm_w && !gate && !prep && ldx >= 2L * h->cfg.in_features),
-                "ktx_linear_forward_fused: glu_in exists in the decode kernel only (T <= 4), without the RMSNorm prologue, on rows of "
-                "2 * in_features elements; run ktx_silu_mul first");
+    KTX_REQUIRE(!p.glu_in || (h->cfg.format == KTX_LIN_FP8 && dec_fits(h, T) && !p.norm_w && !gate && !prep && ldx >= 2L * h->cfg.in_features),
+                "ktx_linear_forward_fused: glu_in exists in the block-fp8 decode kernel only (T <= 4), without the RMSNorm prologue, on "
+                "rows of 2 * in_features elements; run ktx_silu_mul first");
   }
   hipStream_t st = (hipStream_t)stream;
   switch (h->cfg.format) {

@@ -238,9 +238,10 @@ def test_fp8_mlp_runs_gate_and_up_as_one_operator():
 
 @pytest.mark.parametrize("fmt,K,N", [("FP8", 2048, 7168), ("FP8", 1536, 576), ("W4", 2048, 7168), ("W4", 1408, 2048), ("BF16", 512, 200)])
 def test_silu_mul_in_the_prologue_of_a_decode_linear(fmt, K, N):
-    """ktx_linear_fusion.glu_in (round 5): x rows are [gate | up] and the decode kernel stages silu(gate) * up itself — the same
-    roundings as ktx_silu_mul, so bit for bit the two-launch result, with the epilogue adds, the bsz tensor and for every decode
-    row count; a prompt-sized call takes the separate launch inside LinearHandle.forward."""
+    """ktx_linear_fusion.glu_in (round 5): x rows are [gate | up] and the block-fp8 decode kernel stages silu(gate) * up itself — the
+    same roundings as ktx_silu_mul, so bit for bit the two-launch result, with the epilogue adds, the bsz tensor and for every decode
+    row count; a prompt-sized call, and the other formats (their MLPs have the GLU epilogue instead), take the separate launch inside
+    LinearHandle.forward — same call, same bits."""
     n = native()
     torch.manual_seed(K + N)
     h = n.LinearHandle(K, N, fmt, 128 if fmt == "FP8" else 64, 64)
@@ -253,7 +254,17 @@ def test_silu_mul_in_the_prologue_of_a_decode_linear(fmt, K, N):
         a1 = torch.randn(T, N).to(torch.bfloat16).cuda()
         a2 = torch.randn(T, N).to(torch.bfloat16).cuda()
         act = n.silu_mul(gu)
-        assert torch.equal(h.forward(gu, glu_in=True), h.forward(act)), (fmt, T)
+        n.timing_collect()
+        n.timing_enable(2)
+        try:
+            got = h.forward(gu, glu_in=True)
+            torch.cuda.synchronize()
+            labels = [lab for lab, _, _ in n.timing_collect()]
+        finally:
+            n.timing_enable(0)
+        assert torch.equal(got, h.forward(act)), (fmt, T)
+        if fmt == "FP8" and T <= 4:       # one launch, and it is the decode kernel with the prologue
+            assert len(labels) == 1 and "silu*up in" in labels[0], labels
         assert torch.equal(h.forward(gu, add1=a1, add2=a2, glu_in=True), h.forward(act, add1=a1, add2=a2)), (fmt, T, "adds")
         if T == 3:
             bsz = torch.tensor([2], dtype=torch.int32, device="cuda")
