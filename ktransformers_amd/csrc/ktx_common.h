@@ -4,7 +4,9 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
+#include <unordered_map>
 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef float v4f __attribute__((ext_vector_type(4)));
@@ -84,6 +86,35 @@ __device__ __forceinline__ int quant_rne_sat8(float v) {
   float r = rintf(v);
   r = fminf(fmaxf(r, -128.0f), 127.0f);
   return (int)r;
+}
+
+// hipFuncSetAttribute acts on the CURRENT device's copy of a kernel, so "set once" is once per (call site, device): a process that
+// splits a model's layers over several GPUs would otherwise launch with the default dynamic-LDS limit on every device but the first
+// (ADVICE r4).  One of these per call site (function-local static); the check is a hipGetDevice, a thread-local read.
+struct KtxAttrOnce { bool done[64] = {}; };
+// the same for call sites that name their kernel: hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device)
+static inline hipError_t ktx_set_max_lds(const void* kernel, int bytes) {
+  static std::mutex mu;
+  static std::unordered_map<const void*, uint64_t> done;   // kernel -> devices it has been set on
+  int dev = 0;
+  const bool known = hipGetDevice(&dev) == hipSuccess && dev >= 0 && dev < 64;
+  if (known) {
+    std::lock_guard<std::mutex> lk(mu);
+    if ((done[kernel] >> dev) & 1u) return hipSuccess;
+  }
+  const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (known && e == hipSuccess) {
+    std::lock_guard<std::mutex> lk(mu);
+    done[kernel] |= 1ull << dev;
+  }
+  return e;
+}
+static inline bool ktx_attr_needed(KtxAttrOnce& o) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
+  if (o.done[dev]) return false;
+  o.done[dev] = true;
+  return true;
 }
 
 // ---- wave-wide reductions on DPP + v_readlane ------------------------------------------------------------------------

@@ -227,10 +227,9 @@ int launch_gemm(GemmParams p, int batch, hipStream_t st) {
   const long nblk = p.xcd_map ? (long)p.tm * ((p.tn + 7) / 8 * 8) : (long)p.tm * p.tn;
   KTX_REQUIRE(nblk < (1L << 31), "ktx_gemm_bf16_nt: too many tiles");
   const dim3 grid((unsigned)nblk, (unsigned)batch);
-  static bool attr_done = false;
-  if (lds > 48 * 1024 && !attr_done) {
+  static KtxAttrOnce attr_done;
+  if (lds > 48 * 1024 && ktx_attr_needed(attr_done)) {
     KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    attr_done = true;
   }
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());

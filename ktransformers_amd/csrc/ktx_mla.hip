@@ -583,22 +583,19 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
   } else if (shape == 2) {
     KTX_TIMED(st, kv_bytes + (double)total_q_tokens * Hq * (MLA_DC + MLA_DR + MLA_DC) * 2.0,
               "mla_decode_kernel<2,4> T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
-    static hipError_t e2 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<2, 4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const hipError_t e2 = ktx_set_max_lds(reinterpret_cast<const void*>(mla_decode_kernel<2, 4>), 128 * 1024);
     KTX_HIP(e2);
     hipLaunchKernelGGL((mla_decode_kernel<2, 4>), grid, dim3(512), lds, st, p);
   } else if (wide) {
     KTX_TIMED(st, kv_bytes + (double)total_q_tokens * Hq * (MLA_DC + MLA_DR + MLA_DC) * 2.0,
               "mla_decode_kernel<4,2> T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
-    static hipError_t e4 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<4, 2>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const hipError_t e4 = ktx_set_max_lds(reinterpret_cast<const void*>(mla_decode_kernel<4, 2>), 128 * 1024);
     KTX_HIP(e4);
     hipLaunchKernelGGL((mla_decode_kernel<4, 2>), grid, dim3(512), lds, st, p);
   } else {
     KTX_TIMED(st, kv_bytes + (double)total_q_tokens * Hq * (MLA_DC + MLA_DR + MLA_DC) * 2.0,
               "mla_decode_kernel<1,4> T=%d Hq=%d nsplit=%d", total_q_tokens, Hq, nsplit);
-    static hipError_t e1 = hipFuncSetAttribute(reinterpret_cast<const void*>(mla_decode_kernel<1, 4>),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    const hipError_t e1 = ktx_set_max_lds(reinterpret_cast<const void*>(mla_decode_kernel<1, 4>), 128 * 1024);
     KTX_HIP(e1);
     hipLaunchKernelGGL((mla_decode_kernel<1, 4>), grid, dim3(256), lds, st, p);
   }

@@ -286,11 +286,7 @@ __global__ __launch_bounds__(1024) void moe_prep_kernel(PrepParams p) {
 
 // launch: the scatter's bitmaps / count window live in dynamic LDS (beyond 48 KB the attribute is needed)
 static hipError_t launch_moe_prep(const PrepParams& pp, int nblocks, hipStream_t st) {
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_prep_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-  });
+  const hipError_t attr_err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_prep_kernel), 96 * 1024);
   if (attr_err != hipSuccess) return attr_err;
   PrepParams p2 = pp;
   const int E = std::max(pp.E, 1);
@@ -2882,12 +2878,7 @@ static int launch_gemm(const GemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int BUF_BYTES = MT * (SPC * 128 / 16) * 256;
   const size_t lds = 2 * BUF_BYTES + MT * 16 * 8;
   auto kern = moe_gemm_kernel<WBITS, MT, SPC, GATE_UP>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                   (int)lds);
-  });
+  const hipError_t attr_err = ktx_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds);
   KTX_HIP(attr_err);
   const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
@@ -2902,11 +2893,7 @@ static int launch_gemm_stream(const GemmParams& p, int max_tiles, hipStream_t st
   const int kch = std::min(p.K, 2048);
   const size_t lds = (size_t)(kch / 16) * CS + TOK * 8;
   auto kern = moe_gemm_stream_kernel<WBITS, MT, D, GATE_UP>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+  const hipError_t attr_err = ktx_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
   KTX_HIP(attr_err);
   const int strips_per_wg = 8 * (GATE_UP ? 2 : 4);
   hipLaunchKernelGGL(kern, dim3((p.N / 16 + strips_per_wg - 1) / strips_per_wg, max_tiles), dim3(512), lds, st, p, kch);
@@ -2918,11 +2905,7 @@ template <int WBITS, bool GATE_UP>
 static int launch_gemm_rt(const GemmParams& p, int max_tiles, hipStream_t st) {
   const size_t lds = 2 * (8 * 256 * 16 + 16 * 2048) + 256 * 8;
   auto kern = moe_gemm_rt_kernel<WBITS, GATE_UP>;
-  static std::once_flag once;
-  static hipError_t attr_err = hipSuccess;
-  std::call_once(once, [&] {
-    attr_err = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-  });
+  const hipError_t attr_err = ktx_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024);
   KTX_HIP(attr_err);
   const int strips_per_wg = GATE_UP ? 8 : 16;
   hipLaunchKernelGGL(kern, dim3((p.N / 16 + strips_per_wg - 1) / strips_per_wg, max_tiles), dim3(512), lds, st, p);
@@ -2945,8 +2928,7 @@ static int launch_gemm_fp(int mt, const FpGemmParams& p, int max_tiles, hipStrea
 #define KTX_FP_LAUNCH(MT, WIDE, PER_WG, NTH)                                                                                  \
   do {                                                                                                                        \
     constexpr size_t lds = 2 * (MT * 32 * 256) + MT * 16 * sizeof(int);                                                       \
-    static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_gemm_fp_kernel<FP8, MT, GATE_UP, WIDE>),    \
-                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                        \
+    const hipError_t err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_gemm_fp_kernel<FP8, MT, GATE_UP, WIDE>), (int)lds);                        \
     KTX_HIP(err);                                                                                                             \
     hipLaunchKernelGGL((moe_gemm_fp_kernel<FP8, MT, GATE_UP, WIDE>), dim3((nstrips + PER_WG - 1) / PER_WG, max_tiles), dim3(NTH), lds, st, p); \
   } while (0)
@@ -3126,9 +3108,7 @@ static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, 
     } while (0)
 #define KTX_LAUNCH_DN1(WB, DD, EX, SG, SM)                                                                          \
     do {                                                                                                            \
-      static std::once_flag once; static hipError_t err = hipSuccess;                                               \
-      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_down_kernel<WB, DD, EX, SG, SM>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+      const hipError_t err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_dec_down_kernel<WB, DD, EX, SG, SM>), 160 * 1024); \
       KTX_HIP(err);                                                                                                 \
       hipLaunchKernelGGL((moe_dec_down_kernel<WB, DD, EX, SG, SM>), g2, dim3(64 * k), lds2, st, dp);                \
     } while (0)
@@ -3280,17 +3260,13 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
     const int only = g_dbg[2];
 #define KTX_FP_GU(F8, DD)                                                                                            \
     do {                                                                                                             \
-      static std::once_flag once; static hipError_t err = hipSuccess;                                                \
-      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_fp_gateup_kernel<F8, DD, 4>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+      const hipError_t err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_dec_fp_gateup_kernel<F8, DD, 4>), 160 * 1024); \
       KTX_HIP(err);                                                                                                  \
       hipLaunchKernelGGL((moe_dec_fp_gateup_kernel<F8, DD, 4>), g1, dim3(256), lds_gu, st, dp);                      \
     } while (0)
 #define KTX_FP_DN(F8, DD)                                                                                            \
     do {                                                                                                             \
-      static std::once_flag once; static hipError_t err = hipSuccess;                                                \
-      std::call_once(once, [&] { err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_dec_fp_down_kernel<F8, DD>), \
-                                                           hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+      const hipError_t err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_dec_fp_down_kernel<F8, DD>), 160 * 1024); \
       KTX_HIP(err);                                                                                                  \
       hipLaunchKernelGGL((moe_dec_fp_down_kernel<F8, DD>), g2, dim3(64 * k), lds_dn, st, dp);                        \
     } while (0)
@@ -3370,8 +3346,7 @@ static int forward_fp(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, const
 template <int NT, bool GATE_UP>
 static int launch_rawint4(const RawGemmParams& p, int max_tiles, hipStream_t st) {
   const size_t lds = 4 * (size_t)(p.K + 32) + (size_t)(p.K / 32) * 16;
-  static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_rawint4_gemm_kernel<NT, GATE_UP>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+  const hipError_t err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_rawint4_gemm_kernel<NT, GATE_UP>), 96 * 1024);
   KTX_HIP(err);
   KTX_REQUIRE(lds <= 96 * 1024, "ktx_moe_forward: K too large for the RAWINT4 kernel");
   hipLaunchKernelGGL((moe_rawint4_gemm_kernel<NT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
@@ -3382,8 +3357,7 @@ static int launch_rawint4(const RawGemmParams& p, int max_tiles, hipStream_t st)
 template <bool GATE_UP>
 static int launch_rawint4_chunk(const RawGemmParams& p, int max_tiles, hipStream_t st) {
   constexpr size_t lds = 2 * (32 * (64 * 16 + 16) + 16 * 64 * 4);
-  static hipError_t err = hipFuncSetAttribute(reinterpret_cast<const void*>(moe_rawint4_chunk_kernel<GATE_UP>),
-                                              hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  const hipError_t err = ktx_set_max_lds(reinterpret_cast<const void*>(moe_rawint4_chunk_kernel<GATE_UP>), (int)lds);
   KTX_HIP(err);
   const int per_wg = GATE_UP ? 8 : 16;      // strips per workgroup of 8 wavefronts (down: two strips per wavefront)
   hipLaunchKernelGGL((moe_rawint4_chunk_kernel<GATE_UP>), dim3((p.N / 16 + per_wg - 1) / per_wg, max_tiles), dim3(512), lds, st, p);
