@@ -89,3 +89,47 @@ def test_experts_switch_passes_serving_arguments():
         seen.clear()
         ke.forward("x", "ids", "w")
         assert seen["args"] == ("x", "ids", "w", None, 0)
+
+
+def test_decode_step_with_the_router_in_the_shared_gate_up_launch(monkeypatch):
+    """KDeepseekV3MoE._forward with the combined router || shared gate|up launch (operators/experts.py), on stand-ins: a W4 merged
+    operator comes back activated (GLU epilogue) and its down projection may ride with the routed experts (_tail_side is asked with it);
+    a block-fp8 [gate ; up] operator comes back RAW — `down` must be told (glu_in=True: SiLU * up in its prologue, round 5) and the raw
+    rows must never be offered to the routed experts' side strip."""
+    from ktransformers_amd.operators.experts import KDeepseekV3MoE
+    E, H, k, I = 8, 32, 2, 16
+    seen = {}
+
+    class Gate(nn.Module):
+        def forward_with_linear(self, h, norm, handle, glu=True):
+            seen["glu"] = glu
+            g = torch.Generator().manual_seed(3)
+            idx = torch.randperm(E, generator=g)[:k][None]
+            w = torch.rand(1, k, generator=g)
+            act = torch.full((1, I if glu else 2 * I), 1.0 if glu else -1.0, dtype=torch.bfloat16)
+            return idx, w, h.reshape(-1, H) * 2, act
+
+    class Shared(nn.Module):
+        def down(self, a, shape, add1=None, add2=None, glu_in=False):
+            seen["down"] = (tuple(a.shape), float(a.flatten()[0]), glu_in)
+            return add1 + add2
+
+    norm = types.SimpleNamespace(weight=torch.ones(H, dtype=torch.bfloat16), variance_epsilon=1e-6)
+    x = torch.randn(1, 1, H).to(torch.bfloat16)
+    res = torch.randn(1, 1, H).to(torch.bfloat16)
+    for fmt in ("W4", "FP8"):
+        orig = nn.Module()
+        orig.gate, orig.experts, orig.shared_experts = Gate(), DenseExperts(E, H), Shared()
+        blk = KDeepseekV3MoE("model.layers.1.mlp", None, types.SimpleNamespace(n_shared_experts=1), orig)
+        monkeypatch.setattr(blk, "_router_side_linear", lambda h, n, allow_cat=False, fmt=fmt: types.SimpleNamespace(fmt=fmt) if allow_cat else None,
+                            raising=False)
+        asked = []
+        monkeypatch.setattr(blk, "_tail_side", lambda act, r, op: asked.append(act) or None, raising=False)
+        seen.clear()
+        y = blk._forward(x, residual=res, pre_norm=norm)
+        assert seen["glu"] == (fmt == "W4")
+        assert seen["down"] == ((1, I), 1.0, False) if fmt == "W4" else seen["down"] == ((1, 2 * I), -1.0, True)
+        assert asked and (asked[-1] is not None) == (fmt == "W4")       # raw [gate | up] rows are never a side strip
+        idx, w, xn, _ = Gate().forward_with_linear(x, None, None)
+        want = orig.experts(xn, idx, w).view(1, 1, H) + res            # Shared.down returned add1 + add2: routed output + residual
+        assert torch.equal(y, want)
