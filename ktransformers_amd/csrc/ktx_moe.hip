@@ -3519,7 +3519,16 @@ template <int WT, int MT, bool GATE_UP>
 static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = gg_nbs(WT);
   const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4 + (WT == GG_IQ1S ? 4096 * 8 : 0);
-  hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), dim3((p.N / 16 + 3) / 4, max_tiles), dim3(256), lds, st, p);
+  const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
+  if constexpr (gg_foldable(WT)) {   // round 6: the folded-operand kernel; dev knob [21] = 1: gg_block's (the bit-identity test, A/B timing)
+    if (g_dbg[21] != 1) {
+      const size_t lds_f = 2 * 16 * US + 2 * TOK * 4 + TOK * 4;
+      hipLaunchKernelGGL((moe_gguf_fold_kernel<WT, MT, GATE_UP>), grid, dim3(256), lds_f, st, p);
+      KTX_HIP(hipGetLastError());
+      return 0;
+    }
+  }
+  hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), grid, dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
 }

@@ -161,6 +161,36 @@ def test_mixtral_like_shape(T):
     run_case(8, 2, 1024, 3584, T, (Q4, Q4, Q6), seed=9)
 
 
+@pytest.mark.parametrize("types", [(Q4, Q4, Q6), (Q6, Q6, Q4)])
+@pytest.mark.parametrize("T", [3, 19, 70, 300])
+def test_folded_prompt_kernels_give_the_unfolded_bits(types, T):
+    """Round 6: the Q4_K / Q6_K grouped GEMM folds the sub-block scales into the int8 MFMA operand (csrc/ktx_moe_gguf.inc,
+    gg_fold) where gg_block multiplied every 32-wide partial product on the vector ALU.  Every integer is the same and so is the
+    fp32 chain, hence the SAME BITS as the unfolded kernel (dev knob 21 = 1) — at every tile height (MT = 1, 2, 4), on ragged
+    tiles, with ids out of range, on random valid blocks (all 6-bit scales / mins and all int8 Q6_K scales occur)."""
+    from ktransformers_amd import _native as n
+    E, k, H, I = 6, 2, 512, 768
+    r0 = np.random.default_rng(100 + T)
+    gate, up, down = random_kquant(types[0], E, I, H, r0), random_kquant(types[1], E, I, H, r0), random_kquant(types[2], E, H, I, r0)
+    x = torch.from_numpy(f32_to_bf16(r0.standard_normal((T, H)).astype(np.float32)).view(np.int16)).view(torch.bfloat16).cuda()
+    ids = np.stack([r0.permutation(E)[:k] for _ in range(T)]).astype(np.int64)
+    ids[0, 0] = -1
+    ids[T - 1, k - 1] = E + 1
+    ids, w = torch.from_numpy(ids).cuda(), torch.from_numpy(r0.random((T, k)).astype(np.float32)).cuda()
+    h = n.MoEHandle(E, k, H, I, max(T, 16), "GGUF", 0)
+    h.load_gguf(torch.from_numpy(gate).cuda(), torch.from_numpy(up).cuda(), torch.from_numpy(down).cuda(), *types)
+    n.force_generic_path(True)          # (T = 3: the grouped kernels, not the two decode launches)
+    try:
+        y_fold = h.forward(x, ids, w).view(torch.int16).cpu().numpy()
+        n.lib.ktx_debug_set(21, 1)
+        y_ref = h.forward(x, ids, w).view(torch.int16).cpu().numpy()
+    finally:
+        n.lib.ktx_debug_set(21, 0)
+        n.force_generic_path(False)
+    assert np.array_equal(y_fold, y_ref), f"{int((y_fold != y_ref).sum())} of {y_ref.size} outputs differ"
+    assert np.abs(y_ref.view(np.uint16).astype(np.int32)).max() > 0
+
+
 @pytest.mark.parametrize("T", [1, 4])
 def test_mixtral_8x7b_real_dims(T):
     """BASELINE.json configs[0] (Mixtral-8x7B q4_k_m, kt-kernel/bench/bench_moe.py:166-170): 8 experts, top-2, hidden 4096,
