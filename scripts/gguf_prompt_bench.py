@@ -15,8 +15,11 @@ ap.add_argument("--T", type=int, default=2048)
 ap.add_argument("--layers", type=int, default=2)
 ap.add_argument("--iters", type=int, default=5)
 ap.add_argument("--experts", type=int, default=0)
+ap.add_argument("--knob", action="append", default=[], help="idx=val dev knobs (ktx_debug_set), e.g. 21=1: unfolded kernels, 22=1: 64-row tiles")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
+for kv in args.knob:
+    n.lib.ktx_debug_set(int(kv.split("=")[0]), int(kv.split("=")[1]))
 E, k, H, I = (8, 2, 4096, 14336) if args.shape == "mixtral" else (args.experts or 64, 8, 7168, 2048)
 if args.experts:
     E = args.experts
@@ -59,7 +62,7 @@ prof = n.profile_collect()
 n.profile_enable(False)
 calls = args.iters * L
 ms_layer = e0.elapsed_time(e1) / calls
-print(f"shape {args.shape} E={E} k={k} H={H} I={I} T={T} types={types}: {ms_layer:.3f} ms/layer "
+print(f"knobs {args.knob} " + f"shape {args.shape} E={E} k={k} H={H} I={I} T={T} types={types}: {ms_layer:.3f} ms/layer "
       f"({2 * 3 * H * I * k * T / ms_layer / 1e9:.0f} TOP/s whole layer, {T * k / E:.0f} rows/expert)")
 flops = {"gate_up": 2 * 2 * H * I * k * T, "down": 2 * H * I * k * T}
 for name, (ms, cnt) in prof.items():
