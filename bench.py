@@ -95,6 +95,7 @@ WORKLOADS = {
                               "(Q4_K gate/up, Q6_K down), llamafile arithmetic"),
 }
 SECONDARY = ("v2lite-int4", "r1-iq1s", "v3-fp8", "k2-rawint4", "mixtral-q4km")
+PREFILL_LONG = 8192      # the reference's default prompt chunk (archive/ktransformers/local_chat.py:86, chunk_size = 8192)
 # stored bytes per weight (+ scales) of the formats, for the algorithmic-bytes figures
 EXPERT_BPW = {"AMXINT4": 0.5, "AMXINT8": 1.0, "RAWINT4": 0.5 + 2 / 32, "FP8": 1.0 + 4 / 16384, "BF16": 2.0}
 LINEAR_BPW = {"W4": 0.5 + 2 / 64, "FP8": 1.0 + 4 / 16384, "BF16": 2.0}
@@ -1064,7 +1065,9 @@ def run_model_decode(name, args, dev, steps, warmup, dist_on=False, world=1, ran
     n_layers = n_layers or wl["layers"]
     ctx = ctx or args.ctx
     t0 = time.perf_counter()
-    mr = ModelDecodeRunner(wl, n_layers, dev, ctx, steps * (windows + 1) + warmup + 1024, seed=rank, use_graph=not args.no_graph)
+    # (the cache also has to hold the reference's own 8192-token prompt chunk, local_chat.py:86, timed after the decode run)
+    max_new = max(steps * (windows + 1) + warmup + 1024, (0 if args.no_prefill else max(args.prefill_tokens, PREFILL_LONG) + 64) - ctx)
+    mr = ModelDecodeRunner(wl, n_layers, dev, ctx, max_new, seed=rank, use_graph=not args.no_graph)
     cfg = mr.cfg
     n_dense = min(cfg.first_k_dense_replace, n_layers)
     gib = sum(h.weight_bytes for h in mr.moe_handles()) / 2 ** 30
@@ -1268,6 +1271,8 @@ def compact_line(out: dict) -> dict:
 
     if out.get("prefill") is not None:
         line["prefill"] = _prefill(out["prefill"])
+    if out.get("prefill_8192") is not None:
+        line["prefill_8192"] = _prefill(out["prefill_8192"])
     sec = {}
     for name in SECONDARY:
         key = name.replace("-", "_")
@@ -1286,8 +1291,15 @@ def compact_line(out: dict) -> dict:
             if isinstance(pf.get("roofline"), dict):
                 s["prefill_frac"] = pf["roofline"].get("frac")
                 s["prefill_bound"] = pf["roofline"].get("bound")
+        pl = r2.get("prefill_8192")
+        if isinstance(pl, dict) and pl.get("value") is not None:
+            s["prefill_8192"] = pl.get("value")
+            if isinstance(pl.get("roofline"), dict):
+                s["prefill_8192_frac"] = pl["roofline"].get("frac")
         if isinstance(r2.get("ctx_131072"), dict):
             s["ctx_131072"] = r2["ctx_131072"].get("value")
+        if "exact" in r2:
+            s["exact"] = r2["exact"]
         if isinstance(r2.get("cpu_llamafile"), dict):
             s["cpu_llamafile"] = _pick(r2["cpu_llamafile"], ("value", "cores"))
         sec[key] = s
@@ -1297,7 +1309,7 @@ def compact_line(out: dict) -> dict:
         line["timing_s"] = {"total": out["timing_s"].get("total")}
     line["detail"] = DETAIL_FILE
     # last resort (a pathological error string, a future field): drop optional blocks until the line fits
-    for k in ("timing_s", "full_depth_extrapolation", "median_tok_s", "whole_step", "secondary", "prefill"):
+    for k in ("timing_s", "full_depth_extrapolation", "median_tok_s", "whole_step", "secondary", "prefill_8192", "prefill"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(k, None)
@@ -1341,6 +1353,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-prefill-long", action="store_true", help="skip the 8192-token prompt chunk (the reference's default chunk_size)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table / roofline")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the other BASELINE.json configurations")
@@ -1493,7 +1506,7 @@ def main():
                     "the in-graph kernel time of one MoE layer when the per-kernel table is present, else step time / layers",
             "layers": wl["full_layers"]}
 
-    prefill = None
+    prefill = prefill_long = None
     if not dist_on and not args.no_prefill:
         # ---------------- prefill: one prompt chunk through the same resident model -----------------------------------------
         t_sec = time.perf_counter()
@@ -1503,6 +1516,14 @@ def main():
             prefill = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
             torch.cuda.synchronize(dev)
         lap("prefill", t_sec)
+        if args.prefill_tokens != PREFILL_LONG and not args.no_prefill_long:
+            t_sec = time.perf_counter()
+            try:    # the reference's own chunk size: 256 rows per V3 expert, the MFMA-bound regime of SURVEY.md §8(d)
+                prefill_long = whole_model_prefill(mr, PREFILL_LONG, dev, reps=2)
+            except Exception as e:
+                prefill_long = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                torch.cuda.synchronize(dev)
+            lap("prefill_8192", t_sec)
     rows_eager = None
     if dist_on and not args.no_kernels:
         # N > 1: every rank steps together (collectives), so the per-launch events run on all ranks; rank 0 reports
@@ -1514,6 +1535,8 @@ def main():
     torch.cuda.empty_cache()
     if prefill is not None:
         out["prefill"] = prefill
+    if prefill_long is not None:
+        out["prefill_8192"] = prefill_long
 
     lus = None
     if not args.no_kernels:
@@ -1584,8 +1607,10 @@ def main():
                         if not args.no_prefill:
                             try:
                                 r2["prefill"] = run_experts_prefill(name, dev, args.prefill_tokens)
+                                if args.prefill_tokens != PREFILL_LONG and not args.no_prefill_long:
+                                    r2["prefill_8192"] = run_experts_prefill(name, dev, PREFILL_LONG, reps=1)
                             except Exception as e:
-                                r2["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                                r2.setdefault("prefill", {"value": None, "error": f"{type(e).__name__}: {e}"[:300]})
                                 torch.cuda.synchronize(dev)
                         if not args.no_cpu_baseline:
                             r2["cpu_llamafile"] = llamafile_cpu_leg(w2)
@@ -1594,8 +1619,10 @@ def main():
                         if not args.no_prefill:
                             try:   # the same resident model, one prompt chunk (no per-launch pass: the headline workload carries that table)
                                 r2["prefill"] = whole_model_prefill(m2, args.prefill_tokens, dev, reps=1, per_kernel_pass=True)
+                                if args.prefill_tokens != PREFILL_LONG and not args.no_prefill_long:
+                                    r2["prefill_8192"] = whole_model_prefill(m2, PREFILL_LONG, dev, reps=1, per_kernel_pass=False)
                             except Exception as e:
-                                r2["prefill"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                                r2.setdefault("prefill", {"value": None, "error": f"{type(e).__name__}: {e}"[:300]})
                                 torch.cuda.synchronize(dev)
                         m2.close()
                         del m2
@@ -1610,6 +1637,10 @@ def main():
                             except Exception as e:
                                 r2["ctx_131072"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
                     r2["workload"] = w2["desc"]
+                    if w2.get("method") == "RAWINT4":
+                        # the prompt path timed here is the default grouped kernel, which re-associates the fp32 sum over the K groups
+                        # (<= 2 bf16 ulp from the reference's order, include/ktx_moe.h); KTX_MOE_EXACT=1 selects the exact one
+                        r2["exact"] = os.environ.get("KTX_MOE_EXACT", "0") not in ("", "0")
                     out[key] = r2
                 except Exception as e:
                     out[key] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}

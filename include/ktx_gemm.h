@@ -40,8 +40,10 @@ typedef struct ktx_gemm_args {
   int32_t out_f32;                    /* 0: bf16 output, 1: fp32 output */
   int32_t variant;                    /* tile configuration, 0 = auto.  1: 128 x 128 x 64, one LDS stage (32 KiB, two barriers per
                                          k-step); 2: 128 x 128 x 64, two stages (the next k-step's LDS-DMA in flight under the
-                                         MFMAs); 3: 256 x 128 x 32, two stages; 4: 256 x 128 x 64, one stage.  All four add
-                                         the same products in the same order: bit-identical results (tests, A/B) */
+                                         MFMAs); 3: 256 x 128 x 32, two stages; 4: 256 x 128 x 64, one stage; 5 (round 6): 256 x 256 x 64,
+                                         8 wavefronts, half-tile LDS ring with counted waits, the two wavefronts of a SIMD half a phase
+                                         apart (operands of one batch entry < 4 GiB).  All five add the same products in the same
+                                         order: bit-identical results (tests, A/B) */
 } ktx_gemm_args;
 
 int ktx_gemm_bf16_nt(const ktx_gemm_args* args, ktx_stream_t stream);

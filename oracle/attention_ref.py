@@ -75,20 +75,24 @@ def softmax_scale(cfg):
     return s
 
 
-def mla_attention_ref(cfg, w, hidden, position_ids, history):
+def mla_attention_ref(cfg, w, hidden, position_ids, history, lin=None):
     """hidden bf16 [T, hidden]; position_ids int64 [T]; history bf16 [n_past, 576] (already rotated/normalised rows).
     w: dict of bf16 weights (q_proj | q_a_proj,q_a_layernorm,q_b_proj; kv_a_proj_with_mqa; kv_a_layernorm; kv_b_proj; o_proj).
+    lin(name, x): the quantised projection `name` applied to x (default: dense bf16 F.linear on w[name]) — KLinearFP8 layers pass
+    oracle.linear_ref.linear_fp8_ref on their e4m3 blocks (activation quantisation included, linear.py:408-413).
     Returns (out bf16 [T, hidden], new history rows bf16 [T, 576])."""
+    if lin is None:
+        lin = lambda name, x: F.linear(x, w[name])   # noqa: E731
     T = hidden.shape[0]
     H, nope, rope, lora, v = cfg.num_attention_heads, cfg.qk_nope_head_dim, cfg.qk_rope_head_dim, cfg.kv_lora_rank, cfg.v_head_dim
     eps = getattr(cfg, "rms_norm_eps", 1e-6)
     if getattr(cfg, "q_lora_rank", None) is None:
-        q = F.linear(hidden, w["q_proj"])
+        q = lin("q_proj", hidden)
     else:
-        q = F.linear(rmsnorm_ref(F.linear(hidden, w["q_a_proj"]), w["q_a_layernorm"], eps), w["q_b_proj"])
+        q = lin("q_b_proj", rmsnorm_ref(lin("q_a_proj", hidden), w["q_a_layernorm"], eps))
     q = q.view(T, H, nope + rope)
     q_nope, q_pe = torch.split(q, [nope, rope], dim=-1)
-    ckv = F.linear(hidden, w["kv_a_proj_with_mqa"])
+    ckv = lin("kv_a_proj_with_mqa", hidden)
     ckv, k_pe = torch.split(ckv, [lora, rope], dim=-1)
     ckv = rmsnorm_ref(ckv, w["kv_a_layernorm"], eps)
     cos, sin, _, _ = rope_tables(cfg, position_ids, hidden.dtype)
@@ -105,5 +109,5 @@ def mla_attention_ref(cfg, w, hidden, position_ids, history):
     attn, _ = attention_ref_torch(1, torch.cat([q_nope, q_pe], dim=-1), k, vv, True, softmax_scale(cfg))
     attn = attn.to(hidden.dtype)                                     # the wrapper returns bf16
     attn = torch.matmul(attn.transpose(0, 1), out_absorb.mT).transpose(0, 1).contiguous()      # [T, H, v]
-    out = F.linear(attn.reshape(T, H * v), w["o_proj"])
+    out = lin("o_proj", attn.reshape(T, H * v))
     return out, new_rows

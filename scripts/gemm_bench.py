@@ -36,7 +36,7 @@ def timed(fn, reps=20, windows=5):
 
 
 print(f"T = {T}; TFLOP/s (ms)")
-VARIANTS = (1, 2, 3, 4)   # 128x128x64 one stage, 128x128x64 two stages, 256x128x32 two stages, 256x128x64 one stage
+VARIANTS = (1, 2, 3, 4, 5)   # 128x128x64 one stage, 128x128x64 two stages, 256x128x32 two stages, 256x128x64 one stage, 256x256x64 ping-pong (round 6)
 print(f"{'shape':34s} " + " ".join(f"{'ktx variant %d' % v:>16s}" for v in VARIANTS) + f" {'torch F.linear':>16s}")
 tot = [0.0] * (len(VARIANTS) + 1)
 for name, N, K in SHAPES:

@@ -28,7 +28,7 @@ def check(y, a, b, bias=None, f32=False):
     assert not bool(bad.any()), (int(bad.sum()), float((err / tol).max()))
 
 
-@pytest.mark.parametrize("variant", [1, 2, 3, 4])
+@pytest.mark.parametrize("variant", [1, 2, 3, 4, 5])
 @pytest.mark.parametrize("M,N,K", [(1, 8, 64), (130, 2112, 1536), (300, 256, 7168), (128, 128, 64), (257, 1032, 512), (2048, 1152, 2048)])
 def test_gemm_matches_fp64_math(M, N, K, variant):
     from ktransformers_amd._native import gemm_bf16_nt
@@ -48,8 +48,27 @@ def test_variants_and_repeated_calls_are_bit_identical():
     y1 = gemm_bf16_nt(a, b, variant=1)
     for _ in range(3):
         assert torch.equal(gemm_bf16_nt(a, b, variant=1), y1)          # no race between the DMA stages and the fragment reads
-        for v in (2, 3, 4):
+        for v in (2, 3, 4, 5):
             assert torch.equal(gemm_bf16_nt(a, b, variant=v), y1)      # same k order, same sums in every tile configuration
+
+
+@pytest.mark.parametrize("M,N,K", [(4096, 4096, 4096), (2048, 7168, 16384), (8192, 2112, 7168), (1000, 520, 192)])
+def test_ping_pong_tile_race_screen(M, N, K):
+    """Round 6, variant 5 (256 x 256 x 64, half-tile ring with counted waits, the two wavefronts of a SIMD half a phase apart): at
+    prompt-chunk sizes, repeated, with bias and with fp32 output, every call must give the bits of the two-barrier 128 x 128 kernel
+    (the same k order) — a fragment read that overtakes its DMA, or a DMA that overwrites a slot still being read, shows up here as
+    a wrong tile that comes and goes between repetitions."""
+    from ktransformers_amd._native import gemm_bf16_nt
+    g = torch.Generator(device="cpu").manual_seed(M + N + K)
+    a = torch.randn((M, K), generator=g).to(torch.bfloat16).to(DEV)
+    b = (torch.randn((N, K), generator=g) * K ** -0.5).to(torch.bfloat16).to(DEV)
+    bias = torch.randn(N, generator=g).to(torch.bfloat16).to(DEV)
+    y_ref, yb_ref, yf_ref = gemm_bf16_nt(a, b, variant=2), gemm_bf16_nt(a, b, bias=bias, variant=2), gemm_bf16_nt(a, b, out_f32=True, variant=2)
+    for rep in range(4):
+        assert torch.equal(gemm_bf16_nt(a, b, variant=5), y_ref), rep
+        assert torch.equal(gemm_bf16_nt(a, b, bias=bias, variant=5), yb_ref), rep
+        assert torch.equal(gemm_bf16_nt(a, b, out_f32=True, variant=5), yf_ref), rep
+    assert torch.equal(gemm_bf16_nt(a, b), y_ref)                        # whatever the automatic choice is
 
 
 def test_bias_strided_rows_and_fp32_output():
