@@ -7,8 +7,12 @@
   linear_w4_ref        : what gptq_marlin_gemm computes (linear.py:690-702): x @ dequant(q, s), fp32 accumulation.  The CUDA
                          kernel itself is un-vendored (KTransformersOps) => GEMM parity is fp-tolerance against this math;
                          `round_weights=True` applies Marlin's in-register dequant rounding bf16((q-8)*s).
-  act_quant_ref / linear_fp8_ref : ktransformers_ext/triton/fp8gemm.py:10-55, 117-193 (Triton, needs a GPU => restated):
+  act_quant_ref / linear_fp8_ref : ktransformers_ext/triton/fp8gemm.py:10-55, 117-193:
                          s = amax/448 per 128 inputs, y = (x/s)->e4m3; acc += dot(a_blk, b_blk) * a_s * b_s per 128-K block.
+                         PINNED (round 6): tests/golden/triton_golden.npz holds the outputs of the reference's own act_quant_kernel
+                         and fp8_gemm_kernel, run on the CPU by Triton's interpreter (tests/golden/make_triton_golden.py);
+                         tests/test_triton_pin_cpu.py: scales bit-equal, codes equal up to the interpreter's two documented cast
+                         defects, fp32 accumulator within 2 ulp.
   linear_bf16_ref      : KLinearTorch.forward, linear.py:174-183.
 """
 import torch
@@ -66,7 +70,7 @@ def act_quant_ref(x: torch.Tensor, block_size: int = 128):
     return y.reshape(x.shape).to(torch.float8_e4m3fn), s
 
 
-def linear_fp8_ref(x: torch.Tensor, w_fp8: torch.Tensor, scale_inv: torch.Tensor, bias=None, block: int = 128):
+def linear_fp8_ref(x: torch.Tensor, w_fp8: torch.Tensor, scale_inv: torch.Tensor, bias=None, block: int = 128, _raw: bool = False):
     """x bf16 [T,K]; w_fp8 float8_e4m3fn [N,K]; scale_inv fp32 [ceil(N/128), K/128].  fp8gemm.py:117-159."""
     xq, a_s = act_quant_ref(x, block)
     T, K = x.shape
@@ -78,4 +82,6 @@ def linear_fp8_ref(x: torch.Tensor, w_fp8: torch.Tensor, scale_inv: torch.Tensor
     acc = torch.zeros(T, N, dtype=torch.float32)
     for kb in range(K // block):
         acc = acc + dots[:, :, kb] * a_s[:, kb, None] * b_s[None, :, kb]
+    if _raw:                                                                      # the fp32 accumulator (tests/golden pin)
+        return acc
     return _finish(acc, bias)

@@ -1,5 +1,8 @@
 """TEST INFRASTRUCTURE ONLY — fp32 torch restatement of the reference's MLA oracle attention_ref_torch
-(archive/ktransformers/operators/flashinfer_wrapper.py:30-76), applied per request to a paged latent cache."""
+(archive/ktransformers/operators/flashinfer_wrapper.py:30-76), applied per request to a paged latent cache.
+PINNED (round 6): tests/golden/triton_golden.npz holds outputs of the reference's Triton MLA decode (decode_attention_fwd_grouped,
+operators/triton_attention.py:358-385: 4 KV splits + log-sum-exp merge over a permuted page table) run on the CPU by Triton's
+interpreter (tests/golden/make_triton_golden.py); tests/test_triton_pin_cpu.py holds this file to 2e-6 of them (fp32 operands)."""
 import math
 
 import torch
