@@ -30,12 +30,6 @@ extern "C" {
 #define KTX_ATTN_PHASE_MERGE 8     /* merge of the KV splits + un-absorb                                        */
 #define KTX_ATTN_PHASE_OPROJ 16    /* o_proj + residual add                                                     */
 #define KTX_ATTN_PHASE_ALL 31
-/* optional sixth phase, only together with KTX_ATTN_PHASE_OPROJ in one launch: the FRONT of the MoE block that follows the
- * attention in the decoder layer — post_attention_layernorm + router (logits, selection) + the shared experts' merged gate|up GEMV
- * with SiLU*up — i.e. what ktx_linear_forward_fused_gate launches (include/ktx_linear.h), on the row this launch's o_proj phase
- * produces.  The routed experts' launches (ktx_moe_forward_side) then follow directly.  Same arithmetic, same results. */
-#define KTX_ATTN_PHASE_MOE_FRONT 32
-
 typedef struct ktx_attn_decode_args {
   /* operators (include/ktx_linear.h handles, loaded) */
   ktx_linear_t qkv_a;      /* W4 g64, in = hidden, out = q_lora + kv_lora + rope: rows [q_a | ckv | k_pe] */
@@ -62,16 +56,6 @@ typedef struct ktx_attn_decode_args {
   float sm_scale;
   int32_t phases;                /* KTX_ATTN_PHASE_* mask of this launch */
   int32_t last;                  /* 1: this launch ends the step (advances the workspace epoch); the last launch of a split chain */
-  /* KTX_ATTN_PHASE_MOE_FRONT (else ignored / NULL): */
-  ktx_linear_t moe_shared_gate_up;   /* W4 g64 [2 * I_s, hidden], glu-interleaved rows, 256 strips of 56 k-steps */
-  const void* moe_gate;              /* const ktx_gate_config* (include/ktx_gate.h): 256 experts (one logit per workgroup) */
-  const void* d_moe_gate_w;          /* bf16 [256][hidden] */
-  const float* d_moe_gate_bias;      /* fp32 [256] or NULL */
-  const void* d_post_norm_w;   float post_norm_eps;    /* post_attention_layernorm */
-  void* d_xn_out;                    /* bf16 [hidden]: the normalised row (input of the routed experts) */
-  void* d_shared_act_out;            /* bf16 [I_s]: act_fn(gate) * up of the shared experts */
-  int64_t* d_topk_idx;               /* [top_k] */
-  float* d_topk_w;                   /* [top_k] */
 } ktx_attn_decode_args;
 
 /* 1 when ktx_attn_decode covers this configuration on the current device (nope 128 / rope 64 / kv_lora 512 / v 128, hidden 7168 and

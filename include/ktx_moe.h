@@ -213,38 +213,6 @@ int ktx_timing_enable(int mode);
 int ktx_timing_collect(char* buf, size_t cap, size_t* needed);
 int ktx_profile_collect(double* ms5, long long* count5);
 
-/* ---- the MoE half of a decoder layer for ONE decode token as ONE persistent launch (csrc/ktx_moe_layer.inc) ----------------
- * Replaces, for KDeepseekV3MoE.forward on a single token (archive/ktransformers/operators/experts.py:972-1012) with the decoder
- * layer's post_attention_layernorm in front and its residual add behind (models/modeling_deepseek_v3.py:1221-1225):
- *     xn = RMSNorm(x) ; ids, w = MoEGate(xn) ; y = x + ( experts(xn, ids, w) + shared_experts(xn) )
- * i.e. the three launches ktx_linear_forward_fused_gate + ktx_moe_forward_side issue, as phases of one launch of 256 workgroups
- * (1 = norm + router logits + shared gate|up, 2 = selection + routed gate/up, 4 = selection + routed down + shared down + adds);
- * every phase keeps the arithmetic of its stand-alone kernel, so the result is bit-identical to the three launches.  Covered:
- * DeepSeek-V3 / R1 geometry (AMXINT4 experts 256 x [2048, 7168], top-8, all experts on this device, W4 g64 shared experts with
- * the merged glu-interleaved gate|up operator).  `phases` / `last`: as ktx_attn_decode_args (include/ktx_attn.h). */
-typedef struct ktx_moe_layer_args {
-  ktx_moe_t experts;
-  ktx_linear_t shared_gate_up;   /* W4 g64 [2 * I_s, hidden], rows interleaved per 16-row strip as 8 gate | 8 up */
-  ktx_linear_t shared_down;      /* W4 g64 [hidden, I_s] */
-  const ktx_gate_config* gate;
-  const void* d_gate_w;          /* bf16 [E][hidden] */
-  const float* d_gate_bias;      /* e_score_correction_bias fp32 [E] or NULL */
-  const void* d_x;               /* bf16 [hidden]: the residual stream (un-normalised) */
-  const void* d_norm_w;          /* post_attention_layernorm weight, bf16 [hidden] */
-  float norm_eps;
-  void* d_y;                     /* bf16 [hidden] */
-  int64_t* d_topk_idx;           /* optional outputs [top_k] (both or neither) */
-  float* d_topk_w;
-  int32_t phases, last;
-} ktx_moe_layer_args;
-int ktx_moe_layer_decode_eligible(const ktx_moe_layer_args* a);
-int ktx_moe_layer_decode(const ktx_moe_layer_args* a, ktx_stream_t stream);
-int ktx_moe_layer_status(int device, uint32_t* status_out);
-/* tests: copy a workspace array of the last launch (0 router logits fp32 [256], 1 shared activations bf16 [I_s], 2 routed
- * activations bf16 [top_k][I]) into a device buffer; dev probe: 64 wall-clock stamps of workgroup 0 */
-int ktx_moe_layer_debug_read(int device, int which, void* d_dst, size_t bytes);
-int ktx_moe_layer_debug_stamps(unsigned long long* d_buf);
-
 #ifdef __cplusplus
 }
 #endif

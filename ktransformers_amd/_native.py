@@ -68,17 +68,7 @@ class _AttnDecodeArgs(C.Structure):   # include/ktx_attn.h: ktx_attn_decode_args
                 ("d_position", C.c_void_p), ("d_inv_freq", C.c_void_p), ("mscale", C.c_float),
                 ("d_ckv", C.c_void_p), ("d_k_pe", C.c_void_p), ("ckv_token_stride", C.c_int64), ("kpe_token_stride", C.c_int64),
                 ("page_size", C.c_int32), ("d_kv_indptr", C.c_void_p), ("d_kv_indices", C.c_void_p), ("d_kv_len", C.c_void_p),
-                ("kv_len_hint", C.c_int32), ("sm_scale", C.c_float), ("phases", C.c_int32), ("last", C.c_int32),
-                ("moe_shared_gate_up", C.c_void_p), ("moe_gate", C.c_void_p), ("d_moe_gate_w", C.c_void_p), ("d_moe_gate_bias", C.c_void_p),
-                ("d_post_norm_w", C.c_void_p), ("post_norm_eps", C.c_float), ("d_xn_out", C.c_void_p), ("d_shared_act_out", C.c_void_p),
-                ("d_topk_idx", C.c_void_p), ("d_topk_w", C.c_void_p)]
-
-
-class _MoeLayerArgs(C.Structure):   # include/ktx_moe.h: ktx_moe_layer_args
-    _fields_ = [("experts", C.c_void_p), ("shared_gate_up", C.c_void_p), ("shared_down", C.c_void_p), ("gate", C.c_void_p),
-                ("d_gate_w", C.c_void_p), ("d_gate_bias", C.c_void_p), ("d_x", C.c_void_p), ("d_norm_w", C.c_void_p),
-                ("norm_eps", C.c_float), ("d_y", C.c_void_p), ("d_topk_idx", C.c_void_p), ("d_topk_w", C.c_void_p),
-                ("phases", C.c_int32), ("last", C.c_int32)]
+                ("kv_len_hint", C.c_int32), ("sm_scale", C.c_float), ("phases", C.c_int32), ("last", C.c_int32)]
 
 
 class _MoeConfig(C.Structure):
@@ -193,11 +183,6 @@ def _load() -> C.CDLL:
     lib.ktx_gemm_bf16_nt.argtypes = [C.POINTER(_GemmArgs), C.c_void_p]
     lib.ktx_split_f32_bf16x3.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p]
     lib.ktx_profile_collect.argtypes = [C.POINTER(C.c_double), C.POINTER(C.c_longlong)]
-    lib.ktx_moe_layer_decode_eligible.argtypes = [C.POINTER(_MoeLayerArgs)]
-    lib.ktx_moe_layer_decode.argtypes = [C.POINTER(_MoeLayerArgs), C.c_void_p]
-    lib.ktx_moe_layer_status.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
-    lib.ktx_moe_layer_debug_read.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_size_t]
-    lib.ktx_moe_layer_debug_stamps.argtypes = [C.c_void_p]
     lib.ktx_attn_decode_eligible.argtypes = [C.POINTER(_AttnDecodeArgs)]
     lib.ktx_attn_decode.argtypes = [C.POINTER(_AttnDecodeArgs), C.c_void_p]
     lib.ktx_attn_status.argtypes = [C.c_int, C.POINTER(C.c_uint32)]
@@ -217,7 +202,7 @@ STREAM_CALLS = frozenset((
     "ktx_moe_forward", "ktx_moe_forward_ex", "ktx_moe_combine", "ktx_gate_logits", "ktx_gate_select", "ktx_gate_forward",
     "ktx_gate_forward_norm", "ktx_mla_decode", "ktx_mla_decode_append", "ktx_mla_cache_append", "ktx_mla_prefill", "ktx_linear_forward",
     "ktx_linear_forward_batched", "ktx_linear_forward_batched_prep", "ktx_linear_forward_fused", "ktx_rmsnorm", "ktx_fused_add_rmsnorm", "ktx_silu_mul",
-    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt", "ktx_attn_decode", "ktx_moe_layer_decode", "ktx_fp8_act_quant", "ktx_linear_gemm_fp8"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
+    "ktx_mla_prep", "ktx_argmax", "ktx_gemm_bf16_nt", "ktx_attn_decode", "ktx_fp8_act_quant", "ktx_linear_gemm_fp8"))   # (not ktx_ep_*: a gather replayed without its reduce would desynchronise the call tags)
 TRACE: list | None = None
 HANDLES: dict = {}      # native handle address -> weakref to the owning MoEHandle / LinearHandle (labels for traced calls)
 
@@ -982,7 +967,7 @@ def attn_decode_args(qkv_a: "LinearHandle", q_b: "LinearHandle", qabs: "LinearHa
                      inv_freq: torch.Tensor, mscale: float, num_heads: int, nope: int, rope: int, kv_lora: int, v_dim: int,
                      ckv_pages: torch.Tensor, kpe_pages: torch.Tensor, page_size: int, kv_indptr: torch.Tensor,
                      kv_indices: torch.Tensor | None, kv_len: torch.Tensor, kv_len_hint: int, sm_scale: float,
-                     phases: int = ATTN_PHASE_ALL, last: bool = True, moe_front: dict | None = None) -> _AttnDecodeArgs:
+                     phases: int = ATTN_PHASE_ALL, last: bool = True) -> _AttnDecodeArgs:
     """Arguments of the one-launch MLA decode step (include/ktx_attn.h).  x / out: bf16 [hidden] rows; the norm tuples are
     (bf16 weight, eps); position int64 [1]; kv_len int32 [1] = context length including the new token; the cache views as in
     MLAWrapper.run.  The caller keeps every tensor alive until the launch is enqueued."""
@@ -1002,25 +987,6 @@ def attn_decode_args(qkv_a: "LinearHandle", q_b: "LinearHandle", qabs: "LinearHa
                         float(mscale), ckv_pages.data_ptr(), kpe_pages.data_ptr(), ckv_ts, kpe_ts, page_size, kv_indptr.data_ptr(),
                         kv_indices.data_ptr() if kv_indices is not None else None, kv_len.data_ptr(), int(kv_len_hint),
                         float(sm_scale), int(phases), 1 if last else 0)
-    if moe_front is not None:
-        # the MoE block's front rides in this launch (KTX_ATTN_PHASE_MOE_FRONT): shared gate|up LinearHandle, GateHandle, router weight
-        # bf16 [E, hidden] (+ fp32 bias), post_attention_layernorm (weight bf16, eps), and the four output tensors
-        f = moe_front
-        for t, what in ((f["gate_weight"], "router weight"), (f["norm"][0], "post-attention norm"), (f["xn"], "xn"), (f["shared_act"], "shared_act")):
-            if t.dtype != torch.bfloat16 or not t.is_contiguous():
-                raise KtxError(f"attn_decode: MoE front: {what} must be contiguous bf16")
-        if f["topk_idx"].dtype != torch.int64 or f["topk_w"].dtype != torch.float32:
-            raise KtxError("attn_decode: MoE front: topk_idx int64, topk_w fp32")
-        b = f.get("gate_bias")
-        if b is not None and (b.dtype != torch.float32 or not b.is_contiguous()):
-            raise KtxError("attn_decode: MoE front: the router bias must be contiguous fp32")
-        a.moe_shared_gate_up = f["shared_gate_up"]._h
-        a.moe_gate = C.cast(C.pointer(f["gate"].cfg), C.c_void_p)
-        a.d_moe_gate_w, a.d_moe_gate_bias = f["gate_weight"].data_ptr(), (b.data_ptr() if b is not None else None)
-        a.d_post_norm_w, a.post_norm_eps = f["norm"][0].data_ptr(), float(f["norm"][1])
-        a.d_xn_out, a.d_shared_act_out = f["xn"].data_ptr(), f["shared_act"].data_ptr()
-        a.d_topk_idx, a.d_topk_w = f["topk_idx"].data_ptr(), f["topk_w"].data_ptr()
-        a.phases = int(phases) | 32
     return a
 
 
@@ -1065,59 +1031,6 @@ def attn_debug_read(device, name: str, shape, dtype=torch.bfloat16) -> torch.Ten
     torch.cuda.synchronize(dev)
     check(lib.ktx_attn_debug_read(dev.index if dev.index is not None else torch.cuda.current_device(), ATTN_ARRAYS[name], out.data_ptr(),
                                   out.numel() * out.element_size()))
-    return out
-
-
-MOE_LAYER_ARRAYS = {"logits": 0, "shared_act": 1, "a_buf": 2}
-
-
-def moe_layer_args(experts: "MoEHandle", shared_gate_up: "LinearHandle", shared_down: "LinearHandle", gate: "GateHandle",
-                   gate_weight: torch.Tensor, gate_bias: torch.Tensor | None, x: torch.Tensor, out: torch.Tensor, norm: tuple,
-                   topk_idx: torch.Tensor | None = None, topk_w: torch.Tensor | None = None, phases: int = 7,
-                   last: bool = True) -> _MoeLayerArgs:
-    """Arguments of the one-launch MoE half of a decode step (include/ktx_moe.h: ktx_moe_layer_args).  x / out: contiguous bf16
-    [hidden] rows (x = the un-normalised residual stream); norm = (post_attention_layernorm weight bf16, eps); gate_weight bf16
-    [E, hidden] contiguous, gate_bias fp32 [E] or None.  The caller keeps every tensor alive until the launch is enqueued."""
-    for t, what in ((x, "x"), (out, "out"), (norm[0], "norm weight"), (gate_weight, "router weight")):
-        if t.dtype != torch.bfloat16 or not t.is_contiguous():
-            raise KtxError(f"moe_layer_decode: {what} must be contiguous bf16")
-    if gate_bias is not None and (gate_bias.dtype != torch.float32 or not gate_bias.is_contiguous()):
-        raise KtxError("moe_layer_decode: the router bias must be contiguous fp32")
-    if (topk_idx is None) != (topk_w is None):
-        raise KtxError("moe_layer_decode: give both top-k outputs or neither")
-    if topk_idx is not None and (topk_idx.dtype != torch.int64 or topk_w.dtype != torch.float32):
-        raise KtxError("moe_layer_decode: topk_idx int64, topk_w fp32")
-    return _MoeLayerArgs(experts._h, shared_gate_up._h, shared_down._h, C.cast(C.pointer(gate.cfg), C.c_void_p), gate_weight.data_ptr(),
-                         gate_bias.data_ptr() if gate_bias is not None else None, x.data_ptr(), norm[0].data_ptr(), float(norm[1]),
-                         out.data_ptr(), topk_idx.data_ptr() if topk_idx is not None else None,
-                         topk_w.data_ptr() if topk_w is not None else None, int(phases), 1 if last else 0)
-
-
-def moe_layer_decode_eligible(args: _MoeLayerArgs) -> bool:
-    return bool(lib.ktx_moe_layer_decode_eligible(C.byref(args)))
-
-
-def moe_layer_decode(args: _MoeLayerArgs, device, phases: int | None = None, last: bool | None = None) -> None:
-    if phases is not None:
-        args.phases = int(phases)
-    if last is not None:
-        args.last = 1 if last else 0
-    check(lib.ktx_moe_layer_decode(C.byref(args), _stream_ptr(device)))
-
-
-def moe_layer_status(device) -> int:
-    dev = torch.device(device)
-    st = C.c_uint32(0)
-    check(lib.ktx_moe_layer_status(dev.index if dev.index is not None else torch.cuda.current_device(), C.byref(st)))
-    return int(st.value)
-
-
-def moe_layer_debug_read(device, name: str, shape, dtype=torch.bfloat16) -> torch.Tensor:
-    dev = torch.device(device)
-    out = torch.empty(shape, dtype=dtype, device=dev)
-    torch.cuda.synchronize(dev)
-    check(lib.ktx_moe_layer_debug_read(dev.index if dev.index is not None else torch.cuda.current_device(), MOE_LAYER_ARRAYS[name],
-                                       out.data_ptr(), out.numel() * out.element_size()))
     return out
 
 

@@ -101,11 +101,6 @@ struct AttnParams {
   // phase E
   const uint8_t* wE; const bf16_t* scE; int nksE, nksE_sh, nE, eQ, eR;
   bf16_t* y;
-  // phase F (the MoE block's front: post_attention_layernorm + router + shared experts' gate|up on the row phase E produces)
-  const bf16_t* post_norm_w; float post_eps;
-  const bf16_t* gate_w; const float* gate_bias; ktx_gate_config gc;
-  const uint8_t* wS; const bf16_t* scS; int nksS;
-  bf16_t* xn_out; bf16_t* shared_act_out; int64_t* topk_idx; float* topk_w;
   // workspace
   uint8_t* ws; unsigned ws_bytes;
   unsigned* hstatus;   // host-mapped copy of the status word (pinned): the host reads it every step without touching the device
@@ -280,7 +275,7 @@ __device__ __forceinline__ int wave_begin(int Gb, int n, int w) {
 }
 
 constexpr int PH_A = KTX_ATTN_PHASE_QKV_A, PH_B = KTX_ATTN_PHASE_QB, PH_C = KTX_ATTN_PHASE_MLA, PH_D = KTX_ATTN_PHASE_MERGE,
-              PH_E = KTX_ATTN_PHASE_OPROJ, PH_F = KTX_ATTN_PHASE_MOE_FRONT;
+              PH_E = KTX_ATTN_PHASE_OPROJ;
 // lin_glu of ktx_linear.hip (DeepseekV3MLP between the merged gate|up GEMV and down_proj, bf16 tensor arithmetic)
 __device__ __forceinline__ bf16_t glu_bf16(float g, float u) {
   const float gb = bf16_to_f32(f32_to_bf16(g)), ub = bf16_to_f32(f32_to_bf16(u));
@@ -292,9 +287,7 @@ __device__ __forceinline__ bf16_t glu_bf16(float g, float u) {
 // FMT = the format of the three quantised projections (q_a|kv_a, q_b, o_proj): KTX_LIN_W4 (g64) or KTX_LIN_FP8 (128 x 128 blocks)
 template <int MASK, int FMT>
 __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
-  static_assert((MASK & PH_F) == 0 || (MASK & PH_E) != 0, "the MoE front runs in the launch that produces its input row");
   static_assert(FMT == KTX_LIN_W4 || FMT == KTX_LIN_FP8, "W4 g64 or block-FP8 projections");
-  static_assert((MASK & PH_F) == 0 || FMT == KTX_LIN_W4, "the MoE front is built for the W4 shared experts");
   constexpr bool F8 = FMT == KTX_LIN_FP8;
   constexpr int NQ = F8 ? 2 : 1, TB = NQ * 1024;   // 1 KiB planes per weight tile, bytes per tile
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
@@ -912,25 +905,6 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       for (int d = 0; d < 8; d++) load_E(d, (long)gbE * 8 + d);
     }
   };
-  // phase F's registers: one file for both wave roles (wavefront 7 = the router row, wavefronts 0..3 = their k-slice's tiles)
-  uint4 frF[14], nwF[2];
-  uint2 srF[14];
-  auto prefetch_F = [&]() {
-#pragma unroll
-    for (int i = 0; i < 2; i++) nwF[i] = *reinterpret_cast<const uint4*>(p.post_norm_w + min(tid + i * NT, (p.hidden >> 3) - 1) * 8);
-    if (wave == 7) {
-      const bf16_t* row = p.gate_w + (size_t)w * p.hidden;
-#pragma unroll
-      for (int u = 0; u < 14; u++) frF[u] = *reinterpret_cast<const uint4*>(row + min(lane * 8 + u * 512, p.hidden - 8));
-    } else if (wave < 4) {
-      const long tile0 = (long)w * p.nksS + wave * 14;
-#pragma unroll
-      for (int d = 0; d < 14; d++) {
-        frF[d] = nt_load16(p.wS + (tile0 + d) * 1024 + lane * 16);
-        srF[d] = load_w4_scales<2>(p.scS + ((tile0 + d) * 16 + (lane & 15)) * 2);
-      }
-    }
-  };
   if constexpr ((MASK & PH_E) != 0) prefetch_E();
   if constexpr ((MASK & PH_D) != 0) {
    if (doBD) {
@@ -1118,13 +1092,9 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         strip++;
       }
     }
-    // phase F's requests (router row of expert w: wavefront 7; k-slice `wave` of glu strip w: wavefronts 0..3; the norm weights)
-    // go out behind phase E's stream: they land during its epilogue and the hand-off of the output row
-    if constexpr ((MASK & PH_F) != 0) prefetch_F();
     __syncthreads();
     AT_STAMP(14);
     const int n_local = Ge > Gb ? (Ge - 1) / GPS_E - s_first + 1 : 0;
-    bf16_t* ystage = reinterpret_cast<bf16_t*>(tableE + 4 * 8 * 64);   // [<= 4 strips][16]
     for (int sl = wave; sl < n_local; sl += 8) {
       const int s = s_first + sl, g0 = s * GPS_E, g1 = g0 + GPS_E;
       float v = 0.f;
@@ -1137,145 +1107,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       if (lane < 16 && n < p.hidden) {
         bf16_t o = f32_to_bf16(v);
         o = f32_to_bf16(bf16_to_f32(p.x[n]) + bf16_to_f32(o));   // hidden = residual + attn (modeling_deepseek_v3.py:1219)
-        if constexpr ((MASK & PH_F) != 0) ystage[sl * 16 + lane] = o;
-        else p.y[n] = o;
+        p.y[n] = o;
       }
-    }
-    if constexpr ((MASK & PH_F) != 0) {   // the row is phase F's input in every workgroup: write-through, then this workgroup's flag
-      __syncthreads();
-      const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.hidden * 2, 0x00020000);
-      if (tid < 2 * n_local) ws_store16(yrs, (unsigned)(s_first * 32 + tid * 16), *reinterpret_cast<const uint4*>(ystage + tid * 8));
-      drain_stores();
-      __syncthreads();
-      if (tid == 0) st_word(fE + w, epoch);
     }
     AT_STAMP(15);
-  }
-
-  // =========================== phase F: the MoE block's front on the row phase E produced ==========================================
-  // post_attention_layernorm (every workgroup for itself), the router logit of expert w, glu strip w of the shared experts' gate|up
-  // GEMV — lin_dec_gate_kernel's arithmetic (gate_fused_body's dot product; lin_dec_body with two strips per workgroup, i.e. four
-  // k-slices of 14 k-steps) — and, in the LAST workgroup to arrive, the selection.  Results go to plain tensors: the routed experts'
-  // launches read them behind the kernel boundary.
-  if constexpr ((MASK & PH_F) != 0) {
-    __syncthreads();
-    uint8_t* xsF = smem;                                                  // [hidden / 8][16 B]
-    float* auxF = reinterpret_cast<float*>(smem + 16384);                 // [nksS * 2][4]
-    float* redF = auxF + 512;                                             // [8] norm | [4][16] k-slices
-    float* s_logitsF = redF + 128;                                        // [256]
-    bf16_t* stageF = reinterpret_cast<bf16_t*>(s_logitsF + 256);          // [8]
-    int* s_lastF = reinterpret_cast<int*>(stageF + 16);
-    const int H7 = p.hidden, npieceF = H7 >> 3;
-    const int nwgE = min(NWG, p.nE);
-    if (wave == 7) poll_flags(p, fE, nwgE, epoch, 0xF1, [](int k) { return k; });
-    __syncthreads();
-    AT_STAMP(28);
-    const __amdgpu_buffer_rsrc_t yrs = __builtin_amdgcn_make_buffer_rsrc(p.y, 0, p.hidden * 2, 0x00020000);
-    uint4 xrF[2];
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int pc = tid + i * NT;
-      xrF[i] = pc < npieceF ? ws_load16(yrs, (unsigned)pc * 16) : make_uint4(0, 0, 0, 0);
-    }
-    float ss = 0.f;
-#pragma unroll
-    for (int i = 0; i < 2; i++) ss += sumsq8(xrF[i]);
-    const float wsum = wave_sum(ss);
-    if (lane == 0) redF[wave] = wsum;
-    __syncthreads();
-    float tot = redF[0];
-#pragma unroll
-    for (int v = 1; v < 8; v++) tot += redF[v];
-    const float rn = 1.0f / sqrtf(tot / (float)H7 + p.post_eps);
-#pragma unroll
-    for (int i = 0; i < 2; i++) {
-      const int pc = tid + i * NT;
-      if (pc < p.nksS * 16) {
-        uint4 v = make_uint4(0, 0, 0, 0);
-        if (pc < npieceF) v = norm8(xrF[i], rn, nwF[i]);
-        *reinterpret_cast<uint4*>(xsF + (size_t)pc * 16) = v;
-        if (p.xn_out && w == 0 && pc < npieceF) *reinterpret_cast<uint4*>(p.xn_out + pc * 8) = v;
-        const float sg = group_sum64(v);
-        if ((pc & 7) == 0) auxF[(pc >> 3) * 4] = sg;
-      }
-    }
-    __syncthreads();
-    float* sl4 = redF + 16;
-    if (wave == 7) {
-      float acc = 0.f;
-#pragma unroll
-      for (int u = 0; u < 14; u++) {
-        const int j = lane * 8 + u * 512;
-        if (j < H7) {
-          const uint4 a = *reinterpret_cast<const uint4*>(xsF + (size_t)(lane + u * 64) * 16);
-          const uint32_t av[4] = {a.x, a.y, a.z, a.w}, bv[4] = {frF[u].x, frF[u].y, frF[u].z, frF[u].w};
-#pragma unroll
-          for (int q = 0; q < 4; q++) acc = ktx_dot2_bf16(av[q], bv[q], acc);
-        }
-      }
-      acc = wave_sum(acc);
-      if (lane == 0)
-        __hip_atomic_store(reinterpret_cast<unsigned long long*>(p.ws + L.gran) + w, ((unsigned long long)epoch << 32) | __float_as_uint(acc),
-                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    } else if (wave < 4) {
-      float acc = 0.f;
-      const uint8_t* xb0 = xsF + (lane >> 4) * 16;
-      const int ks0 = wave * 14;
-#pragma unroll
-      for (int d = 0; d < 14; d++) w4_kstep1(frF[d], srF[d], xb0 + (size_t)(ks0 + d) * 256, auxF + (ks0 + d) * 8, acc);
-      if (lane < 16) sl4[wave * 16 + lane] = acc;
-    }
-    __syncthreads();
-    if (tid < 8) {   // lin_dec_body's glu epilogue: the k-slices in order, gate columns 0..7, up columns 8..15
-      float v = 0.f, u = 0.f;
-#pragma unroll
-      for (int sI = 0; sI < 4; sI++) v += sl4[sI * 16 + tid];
-#pragma unroll
-      for (int sI = 0; sI < 4; sI++) u += sl4[sI * 16 + tid + 8];
-      stageF[tid] = glu_bf16(v, u);
-    }
-    if (tid == 0) {
-      const unsigned ticket = __hip_atomic_fetch_add(hdr + W_TICKET, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      const int last = ticket == (unsigned)NWG - 1u;
-      if (last) st_word(hdr + W_TICKET, 0u);
-      *s_lastF = last;
-    }
-    __syncthreads();
-    if (tid == 0) *reinterpret_cast<uint4*>(p.shared_act_out + w * 8) = *reinterpret_cast<const uint4*>(stageF);
-    if (*s_lastF) {   // (workgroup-uniform) every logit has been ISSUED before its workgroup's ticket: sweep until the tags are this launch's
-      if (wave == 7) {
-        const unsigned long long* gran = reinterpret_cast<const unsigned long long*>(p.ws + L.gran);
-        const unsigned long long t0 = wall_clock64();
-        float val[4];
-        for (;;) {
-          bool ok = true;
-#pragma unroll
-          for (int s2 = 0; s2 < 4; s2++) {
-            const unsigned long long gv = __hip_atomic_load(gran + s2 * 64 + lane, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            ok = ok && (unsigned)(gv >> 32) == epoch;
-            val[s2] = __uint_as_float((unsigned)gv);
-          }
-          if (__all(ok)) break;
-          if (wall_clock64() - t0 > SPIN_TICKS) {
-            if (lane == 0) {
-              st_word(hdr + W_STATUS, 0xF2u);
-              if (p.hstatus) __hip_atomic_store(p.hstatus, 0xF2u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
-            }
-            break;
-          }
-          __builtin_amdgcn_s_sleep(1);
-        }
-#pragma unroll
-        for (int s2 = 0; s2 < 4; s2++) s_logitsF[s2 * 64 + lane] = val[s2];
-      }
-      __syncthreads();
-      if (gate_select_wg_covers(p.gc, NT)) {
-        gate_select_token_wg<NT>(p.gc, 0, s_logitsF, p.gate_bias, p.topk_idx, p.topk_w, reinterpret_cast<float*>(xsF));
-      } else if (wave == 7) {
-        gate_select_token<4>(p.gc, 0, lane, s_logitsF, p.gate_bias, p.topk_idx, p.topk_w);
-      }
-    }
-    AT_STAMP(29);
   }
 
   // =========================== the step's last launch advances the epoch =========================================================================
@@ -1405,7 +1240,6 @@ int check_args(const ktx_attn_decode_args* a, KtxLinearRaw (&r)[5], int* nsplit_
   KTX_REQUIRE(r[4].format == QF && r[4].group_size == QG && r[4].batch == 1 && r[4].in_features == H * VDIM &&
                   r[4].out_features == a->hidden && r[4].NKS % 8 == 0 && (r[4].NKS & (r[4].NKS - 1)) == 0,
               "ktx_attn_decode: o_proj must be W4 g64 / FP8 [hidden, heads * 128] like qkv_a");
-  KTX_REQUIRE(QF == KTX_LIN_W4 || !(a->phases & PH_F), "ktx_attn_decode: the MoE front rides only with W4 projections");
   KTX_REQUIRE(a->page_size > 0 && a->page_size % TILE == 0 && a->ckv_token_stride % 8 == 0 && a->kpe_token_stride % 8 == 0,
               "ktx_attn_decode: page_size must be a multiple of 32 and the token strides multiples of 8 elements");
   int ncu = 0;
@@ -1454,7 +1288,7 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   if (check_args(a, r, &nsplit) != 0) return -1;
   KTX_REQUIRE(a->d_x && a->d_y && a->d_in_norm_w && a->d_qa_norm_w && a->d_kv_norm_w && a->d_position && a->d_inv_freq && a->d_ckv &&
                   a->d_k_pe && a->d_kv_indptr && a->d_kv_len, "ktx_attn_decode: null pointer");
-  KTX_REQUIRE(a->phases > 0 && a->phases <= (KTX_ATTN_PHASE_ALL | KTX_ATTN_PHASE_MOE_FRONT), "ktx_attn_decode: bad phase mask");
+  KTX_REQUIRE(a->phases > 0 && a->phases <= KTX_ATTN_PHASE_ALL, "ktx_attn_decode: bad phase mask");
   const int dev = r[0].device, H = a->num_heads, NWG = GRID;
   DeviceGuard guard(dev);
   AttnParams p{};
@@ -1483,22 +1317,6 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   if (hstatus_for(dev, &p.hstatus) != 0) return -1;
   p.last = a->last ? 1 : 0;
   p.stamps = g_stamps;
-  KtxLinearRaw rf{};
-  if (a->phases & PH_F) {
-    KTX_REQUIRE(a->moe_shared_gate_up && a->moe_gate && a->d_moe_gate_w && a->d_post_norm_w && a->d_xn_out && a->d_shared_act_out &&
-                    a->d_topk_idx && a->d_topk_w, "ktx_attn_decode: the MoE front needs its operators and outputs");
-    if (ktx_linear_raw(a->moe_shared_gate_up, &rf) != 0) return -1;
-    const ktx_gate_config* gc = (const ktx_gate_config*)a->moe_gate;
-    KTX_REQUIRE(rf.loaded && rf.device == dev && rf.format == KTX_LIN_W4 && rf.group_size == 64 && !rf.bias && rf.batch == 1 &&
-                    rf.in_features == a->hidden && rf.nstrips == NWG && rf.NKS == 56,
-                "ktx_attn_decode: the MoE front covers the merged W4 g64 shared gate|up of 256 glu strips over hidden 7168");
-    KTX_REQUIRE(gc->n_routed_experts == NWG && gc->hidden_size == a->hidden && gc->top_k >= 1 && gc->top_k <= 16,
-                "ktx_attn_decode: the MoE front covers a router of 256 experts (one logit per workgroup)");
-    p.post_norm_w = (const bf16_t*)a->d_post_norm_w; p.post_eps = a->post_norm_eps;
-    p.gate_w = (const bf16_t*)a->d_moe_gate_w; p.gate_bias = a->d_moe_gate_bias; p.gc = *gc;
-    p.wS = rf.w; p.scS = (const bf16_t*)rf.sc; p.nksS = rf.NKS;
-    p.xn_out = (bf16_t*)a->d_xn_out; p.shared_act_out = (bf16_t*)a->d_shared_act_out; p.topk_idx = a->d_topk_idx; p.topk_w = a->d_topk_w;
-  }
   hipStream_t st = (hipStream_t)stream;
   // algorithmic bytes of the phases in this launch (weights as stored + the context's latent rows)
   double bytes = 0;
@@ -1513,7 +1331,6 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   if (a->phases & PH_C) bytes += (double)std::max(a->kv_len_hint, 1) * (LORA + ROPE) * 2.0;
   if (a->phases & PH_D) bytes += lin_bytes(r[3]);
   if (a->phases & PH_E) bytes += lin_bytes(r[4]);
-  if (a->phases & PH_F) bytes += lin_bytes(rf) + (double)NWG * a->hidden * 2.0;
   const bool f8 = r[0].format == KTX_LIN_FP8;
   KTX_TIMED(st, bytes, "attn_decode_kernel<%d%s> H=%d nsplit=%d", a->phases, f8 ? ",FP8" : "", H, nsplit);
   bool eager = false;
@@ -1525,8 +1342,6 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
     default: return -1;
 #else
     case 31: rc = f8 ? launch<31, KTX_LIN_FP8>(p, dev, NWG, st) : launch<31>(p, dev, NWG, st); break;
-    case 63: rc = f8 ? -2 : launch<63>(p, dev, NWG, st); break;
-    case 48: rc = f8 ? -2 : launch<48>(p, dev, NWG, st); break;
     case 1: rc = f8 ? launch<1, KTX_LIN_FP8>(p, dev, NWG, st) : launch<1>(p, dev, NWG, st); break;
     case 2: rc = f8 ? launch<2, KTX_LIN_FP8>(p, dev, NWG, st) : launch<2>(p, dev, NWG, st); break;
     case 4: rc = f8 ? launch<4, KTX_LIN_FP8>(p, dev, NWG, st) : launch<4>(p, dev, NWG, st); break;
@@ -1535,7 +1350,7 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
     case 3: rc = f8 ? -2 : launch<3>(p, dev, NWG, st); break;
     case 24: rc = f8 ? -2 : launch<24>(p, dev, NWG, st); break;
     case 28: rc = f8 ? -2 : launch<28>(p, dev, NWG, st); break;
-    default: return ktx_fail("ktx_attn_decode: this phase subset is not instantiated (31, 63, 48, single phases 1..16, 3, 24, 28)");
+    default: return ktx_fail("ktx_attn_decode: this phase subset is not instantiated (31, single phases 1..16, 3, 24, 28)");
 #endif
   }
   if (rc == -2) return ktx_fail("ktx_attn_decode: this phase subset is not instantiated for FP8 projections (31 and the single phases are)");

@@ -3759,4 +3759,3 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   return 0;
 }
 
-#include "ktx_moe_layer.inc"

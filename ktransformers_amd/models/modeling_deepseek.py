@@ -153,14 +153,10 @@ class DeepseekDecoderLayer(nn.Module):
         fusion hooks, input_layernorm runs inside the attention's first GEMV and both residual adds inside the epilogues
         of o_proj / the MLP's down_proj (same roundings, fewer launches); otherwise the plain sequence."""
         attn, mlp = self.self_attn, self.mlp
-        front = None
         if getattr(type(attn), "SUPPORTS_FUSION", False):
-            # a decode step: the MoE block may hand the attention's one-launch kernel its front (norm, router, shared gate|up)
-            if hidden_states.shape[1] == 1 and hasattr(mlp, "front_request") and getattr(type(mlp), "SUPPORTS_FUSION", False):
-                front = mlp.front_request(hidden_states, self.post_attention_layernorm)
             hidden_states, _, past_key_value = attn(hidden_states, position_ids=position_ids, past_key_value=past_key_value,
                                                     cache_position=cache_position, pre_norm=self.input_layernorm,
-                                                    residual=hidden_states, **({"moe_front": front} if front is not None else {}))
+                                                    residual=hidden_states)
         else:
             residual = hidden_states
             hidden_states = self.input_layernorm(hidden_states)
@@ -169,8 +165,7 @@ class DeepseekDecoderLayer(nn.Module):
             hidden_states = residual + hidden_states
         residual = hidden_states
         if getattr(type(mlp), "SUPPORTS_FUSION", False):   # post_attention_layernorm runs inside the MLP's first launch
-            extra = {"front": front} if (front is not None and front.get("done")) else {}
-            return mlp(hidden_states, **{type(mlp).RESIDUAL_KW: residual, type(mlp).PRE_NORM_KW: self.post_attention_layernorm}, **extra)
+            return mlp(hidden_states, **{type(mlp).RESIDUAL_KW: residual, type(mlp).PRE_NORM_KW: self.post_attention_layernorm})
         hidden_states = self.post_attention_layernorm(hidden_states)
         return residual + mlp(hidden_states)
 

@@ -164,7 +164,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
     def forward(self, hidden_states: torch.Tensor, attention_mask: Optional[torch.Tensor] = None,
                 position_ids: Optional[torch.Tensor] = None, past_key_value=None, output_attentions: bool = False,
                 use_cache: bool = False, cache_position: Optional[torch.Tensor] = None, pre_norm=None, residual=None,
-                moe_front=None, **kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
+                **kwargs) -> Tuple[torch.Tensor, Optional[torch.Tensor], Optional[Tuple[torch.Tensor]]]:
         """`pre_norm` (an RMSNorm module: the layer's input_layernorm, applied to hidden_states here instead of by the
         caller) and `residual` (added to the output) are fusion hooks used by the decoder-layer glue; without them the
         signature and behaviour are the reference's."""
@@ -178,7 +178,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
         dev = hidden_states.device
         H, nope, rope, lora = self.num_heads, self.qk_nope_head_dim, self.qk_rope_head_dim, self.kv_lora_rank
         if q_len == 1 and pre_norm is not None and residual is not None:
-            fused = self._fused_decode(hidden_states, pre_norm, residual, position_ids, past_key_value, moe_front)
+            fused = self._fused_decode(hidden_states, pre_norm, residual, position_ids, past_key_value)
             if fused is not None:
                 return fused.reshape(bsz, q_len, -1), None, past_key_value
         x = hidden_states.reshape(q_len, -1)
@@ -311,7 +311,7 @@ class KDeepseekV2Attention(BaseInjectedModule):
         past_key_value._kv_len_memo = (key, position_ids, kv_len, pos)
         return kv_len, pos
 
-    def _fused_decode(self, hidden_states, pre_norm, residual, position_ids, past_key_value, moe_front=None):
+    def _fused_decode(self, hidden_states, pre_norm, residual, position_ids, past_key_value):
         """q_a|kv_a -> q_b + absorb + RoPE + latent norm + cache append -> split-KV attention -> merge + un-absorb -> o_proj +
         residual as ONE persistent launch (include/ktx_attn.h) when this layer has the covered geometry (DeepSeek-V3 / R1 / Kimi-K2
         attention dimensions: 128 or 64 heads; W4 g64 or block-FP8 projections, all three alike; the identity / paged single-request
@@ -344,20 +344,23 @@ class KDeepseekV2Attention(BaseInjectedModule):
         ln, kln = self.q_a_layernorm, self.kv_a_layernorm
         out = torch.empty_like(hidden_states)
         keep = (pre_norm.weight.to(torch.bfloat16), ln.weight.to(torch.bfloat16), kln.weight.to(torch.bfloat16))
-        front = moe_front if (moe_front is not None and not os.environ.get("KTX_MOE_FRONT_SEPARATE")) else None
         args = N.attn_decode_args(handles[0], handles[1], qabs, oabs, handles[2], hidden_states.reshape(-1), out.reshape(-1),
                                   (keep[0], pre_norm.variance_epsilon), (keep[1], ln.variance_epsilon), (keep[2], kln.variance_epsilon),
                                   pos, inv_freq, mscale, H, nope, rope, lora, self.v_head_dim, cache[:, :, 0, :lora], cache[:, :, 0, lora:],
-                                  past_key_value.page_size, kv_indptr, None if identity else kv_indices, kv_len, hint, self.softmax_scale,
-                                  moe_front=front)
+                                  past_key_value.page_size, kv_indptr, None if identity else kv_indices, kv_len, hint, self.softmax_scale)
         # eligibility depends on the per-call context bound (`hint` picks the split shape), so it is asked on every call — a
-        # host-only check; only the handle formats above are memoised.  A context that leaves the covered range mid-generation
-        # falls back to the five launches (same arithmetic), and comes back when a later request is short again.
+        # host-only check.  A context that leaves the covered range mid-generation falls back to the five launches (same arithmetic),
+        # and comes back when a later request is short again.  The STATIC part (formats, dimensions, CU count) is settled once
+        # (ADVICE r5): a layer that is not covered even at the smallest context bound never will be, and stops building arguments.
         if not N.attn_decode_eligible(args):
+            if ok is None:
+                args.kv_len_hint = min(512, capacity)
+                if not N.attn_decode_eligible(args):
+                    object.__setattr__(self, "_fused_ok", False)
             return None
+        if ok is None:
+            object.__setattr__(self, "_fused_ok", True)
         N.attn_decode(args, dev)
-        if front is not None:
-            front["done"] = True
         past_key_value.note_appended(self.layer_idx, 1)
         object.__setattr__(self, "_decode_plan", kv_len)
         return out

@@ -327,43 +327,11 @@ class _KMoEBlock(BaseInjectedModule):
     def moe_kexperts(self, x: torch.Tensor, topk_ids: torch.Tensor, topk_weight: torch.Tensor) -> torch.Tensor:
         return self.experts(x, topk_ids, topk_weight)
 
-    def forward(self, hidden_states, residual=None, pre_norm=None, front=None):
+    def forward(self, hidden_states, residual=None, pre_norm=None):
         """Fusion hooks of the decoder-layer glue: `residual` -> returns residual + mlp(hidden_states), the two adds riding
         in the shared experts' down_proj epilogue; `pre_norm` (the layer's post_attention_layernorm module) ->
-        hidden_states is the un-normalised residual stream and the norm runs inside the router launch; `front` (a request from
-        front_request() that the attention's one-launch decode step has fulfilled): router and shared gate|up are done already."""
-        return self._forward(hidden_states, residual, pre_norm, front)
-
-    def front_request(self, hidden_states, pre_norm):
-        """What the attention operator's one-launch decode step needs to run THIS block's front (post-attention norm, router, shared
-        experts' gate|up) inside its launch (include/ktx_attn.h, KTX_ATTN_PHASE_MOE_FRONT), or None when the block does not have the
-        covered shape.  The outputs are allocated here; `done` is set by the attention operator when its launch carried the front."""
-        # OPT-IN (KTX_MOE_FRONT_FUSED=1): inside the whole-model graph the attention launch with this sixth phase measured 4.03 against
-        # 3.82 ms per step on a fast box and 4.89 against 4.87 on a slow one (profiles/r04_f_ab_moe_front.txt): the stand-alone launch
-        # overlaps the router's chain with the shared GEMV on different CUs, the phase runs them one after the other behind a hand-off
-        if not os.environ.get("KTX_MOE_FRONT_FUSED") or os.environ.get("KTX_MOE_FRONT_SEPARATE") or hidden_states.numel() != hidden_states.shape[-1]:
-            return None
-        side = self._router_side_linear(hidden_states, pre_norm)
-        if side is None or getattr(self.config, "n_routed_experts", 0) != 256 or side.K != 7168 or side.N != 4096:
-            return None
-        gate = self.gate
-        w = gate.orig_module.weight
-        if not w.is_contiguous():
-            return None
-        bias = getattr(gate.orig_module, "e_score_correction_bias", None)
-        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
-            cached = getattr(self, "_fused_bias", None)
-            if cached is None or cached[0] is not bias:
-                cached = (bias, bias.detach().to(torch.float32).contiguous())
-                object.__setattr__(self, "_fused_bias", cached)
-            bias = cached[1]
-        dev, H, k = hidden_states.device, hidden_states.shape[-1], gate._handle().k
-        nw = pre_norm.weight if pre_norm.weight.dtype == torch.bfloat16 else pre_norm.weight.to(torch.bfloat16)
-        return {"shared_gate_up": side, "gate": gate._handle(), "gate_weight": w, "gate_bias": bias, "norm": (nw, pre_norm.variance_epsilon),
-                "xn": torch.empty((1, H), dtype=torch.bfloat16, device=dev),
-                "shared_act": torch.empty((1, side.N // 2), dtype=torch.bfloat16, device=dev),
-                "topk_idx": torch.empty((1, k), dtype=torch.int64, device=dev), "topk_w": torch.empty((1, k), dtype=torch.float32, device=dev),
-                "done": False}
+        hidden_states is the un-normalised residual stream and the norm runs inside the router launch."""
+        return self._forward(hidden_states, residual, pre_norm)
 
     def _finish(self, y, identity, residual, orig_shape, shared_act=None, shared_raw=False):
         shared = getattr(self.config, "n_shared_experts", None) is not None
@@ -381,68 +349,13 @@ class _KMoEBlock(BaseInjectedModule):
         y = y.view(*orig_shape)
         return y if residual is None else residual + y
 
-    def _fused_decode(self, hidden_states, residual, pre_norm):
-        """post_attention_layernorm -> router || shared gate|up -> routed gate/up -> routed down + shared down + both adds as ONE
-        persistent launch (include/ktx_moe.h: ktx_moe_layer_decode) when the block has the covered geometry (DeepSeek-V3 / R1: 256
-        AMXINT4 experts of 2048 x 7168 on this device, top-8, W4 shared experts with the merged gate|up operator); None otherwise — the
-        caller then takes the three-launch path, whose kernels this launch restates bit for bit.  OPT-IN (KTX_MOE_FUSED=1): inside the
-        whole-model graph it measured 5.03 against 4.79 ms per step on the slower class of boxes and equal on the faster one
-        (profiles/r04_d_ab_fused_slowbox.txt), so the three launches stay the default; KTX_MOE_SEPARATE=1 always forces them."""
-        ok = getattr(self, "_fused_ok", None)
-        if ok is False or not os.environ.get("KTX_MOE_FUSED") or os.environ.get("KTX_MOE_SEPARATE") or pre_norm is None or residual is None:
-            return None
-        if (hidden_states.numel() != hidden_states.shape[-1] or hidden_states.dtype != torch.bfloat16 or not hidden_states.is_contiguous()
-                or residual.data_ptr() != hidden_states.data_ptr() or not hidden_states.is_cuda):
-            return None
-        side = self._router_side_linear(hidden_states, pre_norm)
-        ex = self.experts
-        op = getattr(ex, "generate_experts", None) if getattr(ex, "mode", None) == InferenceState.GENERATE else \
-            getattr(ex, "prefill_experts", None)
-        if side is None or not isinstance(op, KExpertsHIP) or op._ep is not None or op.handle is None:
-            return None
-        tail = self._tail_side(hidden_states, residual, op)      # (only its down_proj handle is used: same conditions)
-        if tail is None:
-            return None
-        from ktransformers_amd import _native as N
-        gate = self.gate
-        w = gate.orig_module.weight
-        bias = getattr(gate.orig_module, "e_score_correction_bias", None)
-        if bias is not None and (bias.dtype != torch.float32 or not bias.is_contiguous()):
-            cached = getattr(self, "_fused_bias", None)
-            if cached is None or cached[0] is not bias:
-                cached = (bias, bias.detach().to(torch.float32).contiguous())
-                object.__setattr__(self, "_fused_bias", cached)
-            bias = cached[1]
-        out = torch.empty_like(hidden_states)
-        nw = pre_norm.weight if pre_norm.weight.dtype == torch.bfloat16 else pre_norm.weight.to(torch.bfloat16)
-        args = N.moe_layer_args(op.handle, side, tail[0], gate._handle(), w if w.is_contiguous() else w.contiguous(), bias,
-                                hidden_states.reshape(-1), out.reshape(-1), (nw, pre_norm.variance_epsilon))
-        if ok is None:
-            ok = N.moe_layer_decode_eligible(args)
-            object.__setattr__(self, "_fused_ok", ok)
-            if not ok:
-                return None
-        N.moe_layer_decode(args, hidden_states.device)
-        return out
-
-    def _forward(self, hidden_states, residual=None, pre_norm=None, front=None):
+    def _forward(self, hidden_states, residual=None, pre_norm=None):
         orig_shape = hidden_states.shape
         sequence_length = orig_shape[1]
         shared_act = None
-        routed = front is not None and front.get("done")
-        side = None
-        if routed:
-            # the attention's launch ran the norm, the router and the shared experts' gate|up on this very row
-            topk_idx, topk_weight, shared_act = front["topk_idx"], front["topk_w"], front["shared_act"]
-            hidden_states = front["xn"].view(*orig_shape)
-        elif sequence_length == 1 and orig_shape[0] == 1 and (fused := self._fused_decode(hidden_states, residual, pre_norm)) is not None:
-            return fused
-        else:
-            side = self._router_side_linear(hidden_states, pre_norm, allow_cat=True)
+        side = self._router_side_linear(hidden_states, pre_norm, allow_cat=True)
         shared_raw = False
-        if routed:
-            pass                                              # ids, weights and the normalised row are already here
-        elif side is not None:
+        if side is not None:
             # decode: the router rides in the launch of the shared experts' gate|up GEMV (same input row, independent results)
             glu = side.fmt == "W4"                           # block-FP8 shared experts: [gate | up] rows, SiLU * up in down_proj's prologue
             topk_idx, topk_weight, xn, shared_act = self.gate.forward_with_linear(

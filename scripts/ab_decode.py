@@ -44,8 +44,6 @@ CONFIGS = {   # name: (knobs {idx: val}, env {k: v})
     "gate: 2 experts per router workgroup (128 workgroups at E = 256)": ({25: 2}, {}),
     "gate: selection by one wavefront (rounds 1-3)": ({28: 1}, {}),
     "attn: five launches (rounds 2-3)": ({}, {"KTX_ATTN_SEPARATE": "1"}),
-    "moe: one launch (opt-in)": ({}, {"KTX_MOE_FUSED": "1"}),
-    "moe: front in its own launch (router || shared gate|up, rounds 2-3)": ({}, {"KTX_MOE_FRONT_SEPARATE": "1"}),
 }
 if ONLY:
     CONFIGS = {k: v for k, v in CONFIGS.items() if k == "default" or any(o in k for o in ONLY.split(","))}

@@ -12,7 +12,7 @@ echo "decode step, eight launches per layer: $ms ms" | tee -a $O/deepdive.txt
 if python -c "import sys; sys.exit(0 if float('$ms') > ${SLOW_MS:-4.6} else 1)"; then
   echo "SLOW CLASS" | tee -a $O/deepdive.txt
   $R/scripts/tlb_probe 48 2>&1 | tee -a $O/deepdive.txt
-  for cfg in "KTX_MOE_SEPARATE=1 KTX_ATTN_SEPARATE=1" "KTX_MOE_SEPARATE=1" "KTX_MOE_FUSED=1"; do
+  for cfg in "KTX_MOE_SEPARATE=1 KTX_ATTN_SEPARATE=1" "KTX_MOE_SEPARATE=1"; do
     tag=$(echo "$cfg" | tr ' =' '__')
     env $cfg python $R/bench.py --steps 60 --warmup 5 --windows 1 --no-prefill --no-secondary --no-cpu-baseline --no-pmc 2>/dev/null > $O/bench_$tag.json
     python - <<PY | tee -a $O/deepdive.txt
@@ -23,5 +23,5 @@ for r in d.get("per_kernel", [])[:14]:
     print("   ", {k: r[k] for k in ("kernel", "avg_launch_us", "launches_per_step", "us_per_step", "GBs") if k in r})
 PY
   done
-  KTX_MOE_FUSED=1 python $R/scripts/model_fused_stamps.py 32 2>&1 | grep -v amdgpu.ids | tee -a $O/deepdive.txt
+  python $R/scripts/model_fused_stamps.py 32 2>&1 | grep -v amdgpu.ids | tee -a $O/deepdive.txt
 fi

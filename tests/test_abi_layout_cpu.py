@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PAIRS = [("ktx_moe_config", "_MoeConfig", "ktx_moe.h"), ("ktx_linear_config", "_LinearConfig", "ktx_linear.h"),
          ("ktx_linear_fusion", "_LinearFusion", "ktx_linear.h"), ("ktx_gate_config", "_GateConfig", "ktx_gate.h"),
          ("ktx_mla_config", "_MlaConfig", "ktx_mla.h"), ("ktx_gemm_args", "_GemmArgs", "ktx_gemm.h"),
-         ("ktx_attn_decode_args", "_AttnDecodeArgs", "ktx_attn.h"), ("ktx_moe_layer_args", "_MoeLayerArgs", "ktx_moe.h")]
+         ("ktx_attn_decode_args", "_AttnDecodeArgs", "ktx_attn.h")]
 
 
 @pytest.fixture(scope="module")

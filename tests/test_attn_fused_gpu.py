@@ -242,64 +242,6 @@ def test_graph_replay_and_changing_inputs(layer):
         assert torch.equal(cache_new.view(torch.int16), cache_ref.view(torch.int16)), f"replay {step}: cache row differs"
 
 
-def test_moe_front_rides_in_the_launch(layer):
-    """KTX_ATTN_PHASE_MOE_FRONT: the MoE block's front — post_attention_layernorm, router (256 experts, top-8 in 4 of 8 groups),
-    shared experts' merged gate|up with SiLU*up — as a sixth phase on the row the o_proj phase produces: normalised row, selected
-    experts (same order), routing weights and shared activations bit-identical to ktx_linear_forward_fused_gate on that row; the
-    attention outputs unchanged; eager and as replays of one captured launch (the arrival ticket must be left at zero)."""
-    H = layer["H"]
-    from ktransformers_amd._native import GateHandle, LinearHandle, attn_decode, attn_decode_args, attn_status, gate_with_linear
-
-    if layer["fmt"] != "W4":
-        pytest.skip("the MoE front rides with W4 projections (the shared experts' W4 gate|up strip deal)")
-    dev, g = layer["dev"], layer["gen"]
-    E, K, IS = 256, 8, 2048
-    sgu = LinearHandle(HIDDEN, 2 * IS, "W4", 64, 8, dev)
-    sgu.load_bf16(_u((2 * IS, HIDDEN), g, dev, 0.02))
-    gate = GateHandle(E, HIDDEN, K, 8, 4, "sigmoid", "noaux_tc", True, 2.5)
-    gate_w = _u((E, HIDDEN), g, dev, 0.05)
-    gate_b = ((torch.rand(E, generator=g, device=dev) - 0.5) * 0.2).float().contiguous()
-    post_w = (1 + _u((HIDDEN,), g, dev, 0.2).float()).to(torch.bfloat16)
-    c = _case(layer, 1500, 32, False)
-    cache_ref = c["cache"].clone()
-    ref = _five_launches(layer, c, cache_ref)
-    idx0, wt0, xn0, act0 = gate_with_linear(gate, sgu, ref["y"], gate_w, gate_b, (post_w, 1e-6), glu=True)
-    torch.cuda.synchronize()
-    eps = 1e-6
-    y = torch.zeros((1, HIDDEN), dtype=torch.bfloat16, device=dev)
-    front = {"shared_gate_up": sgu, "gate": gate, "gate_weight": gate_w, "gate_bias": gate_b, "norm": (post_w, eps),
-             "xn": torch.zeros((1, HIDDEN), dtype=torch.bfloat16, device=dev), "shared_act": torch.zeros((1, IS), dtype=torch.bfloat16, device=dev),
-             "topk_idx": torch.zeros((1, K), dtype=torch.int64, device=dev), "topk_w": torch.zeros((1, K), dtype=torch.float32, device=dev)}
-    cache_new = c["cache"].clone()
-    a = attn_decode_args(layer["qkv_a"], layer["q_b"], layer["qabs"], layer["oabs"], layer["o_proj"], c["x"].reshape(-1), y.reshape(-1),
-                         (layer["in_norm"], eps), (layer["qa_norm"], eps), (layer["kv_norm"], eps), c["position"], layer["inv_freq"], 1.0,
-                         H, NOPE, ROPE, LORA, VDIM, cache_new[:, :, 0, :LORA], cache_new[:, :, 0, LORA:], PAGE, c["kv_indptr"], None,
-                         c["kv_len"], ref["hint"], 0.1147, moe_front=front)
-
-    def check(tag):
-        assert attn_status(dev) == 0, tag
-        assert torch.equal(y.view(torch.int16), ref["y"].view(torch.int16)), f"{tag}: layer output differs"
-        assert torch.equal(front["xn"].view(torch.int16), xn0.view(torch.int16)), f"{tag}: normalised row differs"
-        assert torch.equal(front["topk_idx"], idx0), f"{tag}: experts {front['topk_idx'].tolist()} vs {idx0.tolist()}"
-        assert torch.equal(front["topk_w"], wt0), f"{tag}: routing weights differ"
-        assert torch.equal(front["shared_act"].view(torch.int16), act0.view(torch.int16)), f"{tag}: shared activations differ"
-
-    attn_decode(a, dev)
-    torch.cuda.synchronize()
-    check("eager")
-    cache_new.copy_(c["cache"])
-    gr = torch.cuda.CUDAGraph()
-    with torch.cuda.graph(gr):
-        attn_decode(a, dev)
-    for rep in range(3):
-        for t in (y, front["xn"], front["shared_act"], front["topk_w"]):
-            t.zero_()
-        cache_new.copy_(c["cache"])
-        gr.replay()
-        torch.cuda.synchronize()
-        check(f"replay {rep}")
-
-
 @pytest.mark.parametrize("ctx,pages,permute", [(1000, 32, True), (3000, 64, False)])
 def test_one_launch_against_the_oracle(layer, ctx, pages, permute):
     """The launch held DIRECTLY against the restated reference operator (oracle/attention_ref.py: forward_linux_flashinfer op for op in
