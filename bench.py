@@ -446,12 +446,17 @@ def timed(fn, steps, warmup, dev, dist_on):
     # a bounded hand-off inside the one-launch attention step that gave up leaves undefined results and a status word: no number then
     from ktransformers_amd import _native
     bad_dev, st = _native.attn_status_any()
-    if st != 0:
-        raise RuntimeError(f"one-launch attention step on cuda:{bad_dev}: a hand-off timed out during the timed region (status {st:#x})")
     if dist_on:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        # the status word rides the same all-reduce as the time (MAX over ranks), so every rank raises TOGETHER: a rank that raised
+        # alone left the others blocked in the collective until the process-group timeout
+        t = torch.tensor([dt, float(st)], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
+        dt, st_any = float(t[0].item()), int(t[1].item())
+        if st_any != 0:
+            raise RuntimeError(f"one-launch attention step: a hand-off timed out during the timed region on some rank (status {st_any:#x}"
+                               + (f"; this rank: cuda:{bad_dev} {st:#x})" if st else "; not on this rank)"))
+    elif st != 0:
+        raise RuntimeError(f"one-launch attention step on cuda:{bad_dev}: a hand-off timed out during the timed region (status {st:#x})")
     return dt
 
 
@@ -464,7 +469,7 @@ KTX_KERNEL_NAMES = ("lin_sk_kernel", "lin_sk_gate_kernel", "lin_dec_kernel", "li
                     "moe_dec_fp_gateup_kernel", "moe_dec_fp_down_kernel", "moe_dec_raw_gateup_kernel", "moe_dec_raw_down_kernel",
                     "moe_dec_gguf_gateup_kernel", "moe_dec_gguf_down_kernel", "moe_prep_kernel", "moe_gemm_kernel", "moe_combine_kernel",
                     "mla_decode_kernel", "mla_merge_kernel", "mla_prep_kernel", "mla_cache_append_kernel", "rmsnorm_kernel",
-                    "silu_mul_kernel", "argmax_bf16_kernel", "ep_gather_kernel", "ep_reduce_kernel", "attn_decode_kernel", "moe_layer_kernel")
+                    "silu_mul_kernel", "argmax_bf16_kernel", "ep_gather_kernel", "ep_reduce_kernel", "attn_decode_kernel")
 
 
 def _kclass(text):

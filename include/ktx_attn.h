@@ -66,8 +66,9 @@ int ktx_attn_decode_eligible(const ktx_attn_decode_args* a);
 
 /* The launch is PERSISTENT: 256 workgroups that wait for each other.  All of them must be resident at once, so (1) at most one such
  * launch may be in flight per device — launches of one stream are ordered; launches issued from a second stream are ordered behind the
- * device's previous one by an event the library records (eager mode; inside a stream capture the caller keeps one capture per
- * device) — and (2) a foreign kernel occupying CUs for longer than the poll bound (0.2 s) makes a hand-off give up: the launch then
+ * device's previous one by an event the library records (eager mode: wait, launch and record happen under one per-device lock, so host
+ * threads may launch concurrently; inside a stream capture the caller keeps one capture per device, and REPLAYS of a captured graph are
+ * not recorded — an eager launch issued beside a running replay on another stream is the caller's to order) — and (2) a foreign kernel occupying CUs for longer than the poll bound (0.2 s) makes a hand-off give up: the launch then
  * ends with undefined results and the status word below is set. */
 int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t stream);
 

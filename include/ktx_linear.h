@@ -75,7 +75,13 @@ int ktx_linear_load_w4(ktx_linear_t h, const uint8_t* d_q, const void* d_s, cons
 int ktx_linear_load_fp8(ktx_linear_t h, const void* d_w, const float* d_scale_inv, const void* d_bias);
 
 /* y[t] = x[t] · W^T (+ bias) for t < min(T, *d_bsz) (d_bsz may be NULL = T rows); rows beyond are left untouched.
- * Mirrors KLinear*.forward(x, bsz_tensor) (linear.py:174,409,679). */
+ * Mirrors KLinear*.forward(x, bsz_tensor) (linear.py:174,409,679).
+ * Range note (decode GEMVs whose K is split over several workgroups, lin_sk_kernel: the wide projections of a decode step): the parts
+ * of an output meet in a 64-bit fixed-point word whose in-range window is |part| <= 2^18 = 262144; a NaN, an Inf or a FINITE part beyond
+ * it is carried as a marker and the output becomes NaN (never a silently clamped number).  The un-split decode kernel and the prompt
+ * GEMM have no such window: a layer whose fp32 partial sums legitimately exceed 2^18 (bf16 activations of that size are outside every
+ * model on the list) gets NaN on the split path and the finite value on the others (stated, not widened — the word's 60
+ * sum bits hold 15 biased parts plus the marker with one bit to spare). */
 int ktx_linear_forward(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, void* d_y, ktx_stream_t stream);
 
 /* Fusions around one linear of the decoder layer (all optional, NULL = off):

@@ -1149,6 +1149,10 @@ unsigned* g_hstatus_dev = nullptr;   // the same memory as the devices see it
 // recorded behind that one (eager mode only: inside a stream capture the caller keeps one capture per device).
 struct DevOrder { hipEvent_t ev = nullptr; hipStream_t last = nullptr; bool valid = false; };
 DevOrder g_order[MAX_DEV];
+// held by an eager launch across wait-for-the-previous-launch -> launch -> record (as three separately locked steps two
+// host threads on different streams could interleave between the wait and the record, and two 256-workgroup persistent launches
+// would overlap — the mutual wait the event exists to prevent)
+std::mutex g_launch_mu[MAX_DEV];
 
 int order_before_launch(int dev, hipStream_t st, bool* eager) {
   hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
@@ -1334,6 +1338,7 @@ extern "C" int ktx_attn_decode(const ktx_attn_decode_args* a, ktx_stream_t strea
   const bool f8 = r[0].format == KTX_LIN_FP8;
   KTX_TIMED(st, bytes, "attn_decode_kernel<%d%s> H=%d nsplit=%d", a->phases, f8 ? ",FP8" : "", H, nsplit);
   bool eager = false;
+  std::unique_lock<std::mutex> launch_lk(g_launch_mu[dev]);   // (a captured launch holds it only for the capture call itself)
   if (order_before_launch(dev, st, &eager) != 0) return -1;
   int rc = -1;
   switch (a->phases) {

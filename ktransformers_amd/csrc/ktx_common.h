@@ -90,9 +90,8 @@ __device__ __forceinline__ int quant_rne_sat8(float v) {
 
 // hipFuncSetAttribute acts on the CURRENT device's copy of a kernel, so "set once" is once per (call site, device): a process that
 // splits a model's layers over several GPUs would otherwise launch with the default dynamic-LDS limit on every device but the first
-// (ADVICE r4).  One of these per call site (function-local static); the check is a hipGetDevice, a thread-local read.
-struct KtxAttrOnce { bool done[64] = {}; };
-// the same for call sites that name their kernel: hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device)
+// (ADVICE r4).  hipFuncAttributeMaxDynamicSharedMemorySize once per (kernel, device); the flag is set only after the call succeeded
+// (a failed first attempt must not disable every later one), under a mutex.
 static inline hipError_t ktx_set_max_lds(const void* kernel, int bytes) {
   static std::mutex mu;
   static std::unordered_map<const void*, uint64_t> done;   // kernel -> devices it has been set on
@@ -108,13 +107,6 @@ static inline hipError_t ktx_set_max_lds(const void* kernel, int bytes) {
     done[kernel] |= 1ull << dev;
   }
   return e;
-}
-static inline bool ktx_attr_needed(KtxAttrOnce& o) {
-  int dev = 0;
-  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return true;
-  if (o.done[dev]) return false;
-  o.done[dev] = true;
-  return true;
 }
 
 // ---- wave-wide reductions on DPP + v_readlane ------------------------------------------------------------------------

@@ -459,10 +459,7 @@ int launch_gemm(GemmParams p, int batch, hipStream_t st) {
   const long nblk = p.xcd_map ? (long)p.tm * ((p.tn + 7) / 8 * 8) : (long)p.tm * p.tn;
   KTX_REQUIRE(nblk < (1L << 31), "ktx_gemm_bf16_nt: too many tiles");
   const dim3 grid((unsigned)nblk, (unsigned)batch);
-  static KtxAttrOnce attr_done;
-  if (lds > 48 * 1024 && ktx_attr_needed(attr_done)) {
-    KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-  }
+  if (lds > 48 * 1024) KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), lds));
   hipLaunchKernelGGL(kern, grid, dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
@@ -500,9 +497,12 @@ extern "C" int ktx_gemm_bf16_nt(const ktx_gemm_args* a, ktx_stream_t stream) {
     variant = (a->M >= 256 && t256 >= 400) ? 4 : 2;
     // round 6: the 256 x 256 ping-pong tile (one workgroup per CU) once its grid covers most of the chip and K is deep enough to
     // amortise its 128-register epilogue
-    const long t5 = (long)((a->M + 255) / 256) * ((a->N + 255) / 256) * a->batch;
-    if (t5 >= 192 && a->K >= 512 && (size_t)a->M * a->lda * 2 < ((size_t)1 << 32) && (size_t)a->N * a->ldb * 2 < ((size_t)1 << 32) &&
-        !getenv("KTX_GEMM_NO_PINGPONG"))
+    // (and its 256 x 256 tiles cover the output with little waste: the kv_b expansions of the prompt attention, 128 columns or 128
+    // rows per head, measured 0.6x on it)
+    const long tm5 = (a->M + 255) / 256, tn5 = (a->N + 255) / 256, t5 = tm5 * tn5 * a->batch;
+    const double fill5 = (double)a->M * a->N / ((double)tm5 * tn5 * 65536.0);
+    if (t5 >= 192 && fill5 >= 0.85 && a->K >= 1024 && (size_t)a->M * a->lda * 2 < ((size_t)1 << 32) &&
+        (size_t)a->N * a->ldb * 2 < ((size_t)1 << 32) && !getenv("KTX_GEMM_NO_PINGPONG"))
       variant = 5;
   }
   const double na = a->a_bs ? a->batch : 1, nb = a->b_bs ? a->batch : 1;   // a shared operand is counted once

@@ -1607,10 +1607,7 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs
     KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0 + (double)E * H * 2.0,
               "lin_sk_gate_kernel<W4> %d->%d + router E=%d", p.Kx, p.N, E);
     auto go_g = [&](auto kern) -> int {
-      static KtxAttrOnce attr_set;   // one flag per kernel instantiation
-      if (ktx_attr_needed(attr_set)) {   // (150 KB: gate_fused_body holds ~4 KB of static LDS beside the dynamic region)
-        KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-      }
+      KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), 150 * 1024));   // (150 KB: gate_fused_body holds ~4 KB of static LDS beside the dynamic region)
       // + the router's own workgroups in front (default), or + ONE selector workgroup behind (wavefront-7 placement)
       const size_t smem_g = std::max(std::max(smem, (size_t)gate->c.hidden_size * 2), (size_t)4 * KTX_GATE_MAX_E * 4);
       hipLaunchKernelGGL(kern, dim3(nwg + (gate_wave7 ? 1 : p.sk_gate_wgs)), dim3(512), smem_g, st, p, *gate);
@@ -1629,10 +1626,7 @@ int launch_sk(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArgs
   }
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0, "lin_sk_kernel<W4> %d->%d", p.Kx, p.N);
   auto go = [&](auto kern) -> int {
-    static KtxAttrOnce attr_set;   // one flag per kernel instantiation
-    if (ktx_attr_needed(attr_set)) {
-      KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, dim3(nwg), dim3(512), smem, st, p);
     KTX_HIP(hipGetLastError());
     return 0;
@@ -1734,10 +1728,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
       KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * (p.Kx + p.N) * 2.0 + (double)E * H * 2.0,
                 "lin_dec_gate_kernel<%s> %d->%d + router E=%d", lin_fmt_name(FMT), p.Kx, p.N, E);
       auto go_g = [&](auto kern) -> int {
-        static KtxAttrOnce attr_set;   // one flag per kernel instantiation
-        if (ktx_attr_needed(attr_set)) {
-          KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024));
-        }
+        KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), 150 * 1024));
         hipLaunchKernelGGL(kern, grid_g, dim3(512), smem_g, st, p, *gate, nwg, epw);
         KTX_HIP(hipGetLastError());
         return 0;
@@ -1757,10 +1748,7 @@ int launch_dec(const ktx_linear_s* h, LinParams p, hipStream_t st, const GateArg
     return KTX_LIN_NOT_FUSED;
   }
   auto go = [&](auto kern) -> int {
-    static KtxAttrOnce attr_set;   // one flag per kernel instantiation
-    if (ktx_attr_needed(attr_set)) {
-      KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-    }
+    KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
     hipLaunchKernelGGL(kern, grid, dim3(512), smem, st, p);
     KTX_HIP(hipGetLastError());
     return 0;
@@ -1823,10 +1811,7 @@ int launch_gemm(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
             "lin_gemm_kernel<%s,MT%d> T=%d %d->%d%s", lin_fmt_name(FMT), MT, p.T, p.Kx, p.N,
             h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
-  static KtxAttrOnce attr_set;
-  if (ktx_attr_needed(attr_set)) {
-    KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   KTX_HIP(hipGetLastError());
   return 0;
@@ -1847,10 +1832,7 @@ int launch_gemm_w4n(const ktx_linear_s* h, const LinParams& p, hipStream_t st) {
   KTX_TIMED(st, (double)h->w_bytes + (double)h->sc_bytes + (double)p.T * h->batch * (p.Kx + p.N) * 2.0,
             "lin_gemm_w4n_kernel<MT%d,NSW%d> T=%d %d->%d%s", MT, NSW, p.T, p.Kx, p.N,
             h->batch > 1 ? ktx_fmt(" x%d", h->batch).c_str() : "");
-  static KtxAttrOnce attr_set;
-  if (ktx_attr_needed(attr_set)) {
-    KTX_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
-  }
+  KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), 160 * 1024));
   hipLaunchKernelGGL(kern, grid, dim3(256), smem, st, p);
   KTX_HIP(hipGetLastError());
   return 0;

@@ -2592,8 +2592,8 @@ extern "C" int ktx_moe_create(const ktx_moe_config* cfg, ktx_moe_t* out) {
     need[9] = (4 + KTX_DEC_MAX_PAIRS * 64) * sizeof(int32_t);   // [4] bucket counters | arrival tickets of the GGUF decode launches
     if (gguf) {
       // Q8_K 16-sums, and behind them the 32-sums split into two int8 planes (16 B per 256-block: the folded Q4_K kernel's min operand)
-      need[10] = (size_t)cfg->max_len * (H / 16) * sizeof(int16_t) + (size_t)cfg->max_len * (H / 256) * 16;
-      need[11] = (size_t)h->max_pairs * (I / 16) * sizeof(int16_t) + (size_t)h->max_pairs * (I / 256) * 16;
+      need[10] = (size_t)cfg->max_len * (H / 16) * sizeof(int16_t) + (size_t)cfg->max_len * (H / 256) * (16 + 4);   // (+ the block sums)
+      need[11] = (size_t)h->max_pairs * (I / 16) * sizeof(int16_t) + (size_t)h->max_pairs * (I / 256) * (16 + 4);
     }
     std::shared_ptr<Workspace> cur = g_ws[cfg->device];
     bool fits = cur != nullptr;
@@ -3523,7 +3523,7 @@ static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
   if constexpr (gg_foldable(WT)) {   // round 6: the folded-operand kernel; dev knob [21] = 1: gg_block's (the bit-identity test, A/B timing)
     if (g_dbg[21] != 1) {
-      const size_t lds_f = 2 * TOK * 256 + 2 * TOK * 4 + TOK * 4 + (WT == GG_Q4K ? 2 * TOK * 16 : 0);
+      const size_t lds_f = 2 * TOK * 256 + 2 * TOK * 4 + TOK * 4 + (WT == GG_Q4K ? 2 * TOK * 16 : WT == GG_IQ1S ? 2 * TOK * 4 + 16384 : 0);
       if constexpr (GATE_UP && MT == 8) {
         if (g_dbg[23] == 1) {   // dev knob [23] = 1: gate and up strips on separate wavefronts (8 per workgroup) — measured slower, kept for A/B
           auto kern = moe_gguf_fold_kernel<WT, MT, true, true>;
@@ -3540,7 +3540,7 @@ static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
       return 0;
     }
   }
-  if constexpr (MT > 4) { ktx_fail("launch_gguf: 128-row tiles exist for the folded Q4_K / Q6_K kernels only"); return 1; }
+  if constexpr (MT > 4) { ktx_fail("launch_gguf: 128-row tiles exist for the folded Q4_K / Q6_K / IQ1_S kernels only"); return 1; }
   else {
   hipLaunchKernelGGL((moe_gguf_gemm_kernel<WT, MT, GATE_UP>), grid, dim3(256), lds, st, p);
   KTX_HIP(hipGetLastError());
@@ -3554,7 +3554,7 @@ static int launch_gguf_mt(int mt, const GgGemmParams& p, int max_tiles, hipStrea
     case 2: return launch_gguf<WT, 2, GATE_UP>(p, max_tiles, st);
     case 8:
       if constexpr (gg_foldable(WT)) return launch_gguf<WT, 8, GATE_UP>(p, max_tiles, st);
-      else { ktx_fail("launch_gguf: 128-row tiles exist for the folded Q4_K / Q6_K kernels only"); return 1; }
+      else { ktx_fail("launch_gguf: 128-row tiles exist for the folded Q4_K / Q6_K / IQ1_S kernels only"); return 1; }
     default: return launch_gguf<WT, 4, GATE_UP>(p, max_tiles, st);
   }
 }
@@ -3711,6 +3711,8 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
 
   uint8_t* x_bsp = reinterpret_cast<uint8_t*>(ws->x_bs) + (size_t)h->cfg.max_len * (H / 16) * sizeof(int16_t);
   uint8_t* a_bsp = reinterpret_cast<uint8_t*>(ws->a_bs) + (size_t)h->max_pairs * (I / 16) * sizeof(int16_t);
+  int32_t* x_b256 = reinterpret_cast<int32_t*>(x_bsp + (size_t)h->cfg.max_len * (H / 256) * 16);
+  int32_t* a_b256 = reinterpret_cast<int32_t*>(a_bsp + (size_t)h->max_pairs * (I / 256) * 16);
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;
   pp.rows_per_tile = 16 * mt; pp.ids = d_expert_ids; pp.mask = h->mask; pp.x = (const bf16_t*)d_input;
@@ -3719,12 +3721,12 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   {
     ProfScope ps(0, st);
     KTX_HIP(launch_moe_prep(pp, 1, st));
-    hipLaunchKernelGGL(q8k_quant_kernel<false>, dim3(qlen), dim3(256), 0, st, d_input, H, ws->x_q, ws->x_d, ws->x_bs, x_bsp, d_bsz, 1, qlen);
+    hipLaunchKernelGGL(q8k_quant_kernel<false>, dim3(qlen), dim3(256), 0, st, d_input, H, ws->x_q, ws->x_d, ws->x_bs, x_bsp, x_b256, d_bsz, 1, qlen);
   }
   KTX_HIP(hipGetLastError());
   GgGemmParams g1{};
   g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.stride0 = h->gg_stride[0]; g1.stride1 = h->gg_stride[1]; g1.N = I; g1.K = H;
-  g1.act_q = ws->x_q; g1.act_d = ws->x_d; g1.act_bs = ws->x_bs; g1.act_bsp = x_bsp; g1.row_src = ws->src_of_row; g1.tiles = ws->tiles;
+  g1.act_q = ws->x_q; g1.act_d = ws->x_d; g1.act_bs = ws->x_bs; g1.act_bsp = x_bsp; g1.act_b256 = x_b256; g1.row_src = ws->src_of_row; g1.tiles = ws->tiles;
   g1.counters = ws->counters; g1.out = reinterpret_cast<float*>(ws->a_buf);
   int rc;
   {
@@ -3735,12 +3737,12 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   {
     ProfScope ps(2, st);
     hipLaunchKernelGGL(q8k_quant_kernel<true>, dim3(npairs), dim3(256), 0, st, (const void*)ws->a_buf, I, ws->a_q, ws->a_d, ws->a_bs,
-                       a_bsp, ws->counters, 0, npairs);
+                       a_bsp, a_b256, ws->counters, 0, npairs);
   }
   KTX_HIP(hipGetLastError());
   GgGemmParams g2{};
   g2.w0 = h->down_w; g2.w1 = nullptr; g2.stride0 = h->gg_stride[2]; g2.stride1 = 0; g2.N = H; g2.K = I;
-  g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.act_bs = ws->a_bs; g2.act_bsp = a_bsp; g2.row_src = nullptr; g2.tiles = ws->tiles;
+  g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.act_bs = ws->a_bs; g2.act_bsp = a_bsp; g2.act_b256 = a_b256; g2.row_src = nullptr; g2.tiles = ws->tiles;
   g2.counters = ws->counters; g2.out = reinterpret_cast<float*>(ws->dn_buf);
   {
     ProfScope ps(3, st);

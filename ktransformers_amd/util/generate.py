@@ -15,8 +15,8 @@ from ktransformers_amd.util.utils import InferenceState
 def check_handoffs(full: bool = True) -> None:
     """Bounded in-launch hand-offs must not fail silently.  The one-launch attention step (include/ktx_attn.h) writes its status word
     into pinned host memory when a poll gives up: reading it is a host load, so it is checked after EVERY token, for every device
-    (`full=False`: only that).  The expert-parallel peer-write transport (parallel.py) and the opt-in one-launch MoE half keep their
-    status words on the device (a small copy): checked with `full=True` — every 64 tokens and at the end of a generation."""
+    (`full=False`: only that).  The expert-parallel peer-write transport (parallel.py) keeps its
+    status word on the device (a small copy): checked with `full=True` — every 64 tokens and at the end of a generation."""
     from ktransformers_amd import _native, parallel
     dev, st = _native.attn_status_any()
     if st != 0:
@@ -27,12 +27,6 @@ def check_handoffs(full: bool = True) -> None:
         return
     if parallel.EP_STATE.get("exchange") is not None:
         parallel.check_exchange_status()
-    if torch.cuda.is_available():
-        for i in range(torch.cuda.device_count()):
-            st = _native.moe_layer_status(torch.device("cuda", i))
-            if st != 0:
-                raise RuntimeError(f"one-launch MoE step on cuda:{i}: a hand-off inside the launch timed out (status {st:#x}); "
-                                   "outputs since the previous check are not valid")
 
 
 _check_ep = check_handoffs      # (the name rounds 2-4 used)

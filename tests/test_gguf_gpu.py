@@ -161,11 +161,12 @@ def test_mixtral_like_shape(T):
     run_case(8, 2, 1024, 3584, T, (Q4, Q4, Q6), seed=9)
 
 
-@pytest.mark.parametrize("types", [(Q4, Q4, Q6), (Q6, Q6, Q4)])
+@pytest.mark.parametrize("types", [(Q4, Q4, Q6), (Q6, Q6, Q4), (IQ1, IQ1, IQ1), (IQ1, IQ1, Q4)])
 @pytest.mark.parametrize("T", [3, 19, 70, 300])
 def test_folded_prompt_kernels_give_the_unfolded_bits(types, T):
     """Round 6: the Q4_K / Q6_K grouped GEMM folds the sub-block scales into the int8 MFMA operand (csrc/ktx_moe_gguf.inc,
-    gg_fold) where gg_block multiplied every 32-wide partial product on the vector ALU.  Every integer is the same and so is the
+    gg_fold) where gg_block multiplied every 32-wide partial product on the vector ALU; the IQ1_S one runs ONE int8 chain per block
+    on the operand (s'(8 g - delta) - 1) / 2 plus the block's sum of codes.  Every integer is the same and so is the
     fp32 chain, hence the SAME BITS as the unfolded kernel (dev knob 21 = 1) — at every tile height (MT = 1, 2, 4), on ragged
     tiles, with ids out of range, on random valid blocks (all 6-bit scales / mins and all int8 Q6_K scales occur)."""
     from ktransformers_amd import _native as n
