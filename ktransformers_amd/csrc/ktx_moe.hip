@@ -3521,6 +3521,7 @@ static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   constexpr int TOK = MT * 16, US = TOK * 16 + 16, NBS = gg_nbs(WT);
   const size_t lds = 2 * 16 * US + 2 * NBS * TOK * 4 + 2 * TOK * 4 + TOK * 4 + (WT == GG_IQ1S ? 4096 * 8 : 0);
   const dim3 grid((p.N / 16 + 3) / 4, max_tiles);
+  const dim3 grid_f((unsigned)((p.N / 16 + 3) / 4) * (unsigned)((max_tiles + 7) / 8 * 8));   // folded kernels: (XCD, tile, strip group) in one dimension
   if constexpr (gg_foldable(WT)) {   // round 6: the folded-operand kernel; dev knob [21] = 1: gg_block's (the bit-identity test, A/B timing)
     if (g_dbg[21] != 1) {
       const size_t lds_f = 2 * TOK * 256 + 2 * TOK * 4 + TOK * 4 + (WT == GG_Q4K ? 2 * TOK * 16 : WT == GG_IQ1S ? 2 * TOK * 4 + 16384 : 0);
@@ -3528,14 +3529,14 @@ static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
         if (g_dbg[23] == 1) {   // dev knob [23] = 1: gate and up strips on separate wavefronts (8 per workgroup) — measured slower, kept for A/B
           auto kern = moe_gguf_fold_kernel<WT, MT, true, true>;
           KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds_f));
-          hipLaunchKernelGGL(kern, grid, dim3(512), lds_f, st, p);
+          hipLaunchKernelGGL(kern, grid_f, dim3(512), lds_f, st, p);
           KTX_HIP(hipGetLastError());
           return 0;
         }
       }
       auto kern = moe_gguf_fold_kernel<WT, MT, GATE_UP, false>;
       if (lds_f > 64 * 1024) KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds_f));
-      hipLaunchKernelGGL(kern, grid, dim3(256), lds_f, st, p);
+      hipLaunchKernelGGL(kern, grid_f, dim3(256), lds_f, st, p);
       KTX_HIP(hipGetLastError());
       return 0;
     }
