@@ -1109,6 +1109,92 @@ def run_model_decode(name, args, dev, steps, warmup, dist_on=False, world=1, ran
     return res, mr
 
 
+def batched_decode(mr, B, ctx, steps, warmup, dev):
+    """B requests, ONE new token each per step — the decode batch of the reference's balance_serve engine seam: the flattened-batch
+    attention operator (`flashinfer_attn`, archive/ktransformers/operators/balance_serve_attention.py:66-118) over a paged latent
+    cache (`KDeepSeekV3Cache`, permuted page table) and the MoE / MLP blocks on the [B, hidden] rows, greedy next tokens, one HIP
+    graph per step.  What it shows that bs = 1 cannot: the attention / shared / lm_head weights are streamed once for B tokens, so
+    the step approaches the HBM roof where the bs = 1 step is bound by its chain of dependent launches.  Positions are held at
+    `ctx` (every step rewrites the same cache slot): the step's work does not depend on it."""
+    from ktransformers_amd._native import MLAWrapper, argmax_bf16
+    from ktransformers_amd.models.custom_cache import KDeepSeekV3Cache
+    from ktransformers_amd.operators.balance_serve_attention import flashinfer_attn
+
+    model, cfg = mr.model, mr.cfg
+    page = 64
+    ppr = (ctx + 1 + page - 1) // page + 1                       # pages per request
+    kv = KDeepSeekV3Cache(cfg, page_size=page, device=str(dev))
+    kv.allocate(B * ppr)
+    for kc in kv.k_caches:
+        kc.normal_()
+    g = torch.Generator(device=dev)
+    g.manual_seed(23)
+    i32 = dict(dtype=torch.int32, device=dev)
+    q_indptr = torch.arange(B + 1, **i32)
+    kv_indptr = torch.arange(B + 1, **i32) * ppr
+    kv_indices = torch.randperm(B * ppr, generator=g, device=dev).to(torch.int32)          # a scattered page table
+    kv_len = torch.full((B,), ctx + 1, **i32)
+    pos = torch.full((B,), ctx, dtype=torch.int64, device=dev)
+    bsz = torch.tensor([B], **i32)
+    page_idx, page_off = kv.get_page_table(pos, q_indptr, kv_indptr, kv_indices, bsz)
+    page_idx, page_off = page_idx.to(torch.int32), page_off.to(torch.int32)
+    attn0 = model.model.layers[0].self_attn
+    Hp = (attn0.num_heads + 15) // 16 * 16
+    wrapper = MLAWrapper(B, B * ppr, use_cuda_graph=True, device=dev, max_q_tokens=B)
+    wrapper.plan(q_indptr, kv_indptr, kv_indices, kv_len, bsz, Hp, attn0.kv_lora_rank, attn0.qk_rope_head_dim, page, attn0.softmax_scale,
+                 torch.bfloat16, torch.bfloat16, max_kv_len=ctx + page)
+    tokens = torch.randint(0, cfg.vocab_size, (B,), generator=g, device=dev)
+
+    def step():
+        h = model.model.embed_tokens(tokens)                                             # [B, hidden]
+        for layer in model.model.layers:
+            h = h + flashinfer_attn.forward(layer.self_attn, layer.input_layernorm(h), kv, pos, wrapper, bsz, page_idx, page_off)
+            h = h + layer.mlp(layer.post_attention_layernorm(h).unsqueeze(0)).squeeze(0)
+        logits = model.lm_head(model.model.norm(h))
+        tokens.copy_(argmax_bf16(logits) if logits.dtype == torch.bfloat16 else logits.float().argmax(dim=-1))
+
+    with torch.no_grad():
+        for _ in range(3):
+            step()
+        torch.cuda.synchronize(dev)
+        graph, graph_ok = torch.cuda.CUDAGraph(), True
+        try:
+            with torch.cuda.graph(graph):
+                step()
+        except Exception as e:     # stay eager, and say so
+            graph_ok = False
+            log(f"[bench] bs{B}: graph capture failed ({type(e).__name__}: {e}); running eagerly")
+            torch.cuda.synchronize(dev)
+        run = graph.replay if graph_ok else step
+        for _ in range(warmup):
+            run()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        torch.cuda.synchronize(dev)
+        dt = time.perf_counter() - t0
+    ms = dt / steps * 1e3
+    # algorithmic bytes of the step: every non-expert weight once, the expected number of DISTINCT routed experts of B tokens
+    # (E (1 - (1 - k/E)^B), SURVEY.md section 8d), B requests' latent rows
+    n_layers = cfg.num_hidden_layers
+    tot1, _ = step_bytes(cfg, n_layers, ctx, mr.wl)
+    E, k, H, Im = cfg.n_routed_experts, cfg.num_experts_per_tok, cfg.hidden_size, cfg.moe_intermediate_size
+    n_moe = n_layers - min(cfg.first_k_dense_replace, n_layers)
+    gu, dn = expert_bpw(mr.wl)
+    per_expert = 2 * H * Im * gu + H * Im * dn
+    distinct = E * (1.0 - (1.0 - k / E) ** B)
+    nbytes = tot1 + n_moe * (distinct - k) * per_expert + (B - 1) * n_layers * (ctx + 1) * (cfg.kv_lora_rank + cfg.qk_rope_head_dim) * 2
+    del graph, wrapper, kv
+    gc.collect()
+    torch.cuda.empty_cache()
+    return {"value": round(B * 1e3 / ms, 2), "unit": "tok/s (aggregate over the batch)", "batch": B, "ms_per_step": round(ms, 4), "ctx": ctx,
+            "hip_graph": graph_ok, "expected_distinct_experts_per_layer": round(distinct, 1),
+            "whole_step": {"algorithmic_bytes": int(nbytes), "GBs": round(nbytes / (ms * 1e-3) / 1e9, 1),
+                           "frac_of_hbm_peak": round(nbytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)},
+            "path": "flashinfer_attn (five launches per layer: the one-launch attention step covers one token) + MoE decode kernels on B rows"}
+
+
 def run_experts_decode(name, args, dev, steps):
     """`kind: experts` workloads (BASELINE.json configs[0]: kt-kernel/bench/bench_moe.py's scope): the routed experts of every
     layer alone, one token through all of them per step, one HIP graph."""
@@ -1274,6 +1360,12 @@ def compact_line(out: dict) -> dict:
             r["error"] = str(r["error"])[:100]
         return r
 
+    if isinstance(out.get("bs8"), dict):
+        b8 = out["bs8"]
+        line["bs8"] = dict(_pick(b8, ("value", "ms_per_step", "batch", "error")),
+                           **({"frac_of_hbm_peak": b8["whole_step"]["frac_of_hbm_peak"]} if isinstance(b8.get("whole_step"), dict) else {}))
+        if "error" in line["bs8"]:
+            line["bs8"]["error"] = str(line["bs8"]["error"])[:100]
     if out.get("prefill") is not None:
         line["prefill"] = _prefill(out["prefill"])
     if out.get("prefill_8192") is not None:
@@ -1305,6 +1397,9 @@ def compact_line(out: dict) -> dict:
             s["ctx_131072"] = r2["ctx_131072"].get("value")
         if "exact" in r2:
             s["exact"] = r2["exact"]
+        if isinstance(r2.get("bs8"), dict) and r2["bs8"].get("value") is not None:
+            s["bs8"] = r2["bs8"]["value"]
+            s["bs8_frac"] = r2["bs8"]["whole_step"]["frac_of_hbm_peak"]
         if isinstance(r2.get("cpu_llamafile"), dict):
             s["cpu_llamafile"] = _pick(r2["cpu_llamafile"], ("value", "cores"))
         sec[key] = s
@@ -1314,7 +1409,7 @@ def compact_line(out: dict) -> dict:
         line["timing_s"] = {"total": out["timing_s"].get("total")}
     line["detail"] = DETAIL_FILE
     # last resort (a pathological error string, a future field): drop optional blocks until the line fits
-    for k in ("timing_s", "full_depth_extrapolation", "median_tok_s", "whole_step", "secondary", "prefill_8192", "prefill"):
+    for k in ("timing_s", "full_depth_extrapolation", "median_tok_s", "whole_step", "secondary", "bs8", "prefill_8192", "prefill"):
         if len(json.dumps(line)) < LINE_LIMIT:
             break
         line.pop(k, None)
@@ -1358,6 +1453,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-prefill", action="store_true")
+    ap.add_argument("--no-batched", action="store_true", help="skip the batch-of-8 decode step (serving seam)")
     ap.add_argument("--no-prefill-long", action="store_true", help="skip the 8192-token prompt chunk (the reference's default chunk_size)")
     ap.add_argument("--no-kernels", action="store_true", help="skip the per-kernel table / roofline")
     ap.add_argument("--no-pmc", action="store_true", help="skip the rocprofv3 --pmc child passes (roofline.traffic = null)")
@@ -1511,6 +1607,15 @@ def main():
                     "the in-graph kernel time of one MoE layer when the per-kernel table is present, else step time / layers",
             "layers": wl["full_layers"]}
 
+    bs8 = None
+    if not dist_on and not args.no_batched:
+        t_sec = time.perf_counter()
+        try:
+            bs8 = batched_decode(mr, 8, args.ctx, 50, 10, dev)
+        except Exception as e:
+            bs8 = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+            torch.cuda.synchronize(dev)
+        lap("bs8", t_sec)
     prefill = prefill_long = None
     if not dist_on and not args.no_prefill:
         # ---------------- prefill: one prompt chunk through the same resident model -----------------------------------------
@@ -1538,6 +1643,8 @@ def main():
     del mr
     gc.collect()
     torch.cuda.empty_cache()
+    if bs8 is not None:
+        out["bs8"] = bs8
     if prefill is not None:
         out["prefill"] = prefill
     if prefill_long is not None:
@@ -1621,6 +1728,12 @@ def main():
                             r2["cpu_llamafile"] = llamafile_cpu_leg(w2)
                     else:
                         r2, m2 = run_model_decode(name, args, dev, n2, 10)
+                        if not args.no_batched:
+                            try:
+                                r2["bs8"] = batched_decode(m2, 8, args.ctx, 30, 5, dev)
+                            except Exception as e:
+                                r2["bs8"] = {"value": None, "error": f"{type(e).__name__}: {e}"[:300]}
+                                torch.cuda.synchronize(dev)
                         if not args.no_prefill:
                             try:   # the same resident model, one prompt chunk (no per-launch pass: the headline workload carries that table)
                                 r2["prefill"] = whole_model_prefill(m2, args.prefill_tokens, dev, reps=1, per_kernel_pass=True)

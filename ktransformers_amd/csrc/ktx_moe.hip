@@ -3728,7 +3728,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   GgGemmParams g1{};
   g1.w0 = h->gate_w; g1.w1 = h->up_w; g1.stride0 = h->gg_stride[0]; g1.stride1 = h->gg_stride[1]; g1.N = I; g1.K = H;
   g1.act_q = ws->x_q; g1.act_d = ws->x_d; g1.act_bs = ws->x_bs; g1.act_bsp = x_bsp; g1.act_b256 = x_b256; g1.row_src = ws->src_of_row; g1.tiles = ws->tiles;
-  g1.counters = ws->counters; g1.out = reinterpret_cast<float*>(ws->a_buf);
+  g1.counters = ws->counters; g1.out = reinterpret_cast<float*>(ws->a_buf); g1.dbg = g_dbg[24];
   int rc;
   {
     ProfScope ps(1, st);
@@ -3744,7 +3744,7 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   GgGemmParams g2{};
   g2.w0 = h->down_w; g2.w1 = nullptr; g2.stride0 = h->gg_stride[2]; g2.stride1 = 0; g2.N = H; g2.K = I;
   g2.act_q = ws->a_q; g2.act_d = ws->a_d; g2.act_bs = ws->a_bs; g2.act_bsp = a_bsp; g2.act_b256 = a_b256; g2.row_src = nullptr; g2.tiles = ws->tiles;
-  g2.counters = ws->counters; g2.out = reinterpret_cast<float*>(ws->dn_buf);
+  g2.counters = ws->counters; g2.out = reinterpret_cast<float*>(ws->dn_buf); g2.dbg = g_dbg[24];
   {
     ProfScope ps(3, st);
     rc = launch_gguf_type<false>(h->gg_type[2], mt, g2, max_tiles, st);
