@@ -3525,16 +3525,7 @@ static int launch_gguf(const GgGemmParams& p, int max_tiles, hipStream_t st) {
   if constexpr (gg_foldable(WT)) {   // round 6: the folded-operand kernel; dev knob [21] = 1: gg_block's (the bit-identity test, A/B timing)
     if (g_dbg[21] != 1) {
       const size_t lds_f = 2 * TOK * 256 + 2 * TOK * 4 + TOK * 4 + (WT == GG_Q4K ? 2 * TOK * 16 : WT == GG_IQ1S ? 2 * TOK * 4 + 16384 : 0);
-      if constexpr (GATE_UP && MT == 8) {
-        if (g_dbg[23] == 1) {   // dev knob [23] = 1: gate and up strips on separate wavefronts (8 per workgroup) — measured slower, kept for A/B
-          auto kern = moe_gguf_fold_kernel<WT, MT, true, true>;
-          KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds_f));
-          hipLaunchKernelGGL(kern, grid_f, dim3(512), lds_f, st, p);
-          KTX_HIP(hipGetLastError());
-          return 0;
-        }
-      }
-      auto kern = moe_gguf_fold_kernel<WT, MT, GATE_UP, false>;
+      auto kern = moe_gguf_fold_kernel<WT, MT, GATE_UP>;
       if (lds_f > 64 * 1024) KTX_HIP(ktx_set_max_lds(reinterpret_cast<const void*>(kern), (int)lds_f));
       hipLaunchKernelGGL(kern, grid_f, dim3(256), lds_f, st, p);
       KTX_HIP(hipGetLastError());
@@ -3623,7 +3614,9 @@ static int forward_gguf(ktx_moe_s* h, const int32_t* d_bsz, int qlen, int k, con
   int mt = std::min(4, pick_mt(qlen, k, E));
   // round 6: 128-row tiles for the folded Q4_K / Q6_K kernels once an expert sees ~100 rows — the operand folding of a 256-block is
   // paid once per tile and strip, so twice the rows halve its share (dev knob [22]: 1 = 64-row tiles always, 2 = 128-row tiles always)
-  if (gg_foldable(h->gg_type[0]) && gg_foldable(h->gg_type[2]) && g_dbg[21] != 1 && g_dbg[22] != 1 &&
+  if (gg_foldable(h->gg_type[0]) && gg_foldable(h->gg_type[2]) && h->gg_type[0] != GG_IQ1S && h->gg_type[2] != GG_IQ1S &&   // (IQ1_S: its 16 KiB
+      // grid table beside two 32 KiB stages leaves ONE workgroup per CU — measured 1.6x slower than 64-row tiles)
+      g_dbg[21] != 1 && g_dbg[22] != 1 &&
       (g_dbg[22] == 2 || (double)npairs / std::max(1, E) >= 96.0))
     mt = 8;
   const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
