@@ -607,11 +607,6 @@ __global__ __launch_bounds__(512) void moe_gemm_stream_kernel(GemmParams p, int 
     s_ad[tid] = ad;
   }
 
-  v4i acc[NJ][MT];
-#pragma unroll
-  for (int j = 0; j < NJ; j++)
-#pragma unroll
-    for (int t = 0; t < MT; t++) acc[j][t] = v4i{0, 0, 0, 0};
   // B fragment of k-step s (within the chunk), half hh, token tile t: column s*8 + kc*2 + hh, token t*16 + (lane&15).
   // LDS address of (col, tok) = col*CS + ((tok ^ f(col)) << 4), f(col) = (col & 3) | (col & 4 ? 12 : 0): ds_read_b128 is
   // served in the lane groups {0-3,12-15,20-27}, {4-11,16-19,28-31}, ... over a 256-byte bank row — f keeps the token sets
@@ -623,36 +618,51 @@ __global__ __launch_bounds__(512) void moe_gemm_stream_kernel(GemmParams p, int 
   const uint8_t* bb1 = xs + (size_t)(kc * 2 + 1) * CS + (((lane & 15) ^ (fsw | 1)) << 4);
   const bool wave_ok = strip0 < nstrips;  // wave-uniform
 
+  v4i acc[NJ][MT];
+#pragma unroll
+  for (int j = 0; j < NJ; j++)
+#pragma unroll
+    for (int t = 0; t < MT; t++) acc[j][t] = v4i{0, 0, 0, 0};
   for (int c0 = 0; c0 < NKS; c0 += KSC) {
     const int c1 = c0 + KSC < NKS ? c0 + KSC : NKS;
     const int ncol = (c1 - c0) * 8;
     __syncthreads();  // previous chunk fully consumed (and s_src visible on the first pass)
-    // ---- stage the chunk: thread -> (row, 16-byte column); 4 loads in flight per thread before the LDS writes
-    // (unconditional loads from a clamped row + an explicit vmcnt(0): every path into the k loop then has no load pending,
-    // which lets the compiler's waitcnt pass keep the ring's vmcnt(12..15) waits exact)
-    const int niter = (TOK * ncol) / 512;  // = k-steps of the chunk (TOK = 64)
-    auto stage = [&](auto uc, int it) {
+    // ---- stage the chunk: wavefront -> rows wave, wave + 8, ...; lane -> the row's 16-byte columns lane, lane + 64 (2 KB of one
+    // row per pass: coalesced, and NO integer division — the round-1..5 mapping idx -> (idx / ncol, idx % ncol) spent as many
+    // VALU instructions as the whole k loop: 4.5 VALU per MFMA in profiles/r06_w_pmc_stream8192.txt; the launch time did not
+    // move).  4 rows = 8 loads in flight per thread before the LDS writes.
+    // (unconditional loads from clamped rows / columns + an explicit vmcnt(0): every path into the k loop then has no load
+    // pending, which lets the compiler's waitcnt pass keep the ring's vmcnt(12..15) waits exact)
+    auto stage = [&](auto uc, int r0) {
       constexpr int U = decltype(uc)::value;
-      uint4 v[U];
-      int off[U];
+      uint4 v[U][2];
+      int off[U][2];
       bool live[U];
 #pragma unroll
       for (int u = 0; u < U; u++) {
-        const int idx = tid + (it + u) * 512;
-        const int row = idx / ncol, col = idx - row * ncol;
+        const int row = r0 + u * 8;
         const int src = s_src[row];
         live[u] = src >= 0;
-        off[u] = col * CS + (((row & ~15) | ((row & 15) ^ ((col & 3) | ((col & 4) ? 12 : 0)))) << 4);
-        v[u] = *reinterpret_cast<const uint4*>(p.act_q + (size_t)(src >= 0 ? src : 0) * p.K + (size_t)c0 * 128 + col * 16);
+        const int8_t* rp = p.act_q + (size_t)(src >= 0 ? src : 0) * p.K + (size_t)c0 * 128;
+#pragma unroll
+        for (int h = 0; h < 2; h++) {
+          const int col = lane + h * 64 < ncol ? lane + h * 64 : ncol - 1;
+          off[u][h] = col * CS + (((row & ~15) | ((row & 15) ^ ((col & 3) | ((col & 4) ? 12 : 0)))) << 4);
+          v[u][h] = *reinterpret_cast<const uint4*>(rp + col * 16);
+        }
       }
 #pragma unroll
       for (int u = 0; u < U; u++)
-        *reinterpret_cast<uint4*>(xs + off[u]) = live[u] ? v[u] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+        for (int h = 0; h < 2; h++)
+          if (lane + h * 64 < ncol) *reinterpret_cast<uint4*>(xs + off[u][h]) = live[u] ? v[u][h] : make_uint4(0, 0, 0, 0);
     };
-    int it = 0;
-    for (; it + 8 <= niter; it += 8) stage(std::integral_constant<int, 8>{}, it);
-    for (; it + 4 <= niter; it += 4) stage(std::integral_constant<int, 4>{}, it);
-    for (; it < niter; it++) stage(std::integral_constant<int, 1>{}, it);
+    static_assert(TOK % 16 == 0, "rows per wavefront");
+    {                                  // (kch <= 2048: at most two 64-column passes per row)
+      int r0 = wave;
+      for (; r0 + 24 < TOK; r0 += 32) stage(std::integral_constant<int, 4>{}, r0);
+      for (; r0 < TOK; r0 += 16) stage(std::integral_constant<int, 2>{}, r0);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);  // vmcnt(0)
     __syncthreads();
     if (wave_ok) {
@@ -3169,10 +3179,10 @@ static int moe_forward_impl(ktx_moe_t h, const int32_t* d_bsz, int qlen, int k, 
   const bool use_rt = mt == 4 && g_dbg[4] == 3;   // register-tile kernels (256-row tiles): parity-tested, not yet timed
   if (use_rt) mt = 16;
   const int npairs = qlen * k;
-  const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
   // 64-row tiles (prompts) of large expert matrices take the streaming kernels: measured 1.35x (gate/up) - 1.55x (down) on
   // DeepSeek-V3-shaped experts (7168 x 2048), a wash on V2-Lite's 2048 x 1408.  Dev knob [4]: 1 = never, 2 = always (tests).
   const bool use_stream = mt == 4 && g_dbg[4] != 1 && (g_dbg[4] == 2 || (size_t)H * I >= ((size_t)4 << 20));
+  const int max_tiles = std::min(npairs, E) + npairs / (16 * mt);
 
   PrepParams pp;
   pp.d_bsz = d_bsz; pp.qlen = qlen; pp.k = k; pp.E = E; pp.expert_begin = h->cfg.expert_begin; pp.H = H;

@@ -36,7 +36,7 @@ for _ in range(a.layers):
         h.load_rawint4(rb(E_, I, H // 2), rb(E_, I, H // 2), rb(E_, H, I // 2), sc(I, H), sc(I, H), sc(H, I))
     hs.append(h)
 x = (torch.randn((T, H), generator=g, device=dev) * 0.5).to(torch.bfloat16)
-ids = torch.stack([torch.randperm(E_, generator=g, device=dev)[:k] for _ in range(T)]).to(torch.int64)
+ids = torch.multinomial(torch.ones(T, E_), k, generator=torch.Generator().manual_seed(1)).to(torch.int64).to(dev)   # (device randperm dies under rocprofv3 --pmc)
 w = torch.rand((T, k), generator=g, device=dev)
 for h in hs:
     h.forward(x, ids, w)
