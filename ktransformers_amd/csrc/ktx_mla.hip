@@ -693,6 +693,7 @@ __device__ __forceinline__ void pf_store_tile(const PfTile& t, bf16_t* Ks, bf16_
 // same bits, and they are the bits the shuffle version produced ((x + shfl16) + shfl32 groups the rows as (r0 + r1) + (r2 + r3) for
 // rows 0 / 1 and likewise here after the 32-swap first: see pf_sum_rows).
 typedef unsigned pf_v2u __attribute__((ext_vector_type(2)));
+typedef float pf_v2f __attribute__((ext_vector_type(2)));
 __device__ __forceinline__ float pf_max_rows(float x) {
   pf_v2u r = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
   x = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
@@ -780,12 +781,14 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
     for (int u = 0; u < NU; u++)
 #pragma unroll
       for (int kt = 0; kt < 4; kt++) st[u][kt] = v4f{0.f, 0.f, 0.f, 0.f};
+    // (k-chunk outermost, round 6: 4 x NU independent accumulators between two MFMAs of one chain — with the key tile outermost
+    // every MFMA waited for its predecessor's 8 passes with only the other query tile's MFMA in between; each accumulator still
+    // sums its six chunks in the same order)
 #pragma unroll
-    for (int kt = 0; kt < 4; kt++) {
-      const bf16_t* kb = Ks + (kt * 16 + qi) * PF_KROW + g * 8;
+    for (int s = 0; s < 6; s++) {
 #pragma unroll
-      for (int s = 0; s < 6; s++) {
-        const v8bf a = as_v8bf(*reinterpret_cast<const uint4*>(kb + s * 32));
+      for (int kt = 0; kt < 4; kt++) {
+        const v8bf a = as_v8bf(*reinterpret_cast<const uint4*>(Ks + (kt * 16 + qi) * PF_KROW + g * 8 + s * 32));
 #pragma unroll
         for (int u = 0; u < NU; u++) st[u][kt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[u][s], st[u][kt], 0, 0, 0);
       }
@@ -795,49 +798,61 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
     // (wave-uniform test) skips the 32 compares + selects, and the 64 multiplies of `o *= alpha` are skipped whenever no lane's running
     // maximum moved (alpha == 1 exactly: the common case once the first tiles are past).  Same bits either way.
     const bool tile_full = !p.no_skip && j0 + PF_BN - 1 <= min(pos_off + min(q0, p.T - 1), p.kv_len - 1);
+    // Round 6 (the kernel was VALU-issue-bound: 5.4 VALU per MFMA): the running maximum is kept on the RAW scores and the softmax
+    // scale rides in the exponent's multiply — p = exp2(s * c - m * c), c = sm_scale * log2(e): one packed fma (two scores per
+    // instruction) + v_exp instead of multiply, subtract, multiply, v_exp per score; the row sum is accumulated two scores per
+    // packed add.  sm_scale > 0, so max(s * scale) = scale * max(s): the same softmax to within fp32 rounding of the exponent
+    // (tests: rtol 2^-7 on the bf16 outputs against an fp32 softmax).
+    const float cexp = p.sm_scale * 1.44269504088896340736f;
     uint4 pb[NU][2];
 #pragma unroll
     for (int u = 0; u < NU; u++) {
       const int lim = min(pos_off + tq[u], p.kv_len - 1);       // last visible key of this lane's query
       float mx = -__builtin_inff();
-      if (tile_full) {
+      if (!tile_full) {
+        // (the empty asm keeps this a wave-uniform BRANCH: speculated into selects, its 31 compares + selects ran on every tile)
 #pragma unroll
-        for (int kt = 0; kt < 4; kt++)
-#pragma unroll
-          for (int r = 0; r < 4; r++) {
-            st[u][kt][r] = st[u][kt][r] * p.sm_scale;
-            mx = fmaxf(mx, st[u][kt][r]);
-          }
-      } else {
-#pragma unroll
-        for (int kt = 0; kt < 4; kt++)
+        for (int kt = 0; kt < 4; kt++) {
 #pragma unroll
           for (int r = 0; r < 4; r++) {
             const int key = j0 + kt * 16 + g * 4 + r;
-            st[u][kt][r] = key <= lim ? st[u][kt][r] * p.sm_scale : -__builtin_inff();
-            mx = fmaxf(mx, st[u][kt][r]);
+            st[u][kt][r] = key <= lim ? st[u][kt][r] : -__builtin_inff();
           }
+          asm volatile("" : "+v"(st[u][kt]));
+        }
       }
+#pragma unroll
+      for (int kt = 0; kt < 4; kt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) mx = fmaxf(mx, st[u][kt][r]);
       mx = pf_max_rows(mx);                                     // over the query's four key-chunk lanes (qi, qi + 16, + 32, + 48)
       const float m_new = fmaxf(m_run[u], mx);                  // finite from tile 0 on: key 0 is visible to every query
-      const float alpha = __expf(m_run[u] - m_new);
-      float sum = 0.f;
+      const float alpha = __builtin_amdgcn_exp2f((m_run[u] - m_new) * cexp);
+      const pf_v2f mc = {-m_new * cexp, -m_new * cexp}, cc = {cexp, cexp};
+      pf_v2f sum2 = {0.f, 0.f};
       float pv[4][4];
 #pragma unroll
       for (int kt = 0; kt < 4; kt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) {
-          pv[kt][r] = __expf(st[u][kt][r] - m_new);
-          sum += pv[kt][r];
+        for (int r = 0; r < 4; r += 2) {
+          const pf_v2f e = __builtin_elementwise_fma(pf_v2f{st[u][kt][r], st[u][kt][r + 1]}, cc, mc);
+          pv[kt][r] = __builtin_amdgcn_exp2f(e[0]);
+          pv[kt][r + 1] = __builtin_amdgcn_exp2f(e[1]);
+          sum2 += pf_v2f{pv[kt][r], pv[kt][r + 1]};
         }
-      sum = pf_sum_rows(sum);
+      const float sum = pf_sum_rows(sum2[0] + sum2[1]);
       l_run[u] = l_run[u] * alpha + sum;
       m_run[u] = m_new;
       if (p.no_skip || !__all(alpha == 1.0f)) {
+        const pf_v2f a2 = {alpha, alpha};
 #pragma unroll
         for (int i = 0; i < 8; i++)
 #pragma unroll
-          for (int r = 0; r < 4; r++) o[u][i][r] *= alpha;
+          for (int r = 0; r < 4; r += 2) {
+            const pf_v2f t = pf_v2f{o[u][i][r], o[u][i][r + 1]} * a2;
+            o[u][i][r] = t[0];
+            o[u][i][r + 1] = t[1];
+          }
       }
 #pragma unroll
       for (int ks = 0; ks < 2; ks++)
@@ -846,11 +861,11 @@ __global__ __launch_bounds__(256, MINW) void mla_prefill_kernel(MlaPrefillParams
     }
     // ---- O^T += V^T P^T: o[u][i][r] = O[query qi][dim 16*i + 4*g + r] ----------------------------------------------------
 #pragma unroll
-    for (int i = 0; i < 8; i++) {
-      const bf16_t* vb = Vs + (i * 16 + qi) * PF_VROW + g * 4;
+    for (int ks = 0; ks < 2; ks++) {                  // (key half outermost: 8 x NU independent accumulators, same order per accumulator)
 #pragma unroll
-      for (int ks = 0; ks < 2; ks++) {
-        const uint2 lo = *reinterpret_cast<const uint2*>(vb + ks * 32), hi = *reinterpret_cast<const uint2*>(vb + ks * 32 + 16);
+      for (int i = 0; i < 8; i++) {
+        const bf16_t* vb = Vs + (i * 16 + qi) * PF_VROW + g * 4 + ks * 32;
+        const uint2 lo = *reinterpret_cast<const uint2*>(vb), hi = *reinterpret_cast<const uint2*>(vb + 16);
         const v8bf a = as_v8bf(make_uint4(lo.x, lo.y, hi.x, hi.y));
 #pragma unroll
         for (int u = 0; u < NU; u++) o[u][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, as_v8bf(pb[u][ks]), o[u][i], 0, 0, 0);
