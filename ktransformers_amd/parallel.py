@@ -192,46 +192,76 @@ def ep_decode_forward(local_partial: Callable[[torch.Tensor, torch.Tensor, torch
 
 def ep_prefill_forward(local_rows: Callable[[torch.Tensor, torch.Tensor], torch.Tensor],
                        combine: Callable[[torch.Tensor, torch.Tensor, torch.Tensor], torch.Tensor],
-                       x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, E: int, group=None) -> torch.Tensor:
-    """Prefill / large-T expert parallelism: all-to-all-v dispatch of (token, slot) rows to the rank that
-    owns the slot's expert, local experts, all-to-all-v back, slot-ordered combine at the token's home rank.
+                       x: torch.Tensor, ids: torch.Tensor, w: torch.Tensor, E: int, group=None,
+                       stats: dict | None = None) -> torch.Tensor:
+    """Prefill / large-T expert parallelism: all-to-all-v dispatch of token rows to the ranks that own their
+    slots' experts, local experts, all-to-all-v back of the per-pair outputs, slot-ordered combine at the token's home rank.
 
     x bf16 [T,H], ids int64 [T,k] (global expert ids), w fp32 [T,k] — this rank's tokens; returns bf16 [T,H].
     `local_rows(rows bf16 [n,H], expert_ids int64 [n]) -> bf16 [n,H]` = Expert_id(row) (MoEHandle.forward with k=1 and
     weight 1.0, which returns the expert's bf16 output unchanged); `combine(rows, row_of_pair int32 [T,k], w) -> bf16 [T,H]`
     is the single-GPU combine (ktransformers_amd._native.moe_combine).  Because the per-pair expert outputs and the
     combine are the single-GPU ones, the result is bit-identical to the single-GPU forward (unlike the decode path,
-    whose cross-rank fp32 reduction reorders the sum).  Volume per rank and direction: (#pairs leaving the rank)*H*2 B.
-    The split sizes are read on the host (one small sync): prefill is not graph-captured in the reference either."""
+    whose cross-rank fp32 reduction reorders the sum).
+
+    Dispatch is de-duplicated per destination (round 6): a token whose k slots name several experts of ONE rank crosses the
+    fabric once — the row goes with the (token, destination) pair, the slots travel as 16 bytes of metadata (expert id, index
+    of the row inside the sender's block) and the destination re-expands rows to pairs from its own HBM.  With k = 8 slots dealt
+    uniformly over 8 ranks a token reaches 5.25 distinct ranks on average: 34 % fewer dispatch bytes.  Volume per rank:
+    (#distinct (token, destination) pairs leaving) * H * 2 B out, (#pairs) * H * 2 B back (the outputs differ per pair).
+    The split sizes are read on the host (one small sync): prefill is not graph-captured in the reference either.
+    `stats` (optional dict) receives rows_out / pairs_out / rows_in / pairs_in of this call."""
     world = dist.get_world_size(group)
     T, H = x.shape
     k = ids.shape[1]
     if E % world != 0:
         raise ValueError(f"expert count {E} not divisible by world size {world}")
     per = E // world
+    dev = x.device
     flat = ids.reshape(-1)
     valid = (flat >= 0) & (flat < E)
     dest = torch.where(valid, torch.div(flat, per, rounding_mode="floor"), torch.full_like(flat, world))
-    order = torch.argsort(dest, stable=True)
-    send_counts_t = torch.bincount(dest, minlength=world + 1)[:world]
+    tok = torch.div(torch.arange(T * k, device=dev), k, rounding_mode="floor")
+    key = dest * T + tok                                            # destination-major, token-minor; stable: slot order kept
+    order = torch.argsort(key, stable=True)
+    pair_counts_t = torch.bincount(dest, minlength=world + 1)[:world]
+    n_send = int(pair_counts_t.sum())
+    sel = order[:n_send]                                            # the valid pairs, grouped by destination then token
+    sk = key[sel]
+    first = torch.ones(n_send, dtype=torch.bool, device=dev)
+    first[1:] = sk[1:] != sk[:-1]
+    urow = torch.cumsum(first.to(torch.int64), 0) - 1               # pair -> its row among the distinct (destination, token) rows
+    ukey = sk[first]
+    u_dest, u_tok = torch.div(ukey, T, rounding_mode="floor"), ukey % T
+    row_counts_t = torch.bincount(u_dest, minlength=world)[:world] if n_send else torch.zeros(world, dtype=torch.int64, device=dev)
+    row_off = torch.cumsum(row_counts_t, 0) - row_counts_t
+    send_counts_t = torch.stack([row_counts_t, pair_counts_t], dim=1).contiguous()      # [world, 2]
     recv_counts_t = torch.empty_like(send_counts_t)
     dist.all_to_all_single(recv_counts_t, send_counts_t, group=group)
-    send_counts, recv_counts = send_counts_t.tolist(), recv_counts_t.tolist()
-    n_send, n_recv = sum(send_counts), sum(recv_counts)
-    sel = order[:n_send]
-    send_x = x[torch.div(sel, k, rounding_mode="floor")].contiguous()
-    send_ids = flat[sel].contiguous()
-    recv_x = torch.empty((n_recv, H), dtype=x.dtype, device=x.device)
-    recv_ids = torch.empty((n_recv,), dtype=flat.dtype, device=x.device)
-    dist.all_to_all_single(recv_x, send_x, recv_counts, send_counts, group=group)
-    dist.all_to_all_single(recv_ids, send_ids, recv_counts, send_counts, group=group)
-    out_rows = local_rows(recv_x, recv_ids) if n_recv else recv_x
-    back = torch.empty((n_send, H), dtype=x.dtype, device=x.device)
-    dist.all_to_all_single(back, out_rows.contiguous(), send_counts, recv_counts, group=group)
-    row_of_pair = torch.full((T * k,), -1, dtype=torch.int32, device=x.device)
-    row_of_pair[sel] = torch.arange(n_send, dtype=torch.int32, device=x.device)
+    send_rows, send_pairs = send_counts_t[:, 0].tolist(), send_counts_t[:, 1].tolist()
+    recv_rows, recv_pairs = recv_counts_t[:, 0].tolist(), recv_counts_t[:, 1].tolist()
+    n_rows_out, n_rows_in, n_recv = sum(send_rows), sum(recv_rows), sum(recv_pairs)
+    if stats is not None:
+        stats.update(rows_out=n_rows_out, pairs_out=n_send, rows_in=n_rows_in, pairs_in=n_recv)
+    send_x = x[u_tok].contiguous()
+    meta = torch.stack([flat[sel], urow - row_off[dest[sel]]], dim=1).contiguous()      # (expert id, row inside this rank's block)
+    recv_x = torch.empty((n_rows_in, H), dtype=x.dtype, device=dev)
+    recv_meta = torch.empty((n_recv, 2), dtype=meta.dtype, device=dev)
+    dist.all_to_all_single(recv_x, send_x, recv_rows, send_rows, group=group)
+    dist.all_to_all_single(recv_meta, meta, recv_pairs, send_pairs, group=group)
+    if n_recv:
+        rr = recv_counts_t[:, 0]
+        src = torch.repeat_interleave(torch.arange(world, device=dev), recv_counts_t[:, 1])
+        rows_of_pairs = recv_x[recv_meta[:, 1] + (torch.cumsum(rr, 0) - rr)[src]]
+        out_rows = local_rows(rows_of_pairs, recv_meta[:, 0].contiguous())
+    else:
+        out_rows = recv_x[:0]
+    back = torch.empty((n_send, H), dtype=x.dtype, device=dev)
+    dist.all_to_all_single(back, out_rows.contiguous(), send_pairs, recv_pairs, group=group)
+    row_of_pair = torch.full((T * k,), -1, dtype=torch.int32, device=dev)
+    row_of_pair[sel] = torch.arange(n_send, dtype=torch.int32, device=dev)
     if n_send == 0:
-        back = torch.zeros((1, H), dtype=x.dtype, device=x.device)
+        back = torch.zeros((1, H), dtype=x.dtype, device=dev)
     return combine(back, row_of_pair.view(T, k), w)
 
 

@@ -200,9 +200,16 @@ def _prefill_worker(rank, world, port, q):
     off = sum(5 + r for r in range(rank))
     sl = slice(off, off + Tl)
     x = torch.from_numpy(c["x"][sl].view(np.int16).copy()).view(torch.bfloat16)
-    y = ep_prefill_forward(local_rows, combine, x, torch.from_numpy(c["ids"][sl]), torch.from_numpy(c["w"][sl]), E)
+    st = {}
+    y = ep_prefill_forward(local_rows, combine, x, torch.from_numpy(c["ids"][sl]), torch.from_numpy(c["w"][sl]), E, stats=st)
     full = o.moe_forward(moe, c["ids"], c["w"], c["x"])
-    q.put((rank, y.view(torch.int16).numpy().view(np.uint16).copy(), full[sl].copy(), sum(seen)))
+    # de-duplicated dispatch: one row per distinct (token, destination rank), counted independently here
+    ids_l = c["ids"][sl]
+    want_rows = sum(len({int(e) // cnt for e in row if 0 <= e < E}) for row in ids_l)
+    want_pairs = int(((ids_l >= 0) & (ids_l < E)).sum())
+    assert (st["rows_out"], st["pairs_out"]) == (want_rows, want_pairs), (st, want_rows, want_pairs)
+    assert st["pairs_in"] == sum(seen)
+    q.put((rank, y.view(torch.int16).numpy().view(np.uint16).copy(), full[sl].copy(), sum(seen), st["rows_out"], st["pairs_out"]))
     dist.destroy_process_group()
 
 
@@ -218,8 +225,11 @@ def test_expert_parallel_prefill_all_to_all_is_bit_identical(world):
     for p in procs:
         p.join(timeout=60)
         assert p.exitcode == 0
-    rows = 0
-    for rank, got, want, n in res:
+    rows = sent_rows = sent_pairs = 0
+    for rank, got, want, n, ro, po in res:
         assert np.array_equal(got, want), f"rank {rank}: {(got != want).sum()} elements differ"
         rows += n
-    assert rows > 0
+        sent_rows += ro
+        sent_pairs += po
+    assert rows > 0 and rows == sent_pairs
+    assert sent_rows < sent_pairs, "the seeded routing has tokens naming two experts of one rank: their row must travel once"
