@@ -488,14 +488,18 @@ extern "C" int ktx_mla_decode_partials(const ktx_mla_config* cfg, const void* d_
 
 // Workgroup shape and KV split count of a decode call — one place, because the one-launch decode step (ktx_attn.hip) must
 // split the context exactly as the stand-alone kernel does to reproduce its partials bit for bit.
-static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes, int* shape_out, int* nsplit_out) {
+static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes, int* shape_out, int* nsplit_out,
+                           bool one_launch = false) {
   const int Hq = cfg->num_heads;
   // workgroup shape (head blocks x dim slices): decode-sized calls of many-headed models take 2x4 (32 heads share one staged
   // KV tile, 128 output dims per wave), prompts of those models 4x2, everything else 1x4
   const bool decode_sized = total_q_tokens <= 16;
   // long contexts (many tiles per split): 64 heads per workgroup share each staged tile and twice the splits pay off — measured
   // at 128 heads / 128K tokens (scripts/mla_sweep.py --ctx 131072): 4x2 with 128 splits 103 us, 2x4 with 64 splits 157 us
-  const bool long_ctx = decode_sized && cfg->kv_len_hint >= 8192 && Hq % 64 == 0;
+  // (one_launch: the split rule of csrc/ktx_attn.hip's phase C, which is built on the 2x4 shape — it keeps that shape, with its
+  // <= 256 / head-blocks splits, past 8192 tokens: deeper splits instead of the 4x2 shape's wider ones)
+  const bool long_hint = decode_sized && cfg->kv_len_hint >= 8192 && Hq % 64 == 0;
+  const bool long_ctx = long_hint && !one_launch;
   int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized && !long_ctx) ? 2 : (Hq % 64 == 0) ? 4 : 1;
   {   // tuning knobs (scripts/mla_sweep.py): 6 = force the workgroup shape, 7 = force the split count
     const int fs = ktx_debug_get(6);
@@ -510,8 +514,8 @@ static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t
   // capped where the partials reach ~16 MB and at about one workgroup per CU
   int nsplit = std::max(1, 2048 / std::max(1, hblocks * total_q_tokens));
   const size_t per_split_bytes = (size_t)total_q_tokens * Hq * (MLA_DC + 2) * sizeof(float);
-  nsplit = std::min<int>(nsplit, std::max<size_t>(16, ((size_t)(long_ctx ? 34 : 16) << 20) / per_split_bytes));
-  if (long_ctx) nsplit = std::min(nsplit, 128);
+  nsplit = std::min<int>(nsplit, std::max<size_t>(16, ((size_t)(long_hint ? 34 : 16) << 20) / per_split_bytes));
+  if (long_hint) nsplit = std::min(nsplit, 128);
   if (shape == 2) nsplit = std::min(nsplit, std::max(16, 256 / std::max(1, hblocks * total_q_tokens)));
   if (ktx_debug_get(7) > 0) nsplit = ktx_debug_get(7);
   if (cfg->kv_len_hint > 0) {
@@ -532,7 +536,10 @@ static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t
 extern "C" int ktx_mla_decode_nsplit(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes) {   // ktx_internal.h
   int shape = 0, nsplit = 0;
   if (!cfg || total_q_tokens <= 0) return 0;
-  mla_pick_shape(cfg, total_q_tokens, workspace_bytes, &shape, &nsplit);
+  // Up to 12 K tokens the one launch wins with deeper 2x4 splits (profiles/r06_y_attn_fused_long_ctx.txt, fast box: 65.9 vs 67.0 us
+  // per layer at 8192); from 16 K on the five launches with the 4x2 shape's 128 splits are faster (74.8 vs 72.9, 97.8 vs 85.0 at 32 K).
+  if (cfg->kv_len_hint >= 12288) return 0;
+  mla_pick_shape(cfg, total_q_tokens, workspace_bytes, &shape, &nsplit, true);
   return shape == 2 ? nsplit : 0;   // the one-launch step is built on the 2x4 workgroup shape only
 }
 

@@ -313,8 +313,33 @@ def test_eligibility_follows_the_context_bound(layer):
     c = _case(layer, 100, 160, False)
     y = torch.empty((1, HIDDEN), dtype=torch.bfloat16, device=layer["dev"])
     short = _args(layer, c, c["cache"], y.reshape(-1), hint=612)
-    long_ = _args(layer, c, c["cache"], y.reshape(-1), hint=8704)
-    assert attn_decode_eligible(short) and not attn_decode_eligible(long_) and attn_decode_eligible(short)
+    mid = _args(layer, c, c["cache"], y.reshape(-1), hint=8704)         # round 6: covered with deeper 2x4 splits up to 12 K tokens
+    long_ = _args(layer, c, c["cache"], y.reshape(-1), hint=16384)
+    assert attn_decode_eligible(short) and attn_decode_eligible(mid) and not attn_decode_eligible(long_) and attn_decode_eligible(short)
+
+
+def test_one_launch_past_8192_tokens(layer):
+    """Round 6: between 8192 and 12288 tokens the launch keeps the 2x4 workgroup shape (<= 64 splits, several tiles per split) where
+    the stand-alone kernel switches to 4x2 — so the five-launch reference is pinned to the 2x4 shape (dev knob 6 = 2) and then every
+    intermediate is bit-identical again."""
+    from ktransformers_amd import _native
+    from ktransformers_amd._native import attn_decode, attn_decode_eligible
+
+    ctx, pages = 8500, 144
+    c = _case(layer, ctx, pages, False)
+    cache_ref, cache_new = c["cache"].clone(), c["cache"].clone()
+    _native.check(_native.lib.ktx_debug_set(6, 2))
+    try:
+        ref = _five_launches(layer, c, cache_ref)
+    finally:
+        _native.check(_native.lib.ktx_debug_set(6, 0))
+    y = torch.empty((1, HIDDEN), dtype=torch.bfloat16, device=layer["dev"])
+    a = _args(layer, c, cache_new, y.reshape(-1), hint=ref["hint"])
+    assert attn_decode_eligible(a)
+    attn_decode(a, layer["dev"])
+    torch.cuda.synchronize()
+    _compare(layer, ref, y, f"one launch, ctx {ctx}")
+    assert torch.equal(cache_new.view(torch.int16), cache_ref.view(torch.int16)), "the new token's cache row differs"
 
 
 def test_two_streams_decode_on_one_device(layer):
