@@ -1261,11 +1261,13 @@ __device__ __forceinline__ v8bf u4_as_v8bf(const uint4& u) {
 // 4 e4m3 bytes -> 4 bf16 (two dwords): v_cvt_pk_f32_fp8 is exact, and every e4m3 value is exact in bf16, so taking the
 // upper halves of the fp32 results is exact (OCP e4m3fn on gfx950; 0x7F/0xFF are NaN here, +-480 in the reference's LUT).
 __device__ __forceinline__ uint2 fp8x4_to_bf16x4(uint32_t v) {
-  typedef float v2f __attribute__((ext_vector_type(2)));
-  const v2f lo = __builtin_amdgcn_cvt_pk_f32_fp8(v, false);
-  const v2f hi = __builtin_amdgcn_cvt_pk_f32_fp8(v, true);
-  const uint32_t a = __float_as_uint(lo[0]), b = __float_as_uint(lo[1]), c = __float_as_uint(hi[0]), d = __float_as_uint(hi[1]);
-  return make_uint2((a >> 16) | (b & 0xffff0000u), (c >> 16) | (d & 0xffff0000u));
+  // gfx950: v_cvt_scalef32_pk_bf16_fp8 converts two e4m3 bytes straight to two bf16 (scale 1.0): 2 VALU instructions per four weights
+  // instead of two converts + two packs (scripts/fp8_cvt_probe.hip: the same bits as the two-step path for all 256 codes)
+  typedef __bf16 bf2 __attribute__((ext_vector_type(2)));
+  union { bf2 v; uint32_t u; } lo, hi;
+  lo.v = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, false);
+  hi.v = __builtin_amdgcn_cvt_scalef32_pk_bf16_fp8(v, 1.0f, true);
+  return make_uint2(lo.u, hi.u);
 }
 
 struct FpGemmParams {
