@@ -89,6 +89,7 @@ struct LinParams {
   const bf16_t* x;      // [T][Kx]
   bf16_t* y;            // [T][N]
   const int32_t* d_bsz;
+  int bsz_off;          // rows of the caller's batch in front of this launch's first row (4-row passes of a 5..8-row call)
   int T, N, Kx, NKS, nstrips;
   int TP, SW, SPS;      // decode kernel: token slots (1/2/4), strips per workgroup, k-steps per k-slice
   long ldx, ldy;        // row strides of x / y in elements
@@ -309,7 +310,7 @@ __device__ __forceinline__ void lin_dec_body(LinParams& p, const int bx, const i
   const int strip = strip_ok ? strip_raw : p.nstrips - 1;   // a surplus wave streams a valid strip and stores nothing
   const int ks0 = sl * p.SPS, ks1 = EXACT ? ks0 + p.SPS : (strip_ok ? min(ks0 + p.SPS, NKS) : ks0);
   int bsz = p.T;
-  if (p.d_bsz) bsz = min(max(*p.d_bsz, 0), p.T);
+  if (p.d_bsz) bsz = min(max(*p.d_bsz - p.bsz_off, 0), p.T);
 
   // ---- the activation rows first (vmcnt retires in order and they are needed first): up to XPRE 16-byte pieces per
   // thread go to registers now, the (rare) rest of a long multi-token block is fetched in the staging loops below.
@@ -941,7 +942,7 @@ __global__ __launch_bounds__(256) void lin_gemm_kernel(LinParams p) {
   const int NKS = p.NKS, NC = (NKS + SPC - 1) / SPC;
   const bool strip_ok = strip < p.nstrips;
   int bsz = p.T;
-  if (p.d_bsz) bsz = min(max(*p.d_bsz, 0), p.T);
+  if (p.d_bsz) bsz = min(max(*p.d_bsz - p.bsz_off, 0), p.T);
   if (row0 >= bsz) return;
 
   const uint8_t* wp = p.w + (size_t)strip * NKS * F::TILE + lane * 16;
@@ -1087,7 +1088,7 @@ __global__ __launch_bounds__(256) void lin_gemm_w4n_kernel(LinParams p) {
   const int row0 = blockIdx.y * TOK;
   const int NKS = p.NKS, NC = (NKS + SPC - 1) / SPC;
   int bsz = p.T;
-  if (p.d_bsz) bsz = min(max(*p.d_bsz, 0), p.T);
+  if (p.d_bsz) bsz = min(max(*p.d_bsz - p.bsz_off, 0), p.T);
   if (row0 >= bsz) return;
 
   // a strip past the end streams the last strip again and stores nothing (keeps the loop free of per-strip branches)
@@ -2039,13 +2040,37 @@ extern "C" int ktx_debug_set_ptr(int idx, void* p) {
 
 static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, const void* d_x, long ldx, long xbs, void* d_y,
                                long ldy, long ybs, ktx_stream_t stream, const ktx_linear_fusion* fu = nullptr,
-                               const MlaPrepParams* prep = nullptr, const GateArgs* gate = nullptr) {
+                               const MlaPrepParams* prep = nullptr, const GateArgs* gate = nullptr, int bsz_off = 0) {
   KTX_REQUIRE(h && d_x && d_y, "ktx_linear_forward: null argument");
   KTX_REQUIRE(h->loaded, "ktx_linear_forward: weights not loaded");
   KTX_REQUIRE(T >= 0 && T <= h->cfg.max_len, "ktx_linear_forward: T exceeds max_len");
   KTX_REQUIRE(ldx % 8 == 0 && xbs % 8 == 0, "ktx_linear_forward: x strides must be multiples of 8 elements (16-byte loads)");
   if (T == 0) return 0;
+  // Round 6, small batches (5..8 rows: a batch-of-8 serving step): the strip kernel below deals 16-row strips to wavefronts and walks K
+  // serially — 41.8 us per linear at T = 8 in profiles/r06_final_bench_kernel_stats.csv, 11x the weights' stream time.  The decode
+  // GEMV (stream-K over all CUs, register rings) takes <= 4 rows, so such a call runs as 4-row passes of it: the weights are
+  // streamed once per pass at the decode kernels' rate, every row gets the decode kernel's arithmetic.  Dev knob 3: 1 = off,
+  // n >= 5 = up to n rows.
+  {
+    const int knob = ktx_debug_get(3), tmax = knob >= 5 ? knob : 8;
+    if (T > 4 && T <= tmax && knob != 1 && !prep && !gate && h->batch == 1 && dec_fits(h, 4) && !(fu && fu->norm_weight)) {
+      for (int t0 = 0; t0 < T; t0 += 4) {
+        ktx_linear_fusion f2{};
+        if (fu) {
+          f2 = *fu;
+          const long l1 = fu->add1_ld ? fu->add1_ld : h->cfg.out_features, l2 = fu->add2_ld ? fu->add2_ld : h->cfg.out_features;
+          if (f2.add1) f2.add1 = (const bf16_t*)fu->add1 + (size_t)t0 * l1;
+          if (f2.add2) f2.add2 = (const bf16_t*)fu->add2 + (size_t)t0 * l2;
+        }
+        const int rc = linear_forward_impl(h, d_bsz, std::min(4, T - t0), (const bf16_t*)d_x + (size_t)t0 * ldx, ldx, xbs,
+                                           (bf16_t*)d_y + (size_t)t0 * ldy, ldy, ybs, stream, fu ? &f2 : nullptr, nullptr, nullptr, bsz_off + t0);
+        if (rc) return rc;
+      }
+      return 0;
+    }
+  }
   LinParams p{};
+  p.bsz_off = bsz_off;
   p.w = h->d_w; p.sc = h->d_sc; p.bias = h->d_bias;
   p.x = (const bf16_t*)d_x; p.y = (bf16_t*)d_y; p.d_bsz = d_bsz;
   p.T = T; p.N = h->cfg.out_features; p.Kx = h->cfg.in_features; p.NKS = h->NKS; p.nstrips = h->nstrips;
