@@ -2016,7 +2016,11 @@ extern "C" int ktx_linear_load_fp8(ktx_linear_t h, const void* d_w, const float*
 }
 
 namespace { bool dec_fits(const ktx_linear_s* h, int T); }
-static bool dec_eligible(const ktx_linear_s* h, int T) { return dec_fits(h, T); }
+static bool dec_passes(const ktx_linear_s* h, int T) {   // 5..8 rows as 4-row passes of the decode kernel (linear_forward_impl)
+  const int knob = ktx_debug_get(3), tmax = knob >= 5 ? knob : 8;
+  return T > 4 && T <= tmax && knob != 1 && h->batch == 1 && dec_fits(h, 4);
+}
+static bool dec_eligible(const ktx_linear_s* h, int T) { return dec_fits(h, T) || dec_passes(h, T); }
 namespace {
 bool dec_fits(const ktx_linear_s* h, int T) {
   const int ncol16 = h->cfg.format == KTX_LIN_FP8 ? h->NKS * 8 : h->NKS * 16;
@@ -2052,8 +2056,7 @@ static int linear_forward_impl(ktx_linear_t h, const int32_t* d_bsz, int T, cons
   // streamed once per pass at the decode kernels' rate, every row gets the decode kernel's arithmetic.  Dev knob 3: 1 = off,
   // n >= 5 = up to n rows.
   {
-    const int knob = ktx_debug_get(3), tmax = knob >= 5 ? knob : 8;
-    if (T > 4 && T <= tmax && knob != 1 && !prep && !gate && h->batch == 1 && dec_fits(h, 4) && !(fu && fu->norm_weight)) {
+    if (!prep && !gate && dec_passes(h, T)) {   // (the fused RMSNorm / glu_in prologues are per row: every pass applies them to its rows)
       for (int t0 = 0; t0 < T; t0 += 4) {
         ktx_linear_fusion f2{};
         if (fu) {
