@@ -1146,11 +1146,17 @@ def batched_decode(mr, B, ctx, steps, warmup, dev):
     tokens = torch.randint(0, cfg.vocab_size, (B,), generator=g, device=dev)
 
     def step():
-        h = model.model.embed_tokens(tokens)                                             # [B, hidden]
+        # the layer loop of the reference's serving model (custom_modeling_deepseek_v3.py:93-129): a zero residual, every norm is
+        # flashinfer's fused_add_rmsnorm (residual += h; h = norm(residual)) — one launch where `h + f(norm(h))` is three
+        h = model.model.embed_tokens(tokens).contiguous()                                # [B, hidden]
+        res = torch.zeros_like(h)
         for layer in model.model.layers:
-            h = h + flashinfer_attn.forward(layer.self_attn, layer.input_layernorm(h), kv, pos, wrapper, bsz, page_idx, page_off)
-            h = h + layer.mlp(layer.post_attention_layernorm(h).unsqueeze(0)).squeeze(0)
-        logits = model.lm_head(model.model.norm(h))
+            h, res = layer.input_layernorm(h, bsz, res)
+            h = flashinfer_attn.forward(layer.self_attn, h, kv, pos, wrapper, bsz, page_idx, page_off).contiguous()
+            h, res = layer.post_attention_layernorm(h, bsz, res)
+            h = layer.mlp(h.unsqueeze(0)).squeeze(0).contiguous()
+        h, res = model.model.norm(h, bsz, res)
+        logits = model.lm_head(h)
         tokens.copy_(argmax_bf16(logits) if logits.dtype == torch.bfloat16 else logits.float().argmax(dim=-1))
 
     with torch.no_grad():

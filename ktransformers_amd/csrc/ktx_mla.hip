@@ -500,7 +500,11 @@ static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t
   // <= 256 / head-blocks splits, past 8192 tokens: deeper splits instead of the 4x2 shape's wider ones)
   const bool long_hint = decode_sized && cfg->kv_len_hint >= 8192 && Hq % 64 == 0;
   const bool long_ctx = long_hint && !one_launch;
-  int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized && !long_ctx) ? 2 : (Hq % 64 == 0) ? 4 : 1;
+  // a decode BATCH (>= 8 query tokens, each with its own context): every head block of a token re-reads that token's latent rows, so
+  // 64 heads per workgroup halve the KV traffic (V3 dims, 8 x 4096 tokens: 150 -> 75 MB per layer; batch-of-8 step 14.47 -> 13.91 ms,
+  // profiles/r06_zz_bs8_mla_shape.txt)
+  const bool batched = decode_sized && total_q_tokens >= 8 && Hq % 64 == 0 && !one_launch;
+  int shape = (Hq % 32 == 0 && Hq >= 64 && decode_sized && !long_ctx && !batched) ? 2 : (Hq % 64 == 0) ? 4 : 1;
   {   // tuning knobs (scripts/mla_sweep.py): 6 = force the workgroup shape, 7 = force the split count
     const int fs = ktx_debug_get(6);
     if ((fs == 1) || (fs == 2 && Hq % 32 == 0) || (fs == 4 && Hq % 64 == 0)) shape = fs;
