@@ -87,7 +87,8 @@ int ktx_linear_forward(ktx_linear_t h, const int32_t* d_bsz, int T, const void* 
 /* Fusions around one linear of the decoder layer (all optional, NULL = off):
  *   norm_weight/norm_eps : RMSNorm of the input row inside the kernel (input_layernorm / post_attention_layernorm in front
  *                          of the projections, modeling_deepseek_v3.py:1207,1222) — only where the decode kernel runs
- *                          (ktx_linear_decode_eligible(h, T) != 0, i.e. T <= 4); otherwise call ktx_rmsnorm first.
+ *                          (ktx_linear_decode_eligible(h, T) != 0: T <= 4, or 5..8 rows of an unbatched handle, which run as 4-row
+ *                          passes of that kernel — round 6); otherwise call ktx_rmsnorm first.
  *   add1, add2           : bf16 [T][out_features] tensors (row strides add*_ld, 0 = out_features) added to the result in
  *                          this order with torch's bf16 rounding: y = bf16(add2 + bf16(add1 + linear(x))) — the residual
  *                          adds and the routed + shared sum (modeling_deepseek_v3.py:1219,1225,529). */

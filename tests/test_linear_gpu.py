@@ -645,3 +645,51 @@ def test_marlin_8bit_operator_multiplies_with_the_reference_multiplicand(T, act_
     # the 8-bit grid is 16x finer than the 4-bit one
     dense = x.double() @ w.double().T
     assert float((y.cpu().double() - dense).norm() / dense.norm()) < 1e-2
+
+
+@pytest.mark.parametrize("fmt", ["W4", "FP8", "BF16"])
+@pytest.mark.parametrize("K,N,T", [(2048, 576, 5), (7168, 2112, 8), (1536, 3072, 7), (16384, 7168, 8)])
+def test_five_to_eight_rows_run_as_four_row_passes_of_the_decode_kernel(fmt, K, N, T):
+    """Round 6: a 5..8-row call of an unbatched handle is two launches of the decode GEMV (rows 0-3, rows 4..), so every row carries the
+    decode kernel's bits — with the fused RMSNorm, the addends (offset by the pass), the GLU epilogue, strided rows and a device-side row
+    count — and stays within the file's bound of the 16-row-strip kernel it replaces (dev knob 3 = 1)."""
+    n = native()
+    torch.manual_seed(K + N + T)
+    w = (torch.randn(N, K) / 10).to(torch.bfloat16).cuda()
+    if fmt == "FP8":
+        h = n.LinearHandle(K, N, "FP8", 128, 16)
+        h.load_fp8((w.float() * 4).to(torch.float8_e4m3fn), ((torch.rand((N + 127) // 128, K // 128) + 0.5) / 32).cuda())
+    else:
+        h = n.LinearHandle(K, N, fmt, 64 if fmt == "W4" else 0, 16)
+        h.load_bf16(w)
+    x = (torch.randn(T, K) / 4).to(torch.bfloat16).cuda()
+    add1 = (torch.randn(T, N) / 10).to(torch.bfloat16).cuda()
+    nw = (1 + torch.randn(K) / 10).to(torch.bfloat16).cuda()
+    xs = torch.zeros(T, K + 64, dtype=torch.bfloat16, device="cuda")[:, :K]
+    xs.copy_(x)
+    assert h.decode_eligible(T) and h.decode_eligible(4)
+    calls = [dict(), dict(add1=add1), dict(norm=(nw, 1e-6)), dict(add1=add1, add2=add1), dict(norm=(nw, 1e-6), add1=add1)]
+    if N % 16 == 0 and fmt == "W4":
+        calls.append(dict(glu=True))
+
+    def rows(kw, a, b):
+        kw2 = {k: (v[a:b] if k in ("add1", "add2") else v) for k, v in kw.items()}
+        return h.forward(x[a:b].contiguous(), **kw2)
+
+    for kw in calls:
+        got = h.forward(x, **kw)
+        want = torch.cat([rows(kw, 0, 4), rows(kw, 4, T)], dim=0)
+        assert got.shape == want.shape and torch.equal(got, want), f"{fmt} {tuple(kw)}: the passes are not the decode kernel's rows"
+    assert torch.equal(h.forward(xs), h.forward(x)), "strided rows"
+    bsz = torch.tensor([T - 2], dtype=torch.int32, device="cuda")
+    yb = h.forward(x, bsz_tensor=bsz)
+    assert torch.equal(yb[: T - 2], h.forward(x)[: T - 2]) and not bool(yb[T - 2:].any()), "device-side row count across the passes"
+    fast = [h.forward(x, **kw) for kw in calls[:2]]
+    n.check(n.lib.ktx_debug_set(3, 1))
+    try:
+        assert not h.decode_eligible(T)
+        slow = [h.forward(x, **kw) for kw in calls[:2]]
+    finally:
+        n.check(n.lib.ktx_debug_set(3, 0))
+    for a, b in zip(fast, slow):
+        close(a, b.cpu())
