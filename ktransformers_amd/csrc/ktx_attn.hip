@@ -74,8 +74,8 @@ __host__ __device__ inline WsLayout ws_layout(int H, int nA) {
   const int NWG = GRID, SPG = GRID / (H / 32);   // splits per head group
   L.fA = take(4 * (nA > NWG ? nA : NWG)); L.fKV = take(4); L.fB = take(4 * NWG); L.fX = take(4 * NWG); L.fC = take(4 * NWG);
   L.fM = take(4 * NWG); L.fD = take(4 * NWG); L.fE = take(4 * NWG); L.gran = take(8 * NWG);
-  L.qkv = take(2 * 16 * nA); L.ckv_new = take(2 * LORA); L.kpe_new = take(2 * ROPE);
-  L.qx = take(2 * H * NOPE); L.q_lat = take(2 * H * LORA); L.q_pe = take(2 * H * ROPE); L.om = take(2 * H * LORA);
+  L.qkv = take(4 * 16 * nA); L.ckv_new = take(2 * LORA); L.kpe_new = take(2 * ROPE);   // (qkv, q_lat, q_pe: granules, 4 bytes per bf16)
+  L.qx = take(2 * H * NOPE); L.q_lat = take(4 * H * LORA); L.q_pe = take(4 * H * ROPE); L.om = take(2 * H * LORA);
   L.attn_out = take(2 * H * VDIM); L.part_ml = take(4 * H * SPG * 2); L.part_o = take(4u * H * SPG * LORA);
   L.total = o;
   return L;
@@ -151,6 +151,41 @@ __device__ __forceinline__ void poll_flags(const AttnParams& p, const unsigned* 
     __builtin_amdgcn_s_sleep(2);
   }
 }
+
+// ---- tagged granules (cdna_hip_programming.md Guideline 16, form R2): the data IS the flag ----------------------------------------
+// A small hand-off row travels as naturally aligned 8-byte {two bf16, tag = epoch} granules, two per 16-byte sc1 store; the consumer's
+// lanes re-read exactly the granules they need until every tag carries this launch's epoch.  Against payload -> drain -> flag on
+// the producer and flag poll -> payload load on the consumer this takes one memory round trip off each side of the hop
+// (MI355X_MICROARCH.md, rows handoff-1to1 vs handoff-flag: 2.3 vs 3.8 us between streaming CUs).  Element e of a row sits at byte 4 e.
+__device__ __forceinline__ void gran_store(__amdgpu_buffer_rsrc_t r, unsigned off, unsigned v0, unsigned v1, unsigned epoch) {
+  ws_store16(r, off, make_uint4(v0, epoch, v1, epoch));
+}
+// ONE wavefront: (re)loads its N 16-byte granule pairs until every tag == epoch; g[k] = {v0, tag, v1, tag}.  Bounded like poll_flags.
+template <int N>
+__device__ __forceinline__ void gran_sweep(const AttnParams& p, __amdgpu_buffer_rsrc_t r, const unsigned (&off)[N], const bool (&use)[N],
+                                           unsigned epoch, int code, uint4 (&g)[N]) {
+  unsigned* hdr = reinterpret_cast<unsigned*>(p.ws);
+  const unsigned long long t0 = wall_clock64();
+  for (;;) {
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+      if (use[k]) g[k] = ws_load16(r, off[k]);
+#pragma unroll
+    for (int k = 0; k < N; k++) ok = ok && (!use[k] || (g[k].y == epoch && g[k].w == epoch));
+    if (__all(ok)) return;
+    if (ld_word(hdr + W_STATUS) != 0) return;
+    if (wall_clock64() - t0 > SPIN_TICKS) {
+      if ((threadIdx.x & 63) == 0) {
+        st_word(hdr + W_STATUS, (unsigned)code);
+        if (p.hstatus) __hip_atomic_store(p.hstatus, (unsigned)code, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+      return;
+    }
+    __builtin_amdgcn_s_sleep(1);
+  }
+}
+__device__ __forceinline__ uint4 gran_join(const uint4& a, const uint4& b) { return make_uint4(a.x, a.z, b.x, b.z); }
 
 // ---- k-steps (restated from ktx_linear_sk.inc / ktx_linear.hip: same expressions, same order) ---------------------------------
 // W4 g64, one token row: acc += s_g * ( sum_{k in g} x_k (128 + q_k) - 136 sum_{k in g} x_k )
@@ -303,12 +338,9 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   unsigned* hdr = reinterpret_cast<unsigned*>(p.ws);
   const WsLayout L = ws_layout(H, p.nA);
   const __amdgpu_buffer_rsrc_t rs = ws_rsrc(p);
-  unsigned* fA = reinterpret_cast<unsigned*>(p.ws + L.fA);
   unsigned* fKV = reinterpret_cast<unsigned*>(p.ws + L.fKV);
-  unsigned* fB = reinterpret_cast<unsigned*>(p.ws + L.fB);
   unsigned* fX = reinterpret_cast<unsigned*>(p.ws + L.fX);
   unsigned* fC = reinterpret_cast<unsigned*>(p.ws + L.fC);
-  unsigned* fM = reinterpret_cast<unsigned*>(p.ws + L.fM);
   unsigned* fD = reinterpret_cast<unsigned*>(p.ws + L.fD);
   unsigned* fE = reinterpret_cast<unsigned*>(p.ws + L.fE);
   AT_STAMP(0);
@@ -349,14 +381,41 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   float ropePos = 0.f, ropeIf = 0.f;
   // one register file for both wave roles: waves 0..5 hold rb[0..11] = their q_b strip (k-half kh, step s_ at kh * 6 + s_) and
   // rb[12..15] = their absorb strip; waves 6..7 hold rb[4 i .. 4 i + 3] = absorb strip i of their five
-  constexpr int ABS0 = 2 * NK2 * NQ;               // first absorb register of waves 0..5 (behind their q_b tiles)
-  uint4 rb[ABS0 + 4 > 20 ? ABS0 + 4 : 20];
-  uint2 sb[2 * NK2];
+  // W4 (round 6): NO exchange between the halves — every workgroup of the pair computes ALL eight q_nope strips of its head (it needs
+  // the whole q_nope for its 256 absorbed values), the part-1 workgroup the four rope strips too: 16 / 24 half-strips (strip, k-half)
+  // dealt 2 / 3 per wavefront, then two absorb strips per wavefront.  rb[6 i .. 6 i + 5] = half-strip slot i, rb[18 + 4 i ..] = absorb
+  // strip i.  12.6 MB more q_b bytes per layer (requested behind phase A's k-steps, while HBM idles) for one hand-off less.
+  constexpr int ABS0 = F8 ? 2 * NK2 * NQ : 3 * NK2;   // first absorb register (F8: of waves 0..5, behind their q_b tiles)
+  constexpr int NRB = F8 ? (ABS0 + 4 > 20 ? ABS0 + 4 : 20) : ABS0 + 8;
+  uint4 rb[NRB];
+  uint2 sb[F8 ? 2 * NK2 : 3 * NK2];
+  const int nperB = part == 0 ? 2 : 3;   // W4: half-strips per wavefront
   auto prefetch_B = [&]() {
     nwB = *reinterpret_cast<const uint4*>(p.qa_norm_w + min(tid, (p.q_lora >> 3) - 1) * 8);
     ropePos = (float)p.pos[0];
     ropeIf = p.inv_freq[tid & (ROPE / 2 - 1)];
-    if (wave < 6) {
+    if constexpr (!F8) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        if (i < nperB) {
+          const int hsi = wave * nperB + i;
+          const size_t t0 = ((size_t)h * SPH + (hsi >> 1)) * p.nksB + (size_t)(hsi & 1) * NK2;
+          const uint8_t* wp = p.wB + t0 * TB + lane * 16;
+          const bf16_t* sp = p.scB + (t0 * 16 + (lane & 15)) * 2;
+#pragma unroll
+          for (int s_ = 0; s_ < NK2; s_++) {
+            rb[i * NK2 + s_] = nt_load16(wp + (size_t)s_ * TB);
+            sb[i * NK2 + s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + wave * 2 + i) * 4096 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rb[ABS0 + i * 4 + q] = nt_load16(wp2 + q * 1024);
+      }
+    } else if (wave < 6) {
       const size_t strip = (size_t)h * SPH + part * 6 + wave;
 #pragma unroll
       for (int kh = 0; kh < 2; kh++) {
@@ -471,9 +530,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
           }
           __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
           __builtin_amdgcn_wave_barrier();
-          if (lane < 2) ws_store16(rs, L.qkv + s * 32 + lane * 16, *reinterpret_cast<const uint4*>(ostage + lane * 8));
-          drain_stores();
-          if (lane == 0) st_word(fA + s, epoch);
+          if (lane < 4) {
+            const uint2 v = *reinterpret_cast<const uint2*>(ostage + lane * 4);
+            gran_store(rs, L.qkv + s * 64 + lane * 16, v.x, v.y, epoch);
+          }
         }
       }
     }
@@ -489,20 +549,26 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     uint8_t* xsB = smem + 1280;                                                   // [q_lora / 8][16 B]
     float* auxB = reinterpret_cast<float*>(xsB + (size_t)(p.q_lora >> 3) * 16);   // [nksB * 2][4]
     float* nredB = auxB + p.nksB * 2 * 4;                                         // [8][4]
-    float* red1 = nredB + 32;                                                     // [6][2][16]
-    float* s_cs = red1 + 6 * 2 * 16;                                              // [64]: cos | sin
-    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [96] this half's q_b outputs
-    bf16_t* stage = qh + 96;                                                      // [256] publication staging
+    float* red1 = nredB + 32;                                                     // [12][2][16] (F8: [6][2][16])
+    float* s_cs = red1 + 12 * 2 * 16;                                             // [64]: cos | sin
+    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [192] the head's q_b outputs (F8: [96] this half's)
+    bf16_t* stage = qh + QW;                                                      // [256] publication staging
     uint8_t* xs2 = reinterpret_cast<uint8_t*>(stage + 256);                       // [16][16 B] the head's q_nope
     float* s_redK = reinterpret_cast<float*>(xs2 + 256);                          // [8] (kv prep)
+    bf16_t* qpe_st = reinterpret_cast<bf16_t*>(s_redK + 8);                       // [64] rotated q_pe (W4)
 
-    if (wave == 7) poll_flags(p, fA, p.nA, epoch, 0xA1, [](int k) { return k; });
-    __syncthreads();
-    AT_STAMP(3);
-    // ---- the phase A output row [q_a | ckv | k_pe]: q_a pieces -> RMSNorm -> staging; kv pieces -> LDS
+    // ---- the phase A output row [q_a | ckv | k_pe] (granules: every lane waits for the 8 values it stages): q_a pieces -> RMSNorm ->
+    // staging; kv pieces -> LDS
     const int npq = p.q_lora >> 3, npall = p.nA * 2;
     uint4 xp = make_uint4(0, 0, 0, 0);
-    if (tid < npall) xp = ws_load16(rs, L.qkv + tid * 16);
+    {
+      uint4 g[2];
+      const unsigned off[2] = {L.qkv + (unsigned)tid * 32, L.qkv + (unsigned)tid * 32 + 16};
+      const bool use[2] = {tid < npall, tid < npall};
+      gran_sweep<2>(p, rs, off, use, epoch, 0xA1, g);
+      if (tid < npall) xp = gran_join(g[0], g[1]);
+    }
+    AT_STAMP(3);
     if (tid >= npq && tid < npall) *reinterpret_cast<uint4*>(kvraw + (tid - npq) * 8) = xp;
     {
       const float q = tid < npq ? sumsq8(xp) : 0.f;
@@ -592,6 +658,55 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     AT_STAMP(4);
     // ---- q_b rows of this half: waves 0..5 = one strip each, two k-halves summed in order (lin_qb_absorb_kernel)
     const int kc = lane >> 4;
+    if constexpr (!F8) {
+      // ---- W4: the head's q_b strips without an exchange (see the register arrays above); each half-strip is lin_qb_absorb_kernel's
+      // chain of six k-steps, the two k-halves of a strip summed in its order
+      const uint8_t* xb0 = xsB + kc * 16;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        if (i < nperB) {
+          const int hsi = wave * nperB + i, kh = hsi & 1;
+          float acc = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < NK2; s_++) {
+            const int ks = kh * NK2 + s_;
+            w4_kstep1(rb[i * NK2 + s_], sb[i * NK2 + s_], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
+          }
+          if (lane < 16) red1[hsi * 16 + lane] = acc;   // [(strip * 2 + kh) * 16 + row]
+        }
+      }
+      AT_STAMP(20);
+      __syncthreads();
+      AT_STAMP(21);
+      if (tid < (part == 0 ? NOPE : QW)) {
+        const int sih = tid >> 4, f = tid & 15;
+        float v = 0.f;
+        v += red1[(sih * 2 + 0) * 16 + f];
+        v += red1[(sih * 2 + 1) * 16 + f];
+        qh[tid] = f32_to_bf16(v);
+      }
+      __syncthreads();
+      if (part == 1 && tid < ROPE / 2) prep_rope_pair(qh + NOPE, qpe_st, tid, ROPE / 2, s_cs[tid], s_cs[ROPE / 2 + tid]);
+      AT_STAMP(22);
+      AT_STAMP(27);
+      AT_STAMP(5);
+      {   // absorb: this half's 16 strips of W_UK[h]^T q_nope, two per wavefront, one k-step of 128 each (q_nope = qh[0, 128))
+        const uint8_t* xb2 = reinterpret_cast<const uint8_t*>(qh) + kc * 4 * 16;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          v4f acc = {0.f, 0.f, 0.f, 0.f};
+          const uint4 wt[4] = {rb[ABS0 + i * 4], rb[ABS0 + i * 4 + 1], rb[ABS0 + i * 4 + 2], rb[ABS0 + i * 4 + 3]};
+          bf16_kstep(wt, xb2, acc);
+          if (lane < 16) stage[(wave * 2 + i) * 16 + lane] = f32_to_bf16(0.f + acc[0]);
+        }
+      }
+      __syncthreads();
+      if (part == 1 && tid >= 64 && tid < 64 + ROPE / 4) {
+        const int t = tid - 64;
+        const uint2 v = *reinterpret_cast<const uint2*>(qpe_st + t * 4);
+        gran_store(rs, L.q_pe + (unsigned)h * ROPE * 4 + t * 16, v.x, v.y, epoch);
+      }
+    } else {
     if (wave < 6) {
       if constexpr (F8) {   // lin_dec_kernel<FP8> runs q_b's 12 k-steps as ONE k-slice per strip (8 strips per workgroup): one chain
         const uint8_t* xb0 = xsB + kc * 32;
@@ -632,7 +747,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       if (tid < npc) ws_store16(rs, L.qx + (h * NOPE + part * 96) * 2 + tid * 16, *reinterpret_cast<const uint4*>(qh + tid * 8));
     }
     __syncthreads();
-    if (part == 1 && tid < ROPE / 8) ws_store16(rs, L.q_pe + h * ROPE * 2 + tid * 16, *reinterpret_cast<const uint4*>(stage + tid * 8));
+    if (part == 1 && tid < ROPE / 4) {
+      const uint2 v = *reinterpret_cast<const uint2*>(stage + tid * 4);
+      gran_store(rs, L.q_pe + (unsigned)h * ROPE * 4 + tid * 16, v.x, v.y, epoch);
+    }
     drain_stores();
     __syncthreads();
     if (tid == 0) st_word(fX + w, epoch);
@@ -664,10 +782,11 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       }
     }
     __syncthreads();
-    if (tid < 32) ws_store16(rs, L.q_lat + (h * LORA + part * 256) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stage + tid * 8));
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) st_word(fB + w, epoch);
+    }   // (F8: the exchanging form)
+    if (tid < 64) {   // this half's 256 absorbed values: 128 granules (no drain, no flag: phase C's lanes wait on the tags)
+      const uint2 v = *reinterpret_cast<const uint2*>(stage + tid * 4);
+      gran_store(rs, L.q_lat + (unsigned)(h * LORA + part * 256) * 4 + tid * 16, v.x, v.y, epoch);
+    }
    }
     AT_STAMP(6);
   }
@@ -749,22 +868,27 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       }
       if (work) stage_tile(t_begin, 0);   // depends on nothing else: in flight while the q rows are awaited
       // ---- q rows of this workgroup's 32 heads: produced by the 64 phase-B workgroups (head, half)
-      if (wave == 7) poll_flags(p, fB, 64, epoch, 0xC1, [=](int k) { return hg * 32 + (k & 31) + (k >> 5) * H; });
-      __syncthreads();
-      AT_STAMP(7);
+      // (granules: each wavefront waits for exactly the q pieces its lanes hold — no flag sweep, no second round trip)
       av8bf qf[NQ];
       {
         const int hq = head0 + (lane & 15);
-        const unsigned qn = L.q_lat + (unsigned)(hq * LORA + (lane >> 4) * 8) * 2;
-        const unsigned qr = L.q_pe + (unsigned)(hq * ROPE + (lane >> 4) * 8) * 2;
+        const unsigned qn = L.q_lat + (unsigned)(hq * LORA + (lane >> 4) * 8) * 4;
+        const unsigned qr = L.q_pe + (unsigned)(hq * ROPE + (lane >> 4) * 8) * 4;
+        uint4 g[2 * NQ];
+        unsigned off[2 * NQ];
+        bool use[2 * NQ];
 #pragma unroll
         for (int j = 0; j < NQ; j++) {
           const int s = ds + j * DSPLIT;   // wave-uniform
-          qf[j] = as_av8bf(make_uint4(0, 0, 0, 0));
-          if (s < 16) qf[j] = as_av8bf(ws_load16(rs, qn + s * 64));
-          else if (s < 18) qf[j] = as_av8bf(ws_load16(rs, qr + (s - 16) * 64));
+          off[2 * j] = s < 16 ? qn + s * 128 : qr + (s - 16) * 128;
+          off[2 * j + 1] = off[2 * j] + 16;
+          use[2 * j] = use[2 * j + 1] = work && s < 18;
         }
+        gran_sweep<2 * NQ>(p, rs, off, use, epoch, 0xC1, g);
+#pragma unroll
+        for (int j = 0; j < NQ; j++) qf[j] = as_av8bf(use[2 * j] ? gran_join(g[2 * j], g[2 * j + 1]) : make_uint4(0, 0, 0, 0));
       }
+      AT_STAMP(7);
       if (work) {
         bf16_t* Pw = Pt + wave * 16 * TILE;
         int cur = 0;
@@ -912,28 +1036,29 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     const int S = p.nsplit;
     float* s_w = reinterpret_cast<float*>(smem);              // [MAXS]
     float* s_red = s_w + MAXS;                                // [16]
-    float* s_acc = s_red + 16;                                // [8][256]
-    bf16_t* stageD = reinterpret_cast<bf16_t*>(s_acc + 8 * 256);   // [256]
+    float* s_acc = s_red + 16;                                // [8][512]
+    bf16_t* stageD = reinterpret_cast<bf16_t*>(s_acc + 8 * LORA);  // [256]
     uint8_t* xsD = reinterpret_cast<uint8_t*>(stageD + 256);       // [64][16 B]
     const int hgD = h >> 5;
     if (wave == 7) poll_flags(p, fC, S, epoch, 0xD1, [=](int k) { return hgD * SPG + k; });
     __syncthreads();
     AT_STAMP(10);
-    const int sl = wave, dg = lane;   // split lane, dim group (8 dims) — lanes 0..31 cover this half's 256 dims
+    // Every workgroup of the pair merges ALL 512 dims of its head (64 lanes x 8 dims; the pair sits on one XCD, so the partner's
+    // second read of the partials is L2-served): the merged row stays in this workgroup's LDS and the round-4 exchange of half
+    // rows through the workspace (publish + drain + flag + poll + reload: ~3 us of the chain) is gone.  Same sums in the same order.
+    const int sl = wave, dg = lane;   // split lane, dim group (8 dims)
     const size_t base = (size_t)h * S;
     unsigned long long mlraw = 0;
     if (tid < S) mlraw = __hip_atomic_load(reinterpret_cast<const unsigned long long*>(p.ws + L.part_ml) + base + tid, __ATOMIC_RELAXED,
                                            __HIP_MEMORY_SCOPE_AGENT);
     const float2 ml = tid < S ? make_float2(__uint_as_float((unsigned)mlraw), __uint_as_float((unsigned)(mlraw >> 32))) : make_float2(0.f, 0.f);
     uint4 fa[8], fb[8];
-    if (dg < 32) {
 #pragma unroll
-      for (int u = 0; u < 8; u++) {
-        const int sidx = min(sl + 8 * u, S - 1);
-        const unsigned off = L.part_o + (unsigned)(((base + sidx) * LORA + part * 256 + dg * 8) * 4);
-        fa[u] = ws_load16(rs, off);
-        fb[u] = ws_load16(rs, off + 16);
-      }
+    for (int u = 0; u < 8; u++) {
+      const int sidx = min(sl + 8 * u, S - 1);
+      const unsigned off = L.part_o + (unsigned)(((base + sidx) * LORA + dg * 8) * 4);
+      fa[u] = ws_load16(rs, off);
+      fb[u] = ws_load16(rs, off + 16);
     }
     float mstar = ml.y > 0.f ? ml.x : -__builtin_inff();
     mstar = wave_max(mstar);
@@ -950,7 +1075,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     lsum = 0.f;
 #pragma unroll
     for (int v = 0; v < 8; v++) lsum += s_red[8 + v];
-    if (dg < 32) {
+    {
       float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 #pragma unroll
       for (int u = 0; u < 8; u++) {
@@ -966,7 +1091,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
 #pragma unroll
         for (int u = 0; u < 4; u++) {
           const int sidx = min(s0 + 8 * u, S - 1);
-          const unsigned off = L.part_o + (unsigned)(((base + sidx) * LORA + part * 256 + dg * 8) * 4);
+          const unsigned off = L.part_o + (unsigned)(((base + sidx) * LORA + dg * 8) * 4);
           va[u] = ws_load16(rs, off);
           vb[u] = ws_load16(rs, off + 16);
         }
@@ -981,27 +1106,16 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         }
       }
 #pragma unroll
-      for (int q = 0; q < 8; q++) s_acc[sl * 256 + dg * 8 + q] = acc[q];
+      for (int q = 0; q < 8; q++) s_acc[sl * LORA + dg * 8 + q] = acc[q];
     }
     __syncthreads();
     {
       const float inv = lsum > 0.f ? 1.0f / lsum : 0.f;
-      if (tid < 256) {
-        float v = 0.f;
+      float v = 0.f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) v += s_acc[i * 256 + tid];
-        stageD[tid] = f32_to_bf16(v * inv);
-      }
+      for (int i = 0; i < 8; i++) v += s_acc[i * LORA + tid];
+      reinterpret_cast<bf16_t*>(xsD)[tid] = f32_to_bf16(v * inv);   // the merged row of head h, all 512 dims (NT == LORA)
     }
-    __syncthreads();
-    if (tid < 32) ws_store16(rs, L.om + (unsigned)(h * LORA + part * 256) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stageD + tid * 8));
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) st_word(fM + w, epoch);
-    const int partner = h + (1 - part) * H;
-    if (wave == 7) poll_flags(p, fM, 1, epoch, 0xD2, [partner](int) { return partner; });
-    __syncthreads();
-    if (tid < 64) *reinterpret_cast<uint4*>(xsD + tid * 16) = ws_load16(rs, L.om + (unsigned)(h * LORA) * 2 + tid * 16);
     __syncthreads();
     AT_STAMP(11);
     // ---- un-absorb: waves 0..3 = one strip of this half each, the 4 k-steps in order (lin_merge_unabsorb_kernel)
@@ -1126,6 +1240,12 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       }
     }
   }
+}
+
+// dev / tests (ktx_attn_debug_read): the payload dwords of a granule row
+__global__ void attn_ungranule_kernel(const uint2* g, unsigned* out, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = g[i].x;
 }
 
 // =====================================================================================================================================
@@ -1395,7 +1515,17 @@ extern "C" int ktx_attn_debug_read(int device, int which, void* d_dst, size_t by
   const WsLayout L = ws_layout(d.H, d.nA);
   const unsigned offs[10] = {L.qkv, L.ckv_new, L.kpe_new, L.q_lat, L.q_pe, L.om, L.attn_out, L.part_ml, L.part_o, L.qx};
   KTX_REQUIRE(which >= 0 && which < 10 && offs[which] + bytes <= d.bytes, "ktx_attn_debug_read: bad array or size");
+  KTX_REQUIRE(which != 5, "ktx_attn_debug_read: the merged rows no longer pass through the workspace (each workgroup of a head's pair merges all 512 dims in LDS)");
   DeviceGuard guard(device);
+  if (which == 0 || which == 3 || which == 4) {   // granule rows: the payload dwords only
+    KTX_REQUIRE(bytes % 4 == 0 && offs[which] + 2 * bytes <= d.bytes, "ktx_attn_debug_read: bad size for a granule row");
+    const int n = (int)(bytes / 4);
+    hipLaunchKernelGGL(attn_ungranule_kernel, dim3((n + 255) / 256), dim3(256), 0, nullptr, reinterpret_cast<const uint2*>(d.base + offs[which]),
+                       reinterpret_cast<unsigned*>(d_dst), n);
+    KTX_HIP(hipGetLastError());
+    KTX_HIP(hipDeviceSynchronize());
+    return 0;
+  }
   KTX_HIP(hipMemcpy(d_dst, d.base + offs[which], bytes, hipMemcpyDeviceToDevice));
   return 0;
 }
