@@ -959,7 +959,7 @@ def qb_absorb_and_prep(q_b: "LinearHandle", qabs: "LinearHandle", q_a: torch.Ten
 
 
 ATTN_PHASE_ALL = 31
-ATTN_ARRAYS = {"qkv": 0, "ckv_new": 1, "kpe_new": 2, "q_lat": 3, "q_pe": 4, "merged": 5, "attn_out": 6, "part_ml": 7, "part_o": 8, "qx": 9}
+ATTN_ARRAYS = {"qkv": 0, "ckv_new": 1, "kpe_new": 2, "q_lat": 3, "q_pe": 4, "attn_out": 6, "part_ml": 7, "part_o": 8, "qx": 9}   # (5, the merged rows, no longer pass through the workspace)
 
 
 def attn_decode_args(qkv_a: "LinearHandle", q_b: "LinearHandle", qabs: "LinearHandle", oabs: "LinearHandle", o_proj: "LinearHandle",

@@ -29,6 +29,7 @@
 
 #include <cstring>
 #include <mutex>
+#include <type_traits>
 
 #include "../../include/ktx_attn.h"
 #include "../../include/ktx_gate.h"
@@ -62,9 +63,9 @@ constexpr unsigned long long SPIN_TICKS = 20000000ull;   // 0.2 s of the 100 MHz
 // header words
 constexpr int W_EPOCH = 0, W_EXIT = 1, W_STATUS = 2, W_TICKET = 3;
 struct WsLayout {   // byte offsets from the workspace base
-  unsigned fA, fKV, fB, fX, fC, fM, fD, fE;             // flag arrays (u32 each)
+  unsigned fKV, fX, fC, fD, fE;                         // flag arrays (u32 each)
   unsigned gran;                                        // phase F: {epoch, logit} granules (u64 each)
-  unsigned qkv, ckv_new, kpe_new, qx, q_lat, q_pe, om, attn_out, part_ml, part_o;
+  unsigned qkv, ckv_new, kpe_new, qx, q_lat, q_pe, attn_out, part_ml, part_o;
   unsigned total;
 };
 __host__ __device__ inline WsLayout ws_layout(int H, int nA) {
@@ -72,10 +73,9 @@ __host__ __device__ inline WsLayout ws_layout(int H, int nA) {
   unsigned o = 256;
   auto take = [&](unsigned bytes) { const unsigned r = o; o += (bytes + 255u) & ~255u; return r; };
   const int NWG = GRID, SPG = GRID / (H / 32);   // splits per head group
-  L.fA = take(4 * (nA > NWG ? nA : NWG)); L.fKV = take(4); L.fB = take(4 * NWG); L.fX = take(4 * NWG); L.fC = take(4 * NWG);
-  L.fM = take(4 * NWG); L.fD = take(4 * NWG); L.fE = take(4 * NWG); L.gran = take(8 * NWG);
+  L.fKV = take(4); L.fX = take(4 * NWG); L.fC = take(4 * NWG); L.fD = take(4 * NWG); L.fE = take(4 * NWG); L.gran = take(8 * NWG);
   L.qkv = take(4 * 16 * nA); L.ckv_new = take(2 * LORA); L.kpe_new = take(2 * ROPE);   // (qkv, q_lat, q_pe: granules, 4 bytes per bf16)
-  L.qx = take(2 * H * NOPE); L.q_lat = take(4 * H * LORA); L.q_pe = take(4 * H * ROPE); L.om = take(2 * H * LORA);
+  L.qx = take(2 * H * NOPE); L.q_lat = take(4 * H * LORA); L.q_pe = take(4 * H * ROPE);
   L.attn_out = take(2 * H * VDIM); L.part_ml = take(4 * H * SPG * 2); L.part_o = take(4u * H * SPG * LORA);
   L.total = o;
   return L;
@@ -381,41 +381,14 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   float ropePos = 0.f, ropeIf = 0.f;
   // one register file for both wave roles: waves 0..5 hold rb[0..11] = their q_b strip (k-half kh, step s_ at kh * 6 + s_) and
   // rb[12..15] = their absorb strip; waves 6..7 hold rb[4 i .. 4 i + 3] = absorb strip i of their five
-  // W4 (round 6): NO exchange between the halves — every workgroup of the pair computes ALL eight q_nope strips of its head (it needs
-  // the whole q_nope for its 256 absorbed values), the part-1 workgroup the four rope strips too: 16 / 24 half-strips (strip, k-half)
-  // dealt 2 / 3 per wavefront, then two absorb strips per wavefront.  rb[6 i .. 6 i + 5] = half-strip slot i, rb[18 + 4 i ..] = absorb
-  // strip i.  12.6 MB more q_b bytes per layer (requested behind phase A's k-steps, while HBM idles) for one hand-off less.
-  constexpr int ABS0 = F8 ? 2 * NK2 * NQ : 3 * NK2;   // first absorb register (F8: of waves 0..5, behind their q_b tiles)
-  constexpr int NRB = F8 ? (ABS0 + 4 > 20 ? ABS0 + 4 : 20) : ABS0 + 8;
-  uint4 rb[NRB];
-  uint2 sb[F8 ? 2 * NK2 : 3 * NK2];
-  const int nperB = part == 0 ? 2 : 3;   // W4: half-strips per wavefront
+  constexpr int ABS0 = 2 * NK2 * NQ;               // first absorb register of waves 0..5 (behind their q_b tiles)
+  uint4 rb[ABS0 + 4 > 20 ? ABS0 + 4 : 20];
+  uint2 sb[2 * NK2];
   auto prefetch_B = [&]() {
     nwB = *reinterpret_cast<const uint4*>(p.qa_norm_w + min(tid, (p.q_lora >> 3) - 1) * 8);
     ropePos = (float)p.pos[0];
     ropeIf = p.inv_freq[tid & (ROPE / 2 - 1)];
-    if constexpr (!F8) {
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        if (i < nperB) {
-          const int hsi = wave * nperB + i;
-          const size_t t0 = ((size_t)h * SPH + (hsi >> 1)) * p.nksB + (size_t)(hsi & 1) * NK2;
-          const uint8_t* wp = p.wB + t0 * TB + lane * 16;
-          const bf16_t* sp = p.scB + (t0 * 16 + (lane & 15)) * 2;
-#pragma unroll
-          for (int s_ = 0; s_ < NK2; s_++) {
-            rb[i * NK2 + s_] = nt_load16(wp + (size_t)s_ * TB);
-            sb[i * NK2 + s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
-          }
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < 2; i++) {
-        const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + wave * 2 + i) * 4096 + lane * 16;
-#pragma unroll
-        for (int q = 0; q < 4; q++) rb[ABS0 + i * 4 + q] = nt_load16(wp2 + q * 1024);
-      }
-    } else if (wave < 6) {
+    if (wave < 6) {
       const size_t strip = (size_t)h * SPH + part * 6 + wave;
 #pragma unroll
       for (int kh = 0; kh < 2; kh++) {
@@ -450,7 +423,13 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     if (!doA && doBD) {
       // (workgroups without a strip of phase A: their 136 KiB each would compete chip-wide with the 7 MB of phase A tiles the step
       // is waiting for — measured: those tiles took 6 us to arrive — so they start ~1.5 us late)
-      if constexpr ((MASK & PH_A) != 0) __builtin_amdgcn_s_sleep(56);
+#ifndef KTX_ATTN_BSLEEP
+#define KTX_ATTN_BSLEEP 56
+#endif
+      if constexpr ((MASK & PH_A) != 0) {
+        __builtin_amdgcn_s_sleep(KTX_ATTN_BSLEEP > 127 ? 127 : KTX_ATTN_BSLEEP);
+        if constexpr (KTX_ATTN_BSLEEP > 127) __builtin_amdgcn_s_sleep(KTX_ATTN_BSLEEP - 127);
+      }
       prefetch_B();
     }
   }
@@ -549,13 +528,12 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     uint8_t* xsB = smem + 1280;                                                   // [q_lora / 8][16 B]
     float* auxB = reinterpret_cast<float*>(xsB + (size_t)(p.q_lora >> 3) * 16);   // [nksB * 2][4]
     float* nredB = auxB + p.nksB * 2 * 4;                                         // [8][4]
-    float* red1 = nredB + 32;                                                     // [12][2][16] (F8: [6][2][16])
-    float* s_cs = red1 + 12 * 2 * 16;                                             // [64]: cos | sin
-    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [192] the head's q_b outputs (F8: [96] this half's)
-    bf16_t* stage = qh + QW;                                                      // [256] publication staging
+    float* red1 = nredB + 32;                                                     // [6][2][16]
+    float* s_cs = red1 + 6 * 2 * 16;                                              // [64]: cos | sin
+    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [96] this half's q_b outputs
+    bf16_t* stage = qh + 96;                                                      // [256] publication staging
     uint8_t* xs2 = reinterpret_cast<uint8_t*>(stage + 256);                       // [16][16 B] the head's q_nope
     float* s_redK = reinterpret_cast<float*>(xs2 + 256);                          // [8] (kv prep)
-    bf16_t* qpe_st = reinterpret_cast<bf16_t*>(s_redK + 8);                       // [64] rotated q_pe (W4)
 
     // ---- the phase A output row [q_a | ckv | k_pe] (granules: every lane waits for the 8 values it stages): q_a pieces -> RMSNorm ->
     // staging; kv pieces -> LDS
@@ -658,55 +636,6 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     AT_STAMP(4);
     // ---- q_b rows of this half: waves 0..5 = one strip each, two k-halves summed in order (lin_qb_absorb_kernel)
     const int kc = lane >> 4;
-    if constexpr (!F8) {
-      // ---- W4: the head's q_b strips without an exchange (see the register arrays above); each half-strip is lin_qb_absorb_kernel's
-      // chain of six k-steps, the two k-halves of a strip summed in its order
-      const uint8_t* xb0 = xsB + kc * 16;
-#pragma unroll
-      for (int i = 0; i < 3; i++) {
-        if (i < nperB) {
-          const int hsi = wave * nperB + i, kh = hsi & 1;
-          float acc = 0.f;
-#pragma unroll
-          for (int s_ = 0; s_ < NK2; s_++) {
-            const int ks = kh * NK2 + s_;
-            w4_kstep1(rb[i * NK2 + s_], sb[i * NK2 + s_], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
-          }
-          if (lane < 16) red1[hsi * 16 + lane] = acc;   // [(strip * 2 + kh) * 16 + row]
-        }
-      }
-      AT_STAMP(20);
-      __syncthreads();
-      AT_STAMP(21);
-      if (tid < (part == 0 ? NOPE : QW)) {
-        const int sih = tid >> 4, f = tid & 15;
-        float v = 0.f;
-        v += red1[(sih * 2 + 0) * 16 + f];
-        v += red1[(sih * 2 + 1) * 16 + f];
-        qh[tid] = f32_to_bf16(v);
-      }
-      __syncthreads();
-      if (part == 1 && tid < ROPE / 2) prep_rope_pair(qh + NOPE, qpe_st, tid, ROPE / 2, s_cs[tid], s_cs[ROPE / 2 + tid]);
-      AT_STAMP(22);
-      AT_STAMP(27);
-      AT_STAMP(5);
-      {   // absorb: this half's 16 strips of W_UK[h]^T q_nope, two per wavefront, one k-step of 128 each (q_nope = qh[0, 128))
-        const uint8_t* xb2 = reinterpret_cast<const uint8_t*>(qh) + kc * 4 * 16;
-#pragma unroll
-        for (int i = 0; i < 2; i++) {
-          v4f acc = {0.f, 0.f, 0.f, 0.f};
-          const uint4 wt[4] = {rb[ABS0 + i * 4], rb[ABS0 + i * 4 + 1], rb[ABS0 + i * 4 + 2], rb[ABS0 + i * 4 + 3]};
-          bf16_kstep(wt, xb2, acc);
-          if (lane < 16) stage[(wave * 2 + i) * 16 + lane] = f32_to_bf16(0.f + acc[0]);
-        }
-      }
-      __syncthreads();
-      if (part == 1 && tid >= 64 && tid < 64 + ROPE / 4) {
-        const int t = tid - 64;
-        const uint2 v = *reinterpret_cast<const uint2*>(qpe_st + t * 4);
-        gran_store(rs, L.q_pe + (unsigned)h * ROPE * 4 + t * 16, v.x, v.y, epoch);
-      }
-    } else {
     if (wave < 6) {
       if constexpr (F8) {   // lin_dec_kernel<FP8> runs q_b's 12 k-steps as ONE k-slice per strip (8 strips per workgroup): one chain
         const uint8_t* xb0 = xsB + kc * 32;
@@ -782,7 +711,6 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       }
     }
     __syncthreads();
-    }   // (F8: the exchanging form)
     if (tid < 64) {   // this half's 256 absorbed values: 128 granules (no drain, no flag: phase C's lanes wait on the tags)
       const uint2 v = *reinterpret_cast<const uint2*>(stage + tid * 4);
       gran_store(rs, L.q_lat + (unsigned)(h * LORA + part * 256) * 4 + tid * 16, v.x, v.y, epoch);
@@ -812,9 +740,16 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     __syncthreads();
     if (doC) {
       constexpr int HBW = 2, DSPLIT = 4, NWV = 8, NDT = 32 / DSPLIT, NQ = (18 + DSPLIT - 1) / DSPLIT;
-      bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584]
-      bf16_t* Kp = Kt + 2 * TILE * KROW;                                   // [2][32][64]
-      bf16_t* Pt = Kp + 2 * TILE * ROPE;                                   // [8][16][32]
+      // NTB staged tiles: a tile is requested TWO tiles ahead.  With two buffers a tile's 41 KiB were requested when the previous tile's
+      // arithmetic began and the loop ran at one request latency per tile (~2.3 us for ~1 us of MFMA + softmax per tile: 7 us for the
+      // three tiles of a split at 4 K tokens); same tiles in the same order, so the same sums.
+#ifndef KTX_ATTN_NTB
+#define KTX_ATTN_NTB 3
+#endif
+      constexpr int NTB = KTX_ATTN_NTB;
+      bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [NTB][32][584]
+      bf16_t* Kp = Kt + NTB * TILE * KROW;                                 // [NTB][32][64]
+      bf16_t* Pt = Kp + NTB * TILE * ROPE;                                 // [8][16][32]
       float* Sx = reinterpret_cast<float*>(Pt + NWV * 16 * TILE);          // [8][8][64]
       const int hbw = wave / DSPLIT, ds = wave % DSPLIT;
       const int head0 = (hg * HBW + hbw) * 16;
@@ -836,7 +771,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
 
       auto stage_tile = [&](int tile, int buf) {   // buf = which of the two staged tiles
         const uint32_t dK = smem_lds + (uint32_t)buf * (TILE * KROW * 2);
-        const uint32_t dP = smem_lds + (uint32_t)(2 * TILE * KROW * 2) + (uint32_t)buf * (TILE * ROPE * 2);
+        const uint32_t dP = smem_lds + (uint32_t)(NTB * TILE * KROW * 2) + (uint32_t)buf * (TILE * ROPE * 2);
         const int tok0 = tile * TILE;
         const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
         const int page0 = p.kv_indices ? p.kv_indices[pidx_] : pidx_;
@@ -866,7 +801,10 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the row is fetched by LDS-DMA (a plain load)
         __syncthreads();
       }
-      if (work) stage_tile(t_begin, 0);   // depends on nothing else: in flight while the q rows are awaited
+      if (work) {   // depend on nothing else: in flight while the q rows are awaited
+        stage_tile(t_begin, 0);
+        if (NTB > 2 && t_begin + t_step < t_end) stage_tile(t_begin + t_step, 1);
+      }
       // ---- q rows of this workgroup's 32 heads: produced by the 64 phase-B workgroups (head, half)
       // (granules: each wavefront waits for exactly the q pieces its lanes hold — no flag sweep, no second round trip)
       av8bf qf[NQ];
@@ -892,14 +830,25 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       if (work) {
         bf16_t* Pw = Pt + wave * 16 * TILE;
         int cur = 0;
-        for (int tile = t_begin; tile < t_end; tile += t_step, cur ^= 1) {
+        for (int tile = t_begin; tile < t_end; tile += t_step, cur = cur == NTB - 1 ? 0 : cur + 1) {
           bf16_t* Kc = Kt + cur * TILE * KROW;
           const bf16_t* Pc = Kp + cur * TILE * ROPE;
           const int tok0 = tile * TILE;
           const int ntok = min(TILE, kv_end - tok0);
-          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          __syncthreads();
-          if (tile + t_step < t_end) stage_tile(tile + t_step, cur ^ 1);
+          // this tile has landed; the NEXT tile's requests (this wavefront's four latent rows, and the k_pe rows of wavefronts 0..3:
+          // the youngest of its queue, replies arrive in order) may stay in flight
+          if (NTB > 2 && tile + t_step < t_end) {
+            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
+            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+          } else {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          }
+          __syncthreads();   // (every wavefront is also done with the tile before this one: its buffer takes the tile after the next)
+          if constexpr (NTB > 2) {
+            if (tile + 2 * t_step < t_end) stage_tile(tile + 2 * t_step, cur >= NTB - 2 ? cur + 2 - NTB : cur + 2);
+          } else {
+            if (tile + t_step < t_end) stage_tile(tile + t_step, cur ^ 1);
+          }
 
           v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
           const bf16_t* kb0 = Kc + (lane & 15) * KROW + (lane >> 4) * 8;
@@ -1008,9 +957,21 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // phase E's first ring tiles are requested before phase D starts waiting
   const int GPS_E = p.nksE >> 3;
   int Gb = 0, Ge = 0, gbE = 0, geE = 0;
-  uint4 wrE[8][NQ];
-  uint2 srE[8];
+  // Phase E's register ring is RG groups of 8 k-steps deep.  The first group is requested here (it flies during the C -> D hand-off);
+  // the other RG - 1 groups are requested inside phase D once the merge has consumed the splits' partial rows (their 64 registers
+  // are free from there on), so they fly during the un-absorb k-steps and the D -> E hand-off — the time this CU's memory pipe
+  // otherwise idles.  Phase E then starts with 24 of a wavefront's 16 / 32 k-steps in registers instead of 8.
+#ifndef KTX_ATTN_RG   // (dev builds: -DKTX_ATTN_RG=.. -DKTX_ATTN_FE=.. for the A/B of scripts/ab_attn_libs.sh)
+#define KTX_ATTN_RG 3
+#define KTX_ATTN_FE 2
+#endif
+  constexpr int RG = F8 ? 2 : KTX_ATTN_RG;   // (FP8 tiles are two planes: registers for two groups)
+  constexpr int FE = F8 ? 1 : KTX_ATTN_FE;   // k-steps of phase E between scheduling fences (FP8 tiles are two planes: no registers for pairs)
+  uint4 wrE[8 * RG][NQ];
+  uint2 srE[8 * RG];
+  const long ntileE = (long)p.nE * p.nksE;
   auto load_E = [&](int d, long tile) {
+    tile = min(tile, ntileE - 1);   // (a run-ahead slot past the wavefront's range reads a tile nobody uses: no branch around requests)
 #pragma unroll
     for (int q = 0; q < NQ; q++) wrE[d][q] = nt_load16(p.wE + tile * TB + q * 1024 + lane * 16);
     if constexpr (F8) {   // fp32 scale of (128-row block, k-step): tile = strip * nksE + ks, nksE a power of two
@@ -1029,7 +990,15 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       for (int d = 0; d < 8; d++) load_E(d, (long)gbE * 8 + d);
     }
   };
+  auto prefetch_E2 = [&]() {
+    if (geE > gbE + 1) {
+#pragma unroll
+      for (int d = 8; d < 8 * RG; d++) load_E(d, (long)gbE * 8 + d);
+    }
+  };
   if constexpr ((MASK & PH_E) != 0) prefetch_E();
+  if constexpr ((MASK & PH_E) != 0 && (MASK & PH_D) == 0) prefetch_E2();
+  if constexpr ((MASK & PH_E) != 0 && (MASK & PH_D) != 0) { if (!doBD) prefetch_E2(); }
   if constexpr ((MASK & PH_D) != 0) {
    if (doBD) {
     __syncthreads();
@@ -1128,10 +1097,16 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       if (lane < 16) stageD[wave * 16 + lane] = f32_to_bf16(0.f + acc[0]);
     }
     __syncthreads();
-    if (tid < 8) ws_store16(rs, L.attn_out + (unsigned)(h * VDIM + part * 64) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stageD + tid * 8));
-    drain_stores();
-    __syncthreads();
-    if (tid == 0) st_word(fD + w, epoch);
+    // Wavefront 0 publishes the workgroup's attention rows (store, drain, flag: one wavefront, no barrier in between).  Phase E's
+    // run-ahead groups go out HERE — the other wavefronts at once, wavefront 0 behind its flag: a wavefront stalls in the issue of
+    // 32 requests until the CU's memory pipe has taken them (measured: ~3.5 us when issued inside the merge, on the chain), and
+    // from here on nothing of this workgroup is on anybody's chain until the attention rows of ALL heads have arrived.
+    if (wave == 0) {
+      if (tid < 8) ws_store16(rs, L.attn_out + (unsigned)(h * VDIM + part * 64) * 2 + tid * 16, *reinterpret_cast<const uint4*>(stageD + tid * 8));
+      drain_stores();
+      if (tid == 0) st_word(fD + w, epoch);
+    }
+    if constexpr ((MASK & PH_E) != 0) prefetch_E2();
    }
     AT_STAMP(12);
   }
@@ -1179,31 +1154,56 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       auto flush = [&]() {
         if (lane < 16) tableE[((size_t)(strip - s_first) * 8 + wave) * 64 + lane] = acc;
       };
-      int g = gbE;
-      while (true) {
-        const int seg_end = min((strip + 1) * GPS_E, geE);
-        const bool last_seg = seg_end == geE;
-        const int n_inner = seg_end - g - (last_seg ? 1 : 0);
-        for (int i = 0; i < n_inner; i++, g++, kg++) {
+      // groups gbE .. geE - 1 in order.  Stage 1: the first RG groups sit in the ring (requested before / inside phase D) — straight-line
+      // code, no requests except group RG's, which goes out into the first ring group as soon as group 0 has been used.  Stage 2
+      // (a wavefront with more than RG groups): the round-4 stream through ring group 0, one group of lead.
+      const int ngrp = geE - gbE;
+      auto end_group = [&](int j) {
+        kg++;
+        if (kg == GPS_E || j == ngrp - 1) {
+          flush();
+          acc = 0.f;
+          kg = 0;
+          strip++;
+        }
+      };
+#pragma unroll
+      for (int r = 0; r < RG; r++) {
+        if (r < ngrp) {
           const int ks0 = kg * 8;
 #pragma unroll
-          for (int d = 0; d < 8; d++) {
-            stepE(d, ks0 + d, acc);
-            load_E(d, (long)(g + 1) * 8 + d);
+          for (int d = 0; d < 8; d += FE) {   // (W4 fenced in pairs: a fence per k-step serialises each step's LDS read -> MFMA -> fma chain)
+#pragma unroll
+            for (int e = 0; e < FE; e++) stepE(r * 8 + d + e, ks0 + d + e, acc);
             __builtin_amdgcn_sched_barrier(0);
           }
-        }
-        if (last_seg) {
-          const int ks0 = kg * 8;
+          if (r == 0) {
+            if (ngrp > RG) {
 #pragma unroll
-          for (int d = 0; d < 8; d++) stepE(d, ks0 + d, acc);
-          flush();
-          break;
+              for (int d = 0; d < 8; d++) load_E(d, (long)(gbE + RG) * 8 + d);
+            }
+          }
+          end_group(r);
         }
-        flush();
-        acc = 0.f;
-        kg = 0;
-        strip++;
+      }
+      for (int j = RG; j < ngrp - 1; j++) {
+        const int ks0 = kg * 8;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          stepE(d, ks0 + d, acc);
+          load_E(d, (long)(gbE + j + 1) * 8 + d);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        end_group(j);
+      }
+      if (ngrp > RG) {   // (its own copy of the eight k-steps: sharing one with the loop above lets the compiler lift all eight unpacks)
+        const int ks0 = kg * 8;
+#pragma unroll
+        for (int d = 0; d < 8; d++) {
+          stepE(d, ks0 + d, acc);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        end_group(ngrp - 1);
       }
     }
     __syncthreads();
@@ -1378,7 +1378,7 @@ int check_args(const ktx_attn_decode_args* a, KtxLinearRaw (&r)[5], int* nsplit_
 
 template <int MASK, int FMT = KTX_LIN_W4>
 int launch(const AttnParams& p, int dev, int nwg, hipStream_t st) {
-  constexpr size_t LDS = 108 * 1024;
+  constexpr size_t LDS = 148 * 1024;   // phase C: three staged tiles (3 x 41 KiB) + the score / probability exchange (24 KiB)
   constexpr int SLOT = MASK + (FMT == KTX_LIN_FP8 ? 64 : 0);
   {
     std::lock_guard<std::mutex> lk(g_mu);
@@ -1513,7 +1513,7 @@ extern "C" int ktx_attn_debug_read(int device, int which, void* d_dst, size_t by
   const DevWs& d = g_ws[device][g_last[device]];
   KTX_REQUIRE(d.base, "ktx_attn_debug_read: no workspace on this device yet");
   const WsLayout L = ws_layout(d.H, d.nA);
-  const unsigned offs[10] = {L.qkv, L.ckv_new, L.kpe_new, L.q_lat, L.q_pe, L.om, L.attn_out, L.part_ml, L.part_o, L.qx};
+  const unsigned offs[10] = {L.qkv, L.ckv_new, L.kpe_new, L.q_lat, L.q_pe, 0u, L.attn_out, L.part_ml, L.part_o, L.qx};
   KTX_REQUIRE(which >= 0 && which < 10 && offs[which] + bytes <= d.bytes, "ktx_attn_debug_read: bad array or size");
   KTX_REQUIRE(which != 5, "ktx_attn_debug_read: the merged rows no longer pass through the workspace (each workgroup of a head's pair merges all 512 dims in LDS)");
   DeviceGuard guard(device);
