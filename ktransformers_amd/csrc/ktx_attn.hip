@@ -423,13 +423,8 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     if (!doA && doBD) {
       // (workgroups without a strip of phase A: their 136 KiB each would compete chip-wide with the 7 MB of phase A tiles the step
       // is waiting for — measured: those tiles took 6 us to arrive — so they start ~1.5 us late)
-#ifndef KTX_ATTN_BSLEEP
-#define KTX_ATTN_BSLEEP 56
-#endif
-      if constexpr ((MASK & PH_A) != 0) {
-        __builtin_amdgcn_s_sleep(KTX_ATTN_BSLEEP > 127 ? 127 : KTX_ATTN_BSLEEP);
-        if constexpr (KTX_ATTN_BSLEEP > 127) __builtin_amdgcn_s_sleep(KTX_ATTN_BSLEEP - 127);
-      }
+      // (3.4 and 5.4 us were measured in round 6 as well: phase A ends 1.4 us earlier, phase C starts at the same time)
+      if constexpr ((MASK & PH_A) != 0) __builtin_amdgcn_s_sleep(56);
       prefetch_B();
     }
   }
@@ -740,16 +735,9 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     __syncthreads();
     if (doC) {
       constexpr int HBW = 2, DSPLIT = 4, NWV = 8, NDT = 32 / DSPLIT, NQ = (18 + DSPLIT - 1) / DSPLIT;
-      // NTB staged tiles: a tile is requested TWO tiles ahead.  With two buffers a tile's 41 KiB were requested when the previous tile's
-      // arithmetic began and the loop ran at one request latency per tile (~2.3 us for ~1 us of MFMA + softmax per tile: 7 us for the
-      // three tiles of a split at 4 K tokens); same tiles in the same order, so the same sums.
-#ifndef KTX_ATTN_NTB
-#define KTX_ATTN_NTB 3
-#endif
-      constexpr int NTB = KTX_ATTN_NTB;
-      bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [NTB][32][584]
-      bf16_t* Kp = Kt + NTB * TILE * KROW;                                 // [NTB][32][64]
-      bf16_t* Pt = Kp + NTB * TILE * ROPE;                                 // [8][16][32]
+      bf16_t* Kt = reinterpret_cast<bf16_t*>(smem);                        // [2][32][584]
+      bf16_t* Kp = Kt + 2 * TILE * KROW;                                   // [2][32][64]
+      bf16_t* Pt = Kp + 2 * TILE * ROPE;                                   // [8][16][32]
       float* Sx = reinterpret_cast<float*>(Pt + NWV * 16 * TILE);          // [8][8][64]
       const int hbw = wave / DSPLIT, ds = wave % DSPLIT;
       const int head0 = (hg * HBW + hbw) * 16;
@@ -771,7 +759,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
 
       auto stage_tile = [&](int tile, int buf) {   // buf = which of the two staged tiles
         const uint32_t dK = smem_lds + (uint32_t)buf * (TILE * KROW * 2);
-        const uint32_t dP = smem_lds + (uint32_t)(NTB * TILE * KROW * 2) + (uint32_t)buf * (TILE * ROPE * 2);
+        const uint32_t dP = smem_lds + (uint32_t)(2 * TILE * KROW * 2) + (uint32_t)buf * (TILE * ROPE * 2);
         const int tok0 = tile * TILE;
         const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
         const int page0 = p.kv_indices ? p.kv_indices[pidx_] : pidx_;
@@ -801,11 +789,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");   // the row is fetched by LDS-DMA (a plain load)
         __syncthreads();
       }
-      if (work) {   // depend on nothing else: in flight while the q rows are awaited
-        stage_tile(t_begin, 0);
-        if (NTB > 2 && t_begin + t_step < t_end) stage_tile(t_begin + t_step, 1);
-      }
-      // ---- q rows of this workgroup's 32 heads: produced by the 64 phase-B workgroups (head, half)
+      if (work) stage_tile(t_begin, 0);   // depends on nothing else: in flight while the q rows are awaited
       // (granules: each wavefront waits for exactly the q pieces its lanes hold — no flag sweep, no second round trip)
       av8bf qf[NQ];
       {
@@ -830,25 +814,17 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       if (work) {
         bf16_t* Pw = Pt + wave * 16 * TILE;
         int cur = 0;
-        for (int tile = t_begin; tile < t_end; tile += t_step, cur = cur == NTB - 1 ? 0 : cur + 1) {
+        for (int tile = t_begin; tile < t_end; tile += t_step, cur ^= 1) {
           bf16_t* Kc = Kt + cur * TILE * KROW;
           const bf16_t* Pc = Kp + cur * TILE * ROPE;
           const int tok0 = tile * TILE;
           const int ntok = min(TILE, kv_end - tok0);
-          // this tile has landed; the NEXT tile's requests (this wavefront's four latent rows, and the k_pe rows of wavefronts 0..3:
-          // the youngest of its queue, replies arrive in order) may stay in flight
-          if (NTB > 2 && tile + t_step < t_end) {
-            if (wave < 4) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");
-            else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-          } else {
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-          }
-          __syncthreads();   // (every wavefront is also done with the tile before this one: its buffer takes the tile after the next)
-          if constexpr (NTB > 2) {
-            if (tile + 2 * t_step < t_end) stage_tile(tile + 2 * t_step, cur >= NTB - 2 ? cur + 2 - NTB : cur + 2);
-          } else {
-            if (tile + t_step < t_end) stage_tile(tile + t_step, cur ^ 1);
-          }
+          // (staging tiles TWO ahead — three LDS buffers, counted vmcnt waits — was built and measured in round 6: 56.0 vs 56.1 us per
+          // layer, the three tiles of a split at 4 K tokens took 6.5 instead of 7.0 us and the q rows arrived 0.5 us later behind the
+          // bigger burst: not kept)
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          __syncthreads();
+          if (tile + t_step < t_end) stage_tile(tile + t_step, cur ^ 1);
 
           v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
           const bf16_t* kb0 = Kc + (lane & 15) * KROW + (lane >> 4) * 8;
@@ -961,12 +937,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // the other RG - 1 groups are requested inside phase D once the merge has consumed the splits' partial rows (their 64 registers
   // are free from there on), so they fly during the un-absorb k-steps and the D -> E hand-off — the time this CU's memory pipe
   // otherwise idles.  Phase E then starts with 24 of a wavefront's 16 / 32 k-steps in registers instead of 8.
-#ifndef KTX_ATTN_RG   // (dev builds: -DKTX_ATTN_RG=.. -DKTX_ATTN_FE=.. for the A/B of scripts/ab_attn_libs.sh)
-#define KTX_ATTN_RG 3
-#define KTX_ATTN_FE 2
-#endif
-  constexpr int RG = F8 ? 2 : KTX_ATTN_RG;   // (FP8 tiles are two planes: registers for two groups)
-  constexpr int FE = F8 ? 1 : KTX_ATTN_FE;   // k-steps of phase E between scheduling fences (FP8 tiles are two planes: no registers for pairs)
+  constexpr int RG = F8 ? 2 : 3;   // (FP8 tiles are two planes: registers for two groups; W4 with four groups measured slower)
   uint4 wrE[8 * RG][NQ];
   uint2 srE[8 * RG];
   const long ntileE = (long)p.nE * p.nksE;
@@ -1172,10 +1143,9 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         if (r < ngrp) {
           const int ks0 = kg * 8;
 #pragma unroll
-          for (int d = 0; d < 8; d += FE) {   // (W4 fenced in pairs: a fence per k-step serialises each step's LDS read -> MFMA -> fma chain)
-#pragma unroll
-            for (int e = 0; e < FE; e++) stepE(r * 8 + d + e, ks0 + d + e, acc);
-            __builtin_amdgcn_sched_barrier(0);
+          for (int d = 0; d < 8; d++) {
+            stepE(r * 8 + d, ks0 + d, acc);
+            __builtin_amdgcn_sched_barrier(0);   // (fences every 2 / 4 / 8 k-steps measured the same: 55.8 - 56.3 us per layer)
           }
           if (r == 0) {
             if (ngrp > RG) {
@@ -1378,7 +1348,7 @@ int check_args(const ktx_attn_decode_args* a, KtxLinearRaw (&r)[5], int* nsplit_
 
 template <int MASK, int FMT = KTX_LIN_W4>
 int launch(const AttnParams& p, int dev, int nwg, hipStream_t st) {
-  constexpr size_t LDS = 148 * 1024;   // phase C: three staged tiles (3 x 41 KiB) + the score / probability exchange (24 KiB)
+  constexpr size_t LDS = 108 * 1024;
   constexpr int SLOT = MASK + (FMT == KTX_LIN_FP8 ? 64 : 0);
   {
     std::lock_guard<std::mutex> lk(g_mu);
