@@ -937,7 +937,9 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // the other RG - 1 groups are requested inside phase D once the merge has consumed the splits' partial rows (their 64 registers
   // are free from there on), so they fly during the un-absorb k-steps and the D -> E hand-off — the time this CU's memory pipe
   // otherwise idles.  Phase E then starts with 24 of a wavefront's 16 / 32 k-steps in registers instead of 8.
-  constexpr int RG = F8 ? 2 : 3;   // (FP8 tiles are two planes: registers for two groups; W4 with four groups measured slower)
+  // (FP8 tiles are two planes: registers for two groups.  W4 with four groups, the fourth requested with the others or behind phase E's
+  // staging requests, measured slower: 58.7 / 57.1 against 56.9 / 55.8 us per layer)
+  constexpr int RG = F8 ? 2 : 3;
   uint4 wrE[8 * RG][NQ];
   uint2 srE[8 * RG];
   const long ntileE = (long)p.nE * p.nksE;
@@ -1093,9 +1095,19 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     __syncthreads();
     AT_STAMP(13);
     {
+      // every piece of the attention row this thread stages is requested BEFORE the first one is used (as a loop `load, use` the
+      // compiler waited for each in turn — and with it, replies arriving in order, for every run-ahead tile requested before:
+      // four serial round trips, ~3 us of phase E)
+      constexpr int XRE = 4;   // 16-byte pieces per thread: heads * v_dim <= 16384
       const int np = nksE * 16;
-      for (int pc = tid; pc < np; pc += NT) {   // (whole wavefronts: np is a multiple of 64)
-        const uint4 v = ws_load16(rs, L.attn_out + (unsigned)pc * 16);
+      uint4 xvE[XRE];
+#pragma unroll
+      for (int i = 0; i < XRE; i++) xvE[i] = ws_load16(rs, L.attn_out + (unsigned)min(tid + i * NT, np - 1) * 16);
+#pragma unroll
+      for (int i = 0; i < XRE; i++) {
+        const int pc = tid + i * NT;   // (whole wavefronts: np is a multiple of 64)
+        if (pc >= np) continue;
+        const uint4 v = xvE[i];
         if constexpr (F8) {
           float sq;
           const uint2 q8 = fp8_quant_piece(v, sq);
@@ -1147,7 +1159,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
             stepE(r * 8 + d, ks0 + d, acc);
             __builtin_amdgcn_sched_barrier(0);   // (fences every 2 / 4 / 8 k-steps measured the same: 55.8 - 56.3 us per layer)
           }
-          if (r == 0) {
+          if (r == 0) {   // (requested slot by slot behind each k-step of group 0 instead: 55.2 - 55.5 against 55.1 - 55.2 us per layer)
             if (ngrp > RG) {
 #pragma unroll
               for (int d = 0; d < 8; d++) load_E(d, (long)(gbE + RG) * 8 + d);

@@ -23,6 +23,8 @@ def u(shape, scale):
 
 import os  # noqa: E402
 FMT = os.environ.get("KTX_ATTN_BENCH_FMT", "W4")      # "FP8": block-fp8 projections (DeepSeek fp8 checkpoints)
+if os.environ.get("KTX_ATTN_BENCH_NSPLIT"):           # dev knob 7: force the KV split count (both paths follow it)
+    N.lib.ktx_debug_set(7, int(os.environ["KTX_ATTN_BENCH_NSPLIT"]))
 
 
 def proj(K, Nout, scale):
