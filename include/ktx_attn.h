@@ -80,8 +80,9 @@ int ktx_attn_status(int device, uint32_t* status_out);
 int ktx_attn_status_any(int* device_out, uint32_t* status_out);
 int ktx_attn_reset(int device);
 
-/* tests: copy a workspace array of the last launch (0 q_a|kv_a row, 1 ckv_new, 2 kpe_new, 3 q_lat, 4 q_pe, 5 merged rows, 6 attn_out,
- * 7 part_ml, 8 part_o, 9 exchanged q_nope) into a device buffer */
+/* tests: copy a workspace array of the last launch (0 q_a|kv_a row, 1 ckv_new, 2 kpe_new, 3 q_lat, 4 q_pe, 6 attn_out, 7 part_ml,
+ * 8 part_o, 9 exchanged q_nope) into a device buffer.  Arrays 0, 3 and 4 travel as tagged granules inside the launch; the copy is the
+ * payload alone, in row order.  (5, the merged rows, no longer pass through the workspace: refused.) */
 int ktx_attn_debug_read(int device, int which, void* d_dst, size_t bytes);
 
 /* dev probe: 64 wall-clock stamps (100 MHz) of workgroup 0 per launch, or NULL */

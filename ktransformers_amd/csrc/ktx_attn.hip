@@ -11,15 +11,17 @@
 //   B  q_a_layernorm + q_b rows of a head + RoPE + absorb  TWO workgroups per head: each computes half of the head's q_b rows, the
 //      + (one workgroup) kv_a_layernorm, k_pe RoPE, cache append    halves swap their q_nope pieces, each produces half of the absorbed row
 //   C  split-KV attention over the paged latent cache      (32 heads) x (KV split) per workgroup, mla_decode_kernel<2,4>'s tile loop
-//   D  merge of the splits + un-absorb                     two workgroups per head: each merges half of the 512 dims, they swap,
+//   D  merge of the splits + un-absorb                     two workgroups per head: each merges all 512 dims (round 6: no exchange),
 //                                                          each produces half of the head's v_dim outputs
 //   E  o_proj + residual                                   whole strips dealt to all workgroups
 // A phase's weights are requested BEFORE the workgroup starts waiting for the phase's input (they depend on nothing), so the
-// weight stream runs across the hand-offs; a phase's input arrives through the device workspace: the producer stores it
-// write-through (sc1), drains, and sets a per-workgroup flag to the launch's epoch; consumers poll exactly the flags they
-// depend on (one wavefront, relaxed device-scope loads) and read the payload with sc1 loads (MI355X_MICROARCH.md
-// §inter-workgroup visibility: sc1 stores + sc1 loads need no fence).  The epoch lives in the workspace and is advanced by the
-// last workgroup to leave, so a captured graph replays with fresh flags and nothing has to be zeroed.
+// weight stream runs across the hand-offs; a phase's input arrives through the device workspace.  The small rows (A -> B, B -> C)
+// travel as tagged 8-byte granules {two bf16, tag = the launch's epoch}: the data is the flag, the consumer's lanes re-read the
+// granules they stage until every tag matches (round 6).  The large ones (C -> D: fp32 partials, D -> E: every workgroup reads every
+// head's row) keep payload + flag: the producer stores write-through (sc1), drains, and sets a per-workgroup flag to the epoch;
+// consumers poll exactly the flags they depend on (one wavefront, relaxed device-scope loads) and read the payload with sc1 loads
+// (MI355X_MICROARCH.md §inter-workgroup visibility: sc1 stores + sc1 loads need no fence).  The epoch lives in the workspace and is
+// advanced by the last workgroup to leave, so a captured graph replays with fresh tags and flags and nothing has to be zeroed.
 //
 // Arithmetic.  Every phase restates its stand-alone kernel: same k-steps (ktx_w4_step.inc), same fixed summation orders, same
 // roundings, same KV split rule (ktx_mla_decode_nsplit) — tests/test_attn_fused_gpu.py holds the outputs of all five phases
