@@ -22,7 +22,7 @@ for rnd in $(seq 1 ${AB_ROUNDS:-2}); do
     python - <<PY | tee -a $O/step.txt
 import json
 d = json.load(open("$O/b_${which}_$rnd.json"))
-print(f"{d['ms_per_step']:.4f} ms/step  {d['value']:.2f} tok/s  median {d.get('median_tok_s')}")
+print(f"{d['ms_per_step']:.4f} ms/step  {d['value']:.2f} tok/s  median {d.get('median_tok_s')}  bs8 {(d.get('bs8') or {}).get('value')}")
 PY
   done
 done
