@@ -383,14 +383,41 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   float ropePos = 0.f, ropeIf = 0.f;
   // one register file for both wave roles: waves 0..5 hold rb[0..11] = their q_b strip (k-half kh, step s_ at kh * 6 + s_) and
   // rb[12..15] = their absorb strip; waves 6..7 hold rb[4 i .. 4 i + 3] = absorb strip i of their five
-  constexpr int ABS0 = 2 * NK2 * NQ;               // first absorb register of waves 0..5 (behind their q_b tiles)
-  uint4 rb[ABS0 + 4 > 20 ? ABS0 + 4 : 20];
-  uint2 sb[2 * NK2];
+  // W4 (round 6): NO exchange between the halves — every workgroup of the pair computes ALL eight q_nope strips of its head (it needs
+  // the whole q_nope for its 256 absorbed values), the part-1 workgroup the four rope strips too: 16 / 24 half-strips (strip, k-half)
+  // dealt 2 / 3 per wavefront, then two absorb strips per wavefront.  rb[6 i .. 6 i + 5] = half-strip slot i, rb[18 + 4 i ..] = absorb
+  // strip i.  12.6 MB more q_b bytes per layer (requested behind phase A's k-steps, while HBM idles) for one hand-off less.
+  constexpr int ABS0 = F8 ? 2 * NK2 * NQ : 3 * NK2;   // first absorb register (F8: of waves 0..5, behind their q_b tiles)
+  constexpr int NRB = F8 ? (ABS0 + 4 > 20 ? ABS0 + 4 : 20) : ABS0 + 8;
+  uint4 rb[NRB];
+  uint2 sb[F8 ? 2 * NK2 : 3 * NK2];
+  const int nperB = part == 0 ? 2 : 3;   // W4: half-strips per wavefront
   auto prefetch_B = [&]() {
     nwB = *reinterpret_cast<const uint4*>(p.qa_norm_w + min(tid, (p.q_lora >> 3) - 1) * 8);
     ropePos = (float)p.pos[0];
     ropeIf = p.inv_freq[tid & (ROPE / 2 - 1)];
-    if (wave < 6) {
+    if constexpr (!F8) {
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        if (i < nperB) {
+          const int hsi = wave * nperB + i;
+          const size_t t0 = ((size_t)h * SPH + (hsi >> 1)) * p.nksB + (size_t)(hsi & 1) * NK2;
+          const uint8_t* wp = p.wB + t0 * TB + lane * 16;
+          const bf16_t* sp = p.scB + (t0 * 16 + (lane & 15)) * 2;
+#pragma unroll
+          for (int s_ = 0; s_ < NK2; s_++) {
+            rb[i * NK2 + s_] = nt_load16(wp + (size_t)s_ * TB);
+            sb[i * NK2 + s_] = load_w4_scales<2>(sp + (size_t)s_ * 16 * 2);
+          }
+        }
+      }
+#pragma unroll
+      for (int i = 0; i < 2; i++) {
+        const uint8_t* wp2 = p.wUK + (size_t)h * p.wbsUK + (size_t)(part * 16 + wave * 2 + i) * 4096 + lane * 16;
+#pragma unroll
+        for (int q = 0; q < 4; q++) rb[ABS0 + i * 4 + q] = nt_load16(wp2 + q * 1024);
+      }
+    } else if (wave < 6) {
       const size_t strip = (size_t)h * SPH + part * 6 + wave;
 #pragma unroll
       for (int kh = 0; kh < 2; kh++) {
@@ -525,12 +552,13 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     uint8_t* xsB = smem + 1280;                                                   // [q_lora / 8][16 B]
     float* auxB = reinterpret_cast<float*>(xsB + (size_t)(p.q_lora >> 3) * 16);   // [nksB * 2][4]
     float* nredB = auxB + p.nksB * 2 * 4;                                         // [8][4]
-    float* red1 = nredB + 32;                                                     // [6][2][16]
-    float* s_cs = red1 + 6 * 2 * 16;                                              // [64]: cos | sin
-    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [96] this half's q_b outputs
-    bf16_t* stage = qh + 96;                                                      // [256] publication staging
+    float* red1 = nredB + 32;                                                     // [12][2][16] (F8: [6][2][16])
+    float* s_cs = red1 + 12 * 2 * 16;                                             // [64]: cos | sin
+    bf16_t* qh = reinterpret_cast<bf16_t*>(s_cs + ROPE);                          // [192] the head's q_b outputs (F8: [96] this half's)
+    bf16_t* stage = qh + QW;                                                      // [256] publication staging
     uint8_t* xs2 = reinterpret_cast<uint8_t*>(stage + 256);                       // [16][16 B] the head's q_nope
     float* s_redK = reinterpret_cast<float*>(xs2 + 256);                          // [8] (kv prep)
+    bf16_t* qpe_st = reinterpret_cast<bf16_t*>(s_redK + 8);                       // [64] rotated q_pe (W4)
 
     // ---- the phase A output row [q_a | ckv | k_pe] (granules: every lane waits for the 8 values it stages): q_a pieces -> RMSNorm ->
     // staging; kv pieces -> LDS
@@ -633,6 +661,55 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     AT_STAMP(4);
     // ---- q_b rows of this half: waves 0..5 = one strip each, two k-halves summed in order (lin_qb_absorb_kernel)
     const int kc = lane >> 4;
+    if constexpr (!F8) {
+      // ---- W4: the head's q_b strips without an exchange (see the register arrays above); each half-strip is lin_qb_absorb_kernel's
+      // chain of six k-steps, the two k-halves of a strip summed in its order
+      const uint8_t* xb0 = xsB + kc * 16;
+#pragma unroll
+      for (int i = 0; i < 3; i++) {
+        if (i < nperB) {
+          const int hsi = wave * nperB + i, kh = hsi & 1;
+          float acc = 0.f;
+#pragma unroll
+          for (int s_ = 0; s_ < NK2; s_++) {
+            const int ks = kh * NK2 + s_;
+            w4_kstep1(rb[i * NK2 + s_], sb[i * NK2 + s_], xb0 + (size_t)ks * 256, auxB + ks * 8, acc);
+          }
+          if (lane < 16) red1[hsi * 16 + lane] = acc;   // [(strip * 2 + kh) * 16 + row]
+        }
+      }
+      AT_STAMP(20);
+      __syncthreads();
+      AT_STAMP(21);
+      if (tid < (part == 0 ? NOPE : QW)) {
+        const int sih = tid >> 4, f = tid & 15;
+        float v = 0.f;
+        v += red1[(sih * 2 + 0) * 16 + f];
+        v += red1[(sih * 2 + 1) * 16 + f];
+        qh[tid] = f32_to_bf16(v);
+      }
+      __syncthreads();
+      if (part == 1 && tid < ROPE / 2) prep_rope_pair(qh + NOPE, qpe_st, tid, ROPE / 2, s_cs[tid], s_cs[ROPE / 2 + tid]);
+      AT_STAMP(22);
+      AT_STAMP(27);
+      AT_STAMP(5);
+      {   // absorb: this half's 16 strips of W_UK[h]^T q_nope, two per wavefront, one k-step of 128 each (q_nope = qh[0, 128))
+        const uint8_t* xb2 = reinterpret_cast<const uint8_t*>(qh) + kc * 4 * 16;
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+          v4f acc = {0.f, 0.f, 0.f, 0.f};
+          const uint4 wt[4] = {rb[ABS0 + i * 4], rb[ABS0 + i * 4 + 1], rb[ABS0 + i * 4 + 2], rb[ABS0 + i * 4 + 3]};
+          bf16_kstep(wt, xb2, acc);
+          if (lane < 16) stage[(wave * 2 + i) * 16 + lane] = f32_to_bf16(0.f + acc[0]);
+        }
+      }
+      __syncthreads();
+      if (part == 1 && tid >= 64 && tid < 64 + ROPE / 4) {
+        const int t = tid - 64;
+        const uint2 v = *reinterpret_cast<const uint2*>(qpe_st + t * 4);
+        gran_store(rs, L.q_pe + (unsigned)h * ROPE * 4 + t * 16, v.x, v.y, epoch);
+      }
+    } else {
     if (wave < 6) {
       if constexpr (F8) {   // lin_dec_kernel<FP8> runs q_b's 12 k-steps as ONE k-slice per strip (8 strips per workgroup): one chain
         const uint8_t* xb0 = xsB + kc * 32;
@@ -708,6 +785,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       }
     }
     __syncthreads();
+    }   // (F8: the exchanging form)
     if (tid < 64) {   // this half's 256 absorbed values: 128 granules (no drain, no flag: phase C's lanes wait on the tags)
       const uint2 v = *reinterpret_cast<const uint2*>(stage + tid * 4);
       gran_store(rs, L.q_lat + (unsigned)(h * LORA + part * 256) * 4 + tid * 16, v.x, v.y, epoch);
@@ -984,6 +1062,8 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
     bf16_t* stageD = reinterpret_cast<bf16_t*>(s_acc + 8 * LORA);  // [256]
     uint8_t* xsD = reinterpret_cast<uint8_t*>(stageD + 256);       // [64][16 B]
     const int hgD = h >> 5;
+    // (every wavefront polling the flags of the splits IT merges and requesting their rows at once: 55.5 against 54.2 us per layer — eight
+    //  pollers per CU cost more than the early requests bring)
     if (wave == 7) poll_flags(p, fC, S, epoch, 0xD1, [=](int k) { return hgD * SPG + k; });
     __syncthreads();
     AT_STAMP(10);
