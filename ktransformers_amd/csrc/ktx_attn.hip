@@ -801,7 +801,8 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
   // phase D's weights (waves 0..3: one strip of W_UV[h], 4 k-steps x 4 planes) are requested before phase C starts waiting
   // (measured, profiles/r04_a_*: spreading these 64 KiB over the KV tiles of phase C — one k-step per tile, behind the tile's own
   // requests — made the q poll 1.2 us faster and the tile loop 2.4 us slower: every tile's wait is a wait for ALL of the wavefront's
-  // requests.  One burst in front of the q poll it is.)
+  // requests.  One burst in front of the q poll it is.  Round 6: the whole burst BEHIND the q rows' arrival, the first tile's wait counted:
+  // 54.6-54.8 against 54.1-54.6 us per layer — the second tile's requests then queue behind it.)
   uint4 wrD[4][4];
   const uint8_t* wpD = p.wUV + (size_t)h * p.wbsUV + (size_t)(part * 4 + (wave & 3)) * 4 * 4096 + lane * 16;
 #define KTX_PF_D(KS)                                                                                   \
