@@ -1207,6 +1207,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
       }
     }
     __syncthreads();
+    AT_STAMP(28);
     const int s_first = Gb / GPS_E;
     if (geE > gbE) {
       const int kc = lane >> 4;
@@ -1249,6 +1250,7 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
             }
           }
           end_group(r);
+          AT_STAMP(29 + r);
         }
       }
       for (int j = RG; j < ngrp - 1; j++) {

@@ -153,7 +153,8 @@ for i, nme in enumerate(names):
 extra = {18: "wave 0: every request of the prologue issued", 16: "wave 0: x landed, sum of squares done", 17: "wave 0: past the norm barrier",
          19: "wave 0: its 7 k-steps of phase A done", 23: "wave 7: entry", 25: "wave 7: requests issued", 24: "wave 7: x landed, sum of squares done",
          26: "wave 7: its 7 k-steps of phase A done", 20: "B: wave 0 q_b k-steps done", 21: "B: past the q_b barrier",
-         22: "B: own q_nope piece published", 27: "B: partner's piece polled"}
+         22: "B: own q_nope piece published", 27: "B: partner's piece polled", 28: "E: attention row staged",
+         29: "E: ring group 0 done (wave 0)", 30: "E: ring group 1 done", 31: "E: ring group 2 done"}
 for i, nme in extra.items():
     if t[i]:
         print(f"  [{nme}] {(t[i] - t[0]) * 0.01:7.2f}")
