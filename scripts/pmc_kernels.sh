@@ -17,7 +17,7 @@ acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for i in (1, 2):
     for f in glob.glob(f"/tmp/pmc_k_{i}/**/*counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            name = r["Kernel_Name"].split("(")[0].replace("void ", "")
+            name = r["Kernel_Name"].replace("void ", "").replace("(anonymous namespace)::", "").split("(")[0]
             if sys.argv[2] in name:
                 acc[name][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(sys.argv[1], "w") as out:
