@@ -8,8 +8,9 @@
 // workgroups — half the chip's CUs, each CU pulling ~24 GB/s whatever runs on it.  Here the five stages are
 // PHASES of one launch of 2 x heads = 256 workgroups, one per CU:
 //   A  input RMSNorm + q_a|kv_a GEMV                      one 16-row strip per workgroup (132 of them)
-//   B  q_a_layernorm + q_b rows of a head + RoPE + absorb  TWO workgroups per head: each computes half of the head's q_b rows, the
-//      + (one workgroup) kv_a_layernorm, k_pe RoPE, cache append    halves swap their q_nope pieces, each produces half of the absorbed row
+//   B  q_a_layernorm + q_b rows of a head + RoPE + absorb  TWO workgroups per head, each produces half of the absorbed row.  W4 (round 6):
+//      + (one workgroup) kv_a_layernorm, k_pe RoPE, cache append    each computes all of the head's q_nope rows itself (part 1 the rope rows
+//                                                          too) — no exchange; FP8: each half of the q_b rows, q_nope pieces swapped
 //   C  split-KV attention over the paged latent cache      (32 heads) x (KV split) per workgroup, mla_decode_kernel<2,4>'s tile loop
 //   D  merge of the splits + un-absorb                     two workgroups per head: each merges all 512 dims (round 6: no exchange),
 //                                                          each produces half of the head's v_dim outputs
