@@ -135,6 +135,27 @@ __device__ __forceinline__ float row16_sum(float v) {
   v += ktx_dpp_f<KTX_DPP_ROW_HALF_MIRROR>(v);
   return v + ktx_dpp_f<KTX_DPP_ROW_MIRROR>(v);
 }
+// Four independent row all-reductions at once, as VOP2 instructions that carry the DPP permutation themselves (v = op(perm(v), v)).
+// From C the compiler emits v_mov_b32_dpp + a canonicalising v_max + the operation + s_nop per step (the IEEE-mode quieting of a value
+// it cannot see through the permutation keeps it from folding the DPP into the operation): 14-16 instructions per reduction where this
+// takes 4.  The four values of a step are independent, so the >= 2 wait states a DPP read needs behind the VALU write of its source are
+// filled by the other three; the leading s_nop covers whatever the compiler issued last (VALU write of an input: 2 wait states, EXEC
+// write: 5) — the hazard recogniser does not look inside an asm — and the trailing one a DPP read the compiler may issue next.
+// Same values, same order of operations as row16_max / row16_sum (max and add commute): same bits.
+#define KTX_DPP4_STEP(OP, CTRL)                                                      \
+  OP " %0, %0, %0 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+  OP " %1, %1, %1 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+  OP " %2, %2, %2 " CTRL " row_mask:0xf bank_mask:0xf\n\t"                            \
+  OP " %3, %3, %3 " CTRL " row_mask:0xf bank_mask:0xf\n\t"
+#define KTX_DPP4_REDUCE(OP)                                                          \
+  "s_nop 4\n\t" KTX_DPP4_STEP(OP, "quad_perm:[1,0,3,2]") KTX_DPP4_STEP(OP, "quad_perm:[2,3,0,1]") \
+  KTX_DPP4_STEP(OP, "row_half_mirror") KTX_DPP4_STEP(OP, "row_mirror") "s_nop 1"
+__device__ __forceinline__ void row16_max4(float& a, float& b, float& c, float& d) {
+  asm volatile(KTX_DPP4_REDUCE("v_max_f32_dpp") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
+__device__ __forceinline__ void row16_sum4(float& a, float& b, float& c, float& d) {
+  asm volatile(KTX_DPP4_REDUCE("v_add_f32_dpp") : "+v"(a), "+v"(b), "+v"(c), "+v"(d));
+}
 __device__ __forceinline__ float wave_max(float v) {
   const int b = __float_as_int(row16_max(v));
   const float r0 = __int_as_float(__builtin_amdgcn_readlane(b, 0)), r1 = __int_as_float(__builtin_amdgcn_readlane(b, 16));

@@ -266,15 +266,26 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       if (tile == t_begin) MLA_TS(4);
       // lane holds S[head = (lane>>4)*4 + r][token = tok0 + (lane&15) (+16)]
       const bool v0 = (lane & 15) < ntok, v1 = 16 + (lane & 15) < ntok;
-      float alpha[4];
+      float alpha[4], sa[4], sb[4], mx[4], ps[4];
 #pragma unroll
       for (int r = 0; r < 4; r++) {
-        const float a = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
-        const float b = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
-        const float mx = row16_max(fmaxf(a, b));
-        const float m_new = fmaxf(m_run[r], mx);        // finite: every processed tile has >= 1 visible token
-        const float pa = __expf(a - m_new), pb = __expf(b - m_new);
-        const float sum = row16_sum(pa + pb);
+        sa[r] = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
+        sb[r] = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
+        mx[r] = fmaxf(sa[r], sb[r]);
+      }
+      row16_max4(mx[0], mx[1], mx[2], mx[3]);   // (the four heads' reductions interleaved: ktx_common.h)
+      float pav[4], pbv[4], mnew[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        mnew[r] = fmaxf(m_run[r], mx[r]);        // finite: every processed tile has >= 1 visible token
+        pav[r] = __expf(sa[r] - mnew[r]);
+        pbv[r] = __expf(sb[r] - mnew[r]);
+        ps[r] = pav[r] + pbv[r];
+      }
+      row16_sum4(ps[0], ps[1], ps[2], ps[3]);
+#pragma unroll
+      for (int r = 0; r < 4; r++) {
+        const float pa = pav[r], pb = pbv[r], m_new = mnew[r], sum = ps[r];
         alpha[r] = __expf(m_run[r] - m_new);
         l_run[r] = l_run[r] * alpha[r] + sum;
         m_run[r] = m_new;
@@ -290,10 +301,17 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
 
       // ---- O = O*alpha + P V ; V fragments by transposed reads of the same K tile ------------------------------------
       const bf16_t* vb = Kc + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * MLA_KROW + (lane & 3) * 4 + ds * NDT * 16;
+      // the rescale only where some head's running maximum moved (wave-uniform branch; alpha == 1 exactly otherwise, and o * 1 is o:
+      // same bits) — past the first tiles of a long context that is rare, and the 4 * NDT multiplies were a sixth of the loop's VALU
+      const bool moved = alpha[0] != 1.f || alpha[1] != 1.f || alpha[2] != 1.f || alpha[3] != 1.f;
+      if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {
+#pragma unroll
+        for (int i = 0; i < NDT; i++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
+      }
 #pragma unroll
       for (int i = 0; i < NDT; i++) {
-#pragma unroll
-        for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
         const v8bf b = load_v_frag(vb + i * 16);
         o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
       }

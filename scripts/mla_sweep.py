@@ -9,6 +9,9 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--heads", type=int, default=128)
 ap.add_argument("--ctx", type=int, default=4096)
 ap.add_argument("--layers", type=int, default=64)
+ap.add_argument("--shapes", default="1,2,4", help="knob-6 codes: 1 = 1x4 (head blocks x dim slices), 2 = 2x4, 4 = 4x2")
+ap.add_argument("--splits", default="8,16,32,64,128")
+ap.add_argument("--no-stamps", action="store_true")
 args = ap.parse_args()
 dev = torch.device("cuda", 0)
 Hq, ctx, L = args.heads, args.ctx, args.layers
@@ -46,10 +49,10 @@ def timed(only):
     return tot / 5 / L * 1e3
 
 
-for shape in (1, 2, 4):
+for shape in (int(v) for v in args.shapes.split(",")):
     if (shape == 2 and Hq % 32) or (shape == 4 and Hq % 64):
         continue
-    for ns in (8, 16, 32, 64, 128):
+    for ns in (int(v) for v in args.splits.split(",")):
         n.lib.ktx_debug_set(6, shape); n.lib.ktx_debug_set(7, ns)
         try:
             both, dec, mer = timed(0), timed(1), timed(2)
@@ -57,6 +60,8 @@ for shape in (1, 2, 4):
         except Exception as e:
             print(f"shape={shape} nsplit={ns}: {e}")
 n.lib.ktx_debug_set(6, 0); n.lib.ktx_debug_set(7, 0)
+if args.no_stamps:
+    sys.exit(0)
 
 # phase breakdown of the split-KV kernel (wall-clock stamps, 10 ns ticks): one eager launch per configuration
 names = ["start->request resolved", "->first tile issued", "->first tile landed (barrier)", "->S = QK^T done", "->first tile done",
