@@ -942,15 +942,27 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
               for (int r = 0; r < 4; r++) { s0[r] += sr[d * 512 + r * 64]; s1[r] += sr[d * 512 + (4 + r) * 64]; }
           }
           const bool v0 = (lane & 15) < ntok, v1 = 16 + (lane & 15) < ntok;
-          float alpha[4];
+          // (mla_decode_kernel's round-6 form: the four heads' row reductions interleaved as VOP2-DPP instructions, the O rescale only
+          //  where a running maximum moved — same values, same bits)
+          float alpha[4], sa[4], sb[4], mx4[4], ps[4], pav[4], pbv[4], mnew[4];
 #pragma unroll
           for (int r = 0; r < 4; r++) {
-            const float a = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
-            const float b = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
-            const float mx = row16_max(fmaxf(a, b));
-            const float m_new = fmaxf(m_run[r], mx);
-            const float pa = __expf(a - m_new), pb = __expf(b - m_new);
-            const float sum = row16_sum(pa + pb);
+            sa[r] = v0 ? s0[r] * p.sm_scale : -__builtin_inff();
+            sb[r] = v1 ? s1[r] * p.sm_scale : -__builtin_inff();
+            mx4[r] = fmaxf(sa[r], sb[r]);
+          }
+          row16_max4(mx4[0], mx4[1], mx4[2], mx4[3]);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            mnew[r] = fmaxf(m_run[r], mx4[r]);
+            pav[r] = __expf(sa[r] - mnew[r]);
+            pbv[r] = __expf(sb[r] - mnew[r]);
+            ps[r] = pav[r] + pbv[r];
+          }
+          row16_sum4(ps[0], ps[1], ps[2], ps[3]);
+#pragma unroll
+          for (int r = 0; r < 4; r++) {
+            const float pa = pav[r], pb = pbv[r], m_new = mnew[r], sum = ps[r];
             alpha[r] = __expf(m_run[r] - m_new);
             l_run[r] = l_run[r] * alpha[r] + sum;
             m_run[r] = m_new;
@@ -963,10 +975,15 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
           __builtin_amdgcn_wave_barrier();
           const av8bf pf = as_av8bf(*reinterpret_cast<const uint4*>(Pw + (lane & 15) * TILE + (lane >> 4) * 8));
           const bf16_t* vb = Kc + ((lane >> 4) * 8 + ((lane & 15) >> 2)) * KROW + (lane & 3) * 4 + ds * NDT * 16;
+          const bool moved = alpha[0] != 1.f || alpha[1] != 1.f || alpha[2] != 1.f || alpha[3] != 1.f;
+          if (__builtin_amdgcn_ballot_w64(moved) != 0ull) {
+#pragma unroll
+            for (int i = 0; i < NDT; i++)
+#pragma unroll
+              for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
+          }
 #pragma unroll
           for (int i = 0; i < NDT; i++) {
-#pragma unroll
-            for (int r = 0; r < 4; r++) o[i][r] *= alpha[r];
             const av8bf b = load_v_frag(vb + i * 16);
             o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
           }

@@ -87,6 +87,18 @@ __device__ __forceinline__ void mla_dma_row(const bf16_t* gsrc_lane, const bf16_
                : "memory");
 }
 
+// The same with the row's address as a SCALAR base + a 32-bit per-lane byte offset (the saddr form): a staged ckv row is one wave-uniform
+// pointer, so its arithmetic (page, row, append override) runs on the scalar unit — as 64-bit per-lane pointers it was ~45 of the tile
+// loop's ~260 VALU instructions, and the loop is VALU-issue bound (profiles/r06_W_mla_valu_diet_ab.txt).
+__device__ __forceinline__ void mla_dma_row_s(const bf16_t* gsrc_row, uint32_t lane_byte_off, const bf16_t* lds_row) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds_row);
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(gsrc_row), "s"(lds_addr)
+               : "memory");
+}
+
 // Workgroup = HBW head blocks (16 heads each) x DSPLIT slices: wave (hbw, ds) computes 512/DSPLIT dims of O += P V (which
 // divides the fp32 accumulator registers — the 128-VGPR O tile of the undivided form left one wave per SIMD running a
 // serial chain of LDS reads and MFMAs, ~7 us per 32-token tile) and every DSPLIT-th 32-wide k-step of S = Q K^T; the DSPLIT
@@ -192,15 +204,15 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     auto stage = [&](int tile, bf16_t* dK, bf16_t* dP) {
       const int tok0 = tile * MLA_TILE;
       const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
-      const int page0 = p.kv_indices ? p.kv_indices[pidx_] : pidx_;
+      const int page0 = __builtin_amdgcn_readfirstlane(p.kv_indices ? p.kv_indices[pidx_] : pidx_);
       const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
       const int last = kv_end - 1 - tok0;   // last valid row of the tile (>= 0: the tile holds a visible token)
 #pragma unroll
-      for (int r = wave; r < MLA_TILE; r += NWV) {
+      for (int r = wave; r < MLA_TILE; r += NWV) {   // (every term wave-uniform: scalar arithmetic, mla_dma_row_s)
         const int rr = min(r, last);
         const bf16_t* src = p.ckv + (row0 + rr) * p.ckv_ts;
         if (tok0 + rr == app_pos) src = p.app_ckv + (size_t)req * MLA_DC;
-        mla_dma_row(src + lane * 8, dK + r * MLA_KROW);
+        mla_dma_row_s(src, (uint32_t)lane * 16u, dK + r * MLA_KROW);
       }
       if (wave < 4) {
         const int r = wave * 8 + (lane >> 3), rr = min(r, last);
