@@ -6,7 +6,7 @@
 #include <cstdint>
 
 template <int W>   // W = 8: ds_read_b64, 16: ds_read_b128
-__global__ __launch_bounds__(256) void probe(const uint32_t* offs, long long* cycles, uint32_t* sink, int iters) {
+__global__ __launch_bounds__(256) void probe(const uint32_t* offs, long long* cycles, uint32_t* sink, int iters, int ustride) {
   extern __shared__ __attribute__((aligned(16))) uint8_t smem[];
   for (int i = threadIdx.x; i < 16384; i += 256) reinterpret_cast<uint32_t*>(smem)[i] = i;
   __syncthreads();
@@ -17,7 +17,7 @@ __global__ __launch_bounds__(256) void probe(const uint32_t* offs, long long* cy
     asm volatile("" ::: "memory");          // (the reads are loop-invariant otherwise: hoisted)
 #pragma unroll
     for (int u = 0; u < 16; u++) {
-      const uint32_t a = a0 + u * 4096;      // 16 independent reads per iteration, same bank pattern
+      const uint32_t a = a0 + u * ustride;   // 16 independent reads per iteration, same bank pattern (ustride 4096) or the real loop's step
       if constexpr (W == 8) { const uint2 v = *reinterpret_cast<const uint2*>(smem + a); acc += v.x ^ v.y; }
       else { const uint4 v = *reinterpret_cast<const uint4*>(smem + a); acc += v.x ^ v.y ^ v.z ^ v.w; }
     }
@@ -28,11 +28,11 @@ __global__ __launch_bounds__(256) void probe(const uint32_t* offs, long long* cy
 }
 
 template <int W>
-static void run(const char* name, const uint32_t* h_offs, uint32_t* d_offs, long long* d_cyc, uint32_t* d_sink) {
+static void run(const char* name, const uint32_t* h_offs, uint32_t* d_offs, long long* d_cyc, uint32_t* d_sink, int ustride = 4096) {
   hipMemcpy(d_offs, h_offs, 256, hipMemcpyHostToDevice);
   const int iters = 2000;
   hipFuncSetAttribute(reinterpret_cast<const void*>(probe<W>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536 + 4096 * 2);
-  for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(probe<W>, dim3(256), dim3(256), 65536 + 8192, 0, d_offs, d_cyc, d_sink, iters);
+  for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(probe<W>, dim3(256), dim3(256), 65536 + 8192, 0, d_offs, d_cyc, d_sink, iters, ustride);
   hipDeviceSynchronize();
   long long c;
   hipMemcpy(&c, d_cyc, 8, hipMemcpyDeviceToHost);
@@ -70,5 +70,17 @@ int main() {
   uint32_t s = 12345;
   for (int l = 0; l < 64; l++) { s = s * 1664525u + 1013904223u; o[l] = ((s >> 8) & 2047) * 8; }
   run<8>("b64  random 8-byte entries of a 16 KiB table", o, d_offs, d_cyc, d_sink);
+  // (8)-(12) the MLA split-KV tile loop (csrc/ktx_mla.hip, rows of 1168 B): V fragments by ds_read_b64_tr_b16 — lane (g = lane >> 4,
+  // i = lane & 15) addresses row 8 g + (i >> 2) (+ 4 for the second read), 8 bytes at (i & 3) * 8, 32 bytes further per output tile
+  for (int l = 0; l < 64; l++) { const int g = l >> 4, i = l & 15; o[l] = (g * 8 + (i >> 2)) * 1168 + (i & 3) * 8; }
+  run<8>("b64  MLA V fragment, rows 8g + i/4 (product)", o, d_offs, d_cyc, d_sink, 32);
+  for (int l = 0; l < 64; l++) { const int g = l >> 4, i = l & 15; o[l] = (g * 8 + 2 * (i >> 2)) * 1168 + (i & 3) * 8; }
+  run<8>("b64  MLA V fragment, rows 8g + 2 (i/4) (even rows)", o, d_offs, d_cyc, d_sink, 32);
+  for (int l = 0; l < 64; l++) { const int g = l >> 4, i = l & 15; o[l] = (g * 8 + 2 * (i >> 2) + 1) * 1168 + (i & 3) * 8; }
+  run<8>("b64  MLA V fragment, rows 8g + 2 (i/4) + 1 (odd rows)", o, d_offs, d_cyc, d_sink, 32);
+  for (int l = 0; l < 64; l++) o[l] = (l & 15) * 1168 + (l >> 4) * 16;
+  run<16>("b128 MLA K fragment, row lane & 15, piece lane >> 4", o, d_offs, d_cyc, d_sink, 64);
+  for (int l = 0; l < 64; l++) o[l] = (l & 15) * 64 + (l >> 4) * 16;
+  run<16>("b128 MLA P fragment, 64-byte rows", o, d_offs, d_cyc, d_sink, 0);
   return 0;
 }
