@@ -99,6 +99,16 @@ __device__ __forceinline__ void mla_dma_row_s(const bf16_t* gsrc_row, uint32_t l
                : "memory");
 }
 
+// ... and with the LDS destination as a byte address (computed from the dynamic region's base: a generic pointer costs a null check
+// and a select per cast), for the tile loop's fast path.
+__device__ __forceinline__ void mla_dma_row_sa(const bf16_t* gsrc_row, uint32_t lane_byte_off, uint32_t lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(gsrc_row), "s"(lds_addr)
+               : "memory");
+}
+
 // Workgroup = HBW head blocks (16 heads each) x DSPLIT slices: wave (hbw, ds) computes 512/DSPLIT dims of O += P V (which
 // divides the fp32 accumulator registers — the 128-VGPR O tile of the undivided form left one wave per SIMD running a
 // serial chain of LDS reads and MFMAs, ~7 us per 32-token tile) and every DSPLIT-th 32-wide k-step of S = Q K^T; the DSPLIT
@@ -201,12 +211,28 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     // piece g of row r at position g ^ (r & 7) (the XOR keeps the fragment reads of 16 rows at most 2-way bank-conflicted
     // although the rows are packed).  Rows past the end of the context re-read the last valid row: finite values that the
     // softmax weights them with exactly 0 (their scores are masked), and nothing beyond kv_len is ever touched.
+    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)Kt);
     auto stage = [&](int tile, bf16_t* dK, bf16_t* dP) {
       const int tok0 = tile * MLA_TILE;
       const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
       const int page0 = __builtin_amdgcn_readfirstlane(p.kv_indices ? p.kv_indices[pidx_] : pidx_);
       const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
       const int last = kv_end - 1 - tok0;   // last valid row of the tile (>= 0: the tile holds a visible token)
+      // a whole tile without the appended row (all but one or two tiles of a split): one 64-bit product for the tile, then adds — the
+      // general form below spends ~25 scalar instructions per row on clamps, the append override and pointer casts (SQ counters of
+      // the loop: as many SALU as VALU instructions, profiles/r06_Z_pmc_mla_decode_128k.txt)
+      if (last >= MLA_TILE - 1 && (unsigned)(app_pos - tok0) >= (unsigned)MLA_TILE) {
+        const bf16_t* src = p.ckv + (row0 + wave) * p.ckv_ts;
+        const size_t step = (size_t)NWV * p.ckv_ts;
+        uint32_t dst = lds0 + (uint32_t)((dK - Kt) + wave * MLA_KROW) * 2u;
+#pragma unroll
+        for (int r = wave; r < MLA_TILE; r += NWV, src += step, dst += NWV * MLA_KROW * 2) mla_dma_row_sa(src, (uint32_t)lane * 16u, dst);
+        if (wave < 4) {
+          const int r = wave * 8 + (lane >> 3), g = (lane & 7) ^ (lane >> 3);
+          mla_dma_row(p.k_pe + (row0 + r) * p.kpe_ts + g * 8, dP + wave * 8 * MLA_DR);
+        }
+        return;
+      }
 #pragma unroll
       for (int r = wave; r < MLA_TILE; r += NWV) {   // (every term wave-uniform: scalar arithmetic, mla_dma_row_s)
         const int rr = min(r, last);
