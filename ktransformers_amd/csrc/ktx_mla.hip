@@ -212,10 +212,17 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     // although the rows are packed).  Rows past the end of the context re-read the last valid row: finite values that the
     // softmax weights them with exactly 0 (their scores are masked), and nothing beyond kv_len is ever touched.
     const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)Kt);
-    auto stage = [&](int tile, bf16_t* dK, bf16_t* dP) {
+    // The page of a tile is looked up ONE TILE AHEAD of its staging (page_of: the load is issued behind the previous tile's DMA requests
+    // and waited for by the loop's own vmcnt(0) in front of the barrier): looked up inside stage() the index was a dependent load in
+    // front of every tile's addresses — one exposed L2 round trip per tile with a real page table (the serving seam; the single-request
+    // cache passes kv_indices == NULL).
+    auto page_of = [&](int tile) -> int {
+      const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tile * MLA_TILE / p.page_size);
+      return p.kv_indices ? p.kv_indices[pidx_] : pidx_;
+    };
+    auto stage = [&](int tile, int page_v, bf16_t* dK, bf16_t* dP) {
       const int tok0 = tile * MLA_TILE;
-      const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
-      const int page0 = __builtin_amdgcn_readfirstlane(p.kv_indices ? p.kv_indices[pidx_] : pidx_);
+      const int page0 = __builtin_amdgcn_readfirstlane(page_v);
       const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
       const int last = kv_end - 1 - tok0;   // last valid row of the tile (>= 0: the tile holds a visible token)
       // a whole tile without the appended row (all but one or two tiles of a split): one 64-bit product for the tile, then adds — the
@@ -249,7 +256,8 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       }
     };
 
-    stage(t_begin, Kt, Kp);
+    stage(t_begin, page_of(t_begin), Kt, Kp);
+    int page_nx = page_of(min(t_begin + t_step, t_end - 1));   // (clamped: always a tile of this request)
     MLA_TS(2);
     bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
 
@@ -265,7 +273,10 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
       if (tile == t_begin) MLA_TS(3);
-      if (tile + t_step < t_end) stage(tile + t_step, Kn, Kp + (cur ^ 1) * MLA_TILE * MLA_DR);
+      if (tile + t_step < t_end) {
+        stage(tile + t_step, page_nx, Kn, Kp + (cur ^ 1) * MLA_TILE * MLA_DR);
+        page_nx = page_of(min(tile + 2 * t_step, t_end - 1));
+      }
 
       // ---- S = Q K^T for 2 x 16 tokens: this wave's k-steps -------------------------------------------------------------
       v4f s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
