@@ -33,6 +33,7 @@ struct MlaParams {
   long long ckv_ts, kpe_ts;
   const int32_t *qo_indptr, *kv_indptr, *kv_indices, *kv_len, *d_bsz;
   int batch, total_q, Hq, page_size, nsplit;
+  int tiles_shift;   // log2(page_size / 32) when the page size is a power of two (the reference's 64 and 256), else -1: tile -> page without a division
   float sm_scale;
   float* part_o;   // [total_q][Hq][nsplit][512]
   float* part_ml;  // [total_q][Hq][nsplit][2]
@@ -48,6 +49,14 @@ struct MlaParams {
     if (p.dbg && threadIdx.x == 0)                                                                            \
       p.dbg[(((size_t)blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 16 + (k)] = wall_clock64(); \
   } while (0)
+
+// the three stamps INSIDE the tile loop (first tile: landed, S done, tile done) cost every tile a compare, an exec save and a branch
+// each — compiled in only for the stamp pass of scripts/mla_sweep.py (build with -DKTX_MLA_LOOP_STAMPS)
+#ifdef KTX_MLA_LOOP_STAMPS
+#define MLA_TS_LOOP(k) do { if (tile == t_begin) MLA_TS(k); } while (0)
+#else
+#define MLA_TS_LOOP(k) do { } while (0)
+#endif
 
 typedef short v4s16 __attribute__((ext_vector_type(4)));
 
@@ -78,29 +87,19 @@ __device__ __forceinline__ v8bf load_v_frag(const bf16_t* base) {
 // prefetch with the compute: 3.4 us per tile and workgroup, measured, i.e. one HBM round trip per tile.  Unseen by the
 // compiler, completion is waited for explicitly in front of the per-tile barrier; the compiler's own waits for ITS loads can
 // only wait longer than needed, never shorter (loads retire in order).
-__device__ __forceinline__ void mla_dma_row(const bf16_t* gsrc_lane, const bf16_t* lds_row) {
-  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds_row);
+// The LDS destination is a BYTE ADDRESS off the dynamic region's base: a generic pointer costs a run-time address-space cast per use
+// (a null check and a select), which this compiler also mis-selects in some code shapes (V_CMP_NE_U32 on src_shared_base: a build error).
+__device__ __forceinline__ void mla_dma_row_a(const bf16_t* gsrc_lane, uint32_t lds_byte_addr) {
+  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane(lds_byte_addr);
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
                : "=&s"(keep)
                : "v"(gsrc_lane), "s"(lds_addr)
                : "memory");
 }
-
 // The same with the row's address as a SCALAR base + a 32-bit per-lane byte offset (the saddr form): a staged ckv row is one wave-uniform
 // pointer, so its arithmetic (page, row, append override) runs on the scalar unit — as 64-bit per-lane pointers it was ~45 of the tile
 // loop's ~260 VALU instructions, and the loop is VALU-issue bound (profiles/r06_W_mla_valu_diet_ab.txt).
-__device__ __forceinline__ void mla_dma_row_s(const bf16_t* gsrc_row, uint32_t lane_byte_off, const bf16_t* lds_row) {
-  const uint32_t lds_addr = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)lds_row);
-  unsigned keep;
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep)
-               : "v"(lane_byte_off), "s"(gsrc_row), "s"(lds_addr)
-               : "memory");
-}
-
-// ... and with the LDS destination as a byte address (computed from the dynamic region's base: a generic pointer costs a null check
-// and a select per cast), for the tile loop's fast path.
 __device__ __forceinline__ void mla_dma_row_sa(const bf16_t* gsrc_row, uint32_t lane_byte_off, uint32_t lds_addr) {
   unsigned keep;
   asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
@@ -211,19 +210,22 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     // piece g of row r at position g ^ (r & 7) (the XOR keeps the fragment reads of 16 rows at most 2-way bank-conflicted
     // although the rows are packed).  Rows past the end of the context re-read the last valid row: finite values that the
     // softmax weights them with exactly 0 (their scores are masked), and nothing beyond kv_len is ever touched.
-    const uint32_t lds0 = __builtin_amdgcn_readfirstlane((uint32_t)(size_t)(const __attribute__((address_space(3))) void*)Kt);
+    // (LDS destinations as byte addresses off the dynamic region's base, Kt = smem: see mla_dma_row_a)
+    const uint32_t lds0 = (uint32_t)(size_t)(__attribute__((address_space(3))) uint8_t*)smem;
+    constexpr uint32_t KT_BYTES = MLA_TILE * MLA_KROW * 2, KP_BYTES = MLA_TILE * MLA_DR * 2;
     // The page of a tile is looked up ONE TILE AHEAD of its staging (page_of: the load is issued behind the previous tile's DMA requests
     // and waited for by the loop's own vmcnt(0) in front of the barrier): looked up inside stage() the index was a dependent load in
     // front of every tile's addresses — one exposed L2 round trip per tile with a real page table (the serving seam; the single-request
     // cache passes kv_indices == NULL).
     auto page_of = [&](int tile) -> int {
-      const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tile * MLA_TILE / p.page_size);
+      const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + (p.tiles_shift >= 0 ? tile >> p.tiles_shift : tile * MLA_TILE / p.page_size));
       return p.kv_indices ? p.kv_indices[pidx_] : pidx_;
     };
-    auto stage = [&](int tile, int page_v, bf16_t* dK, bf16_t* dP) {
+    auto stage = [&](int tile, int page_v, int buf) {   // buf = which of the two staged tiles
+      const uint32_t dK = lds0 + (uint32_t)buf * KT_BYTES, dP = lds0 + 2 * KT_BYTES + (uint32_t)buf * KP_BYTES;
       const int tok0 = tile * MLA_TILE;
       const int page0 = __builtin_amdgcn_readfirstlane(page_v);
-      const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
+      const size_t row0 = (size_t)page0 * p.page_size + (p.tiles_shift >= 0 ? tok0 & (p.page_size - 1) : tok0 % p.page_size);
       const int last = kv_end - 1 - tok0;   // last valid row of the tile (>= 0: the tile holds a visible token)
       // a whole tile without the appended row (all but one or two tiles of a split): one 64-bit product for the tile, then adds — the
       // general form below spends ~25 scalar instructions per row on clamps, the append override and pointer casts (SQ counters of
@@ -231,12 +233,12 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       if (last >= MLA_TILE - 1 && (unsigned)(app_pos - tok0) >= (unsigned)MLA_TILE) {
         const bf16_t* src = p.ckv + (row0 + wave) * p.ckv_ts;
         const size_t step = (size_t)NWV * p.ckv_ts;
-        uint32_t dst = lds0 + (uint32_t)((dK - Kt) + wave * MLA_KROW) * 2u;
+        uint32_t dst = dK + (uint32_t)wave * (MLA_KROW * 2);
 #pragma unroll
         for (int r = wave; r < MLA_TILE; r += NWV, src += step, dst += NWV * MLA_KROW * 2) mla_dma_row_sa(src, (uint32_t)lane * 16u, dst);
         if (wave < 4) {
           const int r = wave * 8 + (lane >> 3), g = (lane & 7) ^ (lane >> 3);
-          mla_dma_row(p.k_pe + (row0 + r) * p.kpe_ts + g * 8, dP + wave * 8 * MLA_DR);
+          mla_dma_row_a(p.k_pe + (row0 + r) * p.kpe_ts + g * 8, dP + (uint32_t)wave * (8 * MLA_DR * 2));
         }
         return;
       }
@@ -245,18 +247,18 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         const int rr = min(r, last);
         const bf16_t* src = p.ckv + (row0 + rr) * p.ckv_ts;
         if (tok0 + rr == app_pos) src = p.app_ckv + (size_t)req * MLA_DC;
-        mla_dma_row_s(src, (uint32_t)lane * 16u, dK + r * MLA_KROW);
+        mla_dma_row_sa(src, (uint32_t)lane * 16u, dK + (uint32_t)r * (MLA_KROW * 2));
       }
       if (wave < 4) {
         const int r = wave * 8 + (lane >> 3), rr = min(r, last);
         const int g = (lane & 7) ^ (lane >> 3);
         const bf16_t* src = p.k_pe + (row0 + rr) * p.kpe_ts;
         if (tok0 + rr == app_pos) src = p.app_kpe + (size_t)req * MLA_DR;
-        mla_dma_row(src + g * 8, dP + wave * 8 * MLA_DR);
+        mla_dma_row_a(src + g * 8, dP + (uint32_t)wave * (8 * MLA_DR * 2));
       }
     };
 
-    stage(t_begin, page_of(t_begin), Kt, Kp);
+    stage(t_begin, page_of(t_begin), 0);
     int page_nx = page_of(min(t_begin + t_step, t_end - 1));   // (clamped: always a tile of this request)
     MLA_TS(2);
     bf16_t* Pw = Pt + wave * 16 * MLA_TILE;
@@ -264,7 +266,6 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
     int cur = 0;
     for (int tile = t_begin; tile < t_end; tile += t_step, cur ^= 1) {
       bf16_t* Kc = Kt + cur * MLA_TILE * MLA_KROW;
-      bf16_t* Kn = Kt + (cur ^ 1) * MLA_TILE * MLA_KROW;
       const bf16_t* Pc = Kp + cur * MLA_TILE * MLA_DR;
       const int tok0 = tile * MLA_TILE;
       const int ntok = min(MLA_TILE, kv_end - tok0);
@@ -272,9 +273,9 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
       // proves every wave is done reading the other buffer, which the next tile's DMA may now overwrite.
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();
-      if (tile == t_begin) MLA_TS(3);
+      MLA_TS_LOOP(3);
       if (tile + t_step < t_end) {
-        stage(tile + t_step, page_nx, Kn, Kp + (cur ^ 1) * MLA_TILE * MLA_DR);
+        stage(tile + t_step, page_nx, cur ^ 1);
         page_nx = page_of(min(tile + 2 * t_step, t_end - 1));
       }
 
@@ -312,7 +313,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
 #pragma unroll
           for (int r = 0; r < 4; r++) { s0[r] += sr[d * 512 + r * 64]; s1[r] += sr[d * 512 + (4 + r) * 64]; }
       }
-      if (tile == t_begin) MLA_TS(4);
+      MLA_TS_LOOP(4);
       // lane holds S[head = (lane>>4)*4 + r][token = tok0 + (lane&15) (+16)]
       const bool v0 = (lane & 15) < ntok, v1 = 16 + (lane & 15) < ntok;
       float alpha[4], sa[4], sb[4], mx[4], ps[4];
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         const v8bf b = load_v_frag(vb + i * 16);
         o[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(pf, b, o[i], 0, 0, 0);
       }
-      if (tile == t_begin) MLA_TS(5);
+      MLA_TS_LOOP(5);
     }
   }
   MLA_TS(6);
@@ -643,6 +644,9 @@ static int mla_decode_impl(const ktx_mla_config* cfg, const void* d_q_nope, cons
   p.ckv_ts = ckv_token_stride; p.kpe_ts = kpe_token_stride;
   p.qo_indptr = d_qo_indptr; p.kv_indptr = d_kv_indptr; p.kv_indices = d_kv_indices; p.kv_len = d_kv_len_arr; p.d_bsz = d_bsz;
   p.batch = batch; p.total_q = total_q_tokens; p.Hq = Hq; p.page_size = cfg->page_size; p.nsplit = nsplit;
+  p.tiles_shift = -1;
+  for (int sh = 0; sh < 20; sh++)
+    if (cfg->page_size == (MLA_TILE << sh)) p.tiles_shift = sh;
   p.sm_scale = cfg->sm_scale;
   p.part_o = (float*)d_workspace;
   p.part_ml = p.part_o + (size_t)total_q_tokens * Hq * nsplit * MLA_DC;

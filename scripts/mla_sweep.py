@@ -79,6 +79,8 @@ for shape, ns in ((2, 64), (4, 128), (2, 32)):
     n.lib.ktx_mla_debug_stamps(None)
     t = buf.view(-1, 16).cpu()
     t = t[t[:, 0] > 0][:, :8].double()
+    for k in (3, 4, 5):   # the stamps inside the tile loop exist only in a -DKTX_MLA_LOOP_STAMPS build of csrc/ktx_mla.hip: without them
+        t[:, k] = torch.where(t[:, k] > 0, t[:, k], t[:, k - 1])   # their intervals read 0 and "all tiles done" holds the whole loop
     d = (t[:, 1:] - t[:, :-1]) / 100.0
     span = (t[:, 7].max() - t[:, 0].min()) / 100.0
     print(f"shape={shape} nsplit={ns}: {t.shape[0]} workgroups, first start -> last end {span:.2f} us; start skew {(t[:, 0].max() - t[:, 0].min()) / 100.0:.2f} us")
