@@ -1,6 +1,7 @@
 """A/B of the attention half of a DeepSeek-V3 decode step: ONE persistent launch (csrc/ktx_attn.hip) against the five-launch
 chain, L distinct layers chained in one captured graph (layer l's output row is layer l+1's input), with the phase stamps of
 workgroup 0.  python scripts/attn_fused_bench.py [layers=16] [ctx=4096]"""
+import os
 import sys
 import time
 
@@ -13,6 +14,8 @@ H, NOPE, ROPE, LORA, VDIM, QLORA, HIDDEN, PAGE = 128, 128, 64, 512, 128, 1536, 7
 L = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 CTX = int(sys.argv[2]) if len(sys.argv) > 2 else 4096
 dev = torch.device("cuda", 0)
+if os.environ.get("ATTN_BOUND_K"):   # dev knob 1: context bound (K tokens) up to which the one launch is offered (csrc/ktx_mla.hip)
+    N.lib.ktx_debug_set(1, int(os.environ["ATTN_BOUND_K"]))
 g = torch.Generator(device=dev)
 g.manual_seed(1)
 
