@@ -304,6 +304,15 @@ __device__ __forceinline__ void dma_row(const bf16_t* gsrc_lane, uint32_t lds_by
                : "memory");
 }
 
+// the row as a SCALAR base + a per-lane byte offset (saddr form): a staged ckv row is one wave-uniform pointer (ktx_mla.hip, round 6)
+__device__ __forceinline__ void dma_row_s(const bf16_t* gsrc_row, uint32_t lane_byte_off, uint32_t lds_addr) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep)
+               : "v"(lane_byte_off), "s"(gsrc_row), "s"(lds_addr)
+               : "memory");
+}
+
 // n items over m bins: bins < R take Q + 1 (ktx_linear_sk.inc)
 __device__ __forceinline__ int split_begin(int Q, int R, int b) { return b * Q + (b < R ? b : R); }
 __device__ __forceinline__ int wave_begin(int Gb, int n, int w) {
@@ -844,9 +853,23 @@ __global__ __launch_bounds__(NT, 2) void attn_decode_kernel(AttnParams p) {
         const uint32_t dP = smem_lds + (uint32_t)(2 * TILE * KROW * 2) + (uint32_t)buf * (TILE * ROPE * 2);
         const int tok0 = tile * TILE;
         const int pidx_ = __builtin_amdgcn_readfirstlane(page_base + tok0 / p.page_size);
-        const int page0 = p.kv_indices ? p.kv_indices[pidx_] : pidx_;
+        const int page0 = __builtin_amdgcn_readfirstlane(p.kv_indices ? p.kv_indices[pidx_] : pidx_);
         const size_t row0 = (size_t)page0 * p.page_size + tok0 % p.page_size;
         const int last = kv_end - 1 - tok0;
+        // a whole tile without the newest row: one 64-bit product for the tile, then adds, on the scalar unit (mla_decode_kernel's
+        // round-6 fast path; nothing at the 3 tiles per split of a 4 K context, it pays from 8 tiles per split on: DESIGN 4.1.7)
+        if (last >= TILE - 1 && (unsigned)(app_pos - tok0) >= (unsigned)TILE) {
+          const bf16_t* src = p.ckv + (row0 + wave) * p.ckv_ts;
+          const size_t step = (size_t)NWV * p.ckv_ts;
+          uint32_t dst = __builtin_amdgcn_readfirstlane(dK + (uint32_t)wave * (KROW * 2));
+#pragma unroll
+          for (int r = wave; r < TILE; r += NWV, src += step, dst += NWV * KROW * 2) dma_row_s(src, (uint32_t)lane * 16u, dst);
+          if (wave < 4) {
+            const int r = wave * 8 + (lane >> 3), g = (lane & 7) ^ (lane >> 3);
+            dma_row(p.kpe + (row0 + r) * p.kpe_ts + g * 8, dP + (uint32_t)wave * (8 * ROPE * 2));
+          }
+          return;
+        }
 #pragma unroll
         for (int r = wave; r < TILE; r += NWV) {
           const int rr = min(r, last);
