@@ -243,7 +243,7 @@ __global__ __launch_bounds__(HBW * DSPLIT * 64) void mla_decode_kernel(MlaParams
         return;
       }
 #pragma unroll
-      for (int r = wave; r < MLA_TILE; r += NWV) {   // (every term wave-uniform: scalar arithmetic, mla_dma_row_s)
+      for (int r = wave; r < MLA_TILE; r += NWV) {   // (every term wave-uniform: scalar arithmetic, mla_dma_row_sa)
         const int rr = min(r, last);
         const bf16_t* src = p.ckv + (row0 + rr) * p.ckv_ts;
         if (tok0 + rr == app_pos) src = p.app_ckv + (size_t)req * MLA_DC;
