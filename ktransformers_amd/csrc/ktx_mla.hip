@@ -608,11 +608,12 @@ static void mla_pick_shape(const ktx_mla_config* cfg, int total_q_tokens, size_t
 extern "C" int ktx_mla_decode_nsplit(const ktx_mla_config* cfg, int total_q_tokens, size_t workspace_bytes) {   // ktx_internal.h
   int shape = 0, nsplit = 0;
   if (!cfg || total_q_tokens <= 0) return 0;
-  // Up to 32 K tokens the one launch wins with deeper 2x4 splits: 61.7 vs 68.4 us per layer at 12 K, 65.4 vs 72.0 at 16 K, 73.1 vs 76.0 at
-  // 24 K, 80.5 vs 81.0 at 32 K; at 48 K the five launches with the 4x2 shape's 128 splits are faster, 89.0 vs 95.1
-  // (profiles/r06_AG_attn_fused_long_ctx.txt, final round-6 kernels; the bound was 12 K before the launch lost 7 us to section 4.1.6).
+  // Up to 40 K tokens the one launch wins with deeper 2x4 splits: 61.7 vs 68.4 us per layer at 12 K, 64.1 vs 72.0 at 16 K, 77.9 vs 80.5 at
+  // 32 K, 81.7 vs 83.4 at 36 K, even from 40 K on (84.8 / 84.8; 48 K 95.1 vs 89.0 before phase C's staging fast path) — the five launches
+  // with the 4x2 shape's 128 splits take over there (profiles/r06_AG_attn_fused_long_ctx.txt, final round-6 kernels; the bound was 12 K
+  // before the launch lost 7 us to section 4.1.6).
   const int bound_k = ktx_debug_get(1);   // dev knob 1: the bound in K tokens (scripts/attn_fused_bench.py, ATTN_BOUND_K)
-  if (cfg->kv_len_hint >= (bound_k > 0 ? bound_k * 1024 : 32768)) return 0;
+  if (cfg->kv_len_hint >= (bound_k > 0 ? bound_k * 1024 : 40960)) return 0;
   mla_pick_shape(cfg, total_q_tokens, workspace_bytes, &shape, &nsplit, true);
   return shape == 2 ? nsplit : 0;   // the one-launch step is built on the 2x4 workgroup shape only
 }

@@ -313,14 +313,14 @@ def test_eligibility_follows_the_context_bound(layer):
     c = _case(layer, 100, 160, False)
     y = torch.empty((1, HIDDEN), dtype=torch.bfloat16, device=layer["dev"])
     short = _args(layer, c, c["cache"], y.reshape(-1), hint=612)
-    mid = _args(layer, c, c["cache"], y.reshape(-1), hint=16384)        # round 6: covered with deeper 2x4 splits up to 32 K tokens
-    long_ = _args(layer, c, c["cache"], y.reshape(-1), hint=32768)
+    mid = _args(layer, c, c["cache"], y.reshape(-1), hint=32768)        # round 6: covered with deeper 2x4 splits up to 40 K tokens
+    long_ = _args(layer, c, c["cache"], y.reshape(-1), hint=40960)
     assert attn_decode_eligible(short) and attn_decode_eligible(mid) and not attn_decode_eligible(long_) and attn_decode_eligible(short)
 
 
 @pytest.mark.parametrize("ctx,pages", [(8500, 144), (20000, 320)])
 def test_one_launch_past_8192_tokens(layer, ctx, pages):
-    """Round 6: between 8192 and 32768 tokens the launch keeps the 2x4 workgroup shape (<= 64 splits, several tiles per split) where
+    """Round 6: between 8192 and 40960 tokens the launch keeps the 2x4 workgroup shape (<= 64 splits, several tiles per split) where
     the stand-alone kernel switches to 4x2 — so the five-launch reference is pinned to the 2x4 shape (dev knob 6 = 2) and then every
     intermediate is bit-identical again."""
     from ktransformers_amd import _native
